@@ -1,0 +1,281 @@
+// dvp_dev.hpp — device-side types, numerics primitives and the software sampler of the MI355X
+// PatchMatch engine.  Everything here is plain C++ over IEEE-754 binary32 (explicit fmaf where a
+// fused operation is wanted; the build uses -ffp-contract=off) so that results are bit-stable
+// and can be checked against the CPU oracle bit for bit.
+//
+// DVP_HD marks functions that run on the device.  tests/emul builds the same headers with g++
+// (DVP_HD empty) to exercise kernel logic on machines without a GPU; the shipped library never
+// contains or falls back to that build.
+#ifndef DVP_DEV_HPP_
+#define DVP_DEV_HPP_
+
+#include <stdint.h>
+#include <math.h>
+#include <float.h>
+#include "../../include/dvp_mvs.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define DVP_HD __device__ __forceinline__
+#define DVP_HD_NOINLINE __device__ __noinline__
+#else
+#define DVP_HD inline
+#define DVP_HD_NOINLINE inline
+#endif
+
+namespace dvp {
+
+struct f4 { float x, y, z, w; };
+struct f3 { float x, y, z; };
+struct f2 { float x, y; };
+struct i2 { int x, y; };
+struct s2 { short x, y; };
+
+DVP_HD f4 mk4(float x, float y, float z, float w) { f4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+DVP_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+DVP_HD f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+DVP_HD i2 mki2(int x, int y) { i2 r; r.x = x; r.y = y; return r; }
+DVP_HD s2 mks2(int x, int y) { s2 r; r.x = (short)x; r.y = (short)y; return r; }
+
+// Per source view constants of the plane-induced homography (camera-only sub-expressions of
+// ComputeHomography, APD.cu:681-707, evaluated once per view in the same operation order).
+struct ViewConst {
+	float Rrel[9];
+	float trel[3];
+};
+
+// The buffer bundle every kernel receives (the engine's DataPassHelper, APD.h:60-92).
+struct Dev {
+	int width, height, num_images;
+	int pitch;                 // floats per image row (multiple of 64 -> 256 B aligned rows)
+	size_t plane_stride;       // floats per image plane
+	int sampler;               // 0 = 8-bit interpolation weights, 1 = exact
+	int weak_count;
+	uint64_t seed;
+	DvpParams params;
+	// uniform constants derived from params on the host (GenNeighbours, APD.cu:3375-3380)
+	float nb_cos, nb_sin, nb_thresh;
+	int nb_shift_range;
+	const float* images;       // [num_images][height][pitch]
+	const float* depths;       // [num_images][height][pitch] (geom_consistency only)
+	const DvpCamera* cameras;  // [num_images]
+	const ViewConst* views;    // [num_images] (index 0 unused)
+	const uint8_t* sector_lut; // [(2r+1)^2], r = weak_radius: 30-degree sector of offset (i,j) (APD.cu:797-821)
+	f4* planes;
+	const f4* planes_snap;     // pre-launch copy for the strong update (direction-4 same-colour reads)
+	float* costs;
+	const float* costs_snap;
+	uint32_t* selected_views;  // +width zeroed tail (APD.cu:2473 reads one row past the end)
+	uint8_t* view_weight;      // 32 per pixel
+	uint8_t* weak_info;
+	uint8_t* weak_reliable;
+	s2* weak_nearest_strong;
+	const int* neighbours_map;
+	s2* neighbours;            // 12 per WEAK pixel
+	f4* fit_planes;
+	s2* candidate;             // [pixel][view][8]
+	const uint8_t* edge;
+	s2* edge_neigh;            // 8 per pixel
+	const int* label;
+	s2* label_boundary;        // 8 per WEAK pixel
+	float* complex_;           // per WEAK pixel
+	int* radius;
+	unsigned long long* eval_counter;   // profiling builds only (may be null)
+};
+
+#define DVP_MIN(a, b) ((a) > (b) ? (b) : (a))   // OpenCV cvdef.h semantics (used by the reference)
+#define DVP_MAX(a, b) ((a) < (b) ? (b) : (a))
+
+// ---- exp (specification shared with the oracle: Cephes-style, fmaf only) ---------------------
+DVP_HD float dvp_expf(float x) {
+	if (!(x > -103.0f)) return (x != x) ? x : 0.0f;
+	if (x > 88.72f) return INFINITY;
+	const float n = rintf(x * 1.44269504088896341f);
+	float r = fmaf(n, -0.693359375f, x);
+	r = fmaf(n, 2.12194440e-4f, r);
+	float p = 1.9875691500e-4f;
+	p = fmaf(p, r, 1.3981999507e-3f);
+	p = fmaf(p, r, 8.3334519073e-3f);
+	p = fmaf(p, r, 4.1665795894e-2f);
+	p = fmaf(p, r, 1.6666665459e-1f);
+	p = fmaf(p, r, 5.0000001201e-1f);
+	const float r2 = r * r;
+	const float y = fmaf(p, r2, r) + 1.0f;
+	const int ni = (int)n;
+	const int n1 = ni / 2, n2 = ni - n1;
+	union { uint32_t u; float f; } s1, s2;
+	s1.u = (uint32_t)(n1 + 127) << 23;
+	s2.u = (uint32_t)(n2 + 127) << 23;
+	return (y * s1.f) * s2.f;
+}
+
+// ---- counter-based RNG (replaces curandState; specification shared with the oracle) ----------
+DVP_HD uint32_t rand_u32(uint64_t seed, uint32_t pixel, uint32_t site, uint32_t k) {
+	uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)pixel + ((uint64_t)site << 32));
+	z += 0xD1B54A32D192ED03ull * (uint64_t)(k + 1u);
+	z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+	z ^= z >> 27; z *= 0x94D049BB133111EBull;
+	z ^= z >> 31;
+	return (uint32_t)(z >> 32);
+}
+DVP_HD float rand_uniform(uint64_t seed, uint32_t pixel, uint32_t site, uint32_t k) {   // (0, 1]
+	return (float)((rand_u32(seed, pixel, site, k) >> 8) + 1u) * (1.0f / 16777216.0f);
+}
+enum { PH_RANDOM_INIT = 1, PH_STRONG = 2, PH_RANSAC = 3, PH_WEAK = 4, PH_NEIGHBOURS = 5 };
+enum { SUB_VIEW = 0, SUB_DEPTH_RAND = 1, SUB_NORMAL = 2, SUB_DEPTH_PERT = 3, SUB_LIMIT = 4, SUB_SEARCH = 5, SUB_RANSAC = 6 };
+DVP_HD uint32_t rng_site(int phase, int iter, int sub) {
+	return ((uint32_t)phase << 16) | ((uint32_t)(iter & 0xff) << 8) | (uint32_t)sub;
+}
+struct Rng {
+	uint64_t seed;
+	uint32_t pixel, site, k;
+	DVP_HD Rng(uint64_t s, uint32_t p, uint32_t st) : seed(s), pixel(p), site(st), k(0) {}
+	DVP_HD uint32_t next() { return rand_u32(seed, pixel, site, k++); }
+	DVP_HD float uniform() { return rand_uniform(seed, pixel, site, k++); }
+};
+
+// ---- software texture unit (gfx950 has no tex2D path; semantics of APD.cpp:1501-1517) --------
+DVP_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+DVP_HD float tex_texel(const float* img, int pitch, int W, int H, int ix, int iy) {
+	return img[(size_t)clampi(iy, 0, H - 1) * pitch + clampi(ix, 0, W - 1)];
+}
+
+// x, y are the texture coordinates the reference passes to tex2D (pixel + 0.5)
+DVP_HD float tex_linear(const float* img, int pitch, int W, int H, float x, float y, int sampler) {
+	float xb = x - 0.5f, yb = y - 0.5f;
+	xb = fminf(fmaxf(xb, -1.0f), (float)W);
+	yb = fminf(fmaxf(yb, -1.0f), (float)H);
+	const float fx = floorf(xb), fy = floorf(yb);
+	float a = xb - fx, b = yb - fy;
+	if (sampler == 0) {
+		a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
+		b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
+	}
+	const int i0 = (int)fx, j0 = (int)fy;
+	const int x0 = clampi(i0, 0, W - 1), x1 = clampi(i0 + 1, 0, W - 1);
+	const int y0 = clampi(j0, 0, H - 1), y1 = clampi(j0 + 1, 0, H - 1);
+	const float* r0 = img + (size_t)y0 * pitch;
+	const float* r1 = img + (size_t)y1 * pitch;
+	const float t00 = r0[x0], t10 = r0[x1];
+	const float t01 = r1[x0], t11 = r1[x1];
+	const float top = fmaf(a, t10 - t00, t00);
+	const float bot = fmaf(a, t11 - t01, t01);
+	return fmaf(b, bot - top, top);
+}
+
+// ---- small geometry helpers (APD.cu:181-194, 331-422, 467-499, 750-768) ----------------------
+DVP_HD int is_set(uint32_t v, unsigned n) { return (v >> n) & 1; }
+DVP_HD void set_bit(uint32_t* v, unsigned n) { *v |= (1u << n); }
+DVP_HD void unset_bit_ref(uint32_t* v, unsigned n) { *v &= (0xFFFFFFFEu << n); }   // APD.cu:186-189: clears bits 0..n
+
+DVP_HD void normalize3(f4* v) {   // NormalizeVec3 with rsqrtf -> 1/sqrtf
+	const float n2 = v->x * v->x + v->y * v->y + v->z * v->z;
+	const float inv = 1.0f / sqrtf(n2);
+	v->x *= inv; v->y *= inv; v->z *= inv;
+}
+DVP_HD void normalize2(f2* v) {
+	const float n2 = v->x * v->x + v->y * v->y;
+	const float inv = 1.0f / sqrtf(n2);
+	v->x *= inv; v->y *= inv;
+}
+DVP_HD void get_3d_point(const DvpCamera& cam, int px, int py, float depth, float* X) {   // APD.cu:372-377
+	X[0] = depth * (px - cam.K[2]) / cam.K[0];
+	X[1] = depth * (py - cam.K[5]) / cam.K[4];
+	X[2] = depth;
+}
+DVP_HD f4 view_direction(const DvpCamera& cam, int px, int py, float depth) {              // APD.cu:386-398
+	float X[3];
+	get_3d_point(cam, px, py, depth, X);
+	const float norm = sqrtf(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+	return mk4(X[0] / norm, X[1] / norm, X[2] / norm, 0.0f);
+}
+DVP_HD float distance_to_origin(const DvpCamera& cam, int px, int py, float depth, const f4 n) {   // APD.cu:400-405
+	float X[3];
+	get_3d_point(cam, px, py, depth, X);
+	return -(n.x * X[0] + n.y * X[1] + n.z * X[2]);
+}
+DVP_HD float depth_from_plane(const DvpCamera& cam, const f4 pl, int px, int py) {          // APD.cu:419-422
+	return -pl.w * cam.K[0] / ((px - cam.K[2]) * pl.x + (cam.K[0] / cam.K[4]) * (py - cam.K[5]) * pl.y + cam.K[0] * pl.z);
+}
+DVP_HD f3 point_on_world(float x, float y, float depth, const DvpCamera& cam) {              // APD.cu:467-487
+	f3 P, T;
+	P.x = depth * (x - cam.K[2]) / cam.K[0];
+	P.y = depth * (y - cam.K[5]) / cam.K[4];
+	P.z = depth;
+	T.x = cam.R[0] * P.x + cam.R[3] * P.y + cam.R[6] * P.z;
+	T.y = cam.R[1] * P.x + cam.R[4] * P.y + cam.R[7] * P.z;
+	T.z = cam.R[2] * P.x + cam.R[5] * P.y + cam.R[8] * P.z;
+	P.x = T.x + cam.c[0];
+	P.y = T.y + cam.c[1];
+	P.z = T.z + cam.c[2];
+	return P;
+}
+DVP_HD void project_on_camera(const f3 X, const DvpCamera& cam, f2* pt, float* depth) {      // APD.cu:489-499
+	f3 t;
+	t.x = cam.R[0] * X.x + cam.R[1] * X.y + cam.R[2] * X.z + cam.t[0];
+	t.y = cam.R[3] * X.x + cam.R[4] * X.y + cam.R[5] * X.z + cam.t[1];
+	t.z = cam.R[6] * X.x + cam.R[7] * X.y + cam.R[8] * X.z + cam.t[2];
+	*depth = cam.K[6] * t.x + cam.K[7] * t.y + cam.K[8] * t.z;
+	pt->x = (cam.K[0] * t.x + cam.K[1] * t.y + cam.K[2] * t.z) / *depth;
+	pt->y = (cam.K[3] * t.x + cam.K[4] * t.y + cam.K[5] * t.z) / *depth;
+}
+DVP_HD f4 normal_cam_to_world(const DvpCamera& cam, const f4 pl) {   // TransformNormal, APD.cu:750-758
+	return mk4(cam.R[0] * pl.x + cam.R[3] * pl.y + cam.R[6] * pl.z,
+	           cam.R[1] * pl.x + cam.R[4] * pl.y + cam.R[7] * pl.z,
+	           cam.R[2] * pl.x + cam.R[5] * pl.y + cam.R[8] * pl.z, pl.w);
+}
+DVP_HD f4 normal_world_to_cam(const DvpCamera& cam, const f4 pl) {   // TransformNormal2RefCam, APD.cu:760-768
+	return mk4(cam.R[0] * pl.x + cam.R[1] * pl.y + cam.R[2] * pl.z,
+	           cam.R[3] * pl.x + cam.R[4] * pl.y + cam.R[5] * pl.z,
+	           cam.R[6] * pl.x + cam.R[7] * pl.y + cam.R[8] * pl.z, pl.w);
+}
+
+// camera-only part of ComputeHomography (APD.cu:681-707), once per source view
+DVP_HD void compute_view_const(const DvpCamera& ref, const DvpCamera& src, ViewConst* vc) {
+	float ref_C[3], src_C[3];
+	for (int j = 0; j < 3; ++j) {
+		ref_C[j] = -(ref.R[j] * ref.t[0] + ref.R[3 + j] * ref.t[1] + ref.R[6 + j] * ref.t[2]);
+		src_C[j] = -(src.R[j] * src.t[0] + src.R[3 + j] * src.t[1] + src.R[6 + j] * src.t[2]);
+	}
+	for (int i = 0; i < 3; ++i)
+		for (int j = 0; j < 3; ++j)
+			vc->Rrel[3 * i + j] = src.R[3 * i] * ref.R[3 * j] + src.R[3 * i + 1] * ref.R[3 * j + 1] + src.R[3 * i + 2] * ref.R[3 * j + 2];
+	float C_rel[3];
+	for (int i = 0; i < 3; ++i) C_rel[i] = ref_C[i] - src_C[i];
+	for (int i = 0; i < 3; ++i)
+		vc->trel[i] = src.R[3 * i] * C_rel[0] + src.R[3 * i + 1] * C_rel[1] + src.R[3 * i + 2] * C_rel[2];
+}
+
+// plane-dependent part of ComputeHomography (APD.cu:709-738)
+DVP_HD void homography(const DvpCamera& ref, const DvpCamera& src, const ViewConst& vc, const f4 pl, float* H) {
+	float Hh[9], tmp[9];
+	for (int i = 0; i < 3; ++i) {
+		Hh[3 * i + 0] = vc.Rrel[3 * i + 0] - vc.trel[i] * pl.x / pl.w;
+		Hh[3 * i + 1] = vc.Rrel[3 * i + 1] - vc.trel[i] * pl.y / pl.w;
+		Hh[3 * i + 2] = vc.Rrel[3 * i + 2] - vc.trel[i] * pl.z / pl.w;
+	}
+	for (int i = 0; i < 3; ++i) {
+		tmp[3 * i + 0] = Hh[3 * i + 0] / ref.K[0];
+		tmp[3 * i + 1] = Hh[3 * i + 1] / ref.K[4];
+		tmp[3 * i + 2] = -Hh[3 * i + 0] * ref.K[2] / ref.K[0] - Hh[3 * i + 1] * ref.K[5] / ref.K[4] + Hh[3 * i + 2];
+	}
+	H[0] = src.K[0] * tmp[0] + src.K[2] * tmp[6];
+	H[1] = src.K[0] * tmp[1] + src.K[2] * tmp[7];
+	H[2] = src.K[0] * tmp[2] + src.K[2] * tmp[8];
+	H[3] = src.K[4] * tmp[3] + src.K[5] * tmp[6];
+	H[4] = src.K[4] * tmp[4] + src.K[5] * tmp[7];
+	H[5] = src.K[4] * tmp[5] + src.K[5] * tmp[8];
+	H[6] = src.K[8] * tmp[6];
+	H[7] = src.K[8] * tmp[7];
+	H[8] = src.K[8] * tmp[8];
+}
+DVP_HD f2 apply_homography(const float* H, int px, int py) {   // ComputeCorrespondingPoint, APD.cu:741-748
+	const float x = H[0] * px + H[1] * py + H[2];
+	const float y = H[3] * px + H[4] * py + H[5];
+	const float z = H[6] * px + H[7] * py + H[8];
+	return mk2(x / z, y / z);
+}
+
+}  // namespace dvp
+#endif

@@ -1,0 +1,199 @@
+// dvp_ncc.hpp — bilateral-weighted NCC cost (the roofline kernel core) with the
+// hypothesis-independent half hoisted out.
+//
+// ComputeBilateralNCCOld (APD.cu:1023-1113) evaluates, per (pixel, view, plane): 36 reference
+// texels, 36 bilateral weights (exp + sqrt each), the reference moments, and 36 bilinear source
+// samples.  Everything that touches only the reference image depends on the pixel alone, yet the
+// reference recomputes it for each of the ~20·S evaluations per pixel and iteration.  Here a
+// PatchCtx is built once per pixel per kernel (weights w[t], w[t]*ref[t], the three reference
+// moments in the reference's row-then-total accumulation order) and each evaluation only does the
+// homography, the 36 gathers and three accumulations.  Results are bit-identical to the direct
+// form because every floating-point operation that remains is the same operation on the same
+// operands in the same order.
+#ifndef DVP_NCC_HPP_
+#define DVP_NCC_HPP_
+
+#include "dvp_dev.hpp"
+
+namespace dvp {
+
+constexpr int kTaps = 6;   // taps per axis on the fast path (radius 5k, increment 2k)
+
+struct PatchCtx {
+	float w[kTaps * kTaps];    // bilateral weight of tap (ti, tj), index ti*6+tj (ti = x offset index)
+	float wa[kTaps * kTaps];   // w * ref_pix
+	float sum_ref, sum_ref_ref, wsum;   // un-normalised reference sums (row-then-total order)
+	int radius, inc;
+	int fast;                  // 1: exactly 6 taps per axis (register path); 0: generic loops
+};
+
+// weight of ComputeBilateralWeight (APD.cu:776-781) / ComputeBilateralWeight_YZL (APD.cu:783-788)
+DVP_HD float bilateral_weight(float xd, float yd, float pix, float cpix, float sig_s, float sig_c, int colour_only) {
+	const float color_dist = fabsf(pix - cpix);
+	if (colour_only) return dvp_expf(-color_dist / (2.0f * sig_c * sig_c));
+	const float spatial_dist = sqrtf(xd * xd + yd * yd);
+	return dvp_expf(-spatial_dist / (2.0f * sig_s * sig_s) - color_dist / (2.0f * sig_c * sig_c));
+}
+
+// radius / increment selection of APD.cu:1042-1047 (and 896-902 for the centre patch of NCCNew)
+DVP_HD void patch_geometry(const Dev& d, int center, int* radius, int* inc) {
+	int r = d.params.strong_radius, s = d.params.strong_increment;
+	if (d.params.use_radius) {
+		r = d.radius[center];
+		s = DVP_MAX(2, (int)(2.0 * r / 5.0));
+	}
+	*radius = r;
+	*inc = s;
+}
+
+DVP_HD void build_patch_ctx(const Dev& d, int px, int py, int radius, int inc, int colour_only, PatchCtx* c) {
+	const float* ref = d.images;
+	const int W = d.width, H = d.height, P = d.pitch;
+	c->radius = radius;
+	c->inc = inc;
+	c->fast = (inc > 0 && (2 * radius) / inc + 1 == kTaps) ? 1 : 0;
+	if (!c->fast) return;
+	const float cpix = tex_texel(ref, P, W, H, px, py);
+	const float sig_s = d.params.sigma_spatial, sig_c = d.params.sigma_color;
+	float sr = 0.0f, srr = 0.0f, ws = 0.0f;
+#pragma unroll
+	for (int ti = 0; ti < kTaps; ++ti) {
+		const int i = -radius + ti * inc;
+		float sr_row = 0.0f, srr_row = 0.0f, ws_row = 0.0f;
+#pragma unroll
+		for (int tj = 0; tj < kTaps; ++tj) {
+			const int j = -radius + tj * inc;
+			const float a = tex_texel(ref, P, W, H, px + i, py + j);
+			const float w = bilateral_weight((float)i, (float)j, a, cpix, sig_s, sig_c, colour_only);
+			const float wa = w * a;
+			c->w[ti * kTaps + tj] = w;
+			c->wa[ti * kTaps + tj] = wa;
+			sr_row += wa;
+			srr_row += wa * a;
+			ws_row += w;
+		}
+		sr += sr_row;
+		srr += srr_row;
+		ws += ws_row;
+	}
+	c->sum_ref = sr;
+	c->sum_ref_ref = srr;
+	c->wsum = ws;
+}
+
+// final NCC formula of APD.cu:1091-1109 from the six un-normalised sums
+DVP_HD float ncc_from_sums(float sum_ref, float sum_ref_ref, float sum_src, float sum_src_src, float sum_ref_src, float wsum) {
+	const float inv = 1.0f / wsum;
+	sum_ref *= inv;
+	sum_ref_ref *= inv;
+	sum_src *= inv;
+	sum_src_src *= inv;
+	sum_ref_src *= inv;
+	const float var_ref = sum_ref_ref - sum_ref * sum_ref;
+	const float var_src = sum_src_src - sum_src * sum_src;
+	const float kMinVar = 1e-5f;
+	if (var_ref < kMinVar || var_src < kMinVar) return 2.0f;
+	const float covar = sum_ref_src - sum_ref * sum_src;
+	const float denom = sqrtf(var_ref * var_src);
+	return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
+}
+
+// Generic (non-hoisted) patch loop for tap counts other than 6 per axis; direct restatement of
+// APD.cu:1059-1089 with the weight variant selected by `colour_only`.
+DVP_HD float ncc_patch_generic(const Dev& d, const float* H, const float* src, int px, int py, int radius, int inc, int colour_only) {
+	const float* ref = d.images;
+	const int W = d.width, Hh = d.height, P = d.pitch;
+	const float cpix = tex_texel(ref, P, W, Hh, px, py);
+	float s_r = 0.0f, s_rr = 0.0f, s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f, s_w = 0.0f;
+	if (inc <= 0) inc = 1;
+	for (int i = -radius; i <= radius; i += inc) {
+		float r_r = 0.0f, r_rr = 0.0f, r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f, r_w = 0.0f;
+		for (int j = -radius; j <= radius; j += inc) {
+			const float a = tex_texel(ref, P, W, Hh, px + i, py + j);
+			const f2 sp = apply_homography(H, px + i, py + j);
+			const float b = tex_linear(src, P, W, Hh, sp.x + 0.5f, sp.y + 0.5f, d.sampler);
+			const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, colour_only);
+			r_r += w * a;
+			r_rr += w * a * a;
+			r_s += w * b;
+			r_ss += w * b * b;
+			r_rs += w * a * b;
+			r_w += w;
+		}
+		s_r += r_r; s_rr += r_rr; s_s += r_s; s_ss += r_ss; s_rs += r_rs; s_w += r_w;
+	}
+	return ncc_from_sums(s_r, s_rr, s_s, s_ss, s_rs, s_w);
+}
+
+// 36-tap patch with the hoisted context.  H is the pixel->source homography.
+DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, const float* src, int px, int py) {
+	const int W = d.width, Hh = d.height, P = d.pitch;
+	// H[k]*x and H[k]*y products for the 6 distinct tap columns / rows: same products the
+	// reference forms per tap (H[0]*p.x + H[1]*p.y + H[2], APD.cu:744-746), formed once.
+	float hx0[kTaps], hx3[kTaps], hx6[kTaps], hy1[kTaps], hy4[kTaps], hy7[kTaps];
+#pragma unroll
+	for (int t = 0; t < kTaps; ++t) {
+		const float fx = (float)(px - c.radius + t * c.inc);
+		const float fy = (float)(py - c.radius + t * c.inc);
+		hx0[t] = H[0] * fx; hx3[t] = H[3] * fx; hx6[t] = H[6] * fx;
+		hy1[t] = H[1] * fy; hy4[t] = H[4] * fy; hy7[t] = H[7] * fy;
+	}
+	float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+#pragma unroll
+	for (int ti = 0; ti < kTaps; ++ti) {
+		float r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f;
+#pragma unroll
+		for (int tj = 0; tj < kTaps; ++tj) {
+			const float x = hx0[ti] + hy1[tj] + H[2];
+			const float y = hx3[ti] + hy4[tj] + H[5];
+			const float z = hx6[ti] + hy7[tj] + H[8];
+			const float b = tex_linear(src, P, W, Hh, x / z + 0.5f, y / z + 0.5f, d.sampler);
+			const float wb = c.w[ti * kTaps + tj] * b;
+			r_s += wb;
+			r_ss += wb * b;
+			r_rs += c.wa[ti * kTaps + tj] * b;
+		}
+		s_s += r_s;
+		s_ss += r_ss;
+		s_rs += r_rs;
+	}
+	return ncc_from_sums(c.sum_ref, c.sum_ref_ref, s_s, s_ss, s_rs, c.wsum);
+}
+
+// ComputeBilateralNCCOld (APD.cu:1023-1113) for source view `v` (1-based image index).
+DVP_HD float ncc_old(const Dev& d, const PatchCtx& c, int px, int py, int v, const f4 plane) {
+	const DvpCamera& rc = d.cameras[0];
+	const DvpCamera& sc = d.cameras[v];
+	float H[9];
+	homography(rc, sc, d.views[v], plane, H);
+	const f2 pt = apply_homography(H, px, py);
+	if (pt.x >= sc.width || pt.x < 0.0f || pt.y >= sc.height || pt.y < 0.0f) return 2.0f;
+	const float* src = d.images + (size_t)v * d.plane_stride;
+	if (c.fast) return ncc_patch_fast(d, c, H, src, px, py);
+	return ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 0);
+}
+
+// ComputeGeomConsistencyCost (APD.cu:1218-1256)
+DVP_HD float geom_cost(const Dev& d, int px, int py, int v, const f4 plane) {
+	const DvpCamera& rc = d.cameras[0];
+	const DvpCamera& sc = d.cameras[v];
+	const float* dimg = d.depths + (size_t)v * d.plane_stride;
+	const float depth = depth_from_plane(rc, plane, px, py);
+	const f3 fwd = point_on_world((float)px, (float)py, depth, rc);
+	f2 sp;
+	float sd;
+	project_on_camera(fwd, sc, &sp, &sd);
+	const float cx = fminf(fmaxf(sp.x, -1.0f), (float)d.width);
+	const float cy = fminf(fmaxf(sp.y, -1.0f), (float)d.height);
+	const float src_depth = tex_texel(dimg, d.pitch, d.width, d.height, (int)cx, (int)cy);
+	if (src_depth == 0.0f) return 3.0f;
+	const f3 back = point_on_world(sp.x, sp.y, src_depth, sc);
+	f2 bp;
+	float rd;
+	project_on_camera(back, rc, &bp, &rd);
+	const float dc = px - bp.x, dr = py - bp.y;
+	return fminf(3.0f, sqrtf(dc * dc + dr * dr));
+}
+
+}  // namespace dvp
+#endif

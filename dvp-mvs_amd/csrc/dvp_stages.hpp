@@ -1,0 +1,108 @@
+// dvp_stages.hpp — launch geometry shared by every kernel, per-stage pixel dispatch, and the
+// host-side uniform constants (sector table, anchor-search rotation constants).
+#ifndef DVP_STAGES_HPP_
+#define DVP_STAGES_HPP_
+
+#include "dvp_weak.hpp"
+#include <vector>
+#include <cmath>
+
+namespace dvp {
+
+// Tile = 64 x 4 lanes: a wave is 64 x-adjacent pixels (coalesced state reads, near-contiguous
+// source gathers), a 256-thread workgroup is 4 such rows.
+//  * full launches: pixel (tile_x*64 + lane, tile_y*4 + wave)
+//  * half (red/black) launches: wave = one row PAIR; lane l sits at x = tile_x*64 + l and
+//    y = 2*pair + ((x&1) ^ colour) — the reference's pixel map (APD.cu:3093-3100).  The reference
+//    grid covers 16*ceil((H/2)/16) row pairs (APD.cu:4421-4424): for odd H with (H/2)%16 == 0 the
+//    last row is never updated; `rows()` reproduces that.
+struct LaunchGeom {
+	int tiles_x, tiles_y, tiles, chunk;   // chunk = tiles per XCD
+	int rows;                             // rows (full) or row pairs (half) covered
+	bool half;
+	int grid() const { return chunk * 8; }
+};
+inline LaunchGeom make_geom(int W, int H, bool half) {
+	LaunchGeom g;
+	g.half = half;
+	g.rows = half ? ((H / 2) + 15) / 16 * 16 : H;
+	g.tiles_x = (W + 63) / 64;
+	g.tiles_y = (g.rows + 3) / 4;
+	g.tiles = g.tiles_x * g.tiles_y;
+	g.chunk = (g.tiles + 7) / 8;
+	return g;
+}
+
+// XCD-aware block -> tile map.  Workgroup b is dispatched to XCD b % 8 (observed placement, a
+// speed matter only): give every XCD one contiguous band of tiles so that neighbouring tiles,
+// which gather overlapping source-image lines, share that XCD's 4 MiB L2.
+DVP_HD bool block_to_pixel(int block, int lane, int wave, int tiles_x, int tiles, int chunk, int rows, int half, int colour,
+	int W, int H, int* px, int* py) {
+	const int tile = (block & 7) * chunk + (block >> 3);
+	if (tile >= tiles) return false;
+	const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+	const int x = tx * 64 + lane;
+	const int r = ty * 4 + wave;
+	if (x >= W || r >= rows) return false;
+	int y = r;
+	if (half) y = 2 * r + ((x & 1) ^ colour);
+	if (y >= H) return false;
+	*px = x;
+	*py = y;
+	return true;
+}
+
+// per-pixel predicate + body of launch site `STAGE` (DVP_ST_*), APD.cu:3091-3165, 3296-3328
+template <int STAGE>
+DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long* nevals) {
+	const int center = px + py * d.width;
+	if (STAGE == DVP_ST_GEN_EDGE_INFORM) gen_edge_inform_px(d, px, py);
+	else if (STAGE == DVP_ST_FIND_NEAREST_STRONG) find_nearest_strong_px(d, px, py);
+	else if (STAGE == DVP_ST_GEN_NEIGHBOURS) gen_neighbours_px(d, px, py);
+	else if (STAGE == DVP_ST_NEIGHBOUR_UPDATE) neighbour_update_px(d, px, py);
+	else if (STAGE == DVP_ST_RANDOM_INIT) random_init_px(d, px, py, nevals);
+	else if (STAGE == DVP_ST_STRONG_UPDATE) { if (d.weak_info[center] != DVP_WEAK) strong_update_px(d, px, py, iter, nevals); }
+	else if (STAGE == DVP_ST_RANSAC_FIT) ransac_fit_plane_px(d, px, py, iter);
+	else if (STAGE == DVP_ST_WEAK_UPDATE) { if (d.weak_info[center] == DVP_WEAK) weak_update_px(d, px, py, iter, nevals); }
+	else if (STAGE == DVP_ST_GET_DEPTH_NORMAL) get_depth_normal_px(d, px, py);
+	else if (STAGE == DVP_ST_FILTER_STRONG) { if (d.weak_info[center] != DVP_WEAK) filter_strong_px(d, px, py); }
+	else if (STAGE == DVP_ST_DEPTH_TO_WEAK) depth_to_weak_px(d, px, py, nevals);
+	else if (STAGE == DVP_ST_LOCAL_REFINE) local_refine_px(d, px, py, nevals);
+}
+inline bool stage_is_half(int stage) {
+	return stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_WEAK_UPDATE || stage == DVP_ST_FILTER_STRONG;
+}
+
+// ---- host-side uniform constants ---------------------------------------------------------------
+// 30-degree sector of offset (i, j) exactly as calculateAngle/getRegion compute it
+// (APD.cu:797-821; the angle passes through a float, APD.cu:3759).  255 = no sector.
+inline std::vector<uint8_t> make_sector_lut(int radius) {
+	const double kPI = 3.14159265358979323846;   // APD.h:6
+	const int n = 2 * radius + 1;
+	std::vector<uint8_t> lut((size_t)n * n, 255);
+	for (int i = -radius; i <= radius; ++i)
+		for (int j = -radius; j <= radius; ++j) {
+			double deg = std::atan2((double)j, (double)i) * (180.0 / kPI);
+			if (deg < 0) deg += 360.0;
+			const double a = (double)(float)deg;
+			int r = 255;
+			for (int q = 0; q < 12; ++q)
+				if (a >= 30.0 * q && a < 30.0 * (q + 1)) r = q;
+			lut[(size_t)(i + radius) * n + (j + radius)] = (uint8_t)r;
+		}
+	return lut;
+}
+// GenNeighbours' per-launch constants (APD.cu:3375-3380), evaluated in double like the reference
+inline void set_neighbour_consts(Dev* d) {
+	const double kPI = 3.14159265358979323846;
+	const int rt = d->params.rotate_time > 0 ? d->params.rotate_time : 1;
+	const float angle = 45.0f / rt;
+	d->nb_cos = (float)std::cos(angle * kPI / 180.f);
+	d->nb_sin = (float)std::sin(angle * kPI / 180.f);
+	d->nb_thresh = (float)std::cos((angle / 2.0f) * kPI / 180.0f);
+	const int sr = (int)(std::tan((angle / 2.0f) * kPI / 180.0f) * 20);
+	d->nb_shift_range = sr < 1 ? 1 : sr;
+}
+
+}  // namespace dvp
+#endif

@@ -1,0 +1,623 @@
+// dvp_strong.hpp — per-pixel bodies of the strong path and the post-processing kernels.
+// One lane owns one pixel; a wave owns 64 x-adjacent pixels so that, once planes have locally
+// converged, the 64 bilinear gathers of a tap hit a handful of 128-B lines.
+#ifndef DVP_STRONG_HPP_
+#define DVP_STRONG_HPP_
+
+#include "dvp_ncc.hpp"
+
+namespace dvp {
+
+DVP_HD void sort_small(float* v, int n) {   // insertion sort, APD.cu:114-123
+	for (int i = 1; i < n; i++) {
+		const float tmp = v[i];
+		int j = i;
+		for (; j >= 1 && tmp < v[j - 1]; j--) v[j] = v[j - 1];
+		v[j] = tmp;
+	}
+}
+
+// GenerateRandomNormal_YZL (APD.cu:501-588): rejection-sample a unit normal that faces the
+// reference viewing ray and the (quirkily transformed) viewing rays of every selected source view.
+DVP_HD f4 random_normal_yzl(const Dev& d, int px, int py, Rng& rng, float depth) {
+	const int W = d.width, H = d.height;
+	const int center = py * W + px;
+	const DvpCamera& rc = d.cameras[0];
+	f3 vd[20];
+	{
+		const f4 v0 = view_direction(rc, px, py, depth);
+		vd[0] = mk3(v0.x, v0.y, v0.z);
+	}
+	int index = 1;
+	const uint32_t sel = d.selected_views[center];
+	for (int v = 1; v < d.params.num_images; ++v) {
+		if (!is_set(sel, v - 1)) continue;
+		const DvpCamera& sc = d.cameras[v];
+		const f3 fwd = point_on_world((float)px, (float)py, depth, rc);
+		f2 sp;
+		float sd;
+		project_on_camera(fwd, sc, &sp, &sd);
+		const float sx = fminf(fmaxf(sp.x, -32768.0f), 32767.0f);
+		const float sy = fminf(fmaxf(sp.y, -32768.0f), 32767.0f);
+		const int ix = (int)((float)(int)sx + 0.5f), iy = (int)((float)(int)sy + 0.5f);   // APD.cu:525
+		float src_depth = 1.0f;   // reference leaves it uninitialised outside the image (APD.cu:526)
+		if (d.params.geom_consistency) {
+			if (ix >= 0 && ix < W && iy >= 0 && iy < H)
+				src_depth = tex_texel(d.depths + (size_t)v * d.plane_stride, d.pitch, W, H, (int)sx, (int)sy);
+		}
+		const f4 dir = view_direction(sc, ix, iy, src_depth);
+		// R_c = R_ref * R_src^T ; R_f = R_c * {x, y, x} with row 2 using R_c[7] twice (APD.cu:14-18, 540-544)
+		float Rc[9];
+		for (int i = 0; i < 3; ++i)
+			for (int j = 0; j < 3; ++j) {
+				float acc = 0.0f;
+				for (int k = 0; k < 3; ++k) acc += rc.R[i * 3 + k] * sc.R[j * 3 + k];
+				Rc[i * 3 + j] = acc;
+			}
+		const float b0 = dir.x, b1 = dir.y, b2 = dir.x;
+		const float f0 = Rc[0] * b0 + Rc[1] * b1 + Rc[2] * b2;
+		const float f1 = Rc[3] * b0 + Rc[4] * b1 + Rc[5] * b2;
+		const float f2_ = Rc[6] * b0 + Rc[7] * b1 + Rc[7] * b2;
+		const float norm = sqrtf(f0 * f0 + f1 * f1 + f2_ * f2_);
+		if (index < 20) vd[index++] = mk3(f0 / norm, f1 / norm, f2_ / norm);
+	}
+	int times = 200;
+	f4 n = mk4(0, 0, 0, 0);
+	while (times > 0) {
+		float q1 = 1.0f, q2 = 1.0f, s = 2.0f;
+		while (s >= 1.0f) {
+			q1 = 2.0f * rng.uniform() - 1.0f;
+			q2 = 2.0f * rng.uniform() - 1.0f;
+			s = q1 * q1 + q2 * q2;
+		}
+		const float sq = sqrtf(1.0f - s);
+		n.x = 2.0f * q1 * sq;
+		n.y = 2.0f * q2 * sq;
+		n.z = 1.0f - 2.0f * s;
+		bool ok = true;
+		for (int i = 0; i < index; i++) {
+			const float dp = n.x * vd[i].x + n.y * vd[i].y + n.z * vd[i].z;
+			if (dp > 0.0f) { ok = false; break; }
+		}
+		if (ok) break;
+		times--;
+	}
+	normalize3(&n);
+	return n;
+}
+
+// RandomInitialization (APD.cu:1273-1309)
+DVP_HD void random_init_px(const Dev& d, int px, int py, unsigned long long* nevals) {
+	const int center = py * d.width + px;
+	const DvpParams& P = d.params;
+	const DvpCamera& rc = d.cameras[0];
+	const int S = P.num_images - 1;
+	f4 plane = d.planes[center];
+	PatchCtx c;
+	int radius, inc;
+	patch_geometry(d, center, &radius, &inc);
+	build_patch_ctx(d, px, py, radius, inc, 0, &c);
+
+	if (P.state == DVP_FIRST_INIT) {
+		if (plane.w > P.depth_max || plane.w < P.depth_min) {
+			// GenerateRandomPlaneHypothesis_YZL (APD.cu:663-669)
+			Rng rd(d.seed, (uint32_t)center, rng_site(PH_RANDOM_INIT, 0, SUB_DEPTH_RAND));
+			Rng rn(d.seed, (uint32_t)center, rng_site(PH_RANDOM_INIT, 0, SUB_NORMAL));
+			const float depth = rd.uniform() * (P.depth_max - P.depth_min) + P.depth_min;
+			plane = random_normal_yzl(d, px, py, rn, depth);
+			plane.w = distance_to_origin(rc, px, py, depth, plane);
+		}
+		d.planes[center] = plane;
+		// ComputeMultiViewInitialCostandSelectedViews (APD.cu:1115-1161)
+		float cv[32], cvs[32];
+		int valid = 0;
+		for (int v = 0; v < S; ++v) {
+			const float cst = ncc_old(d, c, px, py, v + 1, plane);
+			cv[v] = cst;
+			cvs[v] = cst;
+			if (cst < 2.0f) valid++;
+		}
+		if (nevals) *nevals += (unsigned long long)S;
+		sort_small(cvs, S);
+		uint32_t sel = 0;
+		const int top_k = DVP_MIN(valid, P.top_k);
+		float cost = 2.0f;
+		if (top_k > 0) {
+			float acc = 0.0f;
+			for (int i = 0; i < top_k; ++i) acc += cvs[i];
+			const float thr = cvs[top_k - 1];
+			for (int i = 0; i < S; ++i)
+				if (cv[i] <= thr) set_bit(&sel, i);
+			cost = acc / top_k;
+		}
+		d.selected_views[center] = sel;
+		d.costs[center] = cost;
+	} else {
+		plane = normal_world_to_cam(rc, plane);
+		const float depth = plane.w;
+		plane.w = distance_to_origin(rc, px, py, depth, plane);
+		d.planes[center] = plane;
+		// ComputeMultiViewInitialCost (APD.cu:1163-1194)
+		uint32_t sel = d.selected_views[center];
+		int cnt = 0;
+		float acc = 0.0f;
+		for (int v = 0; v < S; ++v) {
+			if (!is_set(sel, v)) continue;
+			const float cst = ncc_old(d, c, px, py, v + 1, plane);
+			if (nevals) *nevals += 1;
+			if (cst < 2.0f) { cnt++; acc += cst; }
+			else unset_bit_ref(&sel, v);
+		}
+		d.selected_views[center] = sel;
+		d.costs[center] = (cnt == 0) ? 2.0f : acc / cnt;
+	}
+}
+
+// Multi-hypothesis joint view selection (APD.cu:2483-2530 == 2803-2850)
+DVP_HD void joint_view_selection(const Dev& d, int center, int iter, int phase, const float* cost_array /*[8][32]*/,
+	const float* priors, uint8_t* vw /*[32], zeroed*/, uint32_t* sel_mask, float* weight_norm) {
+	const int S = d.params.num_images - 1;
+	float probs[32];
+	const float thr = (float)(0.8 * dvp_expf((iter) * (iter) / (-90.0f)));
+	for (int i = 0; i < S; i++) {
+		float count = 0;
+		int count_false = 0;
+		float tmpw = 0;
+		for (int j = 0; j < 8; j++) {
+			const float cst = cost_array[j * 32 + i];
+			if (cst < thr) { tmpw += dvp_expf(cst * cst / (-0.18f)); count++; }
+			if (cst > 1.2f) count_false++;
+		}
+		float pr = 0.0f;
+		if (count > 2 && count_false < 3) pr = tmpw / count;
+		else if (count_false < 3) pr = dvp_expf(thr * thr / (-0.32f));
+		probs[i] = pr * priors[i];
+	}
+	// TransformPDFToCDF (APD.cu:356-370)
+	float psum = 0.0f;
+	for (int i = 0; i < S; ++i) psum += probs[i];
+	const float inv = 1.0f / psum;
+	float cum = 0.0f;
+	for (int i = 0; i < S; ++i) { cum += probs[i] * inv; probs[i] = cum; }
+	Rng rv(d.seed, (uint32_t)center, rng_site(phase, iter, SUB_VIEW));
+	for (int s = 0; s < 15; ++s) {
+		const float rp = rv.uniform() - FLT_EPSILON;
+		for (int v = 0; v < S; ++v)
+			if (probs[v] > rp) { vw[v] += 1; break; }
+	}
+	uint32_t m = 0;
+	float wn = 0;
+	for (int i = 0; i < S; ++i)
+		if (vw[i] > 0) { set_bit(&m, i); wn += vw[i]; }
+	*sel_mask = m;
+	*weight_norm = wn;
+}
+
+// edge-adaptive sample search of one direction (APD.cu:2047-2081 / 2104-2118).
+// pass 0: adaptive step; pass 1: 11 samples at stride 2.  Returns the position or -1.
+DVP_HD int strong_sample_search(const Dev& d, int px, int py, int k, int pass) {
+	const int W = d.width, H = d.height;
+	const int center = py * W + px;
+	const int dxs[8] = { 0, 0, -1, 1, -1, 1, -1, 1 };
+	const int dys[8] = { -1, 1, 0, 0, -1, 1, 1, -1 };
+	const int dx = dxs[k], dy = dys[k];
+	int step_num = 11, step_len = 2;
+	if (pass == 0) {
+		const float max_edge_dist = DVP_MAX(H, W) / 30.0f;
+		const s2 ep = d.edge_neigh[(size_t)center * 8 + k];
+		const double ex = (double)(ep.x - px), ey = (double)(ep.y - py);
+		float dist = (float)sqrt(ex * ex + ey * ey);
+		if (k >= 4) dist = (float)((double)dist / sqrt(2.0));
+		if (d.edge[center]) {
+			dist = 22.0f;
+		} else if (ep.y == -1 || dist >= max_edge_dist) {   // `!edge_pt.x == -1` is always false (APD.cu:2059)
+			dist = max_edge_dist;
+			if (k >= 4) dist = (float)((double)dist / sqrt(2.0));
+		}
+		step_num = DVP_MIN(DVP_MAX(11, (int)(1.0f * dist / 2)), 22);
+		step_len = DVP_MAX((int)(1.0f * dist / step_num), 2);
+		if (k < 4 && step_len % 2 == 1) step_len -= 1;
+	}
+	int fx = 0, fy = 0;
+	if (k > 4) { if (k % 2) fx = dx; else fy = dy; }
+	int best = -1;
+	float min_cost = FLT_MAX;
+	for (int step = 0; step < step_num; ++step) {
+		const int tx = px + 5 * dx + step * step_len * dx + fx;
+		const int ty = py + 5 * dy + step * step_len * dy + fy;
+		if (!(tx >= 0 && ty >= 0 && tx < W && ty < H)) continue;
+		const int pc = tx + ty * W;
+		const float cst = d.costs_snap[pc];
+		if (min_cost > cst) { best = pc; min_cost = cst; }
+	}
+	return (min_cost < FLT_MAX) ? best : -1;
+}
+
+// CheckerboardPropagationStrong + PlaneHypothesisRefinementStrong
+// (APD.cu:2010-2141, 2462-2567, 2725-2737, 1311-1383), use_edge branch.
+//
+// The 8 + 8 propagation candidates, the current plane and the 6 refinement hypotheses are walked
+// by ONE loop with a single inlined copy of the 36-tap evaluation (23 "slots"); per slot a
+// prologue picks the plane and the views to evaluate, an epilogue consumes the cost vector.
+// After view selection only views with non-zero weight are evaluated: the reference evaluates all
+// S and multiplies the others by a zero weight, which is the same value.
+DVP_HD void strong_update_px(const Dev& d, int px, int py, int iter, unsigned long long* nevals) {
+	const int W = d.width;
+	const int center = py * W + px;
+	const DvpParams& P = d.params;
+	const DvpCamera& rc = d.cameras[0];
+	const int S = P.num_images - 1;
+	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
+
+	PatchCtx c;
+	{
+		int radius, inc;
+		patch_geometry(d, center, &radius, &inc);
+		build_patch_ctx(d, px, py, radius, inc, 0, &c);
+	}
+	float cost_array[8 * 32];
+	for (int i = 0; i < 8 * 32; ++i) cost_array[i] = 0.0f;
+	cost_array[0] = 2.0f;   // `= { 2.0f }` sets one element (APD.cu:2032)
+	uint32_t flag = 0;      // bit k: direction k has a sample
+	int positions[8];
+	for (int k = 0; k < 8; ++k) positions[k] = 0;
+	const bool is_edge = d.edge[center] != 0;
+	const float good_thr = 0.8f * dvp_expf((iter) * (iter) / (-90.0f));
+
+	uint8_t vw[32];
+	for (int i = 0; i < 32; ++i) vw[i] = 0;
+	uint32_t sel_mask = 0;
+	float weight_norm = 0.0f;
+	float final_costs[8];
+	int min_cost_idx = 0;
+	float cost_now = 0.0f, costs_center = 0.0f, depth_now = 0.0f;
+	f4 plane_now = mk4(0, 0, 0, 0);
+	bool selected_views_written = false;
+	// refinement hypotheses (APD.cu:1359-1360)
+	float ref_depths[6];
+	f4 ref_normals[6];
+
+	float cv[32];
+	for (int slot = 0; slot < 23; ++slot) {
+		// ---- prologue: which plane, which views ----
+		f4 plane = mk4(0, 0, 1, 1);
+		uint32_t mask = 0;
+		int pos = -1;
+		if (slot < 8) {
+			pos = strong_sample_search(d, px, py, slot, 0);
+			if (pos >= 0) { plane = d.planes_snap[pos]; mask = all_views; }
+		} else if (slot < 16) {
+			if (!is_edge) {
+				pos = strong_sample_search(d, px, py, slot - 8, 1);
+				if (pos >= 0) { plane = d.planes_snap[pos]; mask = all_views; }
+			}
+		} else if (slot == 16) {
+			// view selection (APD.cu:2462-2530)
+			float priors[32];
+			for (int i = 0; i < 32; ++i) priors[i] = 0.0f;
+			const int nb[4] = { center - W, center + W, center - 1, center + 1 };
+			for (int i = 0; i < 4; ++i) {
+				if ((flag >> (2 * i)) & 1) {   // guards flag[0],[2],[4],[6] (APD.cu:2471)
+					const uint32_t sv = d.selected_views[nb[i]];
+					for (int j = 0; j < S; ++j) priors[j] += is_set(sv, j) ? 0.9f : 0.1f;
+				}
+			}
+			joint_view_selection(d, center, iter, PH_STRONG, cost_array, priors, vw, &sel_mask, &weight_norm);
+			uint8_t* gvw = d.view_weight + (size_t)center * 32;
+			for (int i = 0; i < 32; ++i) gvw[i] = vw[i];
+			for (int k = 0; k < 8; ++k) {
+				float fc = 0.0f;
+				for (int j = 0; j < S; ++j)
+					if (vw[j] > 0) fc += vw[j] * cost_array[k * 32 + j];
+				final_costs[k] = fc / weight_norm;
+			}
+			min_cost_idx = 0;   // FindMinCostIndex (ties -> last, APD.cu:155-166)
+			{
+				float mc = final_costs[0];
+				for (int k = 1; k < 8; ++k)
+					if (final_costs[k] <= mc) { mc = final_costs[k]; min_cost_idx = k; }
+			}
+			plane = d.planes_snap[center];
+			mask = sel_mask;
+		} else {
+			const int i = slot - 17;
+			plane = ref_normals[i];
+			plane.w = distance_to_origin(rc, px, py, ref_depths[i], plane);
+			mask = sel_mask;
+		}
+
+		// ---- evaluate ----
+		if (mask) {
+			for (int v = 0; v < S; ++v) {
+				if ((mask >> v) & 1) {
+					cv[v] = ncc_old(d, c, px, py, v + 1, plane);
+					if (nevals) *nevals += 1;
+				}
+			}
+		}
+
+		// ---- epilogue ----
+		if (slot < 8) {
+			if (pos >= 0) {
+				flag |= 1u << slot;
+				positions[slot] = pos;
+				for (int v = 0; v < S; ++v) cost_array[slot * 32 + v] = cv[v];
+			}
+		} else if (slot < 16) {
+			const int k = slot - 8;
+			if (pos >= 0) {
+				const bool had = (flag >> k) & 1;
+				flag |= 1u << k;
+				int good0 = 0, good1 = 0, bad0 = 0, bad1 = 0;
+				for (int j = 0; j < S; ++j) {
+					const float a = cost_array[k * 32 + j], b = cv[j];
+					if (a < good_thr) good0++;
+					if (a > 1.2f) bad0++;
+					if (b < good_thr) good1++;
+					if (b > 1.2f) bad1++;
+				}
+				if (!had || good1 > good0 || (good1 == good0 && bad1 < bad0)) {
+					positions[k] = pos;
+					for (int j = 0; j < S; ++j) cost_array[k * 32 + j] = cv[j];
+				}
+			}
+		} else if (slot == 16) {
+			// cost of the current plane under the new weights, adoption of the best neighbour
+			// (APD.cu:2546-2567); a zero weight_norm makes everything NaN and every `<` false.
+			float cn = 0.0f;
+			for (int v = 0; v < S; ++v)
+				if (vw[v] > 0) cn += vw[v] * cv[v];
+			cost_now = cn / weight_norm;
+			costs_center = cost_now;
+			plane_now = d.planes_snap[center];
+			depth_now = depth_from_plane(rc, plane_now, px, py);
+			if ((flag >> min_cost_idx) & 1) {
+				const f4 cand = d.planes_snap[positions[min_cost_idx]];
+				const float db = depth_from_plane(rc, cand, px, py);
+				if (db >= P.depth_min && db <= P.depth_max && final_costs[min_cost_idx] < cost_now) {
+					depth_now = db;
+					plane_now = cand;
+					cost_now = final_costs[min_cost_idx];
+					selected_views_written = true;
+				}
+			}
+			// refinement hypotheses from the values at entry (APD.cu:1333-1360)
+			Rng rd(d.seed, (uint32_t)center, rng_site(PH_STRONG, iter, SUB_DEPTH_RAND));
+			Rng rn(d.seed, (uint32_t)center, rng_site(PH_STRONG, iter, SUB_NORMAL));
+			Rng rp(d.seed, (uint32_t)center, rng_site(PH_STRONG, iter, SUB_DEPTH_PERT));
+			const float depth_rand = rd.uniform() * (P.depth_max - P.depth_min) + P.depth_min;
+			if (selected_views_written) d.selected_views[center] = sel_mask;   // read by random_normal_yzl
+			const f4 n_rand = random_normal_yzl(d, px, py, rn, depth_now);
+			const float dmin_p = (1 - 0.02f) * depth_now, dmax_p = (1 + 0.02f) * depth_now;
+			const float depth_pert = rp.uniform() * (dmax_p - dmin_p) + dmin_p;
+			f4 n_pert = plane_now;   // GeneratePerturbedNormal returns the normalised input (APD.cu:617-661)
+			normalize3(&n_pert);
+			ref_depths[0] = depth_rand; ref_normals[0] = plane_now;
+			ref_depths[1] = depth_now;  ref_normals[1] = n_rand;
+			ref_depths[2] = depth_rand; ref_normals[2] = n_rand;
+			ref_depths[3] = depth_now;  ref_normals[3] = n_pert;
+			ref_depths[4] = depth_now;  ref_normals[4] = n_pert;
+			ref_depths[5] = depth_pert; ref_normals[5] = plane_now;
+		} else {
+			float tc = 0.0f;
+			for (int j = 0; j < S; ++j)
+				if (vw[j] > 0) tc += vw[j] * cv[j];
+			tc /= weight_norm;
+			const float db = depth_from_plane(rc, plane, px, py);
+			if (db >= P.depth_min && db <= P.depth_max && tc < cost_now) {
+				depth_now = db;
+				plane_now = plane;
+				cost_now = tc;
+			}
+		}
+	}
+
+	if (P.state == DVP_REFINE_INIT) {
+		if (cost_now < costs_center - 0.1) {   // double comparison (APD.cu:2728)
+			costs_center = cost_now;
+			d.planes[center] = plane_now;
+		}
+	} else {
+		costs_center = cost_now;
+		d.planes[center] = plane_now;
+	}
+	d.costs[center] = costs_center;
+}
+
+// GetDepthandNormal (APD.cu:3167-3182)
+DVP_HD void get_depth_normal_px(const Dev& d, int px, int py) {
+	const int center = py * d.width + px;
+	f4 pl = d.planes[center];
+	pl.w = depth_from_plane(d.cameras[0], pl, px, py);
+	d.planes[center] = normal_cam_to_world(d.cameras[0], pl);
+}
+
+// CheckerboardFilterStrong (APD.cu:3184-3294): median of the STRONG depths among self + 20 fixed
+// opposite-colour offsets.
+DVP_HD void filter_strong_px(const Dev& d, int px, int py) {
+	const int W = d.width, H = d.height;
+	const int center = py * W + px;
+	if (d.costs[center] < 0.001f) return;
+	float filter[21];
+	int n = 0;
+	filter[n++] = d.planes[center].w;
+	// (dx, dy) in the reference's push order (APD.cu:3222-3284)
+	const int ox[20] = { 0, 0, 0, 0, 0, 0, -1, -3, -5, 1, 3, 5, 2, 2, -2, -2, -1, 1, -1, 1 };
+	const int oy[20] = { -1, -3, -5, 1, 3, 5, 0, 0, 0, 0, 0, 0, -1, 1, -1, 1, -2, -2, 2, 2 };
+	for (int t = 0; t < 20; ++t) {
+		const int x = px + ox[t], y = py + oy[t];
+		if (x < 0 || y < 0 || x >= W || y >= H) continue;
+		if (oy[t] == -2 && py <= 2) continue;   // the (+-1,-2) taps are guarded by p.y > 2 (APD.cu:3271,3275)
+		const int q = x + y * W;
+		if (d.weak_info[q] == DVP_STRONG) filter[n++] = d.planes[q].w;
+	}
+	sort_small(filter, n);
+	const int m = n / 2;
+	d.planes[center].w = (n % 2 == 0) ? (filter[m - 1] + filter[m]) / 2 : filter[m];
+}
+
+// shared prologue of DepthToWeak / LocalRefine (APD.cu:3928-3960, 4076-4108): cost at the current
+// depth, mean baseline, weight sum over the selected views.
+struct SweepCtx {
+	f4 origin;          // camera-frame normal, .w = depth
+	float depth;
+	float cost_now, base_line, weight_normal;
+	int valid;
+	uint32_t sel;
+};
+
+DVP_HD float sweep_cost_view(const Dev& d, const PatchCtx& c, int px, int py, int v, const f4 pl, unsigned long long* nevals) {
+	float cst = ncc_old(d, c, px, py, v + 1, pl);
+	if (nevals) *nevals += 1;
+	if (d.params.geom_consistency) cst += d.params.geom_factor * geom_cost(d, px, py, v + 1, pl);
+	return cst;
+}
+
+// DepthToWeak (APD.cu:3892-4051)
+DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, unsigned long long* nevals) {
+	const int W = d.width, H = d.height;
+	const int center = px + py * W;
+	const DvpParams& P = d.params;
+	const DvpCamera& rc = d.cameras[0];
+	const int S = P.num_images - 1;
+	if (P.use_radius && d.radius[center] == 0) d.radius[center] = P.strong_radius;
+	if (px < 6 || py < 6 || px >= W - 6 || py >= H - 6) { d.weak_info[center] = DVP_UNKNOWN; return; }
+	const f4 origin = normal_world_to_cam(rc, d.planes[center]);
+	const float origin_depth = origin.w;
+	if (origin_depth == 0) { d.weak_info[center] = DVP_UNKNOWN; return; }
+	const uint32_t sel = d.selected_views[center];
+	const uint8_t* vw = d.view_weight + (size_t)center * 32;
+	PatchCtx c;
+	{
+		int radius, inc;
+		patch_geometry(d, center, &radius, &inc);
+		build_patch_ctx(d, px, py, radius, inc, 0, &c);
+	}
+	float base_line = 0, weight_normal = 0.0f;
+	int valid = 0;
+	for (int v = 0; v < S; ++v) {
+		if (!is_set(sel, v)) continue;
+		weight_normal += vw[v];
+		const float c0 = rc.c[0] - d.cameras[v + 1].c[0];
+		const float c1 = rc.c[1] - d.cameras[v + 1].c[1];
+		const float c2 = rc.c[2] - d.cameras[v + 1].c[2];
+		base_line += sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+		valid++;
+	}
+	if (valid == 0) { d.weak_info[center] = DVP_UNKNOWN; return; }
+	base_line /= valid;
+	const float disp = rc.K[0] * base_line / origin_depth;
+	// the reference also evaluates cost_now at the current depth (APD.cu:3937-3941); its value
+	// is never used by DepthToWeak, so those evaluations are not issued.
+	float p_costs[61];
+	for (int pd = -30; pd <= 30; ++pd) {
+		const float p_depth = rc.K[0] * base_line / (disp + pd);
+		if (p_depth < P.depth_min || p_depth > P.depth_max) { p_costs[pd + 30] = 2.0f; continue; }
+		f4 pl = origin;
+		pl.w = distance_to_origin(rc, px, py, p_depth, pl);
+		float pc = 0.0f;
+		for (int v = 0; v < S; ++v) {
+			if (!is_set(sel, v)) continue;
+			// a selected view with zero weight contributes cost*0 = +0: skipped (finite cost)
+			if (vw[v] == 0) continue;
+			const float tc = 0.0f + sweep_cost_view(d, c, px, py, v, pl, nevals);
+			pc += tc * vw[v];
+		}
+		pc /= weight_normal;
+		p_costs[pd + 30] = DVP_MIN(2.0f, pc);
+	}
+	uint64_t is_peak = 0;
+	int peak_count = 0, min_peak = 0;
+	float min_cost = 2.0f;
+	for (int i = 2; i < 59; ++i) {
+		if (p_costs[i - 1] > p_costs[i] && p_costs[i + 1] > p_costs[i]) {
+			is_peak |= (uint64_t)1 << i;
+			peak_count++;
+			if (p_costs[i] < min_cost) { min_peak = i; min_cost = p_costs[i]; }
+		}
+	}
+	const int dpk = min_peak - 30;
+	if ((dpk < 0 ? -dpk : dpk) > P.weak_peak_radius || p_costs[min_peak] > 0.5f) { d.weak_info[center] = DVP_WEAK; return; }
+	if (peak_count == 1) {
+		d.weak_info[center] = (p_costs[min_peak] <= 0.15f) ? DVP_STRONG : DVP_WEAK;
+		return;
+	}
+	float var = 0.0f;
+	for (int i = 2; i < 59; ++i) {
+		if (((is_peak >> i) & 1) && i != min_peak) {
+			const float dist = p_costs[i] - min_cost;
+			var += dist * dist;
+		}
+	}
+	var = sqrtf(var);
+	var /= (peak_count - 1);
+	d.weak_info[center] = (var > 0.2f) ? DVP_STRONG : DVP_WEAK;
+}
+
+// LocalRefine (APD.cu:4053-4139)
+DVP_HD void local_refine_px(const Dev& d, int px, int py, unsigned long long* nevals) {
+	const int W = d.width;
+	const int center = px + py * W;
+	const DvpParams& P = d.params;
+	const DvpCamera& rc = d.cameras[0];
+	const int S = P.num_images - 1;
+	const f4 origin = normal_world_to_cam(rc, d.planes[center]);
+	const float origin_depth = origin.w;
+	if (origin_depth == 0) return;
+	const uint32_t sel = d.selected_views[center];
+	const uint8_t* vw = d.view_weight + (size_t)center * 32;
+	float base_line = 0, weight_normal = 0.0f;
+	int valid = 0;
+	for (int v = 0; v < S; ++v) {
+		if (!is_set(sel, v)) continue;
+		weight_normal += vw[v];
+		const float c0 = rc.c[0] - d.cameras[v + 1].c[0];
+		const float c1 = rc.c[1] - d.cameras[v + 1].c[1];
+		const float c2 = rc.c[2] - d.cameras[v + 1].c[2];
+		base_line += sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+		valid++;
+	}
+	if (weight_normal == 0 || valid == 0) return;
+	PatchCtx c;
+	{
+		int radius, inc;
+		patch_geometry(d, center, &radius, &inc);
+		build_patch_ctx(d, px, py, radius, inc, 0, &c);
+	}
+	base_line /= valid;
+	const float disp = rc.K[0] * base_line / origin_depth;
+	float cost_now = 0.0f, min_cost = 2.0f, best_depth = origin_depth;
+	// slot -6: the current depth (cost_now, APD.cu:4080-4090); slots -5..5: the sweep
+	for (int pd = -6; pd <= 5; ++pd) {
+		float p_depth = origin_depth;
+		if (pd >= -5) {
+			p_depth = rc.K[0] * base_line / (disp + pd);
+			if (p_depth < P.depth_min || p_depth > P.depth_max) continue;
+		}
+		f4 pl = origin;
+		pl.w = distance_to_origin(rc, px, py, p_depth, pl);
+		float tc = 0.0f;
+		for (int v = 0; v < S; ++v) {
+			if (!is_set(sel, v)) continue;
+			if (vw[v] == 0) continue;   // contributes +0 (finite costs)
+			const float ncc = ncc_old(d, c, px, py, v + 1, pl);
+			if (nevals) *nevals += 1;
+			const float gc = P.geom_consistency ? geom_cost(d, px, py, v + 1, pl) : 0.0f;
+			if (pd == -6) {   // (ncc + factor*geom) * w, APD.cu:4085-4089
+				float t = ncc;
+				if (P.geom_consistency) t += P.geom_factor * gc;
+				tc += t * vw[v];
+			} else {          // ncc*w and (factor*geom)*w added separately, APD.cu:4124-4126
+				tc += ncc * vw[v];
+				if (P.geom_consistency) tc += (P.geom_factor * gc * vw[v]);
+			}
+		}
+		tc /= weight_normal;
+		if (pd == -6) cost_now = tc;
+		else if (tc < min_cost) { min_cost = tc; best_depth = p_depth; }
+	}
+	if (cost_now - min_cost > 0.1) d.planes[center].w = best_depth;
+}
+
+}  // namespace dvp
+#endif

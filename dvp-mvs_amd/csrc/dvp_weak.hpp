@@ -1,0 +1,826 @@
+// dvp_weak.hpp — per-pixel bodies of the weak-pixel path: prior preparation (GenEdgeInform),
+// anchor search (FindNearestStrongPoint, GenNeighbours, NeigbourUpdate), RANSAC fit plane and the
+// deformable-NCC weak update.  These touch only WEAK pixels (1-30 % of a view).
+#ifndef DVP_WEAK_HPP_
+#define DVP_WEAK_HPP_
+
+#include "dvp_strong.hpp"
+
+namespace dvp {
+
+// ---- GenEdgeInform (APD.cu:3731-3890) ----------------------------------------------------------
+// The reference bins the 120 offsets of the 11x11 window into 30-degree sectors with fp64 atan2
+// per offset, bubble-sorts each sector and then the 12 winners (24-byte structs in scratch).
+// Here the sector of an offset comes from a 121-entry table and each sector keeps a running
+// arg-max; the stable descending sort of the 12 winners is kept.
+DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
+	const int W = d.width, H = d.height;
+	const int center = px + py * W;
+	const DvpParams& P = d.params;
+	const int S = P.num_images - 1;
+	const float* ref = d.images;
+	const float cpix = tex_texel(ref, d.pitch, W, H, px, py);
+
+	for (int v = 0; v < S; ++v) {
+		float bw[12];
+		int bi[12], bj[12];
+		for (int r = 0; r < 12; ++r) { bw[r] = 0.0f; bi[r] = 0; bj[r] = 0; }
+		uint32_t has = 0;
+		const int radius = P.weak_radius;
+		for (int i = -radius; i <= radius; i++) {
+			for (int j = -radius; j <= radius; j++) {
+				if (i == 0 && j == 0) continue;
+				const int x = px + i, y = py + j;
+				if (!(x >= 0 && x < W && y >= 0 && y < H)) continue;
+				if (!is_set(d.selected_views[x + y * W], v)) continue;
+				const float a = tex_texel(ref, d.pitch, W, H, x, y);
+				const float w = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
+				const int r = d.sector_lut[(i + radius) * (2 * radius + 1) + (j + radius)];   // host-built for this radius
+				if (r >= 12) continue;
+				if (!((has >> r) & 1) || w > bw[r]) {   // first maximum wins (stable bubble sort, APD.cu:823-833)
+					has |= 1u << r;
+					bw[r] = w; bi[r] = i; bj[r] = j;
+				}
+			}
+		}
+		// stable descending sort of the 12 sector winners (empty sectors: weight 0, offset (0,0))
+		for (int a = 1; a < 12; ++a) {
+			const float tw = bw[a];
+			const int ti = bi[a], tj = bj[a];
+			int b = a;
+			for (; b >= 1 && bw[b - 1] < tw; --b) { bw[b] = bw[b - 1]; bi[b] = bi[b - 1]; bj[b] = bj[b - 1]; }
+			bw[b] = tw; bi[b] = ti; bj[b] = tj;
+		}
+		s2* cand = d.candidate + ((size_t)center * S + v) * 8;
+		for (int k = 0; k < 8; ++k) cand[k] = mks2(bi[k], bj[k]);
+	}
+
+	const int dxs[8] = { 0, 0, -1, 1, -1, 1, -1, 1 };
+	const int dys[8] = { -1, 1, 0, 0, -1, 1, 1, -1 };
+	if (P.use_edge) {
+		s2* en = d.edge_neigh + (size_t)center * 8;
+		for (int k = 0; k < 8; k++) {
+			s2 e = mks2(-1, -1);
+			int nx = px + dxs[k], ny = py + dys[k];
+			while (!(nx < 0 || nx >= W || ny < 0 || ny >= H)) {
+				if (d.edge[nx + ny * W]) { e = mks2(nx, ny); break; }
+				nx += dxs[k];
+				ny += dys[k];
+			}
+			en[k] = e;
+		}
+		if (d.weak_info[center] == DVP_WEAK) {
+			const int radius = P.strong_radius;
+			int edge_pix = 0, tot_pix = 0;
+			for (int i = -radius; i <= radius; i++)
+				for (int j = -radius; j <= radius; j++) {
+					const int nx = px + i, ny = py + j;
+					if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
+					if (d.edge[ny * W + nx]) edge_pix++;
+					tot_pix++;
+				}
+			const float density = 1.0f * edge_pix / tot_pix;
+			d.complex_[d.neighbours_map[center]] = 1.0f / (1.0f + dvp_expf(-25.0f * (density - 0.35f)));
+		}
+		if (P.state == DVP_REFINE_INIT && P.use_detail && d.edge[center]) {
+			if (d.weak_info[center] != DVP_STRONG) d.weak_info[center] = DVP_UNKNOWN;
+		}
+	}
+	if (P.use_label && d.weak_info[center] == DVP_WEAK) {
+		s2* lb = d.label_boundary + (size_t)d.neighbours_map[center] * 8;
+		const int cl = d.label[center];
+		if (cl > 0) {
+			for (int k = 0; k < 8; k++) {
+				int nx = px + dxs[k], ny = py + dys[k];
+				int lx = -1, ly = -1;
+				while (!(nx < 0 || nx >= W || ny < 0 || ny >= H)) {
+					const int nl = d.label[nx + ny * W];
+					if (nl == cl) { lx = nx; ly = ny; }
+					else if (nl == -1) break;
+					nx += dxs[k];
+					ny += dys[k];
+				}
+				lb[k] = mks2(lx, ly);
+			}
+		}
+		if (P.state == DVP_REFINE_INIT && P.use_detail && d.label[center] == 0) {
+			if (d.weak_info[center] != DVP_STRONG) d.weak_info[center] = DVP_UNKNOWN;
+		}
+	}
+}
+
+// ---- FindNearestStrongPoint (APD.cu:4159-4193) -------------------------------------------------
+DVP_HD void find_nearest_strong_px(const Dev& d, int px, int py) {
+	const int W = d.width, H = d.height;
+	const int center = px + py * W;
+	s2 res = mks2(-1, -1);
+	if (d.weak_info[center] == DVP_WEAK) {
+		bool found = false;
+		for (int radius = 0; radius <= 100 && !found; ++radius)
+			for (int x = -radius; x <= radius && !found; ++x)
+				for (int y = -radius; y <= radius; ++y) {
+					const int ax = x < 0 ? -x : x, ay = y < 0 ? -y : y;
+					if (ax != radius && ay != radius) continue;
+					const int nx = px + x, ny = py + y;
+					if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
+					if (d.weak_info[nx + ny * W] == DVP_STRONG) { res = mks2(nx, ny); found = true; break; }
+				}
+	}
+	d.weak_nearest_strong[center] = res;
+}
+
+// ---- geometry predicates (APD.cu:244-311) -------------------------------------------------------
+DVP_HD bool point_in_triangle(s2 A, s2 B, s2 C, int px, int py) {
+	const f2 AB = mk2((float)(B.x - A.x), (float)(B.y - A.y));
+	const f2 BC = mk2((float)(C.x - B.x), (float)(C.y - B.y));
+	const f2 CA = mk2((float)(A.x - C.x), (float)(A.y - C.y));
+	const float ab = sqrtf(AB.x * AB.x + AB.y * AB.y);
+	const float bc = sqrtf(BC.x * BC.x + BC.y * BC.y);
+	const float ca = sqrtf(CA.x * CA.x + CA.y * CA.y);
+	if (ab <= 2 || bc <= 2 || ca <= 2) return false;
+	if (!(ab + bc > ca && bc + ca > ab && ab + ca > bc)) return false;
+	const f2 PA = mk2((float)(A.x - px), (float)(A.y - py));
+	const f2 PB = mk2((float)(B.x - px), (float)(B.y - py));
+	const f2 PC = mk2((float)(C.x - px), (float)(C.y - py));
+	const float t1 = PA.x * PB.y - PA.y * PB.x;
+	const float t2 = PB.x * PC.y - PB.y * PC.x;
+	const float t3 = PC.x * PA.y - PC.y * PA.x;
+	return t1 * t2 >= 0 && t1 * t3 >= 0;
+}
+
+// true = the segment B->A crosses an edge pixel (APD.cu:267-311)
+DVP_HD bool bresenham_hits_edge(const Dev& d, int Ax, int Ay, int Bx, int By) {
+	const int W = d.width, H = d.height;
+	const int max_step = (int)(DVP_MAX(H, W) / 30.0);
+	int x0 = Bx, y0 = By;
+	const int x1 = Ax, y1 = Ay;
+	const int ABx = Ax - Bx, ABy = Ay - By;
+	if (ABx * ABx + ABy * ABy > 9 * max_step * max_step) return false;
+	if (d.edge[x0 + y0 * W] || d.edge[x1 + y1 * W]) return false;
+	const int dx = x1 > x0 ? x1 - x0 : x0 - x1, sx = x0 < x1 ? 1 : -1;
+	const int dy = y1 > y0 ? y1 - y0 : y0 - y1, sy = y0 < y1 ? 1 : -1;
+	int erro = (dx > dy ? dx : dy) / 2;
+	int step = 0;
+	bool tagx = true, tagy = true;
+	while (tagx || tagy) {
+		if (x0 == x1) tagx = false;
+		if (y0 == y1) tagy = false;
+		const int e2 = erro;
+		if (e2 > -dx) { erro -= dy; x0 += sx; }
+		if (e2 < dy) { erro += dx; y0 += sy; }
+		if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H && d.edge[x0 + y0 * W]) return true;
+		step += 1;
+		if (step >= max_step) break;
+	}
+	return false;
+}
+
+// ---- GenNeighbours (APD.cu:3330-3711) -----------------------------------------------------------
+DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
+	const int W = d.width, H = d.height;
+	const int center = px + py * W;
+	if (d.weak_info[center] != DVP_WEAK) return;
+	const DvpParams& P = d.params;
+	const DvpCamera& cam = d.cameras[0];
+	const int max_pt_num = 160;
+	const int min_margin = 6;
+	const float depth_diff = P.depth_max - P.depth_min;
+	s2* neighbours = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
+	Rng r_limit(d.seed, (uint32_t)center, rng_site(PH_NEIGHBOURS, 0, SUB_LIMIT));
+	Rng r_search(d.seed, (uint32_t)center, rng_site(PH_NEIGHBOURS, 0, SUB_SEARCH));
+	Rng r_ransac(d.seed, (uint32_t)center, rng_site(PH_NEIGHBOURS, 0, SUB_RANSAC));
+
+	for (int i = 0; i < DVP_NEIGHBOUR_NUM; ++i) neighbours[i] = mks2(-1, -1);
+	neighbours[0] = mks2(px, py);
+	s2 strong_points[max_pt_num];   // (-1,-1) == not valid (the reference's dir_valid[])
+	for (int i = 0; i < max_pt_num; ++i) strong_points[i] = mks2(-1, -1);
+	int strong_point_size = 0;
+	const int rotate_time = P.rotate_time;
+
+	bool edge_limit = false;
+	if (P.use_limit) {
+		edge_limit = true;
+		if (P.use_edge) {
+			const float complex_val = d.complex_[d.neighbours_map[center]];
+			const float rp = r_limit.uniform() - FLT_EPSILON;
+			if (rp < complex_val) edge_limit = false;
+		}
+	}
+
+	int odi = -1;
+	for (int odx = -1; odx <= 1; ++odx) {
+		for (int ody = -1; ody <= 1; ++ody) {
+			if (odx == 0 && ody == 0) continue;
+			f2 od = mk2((float)odx, (float)ody);
+			normalize2(&od);
+			odi++;
+			for (int rot = 0; rot < rotate_time; ++rot) {
+				const int dir_index = odi * 4 + rot;
+				bool found_dir = false;
+				for (int radius = 2; radius <= 4096; radius = DVP_MIN(radius * 2, radius + 25)) {
+					const float tx = px + od.x * radius, ty = py + od.y * radius;
+					if (tx < 0 || ty < 0 || tx >= W || ty >= H) break;
+					for (int ri = 0; ri < 4; ++ri) {
+						const uint32_t sgx = (r_search.next() % 2 == 0) ? 1u : 0xFFFFFFFFu;
+						const int xs = (int)((sgx * r_search.next()) % (uint32_t)d.nb_shift_range);
+						const uint32_t sgy = (r_search.next() % 2 == 0) ? 1u : 0xFFFFFFFFu;
+						const int ys = (int)((sgy * r_search.next()) % (uint32_t)d.nb_shift_range);
+						f2 dir = mk2(od.x * 20 + xs, od.y * 20 + ys);
+						normalize2(&dir);
+						s2 np = mks2((int)(px + dir.x * radius), (int)(py + dir.y * radius));
+						if (np.x < min_margin || np.y < min_margin || np.x >= W - min_margin || np.y >= H - min_margin) continue;
+						int npc = np.x + np.y * W;
+						if (d.weak_info[npc] != DVP_STRONG) {
+							np = d.weak_nearest_strong[npc];
+							if (np.x == -1 || np.y == -1) continue;
+							npc = np.x + np.y * W;
+						}
+						bool same = false;
+						for (int k = 0; k < dir_index; k++)
+							if (strong_points[k].x == np.x && strong_points[k].y == np.y) { same = true; break; }
+						if (same) continue;
+						f2 td = mk2((float)(np.x - px), (float)(np.y - py));
+						normalize2(&td);
+						const float cos_a = td.x * od.x + td.y * od.y;
+						if (cos_a > d.nb_thresh && (!edge_limit || !bresenham_hits_edge(d, px, py, np.x, np.y))) {
+							strong_points[dir_index] = np;
+							strong_point_size++;
+							found_dir = true;
+							break;
+						}
+					}
+					if (found_dir) break;
+				}
+				f2 rd;
+				rd.x = od.x * d.nb_cos - od.y * d.nb_sin;
+				rd.y = od.x * d.nb_sin + od.y * d.nb_cos;
+				normalize2(&rd);
+				od = rd;
+			}
+		}
+	}
+
+	int extend_index = 31;
+	if (P.use_label && d.label[center] > 0) {
+		const int ldx[16] = { 0, 0, -1, 1, -1, 1, -1, 1, 1, 0, 0, -1, -1, 0, 0, 1 };   // APD.cu:3462 (0.5 -> 0)
+		const int ldy[16] = { -1, 1, 0, 0, -1, 1, 1, -1, 0, 1, 1, 0, 0, -1, -1, 0 };
+		const s2* lb = d.label_boundary + (size_t)d.neighbours_map[center] * 8;
+		float bound_dist[16];
+		int dir_step[16];
+		for (int i = 0; i < 16; ++i) { bound_dist[i] = 0.0f; dir_step[i] = 0; }
+		for (int i = 0; i < 8; ++i) {
+			const s2 bp = lb[i];
+			float dist = 0.0f;
+			if (bp.x != -1 && bp.y != -1) {
+				const double ex = (double)(px - bp.x), ey = (double)(py - bp.y);
+				dist = (float)sqrt(ex * ex + ey * ey);
+				if (i >= 4) dist = (float)((double)dist / sqrt(2.0));
+			}
+			bound_dist[i] = dist;
+			if (i % 2 == 1) { dir_step[i - 1] = 4 * rotate_time - 1; dir_step[i] = 1; }   // APD.cu:3477: step == 1
+		}
+		const int ca[8] = { 3, 1, 1, 2, 2, 4, 7, 7 };
+		const int cb[8] = { 5, 5, 6, 6, 4, 0, 0, 3 };
+		for (int q = 0; q < 8; ++q) {
+			dir_step[8 + q] = (dir_step[ca[q]] + dir_step[cb[q]]) / 2;
+			bound_dist[8 + q] = (bound_dist[ca[q]] + bound_dist[cb[q]]) / 2;
+		}
+		for (int i = 0; i < 16; ++i) {
+			const float dist = bound_dist[i];
+			const int gap_num = dir_step[i] + 1;
+			const int step_len = DVP_MAX(1, (int)floor(1.0 * dist / gap_num));
+			for (int step = 1; step <= dir_step[i]; ++step) {
+				s2 np = mks2(px + step * step_len * ldx[i], py + step * step_len * ldy[i]);
+				if (np.x < min_margin || np.y < min_margin || np.x >= W - min_margin || np.y >= H - min_margin) continue;
+				int npc = np.x + np.y * W;
+				if (d.weak_info[npc] != DVP_STRONG) {
+					np = d.weak_nearest_strong[npc];
+					if (np.x == -1 || np.y == -1) continue;
+					npc = np.x + np.y * W;
+				}
+				bool same = false;
+				for (int k = 0; k <= extend_index; k++)
+					if (strong_points[k].x == np.x && strong_points[k].y == np.y) { same = true; break; }
+				if (same) continue;
+				if (extend_index + 1 >= max_pt_num) continue;
+				extend_index++;
+				strong_points[extend_index] = np;
+				strong_point_size++;
+			}
+		}
+	}
+
+	if (strong_point_size <= 3) { d.weak_reliable[center] = 0; return; }
+
+	s2 spv[max_pt_num];
+	f3 sp3[max_pt_num];
+	f3 spn[max_pt_num];
+	int valid_count = 0;
+	float X[3];
+	get_3d_point(cam, px, py, d.planes[center].w, X);
+	const float center_z = X[2];
+	for (int i = 0; i < max_pt_num; ++i) {
+		const s2 sp = strong_points[i];
+		if (sp.x == -1) continue;
+		const int spc = sp.x + sp.y * W;
+		const f4 pl = d.planes[spc];
+		spv[valid_count] = sp;
+		get_3d_point(cam, sp.x, sp.y, pl.w, X);
+		sp3[valid_count] = mk3(X[0], X[1], X[2]);
+		const f4 n4 = normal_world_to_cam(cam, pl);
+		spn[valid_count] = mk3(n4.x, n4.y, n4.z);
+		valid_count++;
+	}
+	for (int i = valid_count; i < max_pt_num; ++i) spv[i] = mks2(-1, -1);
+
+	f4 best_plane = mk4(0, 0, 0, 0);
+	bool has_valid_plane = false;
+	{
+		int iteration = 300, max_iter = 200;
+		float min_cost = FLT_MAX;
+		int max_count = 3;
+		bool has_strong_plane = false;
+		while (iteration > 0 && max_iter > 0) {
+			max_iter--;
+			const int ai = (int)(r_ransac.next() % (uint32_t)valid_count);
+			const int bi = (int)(r_ransac.next() % (uint32_t)valid_count);
+			const int ci = (int)(r_ransac.next() % (uint32_t)valid_count);
+			if (ai == bi || bi == ci || ai == ci) continue;
+			if (!point_in_triangle(spv[ai], spv[bi], spv[ci], px, py)) continue;
+			if (edge_limit) {
+				// the reference memoises these tests in a 25 KB per-thread table (APD.cu:3574); the test
+				// is a pure function of its end points, so it is re-evaluated instead
+				if (bresenham_hits_edge(d, spv[ai].x, spv[ai].y, spv[bi].x, spv[bi].y) ||
+					bresenham_hits_edge(d, spv[bi].x, spv[bi].y, spv[ci].x, spv[ci].y) ||
+					bresenham_hits_edge(d, spv[ci].x, spv[ci].y, spv[ai].x, spv[ai].y)) continue;
+			}
+			const f3 AN = spn[ai];   // the reference uses a_index for all three normals (APD.cu:3605-3607)
+			const float nn = AN.x * AN.x + AN.y * AN.y + AN.z * AN.z;
+			if (nn < 0.9f) continue;
+			const f3 A = sp3[ai], B = sp3[bi], C = sp3[ci];
+			const f3 AC = mk3(A.x - C.x, A.y - C.y, A.z - C.z);
+			const f3 BC = mk3(B.x - C.x, B.y - C.y, B.z - C.z);
+			f4 cv;
+			cv.x = AC.y * BC.z - BC.y * AC.z;
+			cv.y = -(AC.x * BC.z - BC.x * AC.z);
+			cv.z = AC.x * BC.y - BC.x * AC.y;
+			cv.w = 0.0f;
+			if ((cv.x == 0 && cv.y == 0 && cv.z == 0) || cv.x != cv.x || cv.y != cv.y || cv.z != cv.z) continue;
+			iteration--;
+			normalize3(&cv);
+			cv.w = -(cv.x * A.x + cv.y * A.y + cv.z * A.z);
+			bool is_strong_plane = true;
+			if (P.use_label && d.label[center] > 0 && fabsf(AN.x * cv.x + AN.y * cv.y + AN.z * cv.z) < 0.9f) is_strong_plane = false;
+			if (has_strong_plane && !is_strong_plane) continue;
+			int temp_count = 0;
+			for (int si = 0; si < valid_count; ++si) {
+				const float fx = (spv[si].x - cam.K[2]) / cam.K[0];
+				const float fy = (spv[si].y - cam.K[5]) / cam.K[4];
+				const float fit_depth = -cv.w / (cv.x * fx + cv.y * fy + cv.z);
+				const float dist = fabsf(fit_depth - sp3[si].z);
+				if (dist / depth_diff < P.ransac_threshold) temp_count++;
+			}
+			if (temp_count < 6) continue;
+			const float fx = (px - cam.K[2]) / cam.K[0];
+			const float fy = (py - cam.K[5]) / cam.K[4];
+			const float fit_depth = -cv.w / (cv.x * fx + cv.y * fy + cv.z);
+			const float center_distance = fabsf(fit_depth - center_z);
+			if (temp_count > max_count || (!has_strong_plane && is_strong_plane)) {
+				if (!has_strong_plane && is_strong_plane) has_strong_plane = true;
+				best_plane = cv;
+				max_count = temp_count;
+				min_cost = center_distance;
+				has_valid_plane = true;
+			} else if (temp_count == max_count) {
+				if (center_distance < min_cost) { best_plane = cv; max_count = temp_count; min_cost = center_distance; }
+			}
+		}
+	}
+	if (!has_valid_plane) { d.weak_reliable[center] = 0; return; }
+
+	float weight[max_pt_num];
+	for (int i = 0; i < valid_count; ++i) {
+		const float fx = (spv[i].x - cam.K[2]) / cam.K[0];
+		const float fy = (spv[i].y - cam.K[5]) / cam.K[4];
+		const float fit_depth = -best_plane.w / (best_plane.x * fx + best_plane.y * fy + best_plane.z);
+		const float dist = fabsf(fit_depth - sp3[i].z);
+		if (dist / depth_diff >= P.ransac_threshold) { spv[i] = mks2(-1, -1); weight[i] = FLT_MAX; }
+		else weight[i] = dist;
+	}
+	for (int i = 1; i < valid_count; i++) {   // sort_small_weighted (APD.cu:125-138)
+		const s2 tp = spv[i];
+		const float tw = weight[i];
+		int j = i;
+		for (; j >= 1 && tw < weight[j - 1]; j--) { spv[j] = spv[j - 1]; weight[j] = weight[j - 1]; }
+		spv[j] = tp;
+		weight[j] = tw;
+	}
+	for (int i = 1; i < DVP_NEIGHBOUR_NUM; ++i) neighbours[i] = spv[i - 1];
+	d.weak_reliable[center] = 1;
+}
+
+// NeigbourUpdate (APD.cu:3713-3729)
+DVP_HD void neighbour_update_px(const Dev& d, int px, int py) {
+	const int center = px + py * d.width;
+	if (d.weak_info[center] != DVP_WEAK) return;
+	if (d.weak_reliable[center] != 1) d.weak_info[center] = DVP_UNKNOWN;
+}
+
+// ---- RANSACToGetFitPlane (APD.cu:4195-4404) -----------------------------------------------------
+DVP_HD void ransac_fit_plane_px(const Dev& d, int px, int py, int iter) {
+	const int W = d.width;
+	const int center = px + py * W;
+	const DvpParams& P = d.params;
+	if (d.weak_info[center] != DVP_WEAK) { d.fit_planes[center] = d.planes[center]; return; }
+	const DvpCamera& cam = d.cameras[0];
+	Rng r_limit(d.seed, (uint32_t)center, rng_site(PH_RANSAC, iter, SUB_LIMIT));
+	Rng r_ransac(d.seed, (uint32_t)center, rng_site(PH_RANSAC, iter, SUB_RANSAC));
+	bool edge_limit = false;
+	if (P.use_limit) {
+		edge_limit = true;
+		if (P.use_edge) {
+			const float complex_val = d.complex_[d.neighbours_map[center]];
+			const float rp = r_limit.uniform() - FLT_EPSILON;
+			if (rp < complex_val) edge_limit = false;
+		}
+	}
+	s2 sp[11];
+	f3 sp3[11], spn[11];
+	int cnt = 0;
+	const s2* nbs = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
+	for (int i = 1; i < DVP_NEIGHBOUR_NUM; ++i) {
+		const s2 tp = nbs[i];
+		if (tp.x == -1 || tp.y == -1) continue;
+		sp[cnt] = tp;
+		const f4 pl = d.planes[tp.x + tp.y * W];
+		const float depth = depth_from_plane(cam, pl, tp.x, tp.y);
+		float X[3];
+		get_3d_point(cam, tp.x, tp.y, depth, X);
+		sp3[cnt] = mk3(X[0], X[1], X[2]);
+		spn[cnt] = mk3(pl.x, pl.y, pl.z);
+		cnt++;
+	}
+	if (cnt < 3) { d.fit_planes[center] = d.planes[center]; return; }
+
+	int use_a = 0, use_b = 0, use_c = 0;
+	float min_cost = FLT_MAX;
+	f4 best_plane = mk4(0, 0, 0, 0);
+	bool has_best = false;
+	for (int it = 0; it < 50; ++it) {
+		const int ai = (int)(r_ransac.next() % (uint32_t)cnt);
+		const int bi = (int)(r_ransac.next() % (uint32_t)cnt);
+		const int ci = (int)(r_ransac.next() % (uint32_t)cnt);
+		if (ai == bi || bi == ci || ai == ci) continue;
+		const f3 AN = spn[ai], BN = spn[bi], CN = spn[ci];
+		if (AN.x * BN.x + AN.y * BN.y + AN.z * BN.z < 0.9f || AN.x * CN.x + AN.y * CN.y + AN.z * CN.z < 0.9f ||
+			BN.x * CN.x + BN.y * CN.y + BN.z * CN.z < 0.9f) continue;
+		if (!point_in_triangle(sp[ai], sp[bi], sp[ci], px, py)) continue;
+		if (edge_limit) {
+			if (bresenham_hits_edge(d, sp[ai].x, sp[ai].y, sp[bi].x, sp[bi].y) ||
+				bresenham_hits_edge(d, sp[bi].x, sp[bi].y, sp[ci].x, sp[ci].y) ||
+				bresenham_hits_edge(d, sp[ci].x, sp[ci].y, sp[ai].x, sp[ai].y)) continue;
+		}
+		const f3 A = sp3[ai], B = sp3[bi], C = sp3[ci];
+		const f3 AC = mk3(A.x - C.x, A.y - C.y, A.z - C.z);
+		const f3 BC = mk3(B.x - C.x, B.y - C.y, B.z - C.z);
+		f4 cv;
+		cv.x = AC.y * BC.z - BC.y * AC.z;
+		cv.y = -(AC.x * BC.z - BC.x * AC.z);
+		cv.z = AC.x * BC.y - BC.x * AC.y;
+		cv.w = 0.0f;
+		if ((cv.x == 0 && cv.y == 0 && cv.z == 0) || cv.x != cv.x || cv.y != cv.y || cv.z != cv.z) continue;
+		normalize3(&cv);
+		cv.w = -(cv.x * A.x + cv.y * A.y + cv.z * A.z);
+		float temp_cost = 0.0f;
+		for (int si = 0; si < cnt; ++si) {
+			if (si == ai || si == bi || si == ci) continue;
+			const float fx = (sp[si].x - cam.K[2]) / cam.K[0];
+			const float fy = (sp[si].y - cam.K[5]) / cam.K[4];
+			const float fit_depth = -cv.w / (cv.x * fx + cv.y * fy + cv.z);
+			temp_cost += fabsf(fit_depth - sp3[si].z);
+		}
+		if (temp_cost < min_cost) {
+			min_cost = temp_cost;
+			best_plane = cv;
+			has_best = true;
+			use_a = ai; use_b = bi; use_c = ci;   // the reference reads index -1 here (APD.cu:4349); see DESIGN.md quirks
+		}
+	}
+	if (!has_best) {
+		d.fit_planes[center] = mk4(0, 0, 0, 0);
+		if (P.use_radius) d.radius[center] = P.strong_radius;
+		return;
+	}
+	const float depth = depth_from_plane(cam, d.planes[center], px, py);
+	const f4 vdir = view_direction(cam, px, py, depth);
+	const float dp = best_plane.x * vdir.x + best_plane.y * vdir.y + best_plane.z * vdir.z;
+	if (dp > 0) { best_plane.x = -best_plane.x; best_plane.y = -best_plane.y; best_plane.z = -best_plane.z; best_plane.w = -best_plane.w; }
+	d.fit_planes[center] = best_plane;
+	if (P.use_radius) {
+		const s2 A = sp[use_a], B = sp[use_b], C = sp[use_c];
+		const float a = sqrtf((float)((A.x - B.x) * (A.x - B.x) + (A.y - B.y) * (A.y - B.y)));
+		const float b = sqrtf((float)((B.x - C.x) * (B.x - C.x) + (B.y - C.y) * (B.y - C.y)));
+		const float c = sqrtf((float)((C.x - A.x) * (C.x - A.x) + (C.y - A.y) * (C.y - A.y)));
+		const float pp = (float)((a + b + c) / 2.0);
+		const float Sa = sqrtf(pp * (pp - a) * (pp - b) * (pp - c));
+		const double rr = floor(sqrtf(Sa) / 2.0);
+		int radius = (rr == rr) ? (int)rr : 0;
+		const float Ad = sqrtf((float)((A.x - px) * (A.x - px) + (A.y - py) * (A.y - py)));
+		const float Bd = sqrtf((float)((B.x - px) * (B.x - px) + (B.y - py) * (B.y - py)));
+		const float Cd = sqrtf((float)((C.x - px) * (C.x - px) + (C.y - py) * (C.y - py)));
+		const float min_dis = DVP_MIN(DVP_MIN(Ad, Bd), Cd);
+		if (2.5 * min_dis < radius) radius = (int)min_dis;
+		if (edge_limit) {
+			if (P.use_edge) {
+				float med = FLT_MAX;
+				const s2* en = d.edge_neigh + (size_t)center * 8;
+				for (int k = 0; k < 8; ++k) {
+					const s2 ep = en[k];
+					if (ep.x == -1 || ep.y == -1) continue;
+					const float dist = sqrtf((float)((ep.x - px) * (ep.x - px) + (ep.y - py) * (ep.y - py)));
+					med = DVP_MIN(med, dist);
+				}
+				if (med < radius) radius = (int)med;
+			}
+			if (P.use_label) {
+				float mbd = FLT_MAX;
+				const s2* lb = d.label_boundary + (size_t)d.neighbours_map[center] * 8;
+				for (int k = 0; k < 8; ++k) {
+					const s2 bp = lb[k];
+					if (bp.x == -1 || bp.y == -1) continue;
+					const double ex = (double)(px - bp.x), ey = (double)(py - bp.y);
+					const float dist = (float)sqrt(ex * ex + ey * ey);
+					mbd = DVP_MIN(mbd, dist);
+				}
+				if (mbd < radius) radius = (int)mbd;
+			}
+		}
+		if (radius < 0) radius = 0;
+		while ((radius << 1) % 5 != 0) radius--;
+		d.radius[center] = radius < P.strong_radius ? 0 : radius;
+	}
+}
+
+// ---- ComputeBilateralNCCNew (APD.cu:835-1021) ---------------------------------------------------
+// `c` = centre-patch context built with colour-only weights (ComputeBilateralWeight_YZL).
+DVP_HD float ncc_new(const Dev& d, const PatchCtx& c, int px, int py, int v, const f4 plane) {
+	const DvpCamera& rc = d.cameras[0];
+	const DvpCamera& sc = d.cameras[v];
+	const int W = d.width, Hh = d.height, Pt = d.pitch;
+	const int S = d.params.num_images - 1;
+	float H[9];
+	homography(rc, sc, d.views[v], plane, H);
+	const f2 pt = apply_homography(H, px, py);
+	if (pt.x >= sc.width || pt.x < 0.0f || pt.y >= sc.height || pt.y < 0.0f) return 2.0f;
+	const float* ref = d.images;
+	const float* src = d.images + (size_t)v * d.plane_stride;
+	const int center = px + py * W;
+	const float cpix = tex_texel(ref, Pt, W, Hh, px, py);
+	// k == 0: the pixel's own patch (neighbours[0] is the pixel itself, APD.cu:3365)
+	const float center_cost = c.fast ? ncc_patch_fast(d, c, H, src, px, py)
+	                                 : ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
+	float strong_cost = 0.0f;
+	int strong_count = 0;
+	const s2* nbs = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
+	for (int k = 1; k < DVP_NEIGHBOUR_NUM; ++k) {
+		const s2 nb = nbs[k];
+		if (nb.x == -1 || nb.y == -1) continue;
+		const f2 nsp = apply_homography(H, nb.x, nb.y);
+		const int nbc = nb.x + nb.y * W;
+		const int visible = is_set(d.selected_views[nbc], v - 1);
+		if (nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh) {
+			if (visible) { strong_cost += 2.0f; strong_count++; }
+			continue;
+		}
+		float temp_cost = 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
+		if (visible) {
+			float s_r = 0.0f, s_rr = 0.0f, s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f, s_w = 0.0f;
+			const s2* cand = d.candidate + ((size_t)nbc * S + (v - 1)) * 8;
+			for (int t = 0; t < 9; t++) {
+				int i = 0, j = 0;
+				if (t != 8) { i = cand[t].x; j = cand[t].y; }
+				if (i == 0 && j == 0 && t < 8) {   // default +-5 ring (APD.cu:943-952)
+					const int ri[8] = { -5, -5, -5, 0, 0, 5, 5, 5 };
+					const int rj[8] = { -5, 0, 5, -5, 5, -5, 0, 5 };
+					i = ri[t];
+					j = rj[t];
+				}
+				const int rx = nb.x + i, ry = nb.y + j;
+				const float a = tex_texel(ref, Pt, W, Hh, rx, ry);
+				const f2 sp = apply_homography(H, rx, ry);
+				const float b = tex_linear(src, Pt, W, Hh, sp.x + 0.5f, sp.y + 0.5f, d.sampler);
+				const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
+				s_r += w * a;
+				s_rr += w * a * a;
+				s_s += w * b;
+				s_ss += w * b * b;
+				s_rs += w * a * b;
+				s_w += w;
+			}
+			temp_cost = ncc_from_sums(s_r, s_rr, s_s, s_ss, s_rs, s_w);
+		}
+		strong_cost += temp_cost;
+		strong_count++;
+	}
+	if (strong_count == 0) return center_cost;
+	strong_cost /= strong_count;
+	strong_cost = DVP_MIN(strong_cost, 2.0f);
+	return (float)(0.25 * center_cost + 0.75 * strong_cost);
+}
+
+// ---- CheckerboardPropagationWeak + PlaneHypothesisRefinementWeak (APD.cu:2739-3089, 1897-2008) --
+// 16 slots with one inlined copy of ncc_new: 8 anchor planes, the current plane, the RANSAC fit
+// plane, 6 refinement hypotheses.
+DVP_HD void weak_update_px(const Dev& d, int px, int py, int iter, unsigned long long* nevals) {
+	const int W = d.width;
+	const int center = py * W + px;
+	const DvpParams& P = d.params;
+	const DvpCamera& rc = d.cameras[0];
+	const int S = P.num_images - 1;
+	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
+	const s2* nbs = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
+
+	PatchCtx c;
+	{
+		int radius, inc;
+		patch_geometry(d, center, &radius, &inc);
+		build_patch_ctx(d, px, py, radius, inc, 1, &c);
+	}
+	float cost_array[8 * 32];
+	for (int i = 0; i < 8 * 32; ++i) cost_array[i] = 0.0f;
+	cost_array[0] = 2.0f;
+	uint32_t flag = 0;
+	int positions[8];
+	for (int k = 0; k < 8; ++k) positions[k] = 0;
+	uint8_t vw[32];
+	for (int i = 0; i < 32; ++i) vw[i] = 0;
+	uint32_t sel_mask = 0;
+	float weight_norm = 0.0f;
+	float final_costs[8];
+	int min_cost_idx = 0;
+	float cost_now = 0.0f, costs_center = 0.0f, depth_now = 0.0f;
+	f4 plane_now = mk4(0, 0, 0, 0);
+	float ref_depths[6];
+	f4 ref_normals[6];
+	bool skip_refine = false;
+	float cv[32];
+
+	for (int slot = 0; slot < 16; ++slot) {
+		f4 plane = mk4(0, 0, 1, 1);
+		uint32_t mask = 0;
+		if (slot < 8) {
+			const s2 nb = nbs[slot + 1];
+			if (!(nb.x == -1 || nb.y == -1) && d.weak_info[nb.x + nb.y * W] == DVP_STRONG) {
+				positions[slot] = nb.x + nb.y * W;
+				flag |= 1u << slot;
+				plane = d.planes[positions[slot]];
+				mask = all_views;
+			}
+		} else if (slot == 8) {
+			float priors[32];
+			for (int i = 0; i < 32; ++i) priors[i] = 0.0f;
+			for (int i = 0; i < 8; ++i) {
+				const s2 nb = nbs[i + 1];
+				if (nb.x == -1 || nb.y == -1) continue;
+				const uint32_t sv = d.selected_views[nb.x + nb.y * W];
+				for (int j = 0; j < S; ++j) priors[j] += is_set(sv, j) ? 0.9f : 0.1f;
+			}
+			joint_view_selection(d, center, iter, PH_WEAK, cost_array, priors, vw, &sel_mask, &weight_norm);
+			uint8_t* gvw = d.view_weight + (size_t)center * 32;
+			for (int i = 0; i < 32; ++i) gvw[i] = vw[i];
+			for (int k = 0; k < 8; ++k) {
+				float fc = 0.0f;
+				for (int j = 0; j < S; ++j) {
+					if (vw[j] > 0) {
+						if (P.geom_consistency) {
+							if ((flag >> k) & 1) fc += vw[j] * (cost_array[k * 32 + j] + P.geom_factor * geom_cost(d, px, py, j + 1, d.planes[positions[k]]));
+							else fc += vw[j] * (cost_array[k * 32 + j] + P.geom_factor * 3.0f);
+						} else {
+							fc += vw[j] * cost_array[k * 32 + j];
+						}
+					}
+				}
+				final_costs[k] = fc / weight_norm;
+			}
+			min_cost_idx = 0;
+			{
+				float mc = final_costs[0];
+				for (int k = 1; k < 8; ++k)
+					if (final_costs[k] <= mc) { mc = final_costs[k]; min_cost_idx = k; }
+			}
+			plane = d.planes[center];
+			mask = sel_mask;
+		} else if (slot == 9) {
+			// the RANSAC fit plane is tried first (APD.cu:1920-1949); an all-zero fit plane makes
+			// the reference return from the whole refinement (:1923-1925)
+			const f4 fp = d.fit_planes[center];
+			if (fp.x == 0 && fp.y == 0 && fp.z == 0) skip_refine = true;
+			else { plane = fp; mask = sel_mask; }
+		} else {
+			if (!skip_refine) {
+				const int i = slot - 10;
+				plane = ref_normals[i];
+				plane.w = distance_to_origin(rc, px, py, ref_depths[i], plane);
+				mask = sel_mask;
+			}
+		}
+
+		if (mask) {
+			for (int v = 0; v < S; ++v) {
+				if ((mask >> v) & 1) {
+					cv[v] = ncc_new(d, c, px, py, v + 1, plane);
+					if (nevals) *nevals += 1;
+				}
+			}
+		}
+
+		if (slot < 8) {
+			if ((flag >> slot) & 1)
+				for (int v = 0; v < S; ++v) cost_array[slot * 32 + v] = cv[v];
+		} else if (slot == 8) {
+			float cn = 0.0f;
+			for (int v = 0; v < S; ++v) {
+				if (vw[v] > 0) {
+					if (P.geom_consistency) cn += vw[v] * (cv[v] + P.geom_factor * geom_cost(d, px, py, v + 1, plane));
+					else cn += vw[v] * cv[v];
+				}
+			}
+			cost_now = cn / weight_norm;
+			costs_center = cost_now;
+			plane_now = plane;
+			depth_now = depth_from_plane(rc, plane_now, px, py);
+			if ((flag >> min_cost_idx) & 1) {
+				const f4 cand = d.planes[positions[min_cost_idx]];
+				const float db = depth_from_plane(rc, cand, px, py);
+				if (db >= P.depth_min && db <= P.depth_max && final_costs[min_cost_idx] < cost_now) {
+					depth_now = db;
+					plane_now = cand;
+					cost_now = final_costs[min_cost_idx];
+					d.selected_views[center] = sel_mask;
+				}
+			}
+		} else {
+			const bool active = (slot == 9) ? !skip_refine : !skip_refine;
+			if (active) {
+				float tc = 0.0f;
+				for (int j = 0; j < S; ++j) {
+					if (vw[j] > 0) {
+						if (P.geom_consistency) tc += vw[j] * (cv[j] + P.geom_factor * geom_cost(d, px, py, j + 1, plane));
+						else tc += vw[j] * cv[j];
+					}
+				}
+				tc /= weight_norm;
+				const float db = depth_from_plane(rc, plane, px, py);
+				if (db >= P.depth_min && db <= P.depth_max && tc < cost_now) {
+					depth_now = db;
+					plane_now = plane;
+					cost_now = tc;
+				}
+			}
+			if (slot == 9 && !skip_refine) {
+				// random refinement hypotheses are built from the state after the fit-plane test
+				Rng rd(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_DEPTH_RAND));
+				Rng rn(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_NORMAL));
+				Rng rp(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_DEPTH_PERT));
+				const float depth_rand = rd.uniform() * (P.depth_max - P.depth_min) + P.depth_min;
+				const f4 n_rand = random_normal_yzl(d, px, py, rn, depth_now);
+				const float dmin_p = (1 - 0.02f) * depth_now, dmax_p = (1 + 0.02f) * depth_now;
+				const float depth_pert = rp.uniform() * (dmax_p - dmin_p) + dmin_p;
+				f4 n_pert = plane_now;
+				normalize3(&n_pert);
+				ref_depths[0] = depth_rand; ref_normals[0] = plane_now;
+				ref_depths[1] = depth_now;  ref_normals[1] = n_rand;
+				ref_depths[2] = depth_rand; ref_normals[2] = n_rand;
+				ref_depths[3] = depth_now;  ref_normals[3] = n_pert;
+				ref_depths[4] = depth_now;  ref_normals[4] = n_pert;
+				ref_depths[5] = depth_pert; ref_normals[5] = plane_now;
+			}
+		}
+	}
+
+	f4 final_plane = d.planes[center];
+	if (P.state == DVP_REFINE_INIT) {
+		if (cost_now < costs_center - 0.1) final_plane = plane_now;
+	} else {
+		final_plane = plane_now;
+	}
+	d.planes[center] = final_plane;
+
+	// cost of the final plane with the plain bilateral NCC at the default radius (APD.cu:3072-3088)
+	PatchCtx c2;
+	{
+		int r = P.strong_radius, inc = P.strong_increment;
+		if (P.use_radius) inc = DVP_MAX(2, (int)(2.0 * r / 5.0));
+		build_patch_ctx(d, px, py, r, inc, 0, &c2);
+	}
+	float cn = 0.0f;
+	for (int v = 0; v < S; ++v) {
+		if (vw[v] == 0) continue;
+		cn += vw[v] * ncc_old(d, c2, px, py, v + 1, final_plane);
+		if (nevals) *nevals += 1;
+	}
+	d.costs[center] = cn / weight_norm;
+}
+
+}  // namespace dvp
+#endif

@@ -1,0 +1,184 @@
+/* dvp_mvs.h — C ABI of the MI355X PatchMatch engine (libdvp_mvs_hip.so).
+ *
+ * Drop-in boundary for the per-view depth/normal path of ZhenlongYuan/DVP-MVS: these entry
+ * points are what the reference's `class APD` methods (APD.h:94-199) do with the CUDA runtime
+ * — allocate/upload (APD::CudaSpaceInitialization, APD.cpp:1497-1613), bundle the buffers
+ * (APD::SetDataPassHelperInCuda, APD.cpp:1670-1704; DataPassHelper, APD.h:60-92), run the kernel
+ * sequence (APD::RunPatchMatch, APD.cu:4406-4532) and copy the results back (APD.cu:4525-4530).
+ * Plain pointers and sizes only; POD layouts are the reference's (main.h:58-67, 86-112).
+ * All functions return 0 on success, non-zero on error (dvp_last_error() gives the text); the
+ * C++ mirror of `class APD` (dvp-mvs_amd/host/APD.h) turns non-zero into the reference's
+ * print-and-exit (CudaSafeCall, APD.cpp:943-951).
+ * One context == one reference view on one device/stream; contexts are independent (no global
+ * state), so one process can own several and N processes can own one GPU each.
+ */
+#ifndef DVP_MVS_H_
+#define DVP_MVS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVP_MAX_IMAGES 32        /* main.h:39 */
+#define DVP_NEIGHBOUR_NUM 12     /* main.h:40 */
+#define DVP_EDGE_NEIGH_NUM 8     /* main.h:43 */
+#define DVP_LAB_BOUNDARY_NUM 8   /* main.h:44 */
+
+/* struct Camera, main.h:58-67 (112 bytes). x_cam = R X + t, c = -R^T t. */
+typedef struct DvpCamera {
+	float K[9];
+	float R[9];
+	float t[3];
+	float c[3];
+	int32_t height;
+	int32_t width;
+	float depth_min;
+	float depth_max;
+} DvpCamera;
+
+/* enum RunState, main.h:74-78 ; enum PixelState, main.h:80-84 */
+enum { DVP_FIRST_INIT = 0, DVP_REFINE_INIT = 1, DVP_REFINE_ITER = 2 };
+enum { DVP_WEAK = 0, DVP_STRONG = 1, DVP_UNKNOWN = 2 };
+
+/* struct PatchMatchParams, main.h:86-112 (76 bytes; C++ bool == uint8_t) */
+typedef struct DvpParams {
+	int32_t max_iterations;
+	int32_t num_images;
+	float sigma_spatial;
+	float sigma_color;
+	int32_t top_k;
+	float depth_min;
+	float depth_max;
+	uint8_t geom_consistency;
+	int32_t strong_radius;
+	int32_t strong_increment;
+	int32_t weak_radius;
+	int32_t weak_increment;
+	uint8_t use_APD;
+	uint8_t use_edge;
+	uint8_t use_limit;
+	uint8_t use_label;
+	uint8_t use_detail;
+	uint8_t use_radius;
+	int32_t weak_peak_radius;
+	int32_t rotate_time;
+	float ransac_threshold;
+	float geom_factor;
+	int32_t state;
+} DvpParams;
+
+typedef struct dvp_ctx dvp_ctx;
+
+/* Kernel launches of APD::RunPatchMatch, one id per launch site (APD.cu:4430-4505). */
+enum {
+	DVP_ST_GEN_EDGE_INFORM = 0,      /* GenEdgeInform          APD.cu:4433 */
+	DVP_ST_FIND_NEAREST_STRONG = 1,  /* FindNearestStrongPoint APD.cu:4445 */
+	DVP_ST_GEN_NEIGHBOURS = 2,       /* GenNeighbours          APD.cu:4448 */
+	DVP_ST_NEIGHBOUR_UPDATE = 3,     /* NeigbourUpdate         APD.cu:4451 */
+	DVP_ST_RANDOM_INIT = 4,          /* RandomInitialization   APD.cu:4475 */
+	DVP_ST_STRONG_UPDATE = 5,        /* Black/RedPixelUpdateStrong  APD.cu:4479-4481 */
+	DVP_ST_RANSAC_FIT = 6,           /* RANSACToGetFitPlane    APD.cu:4484 */
+	DVP_ST_WEAK_UPDATE = 7,          /* Black/RedPixelUpdateWeak    APD.cu:4487-4489 */
+	DVP_ST_GET_DEPTH_NORMAL = 8,     /* GetDepthandNormal      APD.cu:4494 */
+	DVP_ST_FILTER_STRONG = 9,        /* Black/RedPixelFilterStrong  APD.cu:4497-4499 */
+	DVP_ST_DEPTH_TO_WEAK = 10,       /* DepthToWeak            APD.cu:4502 */
+	DVP_ST_LOCAL_REFINE = 11,        /* LocalRefine            APD.cu:4505 */
+	DVP_ST_COUNT = 12
+};
+
+/* Device buffers (DataPassHelper members, APD.h:60-92) addressable by dvp_download_buffer /
+ * dvp_upload_buffer. */
+enum {
+	DVP_BUF_PLANES = 0,              /* float4 per pixel   plane_hypotheses_cuda */
+	DVP_BUF_COSTS = 1,               /* float              costs_cuda */
+	DVP_BUF_SELECTED_VIEWS = 2,      /* uint32             selected_views_cuda */
+	DVP_BUF_VIEW_WEIGHT = 3,         /* uint8 x 32         view_weight_cuda */
+	DVP_BUF_WEAK_INFO = 4,           /* uint8              weak_info_cuda */
+	DVP_BUF_WEAK_RELIABLE = 5,       /* uint8              weak_reliable_cuda */
+	DVP_BUF_WEAK_NEAREST_STRONG = 6, /* short2             weak_nearest_strong */
+	DVP_BUF_NEIGHBOURS_MAP = 7,      /* int32              neighbours_map_cuda */
+	DVP_BUF_NEIGHBOURS = 8,          /* short2 x 12 per WEAK pixel   neighbours_cuda */
+	DVP_BUF_FIT_PLANES = 9,          /* float4             fit_plane_hypotheses_cuda */
+	DVP_BUF_CANDIDATE = 10,          /* short2 x 8 x (num_images-1) per pixel  candidate_cuda */
+	DVP_BUF_EDGE = 11,               /* uint8              edge_cuda */
+	DVP_BUF_EDGE_NEIGH = 12,         /* short2 x 8         edge_neigh_cuda */
+	DVP_BUF_LABEL = 13,              /* int32              label_cuda */
+	DVP_BUF_LABEL_BOUNDARY = 14,     /* short2 x 8 per WEAK pixel    label_boundary_cuda */
+	DVP_BUF_COMPLEX = 15,            /* float per WEAK pixel         complex_cuda */
+	DVP_BUF_RADIUS = 16,             /* int32              radius_cuda */
+	DVP_BUF_COUNT = 17
+};
+
+/* Per-launch-site timing, measured with HIP events on the engine's own stream. */
+typedef struct DvpTimings {
+	double stage_ms[DVP_ST_COUNT];      /* accumulated kernel time per launch site */
+	int32_t stage_launches[DVP_ST_COUNT];
+	double iter_loop_ms;                /* the iteration loop, APD.cu:4478-4492 */
+	double total_ms;                    /* whole dvp_run_patchmatch */
+	uint64_t ncc_evals[DVP_ST_COUNT];   /* bilateral-NCC evaluations per launch site (only when
+	                                       dvp_set_profiling(ctx, 1): counting build) */
+} DvpTimings;
+
+/* ---- lifetime (APD::APD / ~APD, APD.cpp:984-1043; cudaSetDevice, main.cpp:430-434) ---------- */
+int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** out);
+int dvp_ctx_destroy(dvp_ctx* ctx);
+const char* dvp_last_error(const dvp_ctx* ctx);   /* ctx may be NULL: last create error */
+
+/* ---- uploads (APD::CudaSpaceInitialization, APD.cpp:1497-1613) ------------------------------- */
+/* images[i]: host pointer, row-major float32, `pitch_floats` elements per row (>= width);
+ * replaces cudaMemcpy2DToArray + cudaCreateTextureObject (APD.cpp:1501-1517). */
+int dvp_upload_images(dvp_ctx* ctx, const float* const* images, int pitch_floats);
+/* depth maps of ref + src views for geom_consistency (APD.cpp:1522-1545) */
+int dvp_upload_depths(dvp_ctx* ctx, const float* const* depths, int pitch_floats);
+/* same, from device memory already resident on ctx's device (e.g. an RCCL broadcast buffer):
+ * images/depths are copied device-to-device on the engine's stream. */
+int dvp_upload_images_device(dvp_ctx* ctx, const float* const* dev_images, int pitch_floats);
+int dvp_upload_depths_device(dvp_ctx* ctx, const float* const* dev_depths, int pitch_floats);
+int dvp_upload_cameras(dvp_ctx* ctx, const DvpCamera* cams, int n);            /* APD.cpp:1549-1550 */
+/* per-pixel input state; any pointer may be NULL (keeps the current/default content):
+ * planes float4 (world normal, depth) APD.cpp:1566-1567 · selected_views APD.cpp:1560-1561 ·
+ * weak_info APD.cpp:1595-1596 (also rebuilds neighbours_map/weak_count, APD.cpp:1182-1193) ·
+ * edge APD.cpp:1577-1578 · label APD.cpp:1585-1586 · radius APD.cpp:1590-1591. */
+int dvp_upload_state(dvp_ctx* ctx, const float* planes_xyzw, const uint32_t* selected_views,
+                     const uint8_t* weak_info, const uint8_t* edge, const int32_t* label,
+                     const int32_t* radius);
+int dvp_set_params(dvp_ctx* ctx, const DvpParams* params);                     /* APD.cpp:1607-1608 */
+/* The reference seeds cuRAND with clock64() (APD.cu:1270); here the seed is explicit. */
+int dvp_set_seed(dvp_ctx* ctx, uint64_t seed);
+/* 0 = CUDA-texture-like 8-bit interpolation weights (default), 1 = exact fractions */
+int dvp_set_sampler(dvp_ctx* ctx, int sampler);
+int dvp_set_profiling(dvp_ctx* ctx, int count_evals);
+
+/* ---- run (APD::RunPatchMatch, APD.cu:4406-4532) ---------------------------------------------- */
+int dvp_run_patchmatch(dvp_ctx* ctx);
+/* one launch site of the sequence; colour: 0 = Black*, 1 = Red* for the half launches */
+int dvp_run_stage(dvp_ctx* ctx, int stage, int iter, int colour);
+int dvp_synchronize(dvp_ctx* ctx);
+
+/* ---- results (cudaMemcpy D2H, APD.cu:4525-4530; getters APD.cpp:1706-1748) ------------------- */
+/* any pointer may be NULL. planes: (world normal xyz, depth w) per pixel. */
+int dvp_download_state(dvp_ctx* ctx, float* planes_xyzw, uint32_t* selected_views,
+                       uint8_t* weak_info, int32_t* radius);
+long long dvp_buffer_bytes(dvp_ctx* ctx, int buffer);
+int dvp_download_buffer(dvp_ctx* ctx, int buffer, void* dst);
+int dvp_upload_buffer(dvp_ctx* ctx, int buffer, const void* src);
+int dvp_weak_count(dvp_ctx* ctx);
+int dvp_get_timings(dvp_ctx* ctx, DvpTimings* out);
+int dvp_reset_timings(dvp_ctx* ctx);
+
+/* ---- roofline micro-benchmark / known-answer tests ------------------------------------------- */
+/* n (pixel, plane) pairs -> out[n * (num_images-1)] = ComputeMultiViewCostVectorOld
+ * (APD.cu:1207-1216).  px = {x0,y0,x1,y1,...}; planes = camera-frame (nx,ny,nz,d) per pair.
+ * Host pointers.  If kernel_ms != NULL it receives the kernel's HIP-event time. */
+int dvp_eval_cost_vectors(dvp_ctx* ctx, const int32_t* px, const float* planes, int n, float* out,
+                          float* kernel_ms);
+/* device-resident variant for benchmarking: same computation on every pixel of the image with
+ * plane = current plane_hypotheses (camera frame), `repeat` launches; returns the mean kernel ms */
+int dvp_bench_cost_kernel(dvp_ctx* ctx, int repeat, float* mean_kernel_ms, uint64_t* evals_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVP_MVS_H_ */

@@ -1,0 +1,258 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see ora_common.h).
+// NCC / geometric cost functions: APD.cu:835-1256.
+#include "ora_core.h"
+
+namespace ora {
+
+// APD.cu:1023-1113
+float ComputeBilateralNCCOld(const int2 p, const int src_idx, const float4 plane_hypothesis, Ctx& h) {
+	const float* ref_image = h.images[0].data();
+	const Camera& ref_camera = h.cameras[0];
+	const float* src_image = h.images[src_idx].data();
+	const Camera& src_camera = h.cameras[src_idx];
+	const int W = h.width, Hh = h.height;
+	const float cost_max = 2.0f;
+	if (h.count_evals) {
+#pragma omp atomic
+		h.ncc_evals++;
+	}
+
+	float H[9];
+	ComputeHomography(ref_camera, src_camera, plane_hypothesis, H);
+	float2 pt = ComputeCorrespondingPoint(H, p);
+	if (pt.x >= src_camera.width || pt.x < 0.0f || pt.y >= src_camera.height || pt.y < 0.0f) {
+		return cost_max;
+	}
+	int radius = h.params.strong_radius;
+	int increment = h.params.strong_increment;
+	if (h.params.use_radius) {
+		radius = h.radius[p.x + p.y * W];
+		increment = ORA_MAX(2, (int)(2.0 * radius / 5.0));
+	}
+
+	float cost = 0.0f;
+	{
+		float sum_ref = 0.0f, sum_ref_ref = 0.0f, sum_src = 0.0f, sum_src_src = 0.0f, sum_ref_src = 0.0f;
+		float bilateral_weight_sum = 0.0f;
+		const float ref_center_pix = tex_texel(ref_image, W, Hh, p.x, p.y);
+
+		for (int i = -radius; i <= radius; i += increment) {
+			float sum_ref_row = 0.0f, sum_src_row = 0.0f, sum_ref_ref_row = 0.0f;
+			float sum_src_src_row = 0.0f, sum_ref_src_row = 0.0f, bilateral_weight_sum_row = 0.0f;
+			for (int j = -radius; j <= radius; j += increment) {
+				const int2 ref_pt = make_int2(p.x + i, p.y + j);
+				const float ref_pix = tex_texel(ref_image, W, Hh, ref_pt.x, ref_pt.y);
+				float2 src_pt = ComputeCorrespondingPoint(H, ref_pt);
+				const float src_pix = tex_linear(src_image, W, Hh, src_pt.x + 0.5f, src_pt.y + 0.5f, h.sampler);
+				float weight = ComputeBilateralWeight((float)i, (float)j, ref_pix, ref_center_pix, h.params.sigma_spatial, h.params.sigma_color);
+				sum_ref_row += weight * ref_pix;
+				sum_ref_ref_row += weight * ref_pix * ref_pix;
+				sum_src_row += weight * src_pix;
+				sum_src_src_row += weight * src_pix * src_pix;
+				sum_ref_src_row += weight * ref_pix * src_pix;
+				bilateral_weight_sum_row += weight;
+			}
+			sum_ref += sum_ref_row;
+			sum_ref_ref += sum_ref_ref_row;
+			sum_src += sum_src_row;
+			sum_src_src += sum_src_src_row;
+			sum_ref_src += sum_ref_src_row;
+			bilateral_weight_sum += bilateral_weight_sum_row;
+		}
+		const float inv_bilateral_weight_sum = 1.0f / bilateral_weight_sum;
+		sum_ref *= inv_bilateral_weight_sum;
+		sum_ref_ref *= inv_bilateral_weight_sum;
+		sum_src *= inv_bilateral_weight_sum;
+		sum_src_src *= inv_bilateral_weight_sum;
+		sum_ref_src *= inv_bilateral_weight_sum;
+		const float var_ref = sum_ref_ref - sum_ref * sum_ref;
+		const float var_src = sum_src_src - sum_src * sum_src;
+		const float kMinVar = 1e-5f;
+		if (var_ref < kMinVar || var_src < kMinVar) {
+			cost = cost_max;
+		} else {
+			const float covar_src_ref = sum_ref_src - sum_ref * sum_src;
+			const float var_ref_src = sqrtf(var_ref * var_src);
+			cost = fmaxf(0.0f, fminf(cost_max, 1.0f - covar_src_ref / var_ref_src));
+		}
+	}
+	return cost;
+}
+
+// APD.cu:835-1021.  Only valid for WEAK pixels (the reference printf("error") otherwise, :1017).
+float ComputeBilateralNCCNew(const int2 p, const int src_idx, const float4 plane_hypothesis, Ctx& h) {
+	const float* ref_image = h.images[0].data();
+	const Camera& ref_camera = h.cameras[0];
+	const float* src_image = h.images[src_idx].data();
+	const Camera& src_camera = h.cameras[src_idx];
+	const PatchMatchParams& params = h.params;
+	const int width = h.width, height = h.height;
+	const int S = h.num_images - 1;
+	const float cost_max = 2.0f;
+	if (h.count_evals) {
+#pragma omp atomic
+		h.ncc_evals++;
+	}
+
+	float H[9];
+	ComputeHomography(ref_camera, src_camera, plane_hypothesis, H);
+	float2 pt = ComputeCorrespondingPoint(H, p);
+	if (pt.x >= src_camera.width || pt.x < 0.0f || pt.y >= src_camera.height || pt.y < 0.0f) {
+		return cost_max;
+	}
+	float cost = 0.0f;
+	const float ref_center_pix = tex_texel(ref_image, width, height, p.x, p.y);
+	float center_cost = 0.0f, strong_cost = 0.0f;
+	int strong_count = 0;
+	for (int k = 0; k < NEIGHBOUR_NUM; ++k) {
+		const short2 neighbour_pt = GetNeighbourPoint(p, k, h);
+		if (neighbour_pt.x == -1 || neighbour_pt.y == -1) continue;
+		float2 neighbour_src_pt = ComputeCorrespondingPoint(H, make_int2(neighbour_pt.x, neighbour_pt.y));
+		if (neighbour_src_pt.x < 0 || neighbour_src_pt.y < 0 || neighbour_src_pt.x >= width || neighbour_src_pt.y >= height) {
+			if (k != 0) {
+				uint32_t view_info = h.selected_views[neighbour_pt.x + neighbour_pt.y * width];
+				if (isSet(view_info, src_idx - 1)) {
+					strong_cost += cost_max;
+					strong_count++;
+				}
+				continue;
+			} else {
+				return cost_max;
+			}
+		}
+		float sum_ref = 0.0f, sum_ref_ref = 0.0f, sum_src = 0.0f, sum_src_src = 0.0f, sum_ref_src = 0.0f;
+		float bilateral_weight_sum = 0.0f;
+		int radius = (k == 0 ? params.strong_radius : params.weak_radius);
+		int increment = (k == 0 ? params.strong_increment : params.weak_increment);
+		if (params.use_radius && k == 0) {
+			radius = h.radius[p.x + p.y * width];
+			increment = ORA_MAX(2, (int)(2.0 * radius / 5.0));
+		}
+		if (k == 0) {
+			for (int i = -radius; i <= radius; i += increment) {
+				float sum_ref_row = 0.0f, sum_src_row = 0.0f, sum_ref_ref_row = 0.0f;
+				float sum_src_src_row = 0.0f, sum_ref_src_row = 0.0f, bilateral_weight_sum_row = 0.0f;
+				for (int j = -radius; j <= radius; j += increment) {
+					const int2 ref_pt = make_int2(neighbour_pt.x + i, neighbour_pt.y + j);
+					const float ref_pix = tex_texel(ref_image, width, height, ref_pt.x, ref_pt.y);
+					float2 src_pt = ComputeCorrespondingPoint(H, ref_pt);
+					const float src_pix = tex_linear(src_image, width, height, src_pt.x + 0.5f, src_pt.y + 0.5f, h.sampler);
+					float weight = ComputeBilateralWeight_YZL((float)i, (float)j, ref_pix, ref_center_pix, params.sigma_spatial, params.sigma_color);
+					sum_ref_row += weight * ref_pix;
+					sum_ref_ref_row += weight * ref_pix * ref_pix;
+					sum_src_row += weight * src_pix;
+					sum_src_src_row += weight * src_pix * src_pix;
+					sum_ref_src_row += weight * ref_pix * src_pix;
+					bilateral_weight_sum_row += weight;
+				}
+				sum_ref += sum_ref_row;
+				sum_ref_ref += sum_ref_ref_row;
+				sum_src += sum_src_row;
+				sum_src_src += sum_src_src_row;
+				sum_ref_src += sum_ref_src_row;
+				bilateral_weight_sum += bilateral_weight_sum_row;
+			}
+		} else {
+			if (isSet(h.selected_views[neighbour_pt.x + neighbour_pt.y * width], src_idx - 1) == 1) {
+				int nei_center = neighbour_pt.x + neighbour_pt.y * width;
+				for (int kk = 0; kk < 9; kk++) {
+					int i = 0, j = 0;
+					if (kk != 8) {
+						// reference index: nei_center*8*NUM_IMAGES + (src_idx-1)*8 + kk with NUM_IMAGES=4
+						// (APD.cu:940, aliases for S>4); here the per-pixel stride is S.
+						const short2 c = h.candidate[((size_t)nei_center * S + (src_idx - 1)) * LAB_BOUNDARY_NUM + kk];
+						i = c.x;
+						j = c.y;
+					}
+					if (i == 0 && j == 0) {
+						if (kk == 0) { i = -5; j = -5; }
+						else if (kk == 1) { i = -5; j = 0; }
+						else if (kk == 2) { i = -5; j = 5; }
+						else if (kk == 3) { i = 0; j = -5; }
+						else if (kk == 4) { i = 0; j = 5; }
+						else if (kk == 5) { i = 5; j = -5; }
+						else if (kk == 6) { i = 5; j = 0; }
+						else if (kk == 7) { i = 5; j = 5; }
+					}
+					const int2 ref_pt = make_int2(neighbour_pt.x + i, neighbour_pt.y + j);
+					const float ref_pix = tex_texel(ref_image, width, height, ref_pt.x, ref_pt.y);
+					float2 src_pt = ComputeCorrespondingPoint(H, ref_pt);
+					const float src_pix = tex_linear(src_image, width, height, src_pt.x + 0.5f, src_pt.y + 0.5f, h.sampler);
+					float weight = ComputeBilateralWeight_YZL((float)i, (float)j, ref_pix, ref_center_pix, params.sigma_spatial, params.sigma_color);
+					// one-element "rows" (APD.cu:953-976): 0 + x is exact, so plain accumulation
+					sum_ref += (0.0f + weight * ref_pix);
+					sum_ref_ref += (0.0f + weight * ref_pix * ref_pix);
+					sum_src += (0.0f + weight * src_pix);
+					sum_src_src += (0.0f + weight * src_pix * src_pix);
+					sum_ref_src += (0.0f + weight * ref_pix * src_pix);
+					bilateral_weight_sum += (0.0f + weight);
+				}
+			}
+		}
+		// When the anchor is not visible in this view all sums are 0: 1/0 = inf, 0*inf = NaN,
+		// the kMinVar test is false for NaN and CUDA's fminf/fmaxf drop the NaN: cost == 2.
+		const float inv_bilateral_weight_sum = 1.0f / bilateral_weight_sum;
+		sum_ref *= inv_bilateral_weight_sum;
+		sum_ref_ref *= inv_bilateral_weight_sum;
+		sum_src *= inv_bilateral_weight_sum;
+		sum_src_src *= inv_bilateral_weight_sum;
+		sum_ref_src *= inv_bilateral_weight_sum;
+		const float var_ref = sum_ref_ref - sum_ref * sum_ref;
+		const float var_src = sum_src_src - sum_src * sum_src;
+		const float kMinVar = 1e-5f;
+		float temp_cost = 0.0f;
+		if (var_ref < kMinVar || var_src < kMinVar) {
+			temp_cost = cost_max;
+		} else {
+			const float covar_src_ref = sum_ref_src - sum_ref * sum_src;
+			const float var_ref_src = sqrtf(var_ref * var_src);
+			temp_cost = fmaxf(0.0f, fminf(cost_max, 1.0f - covar_src_ref / var_ref_src));
+		}
+		if (k == 0) {
+			center_cost = temp_cost;
+		} else {
+			strong_cost += temp_cost;
+			strong_count++;
+		}
+	}
+	if (strong_count == 0) {
+		cost = center_cost;
+	} else {
+		strong_cost /= strong_count;
+		strong_cost = ORA_MIN(strong_cost, cost_max);
+		cost = (float)(0.25 * center_cost + 0.75 * strong_cost);   // double arithmetic, APD.cu:1013
+	}
+	return cost;
+}
+
+// APD.cu:1218-1256
+float ComputeGeomConsistencyCost(const int2 p, const int src_idx, const float4 plane_hypothesis, Ctx& h) {
+	const Camera& ref_camera = h.cameras[0];
+	const Camera& src_camera = h.cameras[src_idx];
+	const float* depth_image = h.depths[src_idx].data();
+	const float max_cost = 3.0f;
+	float center_cost = 0.0f;
+	{
+		float depth = ComputeDepthfromPlaneHypothesis(ref_camera, plane_hypothesis, p);
+		float3 forward_point = Get3DPointonWorld_cu((float)p.x, (float)p.y, depth, ref_camera);
+		float2 src_pt;
+		float src_d;
+		ProjectonCamera_cu(forward_point, src_camera, src_pt, src_d);
+		// tex2D(depth, (int)x + 0.5f, (int)y + 0.5f): exact texel, clamp.  (int) of a NaN/huge
+		// value is undefined in C++; defined here as clamp-to-range first (NaN -> 0).
+		const float cx = fminf(fmaxf(src_pt.x, -1.0f), (float)h.width);
+		const float cy = fminf(fmaxf(src_pt.y, -1.0f), (float)h.height);
+		const float src_depth = tex_texel(depth_image, h.width, h.height, (int)cx, (int)cy);
+		if (src_depth == 0.0f) return max_cost;
+		float3 src_3D_pt = Get3DPointonWorld_cu(src_pt.x, src_pt.y, src_depth, src_camera);
+		float2 backward_point;
+		float ref_d;
+		ProjectonCamera_cu(src_3D_pt, ref_camera, backward_point, ref_d);
+		const float diff_col = p.x - backward_point.x;
+		const float diff_row = p.y - backward_point.y;
+		center_cost = sqrtf(diff_col * diff_col + diff_row * diff_row);
+	}
+	return fminf(max_cost, center_cost);
+}
+
+}  // namespace ora

@@ -1,0 +1,258 @@
+// TEST INFRASTRUCTURE — host emulation of the engine's kernels.
+//
+// Compiles the SAME device headers the HIP engine is built from (dvp-mvs_amd/csrc/*.hpp) with
+// g++ and emulates kernel launches by looping over (block, wave, lane) through the same
+// block->pixel map.  Purpose: check kernel logic, launch geometry and bit-parity against the CPU
+// oracle on machines without a GPU (`pytest -m "not gpu"`).  It is built only by the test suite
+// into tests/emul/; libdvp_mvs_hip.so neither contains nor falls back to it.
+#include "../../dvp-mvs_amd/csrc/dvp_stages.hpp"
+#include <cstring>
+#include <vector>
+
+using namespace dvp;
+
+namespace {
+
+struct Emu {
+	int W, H, NI, pitch;
+	std::vector<float> images, depths;
+	std::vector<DvpCamera> cameras;
+	std::vector<ViewConst> views;
+	std::vector<uint8_t> lut;
+	std::vector<f4> planes, planes_snap, fit_planes;
+	std::vector<float> costs, costs_snap, complex_;
+	std::vector<uint32_t> selected_views;
+	std::vector<uint8_t> view_weight, weak_info, weak_reliable, edge;
+	std::vector<s2> weak_nearest_strong, neighbours, candidate, edge_neigh, label_boundary;
+	std::vector<int> neighbours_map, label, radius;
+	unsigned long long evals = 0;
+	bool count = false;
+	Dev d;
+};
+
+void refresh(Emu& e) {
+	Dev& d = e.d;
+	d.width = e.W; d.height = e.H; d.num_images = e.NI; d.pitch = e.pitch;
+	d.plane_stride = (size_t)e.pitch * e.H;
+	d.images = e.images.data();
+	d.depths = e.depths.data();
+	d.cameras = e.cameras.data();
+	d.views = e.views.data();
+	d.sector_lut = e.lut.data();
+	d.planes = e.planes.data(); d.planes_snap = e.planes_snap.data();
+	d.costs = e.costs.data(); d.costs_snap = e.costs_snap.data();
+	d.selected_views = e.selected_views.data();
+	d.view_weight = e.view_weight.data();
+	d.weak_info = e.weak_info.data();
+	d.weak_reliable = e.weak_reliable.data();
+	d.weak_nearest_strong = e.weak_nearest_strong.data();
+	d.neighbours_map = e.neighbours_map.data();
+	d.neighbours = e.neighbours.data();
+	d.fit_planes = e.fit_planes.data();
+	d.candidate = e.candidate.data();
+	d.edge = e.edge.data();
+	d.edge_neigh = e.edge_neigh.data();
+	d.label = e.label.data();
+	d.label_boundary = e.label_boundary.data();
+	d.complex_ = e.complex_.data();
+	d.radius = e.radius.data();
+	d.eval_counter = nullptr;
+}
+
+template <int STAGE>
+void launch(Emu& e, int iter, int colour) {
+	const LaunchGeom g = make_geom(e.W, e.H, stage_is_half(STAGE));
+	unsigned long long total = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+	for (int b = 0; b < g.grid(); ++b)
+		for (int wave = 0; wave < 4; ++wave)
+			for (int lane = 0; lane < 64; ++lane) {
+				int px, py;
+				if (!block_to_pixel(b, lane, wave, g.tiles_x, g.tiles, g.chunk, g.rows, g.half ? 1 : 0, colour, e.W, e.H, &px, &py)) continue;
+				unsigned long long n = 0;
+				run_pixel<STAGE>(e.d, px, py, iter, e.count ? &n : nullptr);
+				total += n;
+			}
+	e.evals += total;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* emu_create(int W, int H, int NI) {
+	Emu* e = new Emu();
+	e->W = W; e->H = H; e->NI = NI;
+	e->pitch = (W + 63) / 64 * 64;
+	const size_t L = (size_t)W * H;
+	const int S = NI - 1;
+	e->images.assign((size_t)e->pitch * H * NI, 0.0f);
+	e->depths.assign((size_t)e->pitch * H * NI, 0.0f);
+	e->cameras.resize(NI);
+	e->views.resize(NI);
+	e->planes.assign(L, mk4(0, 0, 0, 0));
+	e->planes_snap = e->planes;
+	e->fit_planes = e->planes;
+	e->costs.assign(L, 0.0f);
+	e->costs_snap = e->costs;
+	e->selected_views.assign(L + W, 0u);
+	e->view_weight.assign(L * 32, 0);
+	e->weak_info.assign(L, (uint8_t)DVP_STRONG);
+	e->weak_reliable.assign(L, 0);
+	e->weak_nearest_strong.assign(L, mks2(-1, -1));
+	e->neighbours_map.assign(L, 0);
+	e->neighbours.assign(DVP_NEIGHBOUR_NUM, mks2(-1, -1));
+	e->candidate.assign(L * (size_t)(S > 0 ? S : 1) * 8, mks2(0, 0));
+	e->edge.assign(L, 0);
+	e->edge_neigh.assign(L * 8, mks2(-1, -1));
+	e->label.assign(L, 0);
+	e->label_boundary.assign(8, mks2(-1, -1));
+	e->complex_.assign(1, 0.0f);
+	e->radius.assign(L, 5);
+	std::memset(&e->d, 0, sizeof(Dev));
+	e->lut = make_sector_lut(5);
+	refresh(*e);
+	return e;
+}
+void emu_destroy(void* c) { delete (Emu*)c; }
+void emu_set_image(void* c, int idx, const float* data) {
+	Emu& e = *(Emu*)c;
+	for (int y = 0; y < e.H; ++y) std::memcpy(&e.images[((size_t)idx * e.H + y) * e.pitch], data + (size_t)y * e.W, e.W * 4);
+}
+void emu_set_depth(void* c, int idx, const float* data) {
+	Emu& e = *(Emu*)c;
+	for (int y = 0; y < e.H; ++y) std::memcpy(&e.depths[((size_t)idx * e.H + y) * e.pitch], data + (size_t)y * e.W, e.W * 4);
+}
+void emu_set_cameras(void* c, const DvpCamera* cams, int n) {
+	Emu& e = *(Emu*)c;
+	for (int i = 0; i < n; ++i) e.cameras[i] = cams[i];
+	for (int i = 1; i < n; ++i) compute_view_const(e.cameras[0], e.cameras[i], &e.views[i]);
+}
+void emu_set_params(void* c, const DvpParams* p) {
+	Emu& e = *(Emu*)c;
+	e.d.params = *p;
+	set_neighbour_consts(&e.d);
+	e.lut = make_sector_lut(p->weak_radius);
+	refresh(e);
+}
+void emu_set_seed(void* c, uint64_t s) { ((Emu*)c)->d.seed = s; }
+void emu_set_sampler(void* c, int s) { ((Emu*)c)->d.sampler = s; }
+void emu_count_evals(void* c, int on) { Emu& e = *(Emu*)c; e.count = on != 0; e.evals = 0; }
+long long emu_get_evals(void* c) { return (long long)((Emu*)c)->evals; }
+
+void emu_upload_state(void* c, const f4* planes, const uint32_t* views, const uint8_t* weak,
+	const uint8_t* edge, const int* label, const int* radius) {
+	Emu& e = *(Emu*)c;
+	const size_t L = (size_t)e.W * e.H;
+	if (planes) std::memcpy(e.planes.data(), planes, L * sizeof(f4));
+	if (views) std::memcpy(e.selected_views.data(), views, L * 4);
+	if (edge) std::memcpy(e.edge.data(), edge, L);
+	if (label) std::memcpy(e.label.data(), label, L * 4);
+	if (radius) std::memcpy(e.radius.data(), radius, L * 4);
+	if (weak) std::memcpy(e.weak_info.data(), weak, L);
+	int wc = 0;
+	for (size_t i = 0; i < L; ++i) {
+		e.neighbours_map[i] = 0;
+		if (e.weak_info[i] == DVP_WEAK) e.neighbours_map[i] = wc++;
+	}
+	e.d.weak_count = wc;
+	const size_t n = (size_t)(wc > 0 ? wc : 1);
+	e.neighbours.assign(n * DVP_NEIGHBOUR_NUM, mks2(-1, -1));
+	e.complex_.assign(n, 0.0f);
+	e.label_boundary.assign(n * 8, mks2(-1, -1));
+	refresh(e);
+}
+
+static void* buf_ptr(Emu& e, int id, size_t* bytes) {
+	const size_t L = (size_t)e.W * e.H;
+	switch (id) {
+	case DVP_BUF_PLANES: *bytes = L * 16; return e.planes.data();
+	case DVP_BUF_COSTS: *bytes = L * 4; return e.costs.data();
+	case DVP_BUF_SELECTED_VIEWS: *bytes = L * 4; return e.selected_views.data();
+	case DVP_BUF_VIEW_WEIGHT: *bytes = L * 32; return e.view_weight.data();
+	case DVP_BUF_WEAK_INFO: *bytes = L; return e.weak_info.data();
+	case DVP_BUF_WEAK_RELIABLE: *bytes = L; return e.weak_reliable.data();
+	case DVP_BUF_WEAK_NEAREST_STRONG: *bytes = L * 4; return e.weak_nearest_strong.data();
+	case DVP_BUF_NEIGHBOURS_MAP: *bytes = L * 4; return e.neighbours_map.data();
+	case DVP_BUF_NEIGHBOURS: *bytes = e.neighbours.size() * 4; return e.neighbours.data();
+	case DVP_BUF_FIT_PLANES: *bytes = L * 16; return e.fit_planes.data();
+	case DVP_BUF_CANDIDATE: *bytes = e.candidate.size() * 4; return e.candidate.data();
+	case DVP_BUF_EDGE: *bytes = L; return e.edge.data();
+	case DVP_BUF_EDGE_NEIGH: *bytes = L * 32; return e.edge_neigh.data();
+	case DVP_BUF_LABEL: *bytes = L * 4; return e.label.data();
+	case DVP_BUF_LABEL_BOUNDARY: *bytes = e.label_boundary.size() * 4; return e.label_boundary.data();
+	case DVP_BUF_COMPLEX: *bytes = e.complex_.size() * 4; return e.complex_.data();
+	case DVP_BUF_RADIUS: *bytes = L * 4; return e.radius.data();
+	}
+	*bytes = 0;
+	return nullptr;
+}
+long long emu_buffer_bytes(void* c, int id) { size_t b; buf_ptr(*(Emu*)c, id, &b); return (long long)b; }
+int emu_get_buffer(void* c, int id, void* dst) { size_t b; void* p = buf_ptr(*(Emu*)c, id, &b); if (!p) return -1; std::memcpy(dst, p, b); return 0; }
+int emu_set_buffer(void* c, int id, const void* src) { size_t b; void* p = buf_ptr(*(Emu*)c, id, &b); if (!p) return -1; std::memcpy(p, src, b); return 0; }
+int emu_weak_count(void* c) { return ((Emu*)c)->d.weak_count; }
+
+int emu_run_stage(void* c, int stage, int iter, int colour) {
+	Emu& e = *(Emu*)c;
+	switch (stage) {
+	case DVP_ST_GEN_EDGE_INFORM: launch<DVP_ST_GEN_EDGE_INFORM>(e, iter, colour); break;
+	case DVP_ST_FIND_NEAREST_STRONG: launch<DVP_ST_FIND_NEAREST_STRONG>(e, iter, colour); break;
+	case DVP_ST_GEN_NEIGHBOURS: launch<DVP_ST_GEN_NEIGHBOURS>(e, iter, colour); break;
+	case DVP_ST_NEIGHBOUR_UPDATE: launch<DVP_ST_NEIGHBOUR_UPDATE>(e, iter, colour); break;
+	case DVP_ST_RANDOM_INIT: launch<DVP_ST_RANDOM_INIT>(e, iter, colour); break;
+	case DVP_ST_STRONG_UPDATE:
+		e.planes_snap = e.planes;
+		e.costs_snap = e.costs;
+		refresh(e);
+		launch<DVP_ST_STRONG_UPDATE>(e, iter, colour);
+		break;
+	case DVP_ST_RANSAC_FIT: launch<DVP_ST_RANSAC_FIT>(e, iter, colour); break;
+	case DVP_ST_WEAK_UPDATE: launch<DVP_ST_WEAK_UPDATE>(e, iter, colour); break;
+	case DVP_ST_GET_DEPTH_NORMAL: launch<DVP_ST_GET_DEPTH_NORMAL>(e, iter, colour); break;
+	case DVP_ST_FILTER_STRONG: launch<DVP_ST_FILTER_STRONG>(e, iter, colour); break;
+	case DVP_ST_DEPTH_TO_WEAK: launch<DVP_ST_DEPTH_TO_WEAK>(e, iter, colour); break;
+	case DVP_ST_LOCAL_REFINE: launch<DVP_ST_LOCAL_REFINE>(e, iter, colour); break;
+	default: return -1;
+	}
+	return 0;
+}
+
+int emu_run_patchmatch(void* c) {
+	Emu& e = *(Emu*)c;
+	emu_run_stage(c, DVP_ST_GEN_EDGE_INFORM, 0, 0);
+	emu_run_stage(c, DVP_ST_FIND_NEAREST_STRONG, 0, 0);
+	emu_run_stage(c, DVP_ST_GEN_NEIGHBOURS, 0, 0);
+	emu_run_stage(c, DVP_ST_NEIGHBOUR_UPDATE, 0, 0);
+	emu_run_stage(c, DVP_ST_RANDOM_INIT, 0, 0);
+	for (int i = 0; i < e.d.params.max_iterations; ++i) {
+		emu_run_stage(c, DVP_ST_STRONG_UPDATE, i, 0);
+		emu_run_stage(c, DVP_ST_STRONG_UPDATE, i, 1);
+		emu_run_stage(c, DVP_ST_RANSAC_FIT, i, 0);
+		emu_run_stage(c, DVP_ST_WEAK_UPDATE, i, 0);
+		emu_run_stage(c, DVP_ST_WEAK_UPDATE, i, 1);
+	}
+	emu_run_stage(c, DVP_ST_GET_DEPTH_NORMAL, 0, 0);
+	emu_run_stage(c, DVP_ST_FILTER_STRONG, 0, 0);
+	emu_run_stage(c, DVP_ST_FILTER_STRONG, 0, 1);
+	emu_run_stage(c, DVP_ST_DEPTH_TO_WEAK, 0, 0);
+	emu_run_stage(c, DVP_ST_LOCAL_REFINE, 0, 0);
+	return 0;
+}
+
+float emu_expf(float x) { return dvp_expf(x); }
+void emu_eval_cost_vectors(void* c, const int* px, const float* planes, int n, float* out) {
+	Emu& e = *(Emu*)c;
+	const int S = e.NI - 1;
+#pragma omp parallel for schedule(dynamic, 64)
+	for (int i = 0; i < n; ++i) {
+		const int x = px[2 * i], y = px[2 * i + 1];
+		PatchCtx pc;
+		int radius, inc;
+		patch_geometry(e.d, x + y * e.W, &radius, &inc);
+		build_patch_ctx(e.d, x, y, radius, inc, 0, &pc);
+		for (int v = 0; v < S; ++v)
+			out[(size_t)i * S + v] = ncc_old(e.d, pc, x, y, v + 1, mk4(planes[4 * i], planes[4 * i + 1], planes[4 * i + 2], planes[4 * i + 3]));
+	}
+}
+
+}  // extern "C"
