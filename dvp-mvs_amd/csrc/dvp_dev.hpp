@@ -16,8 +16,8 @@
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
-#define DVP_HD __device__ __forceinline__
-#define DVP_HD_NOINLINE __device__ __noinline__
+#define DVP_HD __host__ __device__ __forceinline__
+#define DVP_HD_NOINLINE __host__ __device__ __noinline__
 #else
 #define DVP_HD inline
 #define DVP_HD_NOINLINE inline

@@ -1,0 +1,593 @@
+// dvp_engine.hip — gfx950 kernels + the C ABI of include/dvp_mvs.h.
+//
+// Replaces APD::CudaSpaceInitialization / SetDataPassHelperInCuda / RunPatchMatch
+// (/root/reference/APD.cpp:1497-1613, 1670-1704; APD.cu:4406-4532).  One context owns one HIP
+// stream and every device buffer of one reference view; launches are queued back to back on that
+// stream (the reference calls cudaDeviceSynchronize after each of its 16+5*iters launches).
+#include "dvp_stages.hpp"
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+
+using namespace dvp;
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+struct LaunchArgs {
+	int tiles_x, tiles, chunk, rows, half, colour, iter;
+};
+
+template <int STAGE>
+__device__ __forceinline__ void stage_body(const Dev& d, const LaunchArgs& a) {
+	const int lane = threadIdx.x & 63;
+	const int wave = threadIdx.x >> 6;
+	int px, py;
+	unsigned long long n = 0;
+	if (block_to_pixel(blockIdx.x, lane, wave, a.tiles_x, a.tiles, a.chunk, a.rows, a.half, a.colour, d.width, d.height, &px, &py))
+		run_pixel<STAGE>(d, px, py, a.iter, d.eval_counter ? &n : nullptr);
+	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
+}
+
+// One named kernel per launch site so that rocprofv3 --kernel-trace shows the reference's names.
+#define DVP_KERNEL(NAME, STAGE, MINW)                                                              \
+	extern "C" __global__ void __launch_bounds__(256, MINW) NAME(const Dev d, const LaunchArgs a) { \
+		stage_body<STAGE>(d, a);                                                                    \
+	}
+
+DVP_KERNEL(dvp_gen_edge_inform, DVP_ST_GEN_EDGE_INFORM, 1)
+DVP_KERNEL(dvp_find_nearest_strong, DVP_ST_FIND_NEAREST_STRONG, 1)
+DVP_KERNEL(dvp_gen_neighbours, DVP_ST_GEN_NEIGHBOURS, 1)
+DVP_KERNEL(dvp_neighbour_update, DVP_ST_NEIGHBOUR_UPDATE, 1)
+DVP_KERNEL(dvp_random_init, DVP_ST_RANDOM_INIT, 4)
+DVP_KERNEL(dvp_strong_update, DVP_ST_STRONG_UPDATE, 4)
+DVP_KERNEL(dvp_ransac_fit_plane, DVP_ST_RANSAC_FIT, 1)
+DVP_KERNEL(dvp_weak_update, DVP_ST_WEAK_UPDATE, 2)
+DVP_KERNEL(dvp_get_depth_normal, DVP_ST_GET_DEPTH_NORMAL, 1)
+DVP_KERNEL(dvp_filter_strong, DVP_ST_FILTER_STRONG, 1)
+DVP_KERNEL(dvp_depth_to_weak, DVP_ST_DEPTH_TO_WEAK, 4)
+DVP_KERNEL(dvp_local_refine, DVP_ST_LOCAL_REFINE, 4)
+
+extern "C" __global__ void dvp_prepare_views(const DvpCamera* cams, ViewConst* views, int n) {
+	const int v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= 1 && v < n) compute_view_const(cams[0], cams[v], &views[v]);
+}
+
+// ComputeMultiViewCostVectorOld over a list of (pixel, plane) pairs — KATs and the roofline
+// micro-benchmark.  One lane per pair.
+extern "C" __global__ void __launch_bounds__(256) dvp_cost_vectors(const Dev d, const int* px, const f4* planes, int n, float* out) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const int x = px[2 * i], y = px[2 * i + 1];
+	const int S = d.num_images - 1;
+	PatchCtx c;
+	int radius, inc;
+	patch_geometry(d, x + y * d.width, &radius, &inc);
+	build_patch_ctx(d, x, y, radius, inc, 0, &c);
+	const f4 pl = planes[i];
+	for (int v = 0; v < S; ++v) out[(size_t)i * S + v] = ncc_old(d, c, x, y, v + 1, pl);
+}
+
+// same computation on every pixel with its current plane (camera frame); writes the view-mean
+extern "C" __global__ void __launch_bounds__(256) dvp_cost_all_pixels(const Dev d, const LaunchArgs a, float* out) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	int px, py;
+	if (!block_to_pixel(blockIdx.x, lane, wave, a.tiles_x, a.tiles, a.chunk, a.rows, 0, 0, d.width, d.height, &px, &py)) return;
+	const int center = px + py * d.width;
+	const int S = d.num_images - 1;
+	PatchCtx c;
+	int radius, inc;
+	patch_geometry(d, center, &radius, &inc);
+	build_patch_ctx(d, px, py, radius, inc, 0, &c);
+	const f4 pl = d.planes[center];
+	float acc = 0.0f;
+	for (int v = 0; v < S; ++v) acc += ncc_old(d, c, px, py, v + 1, pl);
+	out[center] = acc / S;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct EventPair { int stage; hipEvent_t a, b; };
+
+struct dvp_ctx {
+	int device = 0;
+	int W = 0, H = 0, NI = 0, pitch = 0;
+	size_t L = 0;
+	hipStream_t stream = nullptr;
+	Dev d{};
+	std::vector<void*> allocs;
+	// named device buffers
+	float* images = nullptr; float* depths = nullptr;
+	DvpCamera* cameras = nullptr; ViewConst* views = nullptr; uint8_t* lut = nullptr;
+	f4* planes = nullptr; f4* planes_snap = nullptr; f4* fit_planes = nullptr;
+	float* costs = nullptr; float* costs_snap = nullptr; float* complex_ = nullptr;
+	uint32_t* selected_views = nullptr;
+	uint8_t* view_weight = nullptr; uint8_t* weak_info = nullptr; uint8_t* weak_reliable = nullptr; uint8_t* edge = nullptr;
+	s2* weak_nearest_strong = nullptr; s2* neighbours = nullptr; s2* candidate = nullptr; s2* edge_neigh = nullptr; s2* label_boundary = nullptr;
+	int* neighbours_map = nullptr; int* label = nullptr; int* radius = nullptr;
+	unsigned long long* eval_counter = nullptr;
+	float* scratch_out = nullptr;
+	size_t weak_alloc = 0;       // capacity (in WEAK pixels) of the per-WEAK buffers
+	int lut_radius = -1;
+	bool have_depths = false;
+	bool profiling = false;
+	std::vector<EventPair> events;
+	hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr, ev_iter_a = nullptr, ev_iter_b = nullptr;
+	bool total_pending = false;
+	DvpTimings timings{};
+	std::string error;
+};
+
+static std::string g_create_error;
+
+#define HIP_TRY(ctx, expr)                                                                          \
+	do {                                                                                            \
+		hipError_t e_ = (expr);                                                                     \
+		if (e_ != hipSuccess) {                                                                     \
+			char buf_[512];                                                                         \
+			snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+			(ctx)->error = buf_;                                                                    \
+			return 1;                                                                               \
+		}                                                                                           \
+	} while (0)
+
+template <class T>
+static int dalloc(dvp_ctx* c, T** p, size_t count, bool zero = true) {
+	void* q = nullptr;
+	const size_t bytes = (count ? count : 1) * sizeof(T);
+	HIP_TRY(c, hipMalloc(&q, bytes));
+	c->allocs.push_back(q);
+	if (zero) HIP_TRY(c, hipMemsetAsync(q, 0, bytes, c->stream));
+	*p = (T*)q;
+	return 0;
+}
+
+static void sync_dev_struct(dvp_ctx* c) {
+	Dev& d = c->d;
+	d.width = c->W; d.height = c->H; d.num_images = c->NI; d.pitch = c->pitch;
+	d.plane_stride = (size_t)c->pitch * c->H;
+	d.images = c->images; d.depths = c->depths; d.cameras = c->cameras; d.views = c->views; d.sector_lut = c->lut;
+	d.planes = c->planes; d.planes_snap = c->planes_snap; d.costs = c->costs; d.costs_snap = c->costs_snap;
+	d.selected_views = c->selected_views; d.view_weight = c->view_weight; d.weak_info = c->weak_info;
+	d.weak_reliable = c->weak_reliable; d.weak_nearest_strong = c->weak_nearest_strong;
+	d.neighbours_map = c->neighbours_map; d.neighbours = c->neighbours; d.fit_planes = c->fit_planes;
+	d.candidate = c->candidate; d.edge = c->edge; d.edge_neigh = c->edge_neigh; d.label = c->label;
+	d.label_boundary = c->label_boundary; d.complex_ = c->complex_; d.radius = c->radius;
+	d.eval_counter = c->profiling ? c->eval_counter : nullptr;
+}
+
+static int set_device(dvp_ctx* c) {
+	HIP_TRY(c, hipSetDevice(c->device));
+	return 0;
+}
+
+extern "C" {
+
+int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** out) {
+	if (!out) return 1;
+	*out = nullptr;
+	if (width <= 0 || height <= 0 || num_images < 2 || num_images > DVP_MAX_IMAGES || width > 32767 || height > 32767) {
+		g_create_error = "dvp_ctx_create: bad dimensions (2 <= num_images <= 32, sizes <= 32767: short2 pixel coordinates)";
+		return 1;
+	}
+	dvp_ctx* c = new dvp_ctx();
+	c->device = device; c->W = width; c->H = height; c->NI = num_images;
+	c->pitch = (width + 63) / 64 * 64;
+	c->L = (size_t)width * height;
+	auto fail = [&](int) { g_create_error = c->error; dvp_ctx_destroy(c); return 1; };
+	if (set_device(c)) return fail(0);
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->error = "hipStreamCreate failed"; return fail(0); }
+	const size_t L = c->L, S = (size_t)num_images - 1, plane = (size_t)c->pitch * height;
+	int r = 0;
+	r |= dalloc(c, &c->images, plane * num_images);
+	r |= dalloc(c, &c->cameras, (size_t)num_images);
+	r |= dalloc(c, &c->views, (size_t)num_images);
+	r |= dalloc(c, &c->planes, L);
+	r |= dalloc(c, &c->planes_snap, L);
+	r |= dalloc(c, &c->fit_planes, L);                     // cudaMemset 0, APD.cpp:1571
+	r |= dalloc(c, &c->costs, L);
+	r |= dalloc(c, &c->costs_snap, L);
+	r |= dalloc(c, &c->selected_views, L + (size_t)width); // + one zeroed row (APD.cu:2473)
+	r |= dalloc(c, &c->view_weight, L * 32);
+	r |= dalloc(c, &c->weak_info, L);
+	r |= dalloc(c, &c->weak_reliable, L);
+	r |= dalloc(c, &c->weak_nearest_strong, L);
+	r |= dalloc(c, &c->neighbours_map, L);
+	r |= dalloc(c, &c->candidate, L * S * 8);
+	r |= dalloc(c, &c->edge, L);
+	r |= dalloc(c, &c->edge_neigh, L * 8);
+	r |= dalloc(c, &c->label, L);
+	r |= dalloc(c, &c->radius, L);
+	r |= dalloc(c, &c->eval_counter, (size_t)1);
+	r |= dalloc(c, &c->scratch_out, L);
+	if (r) return fail(0);
+	// defaults: every pixel STRONG (APD.cpp:1196-1204), radius = strong_radius (APD.cpp:1649-1653)
+	{
+		std::vector<uint8_t> st(L, (uint8_t)DVP_STRONG);
+		std::vector<int> rad(L, 5);
+		std::vector<s2> m1(L * 8, mks2(-1, -1));
+		if (hipMemcpyAsync(c->weak_info, st.data(), L, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+			hipMemcpyAsync(c->radius, rad.data(), L * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+			hipMemcpyAsync(c->edge_neigh, m1.data(), L * 8 * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+			hipMemcpyAsync(c->weak_nearest_strong, m1.data(), L * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+			hipStreamSynchronize(c->stream) != hipSuccess) { c->error = "default state upload failed"; return fail(0); }
+	}
+	std::memset(&c->d.params, 0, sizeof(DvpParams));
+	c->d.params.num_images = num_images;
+	c->d.params.strong_radius = 5; c->d.params.strong_increment = 2; c->d.params.weak_radius = 5; c->d.params.weak_increment = 5;
+	c->d.params.rotate_time = 4;
+	hipEventCreate(&c->ev_total_a); hipEventCreate(&c->ev_total_b);
+	hipEventCreate(&c->ev_iter_a); hipEventCreate(&c->ev_iter_b);
+	sync_dev_struct(c);
+	*out = c;
+	return 0;
+}
+
+int dvp_ctx_destroy(dvp_ctx* c) {
+	if (!c) return 0;
+	hipSetDevice(c->device);
+	if (c->stream) hipStreamSynchronize(c->stream);
+	for (auto& e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+	if (c->ev_total_a) { hipEventDestroy(c->ev_total_a); hipEventDestroy(c->ev_total_b); hipEventDestroy(c->ev_iter_a); hipEventDestroy(c->ev_iter_b); }
+	for (void* p : c->allocs) hipFree(p);
+	if (c->stream) hipStreamDestroy(c->stream);
+	delete c;
+	return 0;
+}
+
+const char* dvp_last_error(const dvp_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+static int upload_planes(dvp_ctx* c, float* dst, const float* const* src, int pitch_floats, hipMemcpyKind kind) {
+	if (set_device(c)) return 1;
+	if (pitch_floats < c->W) { c->error = "pitch_floats < width"; return 1; }
+	for (int i = 0; i < c->NI; ++i) {
+		if (!src[i]) { c->error = "null image pointer"; return 1; }
+		HIP_TRY(c, hipMemcpy2DAsync(dst + (size_t)i * c->pitch * c->H, (size_t)c->pitch * 4, src[i], (size_t)pitch_floats * 4,
+		                            (size_t)c->W * 4, (size_t)c->H, kind, c->stream));
+	}
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+int dvp_upload_images(dvp_ctx* c, const float* const* images, int pitch_floats) {
+	return upload_planes(c, c->images, images, pitch_floats, hipMemcpyHostToDevice);
+}
+int dvp_upload_images_device(dvp_ctx* c, const float* const* images, int pitch_floats) {
+	return upload_planes(c, c->images, images, pitch_floats, hipMemcpyDeviceToDevice);
+}
+static int ensure_depths(dvp_ctx* c) {
+	if (!c->depths) {
+		if (dalloc(c, &c->depths, (size_t)c->pitch * c->H * c->NI)) return 1;
+		sync_dev_struct(c);
+	}
+	c->have_depths = true;
+	return 0;
+}
+int dvp_upload_depths(dvp_ctx* c, const float* const* depths, int pitch_floats) {
+	if (set_device(c) || ensure_depths(c)) return 1;
+	return upload_planes(c, c->depths, depths, pitch_floats, hipMemcpyHostToDevice);
+}
+int dvp_upload_depths_device(dvp_ctx* c, const float* const* depths, int pitch_floats) {
+	if (set_device(c) || ensure_depths(c)) return 1;
+	return upload_planes(c, c->depths, depths, pitch_floats, hipMemcpyDeviceToDevice);
+}
+
+int dvp_upload_cameras(dvp_ctx* c, const DvpCamera* cams, int n) {
+	if (set_device(c)) return 1;
+	if (n != c->NI) { c->error = "dvp_upload_cameras: n != num_images"; return 1; }
+	HIP_TRY(c, hipMemcpyAsync(c->cameras, cams, sizeof(DvpCamera) * n, hipMemcpyHostToDevice, c->stream));
+	hipLaunchKernelGGL(dvp_prepare_views, dim3(1), dim3(64), 0, c->stream, c->cameras, c->views, n);
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+static int ensure_weak_buffers(dvp_ctx* c, size_t weak_count) {
+	const size_t need = weak_count ? weak_count : 1;
+	if (need > c->weak_alloc) {
+		// grow (old blocks stay owned by the context until destroy; growth is rare)
+		if (dalloc(c, &c->neighbours, need * DVP_NEIGHBOUR_NUM, false)) return 1;
+		if (dalloc(c, &c->complex_, need)) return 1;
+		if (dalloc(c, &c->label_boundary, need * 8, false)) return 1;
+		c->weak_alloc = need;
+	}
+	HIP_TRY(c, hipMemsetAsync(c->neighbours, 0xFF, need * DVP_NEIGHBOUR_NUM * sizeof(s2), c->stream));   // (-1,-1)
+	HIP_TRY(c, hipMemsetAsync(c->label_boundary, 0xFF, need * 8 * sizeof(s2), c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->complex_, 0, need * 4, c->stream));
+	return 0;
+}
+
+int dvp_upload_state(dvp_ctx* c, const float* planes, const uint32_t* views, const uint8_t* weak,
+                     const uint8_t* edge, const int32_t* label, const int32_t* radius) {
+	if (set_device(c)) return 1;
+	const size_t L = c->L;
+	if (planes) HIP_TRY(c, hipMemcpyAsync(c->planes, planes, L * 16, hipMemcpyHostToDevice, c->stream));
+	if (views) HIP_TRY(c, hipMemcpyAsync(c->selected_views, views, L * 4, hipMemcpyHostToDevice, c->stream));
+	if (edge) HIP_TRY(c, hipMemcpyAsync(c->edge, edge, L, hipMemcpyHostToDevice, c->stream));
+	if (label) HIP_TRY(c, hipMemcpyAsync(c->label, label, L * 4, hipMemcpyHostToDevice, c->stream));
+	if (radius) HIP_TRY(c, hipMemcpyAsync(c->radius, radius, L * 4, hipMemcpyHostToDevice, c->stream));
+	// weak_info -> neighbours_map: running index of WEAK pixels (APD.cpp:1182-1193)
+	std::vector<uint8_t> wi(L);
+	if (weak) {
+		std::memcpy(wi.data(), weak, L);
+		HIP_TRY(c, hipMemcpyAsync(c->weak_info, weak, L, hipMemcpyHostToDevice, c->stream));
+	} else {
+		HIP_TRY(c, hipMemcpyAsync(wi.data(), c->weak_info, L, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+	}
+	std::vector<int> map(L, 0);
+	int wc = 0;
+	for (size_t i = 0; i < L; ++i)
+		if (wi[i] == DVP_WEAK) map[i] = wc++;
+	c->d.weak_count = wc;
+	HIP_TRY(c, hipMemcpyAsync(c->neighbours_map, map.data(), L * 4, hipMemcpyHostToDevice, c->stream));
+	if (ensure_weak_buffers(c, (size_t)wc)) return 1;
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	sync_dev_struct(c);
+	return 0;
+}
+
+int dvp_reset_state(dvp_ctx* c) {
+	if (set_device(c)) return 1;
+	const size_t L = c->L;
+	HIP_TRY(c, hipMemsetAsync(c->planes, 0, L * 16, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->fit_planes, 0, L * 16, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->costs, 0, L * 4, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->selected_views, 0, (L + c->W) * 4, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->view_weight, 0, L * 32, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->weak_info, DVP_STRONG, L, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->neighbours_map, 0, L * 4, c->stream));
+	HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->radius, c->d.params.strong_radius, L, c->stream));
+	c->d.weak_count = 0;
+	if (ensure_weak_buffers(c, 0)) return 1;
+	sync_dev_struct(c);
+	return 0;
+}
+
+int dvp_set_params(dvp_ctx* c, const DvpParams* p) {
+	if (set_device(c)) return 1;
+	if (p->num_images != c->NI) { c->error = "dvp_set_params: params.num_images != context num_images"; return 1; }
+	if (p->use_edge == 0) { c->error = "dvp_set_params: use_edge=false (legacy ACMH sampling, APD.cu:2142-2460) is not implemented"; return 1; }
+	if (p->weak_radius < 0 || p->weak_radius > 15) { c->error = "dvp_set_params: weak_radius out of range [0,15]"; return 1; }
+	c->d.params = *p;
+	set_neighbour_consts(&c->d);
+	if (c->lut_radius != p->weak_radius) {
+		const std::vector<uint8_t> lut = make_sector_lut(p->weak_radius);
+		if (dalloc(c, &c->lut, lut.size(), false)) return 1;
+		HIP_TRY(c, hipMemcpyAsync(c->lut, lut.data(), lut.size(), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		c->lut_radius = p->weak_radius;
+	}
+	sync_dev_struct(c);
+	return 0;
+}
+int dvp_set_seed(dvp_ctx* c, uint64_t seed) { c->d.seed = seed; return 0; }
+int dvp_set_sampler(dvp_ctx* c, int s) { c->d.sampler = s ? 1 : 0; return 0; }
+int dvp_set_profiling(dvp_ctx* c, int on) { c->profiling = on != 0; sync_dev_struct(c); return 0; }
+
+// ---- launches ---------------------------------------------------------------------------------
+static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
+	if (stage < 0 || stage >= DVP_ST_COUNT) { c->error = "bad stage id"; return 1; }
+	if (!c->lut) { c->error = "dvp_set_params must be called before running kernels"; return 1; }
+	if (c->d.params.geom_consistency && !c->have_depths) { c->error = "geom_consistency is on but no depth maps were uploaded"; return 1; }
+	const LaunchGeom g = make_geom(c->W, c->H, stage_is_half(stage));
+	LaunchArgs a;
+	a.tiles_x = g.tiles_x; a.tiles = g.tiles; a.chunk = g.chunk; a.rows = g.rows; a.half = g.half ? 1 : 0;
+	a.colour = colour; a.iter = iter;
+	if (stage == DVP_ST_STRONG_UPDATE) {
+		// pre-launch snapshot: the direction-4 samples of the strong update are same-colour pixels
+		// (APD.cu:2071-2074); every neighbour read of that kernel sees the state before the launch
+		HIP_TRY(c, hipMemcpyAsync(c->planes_snap, c->planes, c->L * 16, hipMemcpyDeviceToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->costs_snap, c->costs, c->L * 4, hipMemcpyDeviceToDevice, c->stream));
+	}
+	EventPair ep;
+	ep.stage = stage;
+	HIP_TRY(c, hipEventCreate(&ep.a));
+	HIP_TRY(c, hipEventCreate(&ep.b));
+	if (c->profiling) HIP_TRY(c, hipMemsetAsync(c->eval_counter, 0, 8, c->stream));
+	HIP_TRY(c, hipEventRecord(ep.a, c->stream));
+	const dim3 grid(g.grid()), block(256);
+	switch (stage) {
+	case DVP_ST_GEN_EDGE_INFORM: hipLaunchKernelGGL(dvp_gen_edge_inform, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_FIND_NEAREST_STRONG: hipLaunchKernelGGL(dvp_find_nearest_strong, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_GEN_NEIGHBOURS: hipLaunchKernelGGL(dvp_gen_neighbours, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(dvp_neighbour_update, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_RANDOM_INIT: hipLaunchKernelGGL(dvp_random_init, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_STRONG_UPDATE: hipLaunchKernelGGL(dvp_strong_update, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(dvp_ransac_fit_plane, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_WEAK_UPDATE: hipLaunchKernelGGL(dvp_weak_update, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_GET_DEPTH_NORMAL: hipLaunchKernelGGL(dvp_get_depth_normal, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_FILTER_STRONG: hipLaunchKernelGGL(dvp_filter_strong, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_DEPTH_TO_WEAK: hipLaunchKernelGGL(dvp_depth_to_weak, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_LOCAL_REFINE: hipLaunchKernelGGL(dvp_local_refine, grid, block, 0, c->stream, c->d, a); break;
+	}
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipEventRecord(ep.b, c->stream));
+	c->events.push_back(ep);
+	if (c->profiling) {
+		unsigned long long n = 0;
+		HIP_TRY(c, hipMemcpyAsync(&n, c->eval_counter, 8, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		c->timings.ncc_evals[stage] += n;
+	}
+	return 0;
+}
+
+int dvp_run_stage(dvp_ctx* c, int stage, int iter, int colour) {
+	if (set_device(c)) return 1;
+	return launch_stage(c, stage, iter, colour);
+}
+
+int dvp_synchronize(dvp_ctx* c) {
+	if (set_device(c)) return 1;
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+// APD::RunPatchMatch (APD.cu:4406-4532): same launch order; no host sync between launches.
+int dvp_run_patchmatch(dvp_ctx* c) {
+	if (set_device(c)) return 1;
+	HIP_TRY(c, hipEventRecord(c->ev_total_a, c->stream));
+	if (launch_stage(c, DVP_ST_GEN_EDGE_INFORM, 0, 0)) return 1;
+	if (launch_stage(c, DVP_ST_FIND_NEAREST_STRONG, 0, 0)) return 1;
+	if (launch_stage(c, DVP_ST_GEN_NEIGHBOURS, 0, 0)) return 1;
+	if (launch_stage(c, DVP_ST_NEIGHBOUR_UPDATE, 0, 0)) return 1;
+	if (launch_stage(c, DVP_ST_RANDOM_INIT, 0, 0)) return 1;
+	HIP_TRY(c, hipEventRecord(c->ev_iter_a, c->stream));
+	for (int i = 0; i < c->d.params.max_iterations; ++i) {
+		if (launch_stage(c, DVP_ST_STRONG_UPDATE, i, 0)) return 1;
+		if (launch_stage(c, DVP_ST_STRONG_UPDATE, i, 1)) return 1;
+		if (c->d.weak_count > 0) {   // these three only touch WEAK pixels
+			if (launch_stage(c, DVP_ST_RANSAC_FIT, i, 0)) return 1;
+			if (launch_stage(c, DVP_ST_WEAK_UPDATE, i, 0)) return 1;
+			if (launch_stage(c, DVP_ST_WEAK_UPDATE, i, 1)) return 1;
+		}
+	}
+	HIP_TRY(c, hipEventRecord(c->ev_iter_b, c->stream));
+	if (launch_stage(c, DVP_ST_GET_DEPTH_NORMAL, 0, 0)) return 1;
+	if (launch_stage(c, DVP_ST_FILTER_STRONG, 0, 0)) return 1;
+	if (launch_stage(c, DVP_ST_FILTER_STRONG, 0, 1)) return 1;
+	if (launch_stage(c, DVP_ST_DEPTH_TO_WEAK, 0, 0)) return 1;
+	if (launch_stage(c, DVP_ST_LOCAL_REFINE, 0, 0)) return 1;
+	HIP_TRY(c, hipEventRecord(c->ev_total_b, c->stream));
+	c->total_pending = true;
+	return 0;
+}
+
+// ---- results ----------------------------------------------------------------------------------
+int dvp_download_state(dvp_ctx* c, float* planes, uint32_t* views, uint8_t* weak, int32_t* radius) {
+	if (set_device(c)) return 1;
+	const size_t L = c->L;
+	if (planes) HIP_TRY(c, hipMemcpyAsync(planes, c->planes, L * 16, hipMemcpyDeviceToHost, c->stream));
+	if (views) HIP_TRY(c, hipMemcpyAsync(views, c->selected_views, L * 4, hipMemcpyDeviceToHost, c->stream));
+	if (weak) HIP_TRY(c, hipMemcpyAsync(weak, c->weak_info, L, hipMemcpyDeviceToHost, c->stream));
+	if (radius) HIP_TRY(c, hipMemcpyAsync(radius, c->radius, L * 4, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+static void* buffer_ptr(dvp_ctx* c, int id, size_t* bytes) {
+	const size_t L = c->L, S = (size_t)c->NI - 1;
+	const size_t wc = c->d.weak_count > 0 ? (size_t)c->d.weak_count : 1;
+	switch (id) {
+	case DVP_BUF_PLANES: *bytes = L * 16; return c->planes;
+	case DVP_BUF_COSTS: *bytes = L * 4; return c->costs;
+	case DVP_BUF_SELECTED_VIEWS: *bytes = L * 4; return c->selected_views;
+	case DVP_BUF_VIEW_WEIGHT: *bytes = L * 32; return c->view_weight;
+	case DVP_BUF_WEAK_INFO: *bytes = L; return c->weak_info;
+	case DVP_BUF_WEAK_RELIABLE: *bytes = L; return c->weak_reliable;
+	case DVP_BUF_WEAK_NEAREST_STRONG: *bytes = L * 4; return c->weak_nearest_strong;
+	case DVP_BUF_NEIGHBOURS_MAP: *bytes = L * 4; return c->neighbours_map;
+	case DVP_BUF_NEIGHBOURS: *bytes = wc * DVP_NEIGHBOUR_NUM * 4; return c->neighbours;
+	case DVP_BUF_FIT_PLANES: *bytes = L * 16; return c->fit_planes;
+	case DVP_BUF_CANDIDATE: *bytes = L * S * 8 * 4; return c->candidate;
+	case DVP_BUF_EDGE: *bytes = L; return c->edge;
+	case DVP_BUF_EDGE_NEIGH: *bytes = L * 8 * 4; return c->edge_neigh;
+	case DVP_BUF_LABEL: *bytes = L * 4; return c->label;
+	case DVP_BUF_LABEL_BOUNDARY: *bytes = wc * 8 * 4; return c->label_boundary;
+	case DVP_BUF_COMPLEX: *bytes = wc * 4; return c->complex_;
+	case DVP_BUF_RADIUS: *bytes = L * 4; return c->radius;
+	}
+	*bytes = 0;
+	return nullptr;
+}
+long long dvp_buffer_bytes(dvp_ctx* c, int id) { size_t b; buffer_ptr(c, id, &b); return (long long)b; }
+int dvp_download_buffer(dvp_ctx* c, int id, void* dst) {
+	if (set_device(c)) return 1;
+	size_t b; void* p = buffer_ptr(c, id, &b);
+	if (!p) { c->error = "bad or unallocated buffer id"; return 1; }
+	HIP_TRY(c, hipMemcpyAsync(dst, p, b, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+int dvp_upload_buffer(dvp_ctx* c, int id, const void* src) {
+	if (set_device(c)) return 1;
+	size_t b; void* p = buffer_ptr(c, id, &b);
+	if (!p) { c->error = "bad or unallocated buffer id"; return 1; }
+	HIP_TRY(c, hipMemcpyAsync(p, src, b, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+int dvp_weak_count(dvp_ctx* c) { return c->d.weak_count; }
+
+int dvp_get_timings(dvp_ctx* c, DvpTimings* out) {
+	if (set_device(c)) return 1;
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	for (auto& e : c->events) {
+		float ms = 0.0f;
+		HIP_TRY(c, hipEventElapsedTime(&ms, e.a, e.b));
+		c->timings.stage_ms[e.stage] += ms;
+		c->timings.stage_launches[e.stage] += 1;
+		hipEventDestroy(e.a);
+		hipEventDestroy(e.b);
+	}
+	c->events.clear();
+	if (c->total_pending) {
+		float ms = 0.0f;
+		HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_total_a, c->ev_total_b));
+		c->timings.total_ms += ms;
+		HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_iter_a, c->ev_iter_b));
+		c->timings.iter_loop_ms += ms;
+		c->total_pending = false;
+	}
+	if (out) *out = c->timings;
+	return 0;
+}
+int dvp_reset_timings(dvp_ctx* c) {
+	if (dvp_get_timings(c, nullptr)) return 1;
+	std::memset(&c->timings, 0, sizeof(DvpTimings));
+	return 0;
+}
+
+// ---- KAT / micro-benchmark ---------------------------------------------------------------------
+int dvp_eval_cost_vectors(dvp_ctx* c, const int32_t* px, const float* planes, int n, float* out, float* kernel_ms) {
+	if (set_device(c)) return 1;
+	if (!c->lut) { c->error = "dvp_set_params must be called first"; return 1; }
+	if (n <= 0) return 0;
+	const size_t S = (size_t)c->NI - 1;
+	int* dpx = nullptr; f4* dpl = nullptr; float* dout = nullptr;
+	HIP_TRY(c, hipMalloc((void**)&dpx, (size_t)n * 8));
+	HIP_TRY(c, hipMalloc((void**)&dpl, (size_t)n * 16));
+	HIP_TRY(c, hipMalloc((void**)&dout, (size_t)n * S * 4));
+	HIP_TRY(c, hipMemcpyAsync(dpx, px, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(dpl, planes, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+	hipEvent_t a, b;
+	hipEventCreate(&a); hipEventCreate(&b);
+	hipEventRecord(a, c->stream);
+	hipLaunchKernelGGL(dvp_cost_vectors, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, dpx, dpl, n, dout);
+	hipEventRecord(b, c->stream);
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipMemcpyAsync(out, dout, (size_t)n * S * 4, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	if (kernel_ms) hipEventElapsedTime(kernel_ms, a, b);
+	hipEventDestroy(a); hipEventDestroy(b);
+	hipFree(dpx); hipFree(dpl); hipFree(dout);
+	return 0;
+}
+
+int dvp_bench_cost_kernel(dvp_ctx* c, int repeat, float* mean_kernel_ms, uint64_t* evals_per_launch) {
+	if (set_device(c)) return 1;
+	if (!c->lut) { c->error = "dvp_set_params must be called first"; return 1; }
+	const LaunchGeom g = make_geom(c->W, c->H, false);
+	LaunchArgs a;
+	a.tiles_x = g.tiles_x; a.tiles = g.tiles; a.chunk = g.chunk; a.rows = g.rows; a.half = 0; a.colour = 0; a.iter = 0;
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	hipLaunchKernelGGL(dvp_cost_all_pixels, dim3(g.grid()), dim3(256), 0, c->stream, c->d, a, c->scratch_out);   // warm-up
+	hipEventRecord(e0, c->stream);
+	for (int i = 0; i < repeat; ++i)
+		hipLaunchKernelGGL(dvp_cost_all_pixels, dim3(g.grid()), dim3(256), 0, c->stream, c->d, a, c->scratch_out);
+	hipEventRecord(e1, c->stream);
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	float ms = 0.0f;
+	hipEventElapsedTime(&ms, e0, e1);
+	hipEventDestroy(e0); hipEventDestroy(e1);
+	if (mean_kernel_ms) *mean_kernel_ms = ms / (repeat > 0 ? repeat : 1);
+	if (evals_per_launch) *evals_per_launch = (uint64_t)c->L * (uint64_t)(c->NI - 1);
+	return 0;
+}
+
+}  // extern "C"

@@ -123,7 +123,7 @@ def render_view(W, H, cam, px_world, x_step=0.35, step=0.45, flat=(-0.55, -0.15,
         # wall X = x_step between the two planes
         with np.errstate(divide="ignore", invalid="ignore"):
             sW = (x_step - C[0]) / dx
-        YW, ZW = C[1] + sW * dy, C[2] + sW
+            YW, ZW = C[1] + sW * dy, C[2] + sW
         zA_w = 4.0 + 0.25 * x_step + 0.1 * YW
         validW = np.isfinite(sW) & (sW > 0) & (ZW >= zA_w) & (ZW <= zA_w + step)
         big = 1e30

@@ -144,6 +144,12 @@ int dvp_upload_cameras(dvp_ctx* ctx, const DvpCamera* cams, int n);            /
 int dvp_upload_state(dvp_ctx* ctx, const float* planes_xyzw, const uint32_t* selected_views,
                      const uint8_t* weak_info, const uint8_t* edge, const int32_t* label,
                      const int32_t* radius);
+/* device-side reset to the state a freshly constructed APD has before a FIRST_INIT pass without
+ * prior: planes = 0 (out of range -> random init, APD.cu:1289-1291), selected_views = 0, every
+ * pixel STRONG (APD.cpp:1196-1204), radius = strong_radius (APD.cpp:1649-1653), fit planes = 0
+ * (APD.cpp:1571); edge/label maps are kept.  Lets one context process consecutive views without
+ * host round trips. */
+int dvp_reset_state(dvp_ctx* ctx);
 int dvp_set_params(dvp_ctx* ctx, const DvpParams* params);                     /* APD.cpp:1607-1608 */
 /* The reference seeds cuRAND with clock64() (APD.cu:1270); here the seed is explicit. */
 int dvp_set_seed(dvp_ctx* ctx, uint64_t seed);

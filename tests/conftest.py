@@ -1,0 +1,98 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pkg(name=""):
+    return importlib.import_module("dvp-mvs_amd" + ("." + name if name else ""))
+
+
+synth = pkg("synth")
+
+
+def has_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+def make_params(num_images, **kw):
+    """PatchMatchParams as APD::InuputInitialization leaves them (depth range 0.6/1.2, APD.cpp:1109-1110)."""
+    p = synth.default_params(num_images, **kw)
+    if "depth_min" not in kw:
+        p["depth_min"] = np.float32(2.5) * np.float32(0.6)
+    if "depth_max" not in kw:
+        p["depth_max"] = np.float32(6.5) * np.float32(1.2)
+    return p
+
+
+def bits_equal(a, b):
+    """bitwise equality, NaN == NaN"""
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    return bool((a.view(np.uint8) == b.view(np.uint8)).all())
+
+
+def count_diff(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    if a.dtype == np.float32:
+        d = a.view(np.uint32) != b.view(np.uint32)
+        d &= ~(np.isnan(a) & np.isnan(b))
+        return int(d.sum())
+    return int((a != b).sum())
+
+
+FULL_SEQ_HEAD = [("gen_edge_inform", 0, 0), ("find_nearest_strong", 0, 0), ("gen_neighbours", 0, 0),
+                 ("neighbour_update", 0, 0), ("random_init", 0, 0)]
+FULL_SEQ_TAIL = [("get_depth_normal", 0, 0), ("filter_strong", 0, 0), ("filter_strong", 0, 1),
+                 ("depth_to_weak", 0, 0), ("local_refine", 0, 0)]
+
+
+def stage_sequence(iters):
+    seq = list(FULL_SEQ_HEAD)
+    for it in range(iters):
+        seq += [("strong_update", it, 0), ("strong_update", it, 1), ("ransac_fit", it, 0),
+                ("weak_update", it, 0), ("weak_update", it, 1)]
+    return seq + FULL_SEQ_TAIL
+
+
+CHECKED = ["planes", "costs", "selected_views", "view_weight", "weak_info", "radius", "fit_planes",
+           "edge_neigh", "candidate", "weak_nearest_strong", "weak_reliable", "neighbours", "complex",
+           "label_boundary"]
+
+
+def first_pass_state(scene):
+    """Input state of a FIRST_INIT pass without a depth prior: planes.w = 0 is out of range, so
+    every pixel gets a random plane (APD.cu:1289-1291)."""
+    H, W = scene["height"], scene["width"]
+    return dict(planes=np.zeros((H * W, 4), np.float32), edge=scene["edge"], label=scene["label"],
+                radius=np.full(H * W, 5, np.int32), weak=np.full(H * W, synth.STRONG, np.uint8),
+                views=np.zeros(H * W, np.uint32))
+
+
+def second_pass_inputs(eng, scene):
+    """What ProcessProblem writes to disk after a pass and the next pass reloads
+    (main.cpp:298-376, APD.cpp:1169-1195, 1428-1456): planes (world normal, depth), weak map,
+    selected views, radius; depths out of range are zeroed and marked UNKNOWN."""
+    planes = eng.get("planes").copy()
+    weak = eng.get("weak_info").copy()
+    views = eng.get("selected_views").copy()
+    radius = eng.get("radius").copy()
+    p = eng.params
+    bad = (planes[:, 3] < p["depth_min"][0]) | (planes[:, 3] > p["depth_max"][0])
+    planes[bad, 3] = 0
+    weak[bad] = synth.UNKNOWN
+    radius[weak == synth.UNKNOWN] = 5    # APD.cpp:1663-1666
+    return dict(planes=planes, weak=weak, views=views, radius=radius, edge=scene["edge"], label=scene["label"])

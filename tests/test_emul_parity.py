@@ -1,0 +1,84 @@
+"""Kernel logic on CPU: the engine's device headers, compiled for the host (tests/emul), must
+reproduce the oracle bit for bit, launch site by launch site (integer buffers exactly, float
+buffers bitwise with NaN == NaN)."""
+import numpy as np
+import pytest
+
+from conftest import (synth, make_params, count_diff, stage_sequence, CHECKED, first_pass_state,
+                      second_pass_inputs)
+from oracle import oracle as O
+from tests.emul import emul as E
+
+
+def _pair(scene, params, state, seed=1234, sampler=0, depths=None):
+    a = O.from_scene(scene, params, seed=seed, sampler=sampler, depths=depths, cls=O.Oracle)
+    b = O.from_scene(scene, params, seed=seed, sampler=sampler, depths=depths, cls=E.Emul)
+    a.upload_state(**state)
+    b.upload_state(**state)
+    return a, b
+
+
+def _run_and_compare(a, b, iters, names=CHECKED):
+    for st, it, col in stage_sequence(iters):
+        a.run_stage(st, it, col)
+        b.run_stage(st, it, col)
+        for n in names:
+            nd = count_diff(a.get(n), b.get(n))
+            assert nd == 0, "%s differs in %d entries after %s(it=%d, colour=%d)" % (n, nd, st, it, col)
+
+
+@pytest.mark.parametrize("W,H,S,sampler", [(96, 72, 3, 0), (131, 67, 2, 1)])
+def test_first_pass_strong_path(W, H, S, sampler):
+    sc = synth.make_scene(W, H, S)
+    p = make_params(S + 1, max_iterations=2, state=synth.FIRST_INIT, use_APD=0)
+    a, b = _pair(sc, p, first_pass_state(sc), sampler=sampler)
+    _run_and_compare(a, b, 2)
+
+
+def test_two_pass_weak_path_with_geom():
+    """pass 1 (FIRST_INIT) on the oracle, then a REFINE_ITER pass with WEAK pixels, labels, adaptive
+    radius and geometric consistency on both."""
+    W, H, S = 112, 80, 3
+    sc = synth.make_scene(W, H, S)
+    p1 = make_params(S + 1, max_iterations=2, state=synth.FIRST_INIT, use_APD=0)
+    o = O.from_scene(sc, p1)
+    o.upload_state(**first_pass_state(sc))
+    o.run_patchmatch()
+    st = second_pass_inputs(o, sc)
+    # force a block of WEAK pixels in the low-texture window so the weak path has work
+    weak = st["weak"].reshape(H, W)
+    weak[sc["flat"] & (weak == synth.STRONG)] = synth.WEAK
+    weak[:6, :] = synth.UNKNOWN
+    st["weak"] = weak.reshape(-1)
+    assert (st["weak"] == synth.WEAK).sum() > 50
+    p2 = make_params(S + 1, max_iterations=2, state=synth.REFINE_ITER, use_APD=1, geom_consistency=1,
+                     weak_peak_radius=4, rotate_time=2, ransac_threshold=0.01)
+    depths = sc["depth_gt"]   # stand-in for the neighbours' depths.dmb
+    a, b = _pair(sc, p2, st, depths=depths)
+    assert a.weak_count() == b.weak_count() > 0
+    _run_and_compare(a, b, 2)
+    # the weak path really ran
+    assert (a.get("weak_reliable") == 1).sum() > 0
+    assert np.abs(a.get("fit_planes")).sum() > 0
+
+
+def test_refine_init_and_generic_radius():
+    """REFINE_INIT acceptance rule (cost must improve by 0.1) + radii that are not multiples of 5
+    (generic tap loop) + use_radius off."""
+    W, H, S = 80, 64, 2
+    sc = synth.make_scene(W, H, S)
+    p1 = make_params(S + 1, max_iterations=1, state=synth.FIRST_INIT, use_APD=0)
+    o = O.from_scene(sc, p1)
+    o.upload_state(**first_pass_state(sc))
+    o.run_patchmatch()
+    st = second_pass_inputs(o, sc)
+    rad = st["radius"].copy()
+    rad[::7] = 7
+    rad[3::11] = 10
+    st["radius"] = rad
+    p2 = make_params(S + 1, max_iterations=1, state=synth.REFINE_INIT, use_APD=1, use_detail=1, weak_peak_radius=6)
+    a, b = _pair(sc, p2, st)
+    _run_and_compare(a, b, 1)
+    p3 = make_params(S + 1, max_iterations=1, state=synth.REFINE_INIT, use_APD=1, use_radius=0)
+    a, b = _pair(sc, p3, st)
+    _run_and_compare(a, b, 1)
