@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libdvp_mvs_hip.so")
+_SO = os.environ.get("DVP_MVS_LIB") or os.path.join(_HERE, "libdvp_mvs_hip.so")   # override: A/B builds
 _LIB = None
 
 STAGES = dict(gen_edge_inform=0, find_nearest_strong=1, gen_neighbours=2, neighbour_update=3,

@@ -41,14 +41,21 @@ DVP_KERNEL(dvp_gen_edge_inform, DVP_ST_GEN_EDGE_INFORM, 1)
 DVP_KERNEL(dvp_find_nearest_strong, DVP_ST_FIND_NEAREST_STRONG, 1)
 DVP_KERNEL(dvp_gen_neighbours, DVP_ST_GEN_NEIGHBOURS, 1)
 DVP_KERNEL(dvp_neighbour_update, DVP_ST_NEIGHBOUR_UPDATE, 1)
-DVP_KERNEL(dvp_random_init, DVP_ST_RANDOM_INIT, 4)
-DVP_KERNEL(dvp_strong_update, DVP_ST_STRONG_UPDATE, 4)
+#ifndef DVP_LB_HEAVY
+// min waves/SIMD the heavy NCC kernels are compiled for.  Measured on MI355X (3104x2064, S=5):
+// 1 -> 64 ms per strong-update launch, 2 -> 110 ms, 3 -> 135 ms, 4 -> 154 ms: the fully unrolled
+// 36-tap evaluation wants the whole 512-entry register file (144 gathers in flight per lane);
+// any tighter bound spills the weight table to scratch inside the tap loop.
+#define DVP_LB_HEAVY 1
+#endif
+DVP_KERNEL(dvp_random_init, DVP_ST_RANDOM_INIT, DVP_LB_HEAVY)
+DVP_KERNEL(dvp_strong_update, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY)
 DVP_KERNEL(dvp_ransac_fit_plane, DVP_ST_RANSAC_FIT, 1)
 DVP_KERNEL(dvp_weak_update, DVP_ST_WEAK_UPDATE, 2)
 DVP_KERNEL(dvp_get_depth_normal, DVP_ST_GET_DEPTH_NORMAL, 1)
 DVP_KERNEL(dvp_filter_strong, DVP_ST_FILTER_STRONG, 1)
-DVP_KERNEL(dvp_depth_to_weak, DVP_ST_DEPTH_TO_WEAK, 4)
-DVP_KERNEL(dvp_local_refine, DVP_ST_LOCAL_REFINE, 4)
+DVP_KERNEL(dvp_depth_to_weak, DVP_ST_DEPTH_TO_WEAK, DVP_LB_HEAVY)
+DVP_KERNEL(dvp_local_refine, DVP_ST_LOCAL_REFINE, DVP_LB_HEAVY)
 
 extern "C" __global__ void dvp_prepare_views(const DvpCamera* cams, ViewConst* views, int n) {
 	const int v = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,262 @@
+// APD.cpp — `class APD` on top of the HIP engine's C ABI.  Mirrors /root/reference/APD.cpp:984-1748:
+// same methods, same call order (InuputInitialization -> SupportInitialization ->
+// CudaSpaceInitialization -> SetDataPassHelperInCuda -> RunPatchMatch, main.cpp:276-280), same
+// files read per pass.
+#include "APD.h"
+#include <cstdlib>
+
+static int g_device = 0;
+static uint64_t g_seed = 0x5eed5eedULL;
+void APD::SetDevice(int device) { g_device = device; }   // cudaSetDevice(argv[2]), main.cpp:430-434
+void APD::SetSeed(uint64_t seed) { g_seed = seed; }      // the reference seeds with clock64() (APD.cu:1270)
+
+APD::APD(const Problem& problem) {   // APD.cpp:984-987
+	params_host = problem.params;
+	this->problem = problem;
+}
+
+APD::~APD() {                        // APD.cpp:989-1043
+	delete[] plane_hypotheses_host;
+	if (ctx) dvp_ctx_destroy(ctx);
+}
+
+// APD.cpp:1045-1495 (without the Depth-Anything prior block :1210-1424, see DESIGN.md "next")
+void APD::InuputInitialization() {
+	images.clear();
+	cameras.clear();
+	path image_folder = problem.dense_folder / path("images");
+	path cam_folder = problem.dense_folder / path("cams");
+	auto to_float = [](const Mat& u8) {
+		Mat f(u8.rows, u8.cols, CV_32FC1);
+		for (int r = 0; r < u8.rows; ++r)
+			for (int c = 0; c < u8.cols; ++c) f.at<float>(r, c) = (float)u8.at<uint8_t>(r, c);
+		return f;
+	};
+	{
+		Mat image_uint = ReadImageGray(image_folder / path(ToFormatIndex(problem.ref_image_id) + ".jpg"));
+		if (image_uint.empty()) {
+			std::cerr << "Can't read reference image " << problem.ref_image_id << std::endl;
+			exit(EXIT_FAILURE);
+		}
+		Mat image_float = to_float(image_uint);
+		images.push_back(image_float);
+		width = image_float.cols;
+		height = image_float.rows;
+	}
+	for (const auto& src_idx : problem.src_image_ids) {
+		Mat image_uint = ReadImageGray(image_folder / path(ToFormatIndex(src_idx) + ".jpg"));
+		if (image_uint.empty()) {
+			std::cerr << "Can't read source image " << src_idx << std::endl;
+			exit(EXIT_FAILURE);
+		}
+		Mat image_float = to_float(image_uint);
+		Mat resized = Mat::zeros(height, width, CV_32FC1);   // zero-pad / crop to the reference size (APD.cpp:1071-1079)
+		for (int i = 0; i < height; i++)
+			for (int j = 0; j < width; j++)
+				if (i < image_float.rows && j < image_float.cols) resized.at<float>(i, j) = image_float.at<float>(i, j);
+		images.push_back(resized);
+	}
+	if (images.size() > MAX_IMAGES) {
+		std::cerr << "Can't process so much images: " << images.size() << std::endl;
+		exit(EXIT_FAILURE);
+	}
+	{
+		Camera cam;
+		ReadCamera(cam_folder / path(ToFormatIndex(problem.ref_image_id) + "_cam.txt"), cam);
+		cam.width = width;
+		cam.height = height;
+		cameras.push_back(cam);
+	}
+	for (const auto& src_idx : problem.src_image_ids) {
+		Camera cam;
+		ReadCamera(cam_folder / path(ToFormatIndex(src_idx) + "_cam.txt"), cam);
+		cam.width = width;
+		cam.height = height;
+		cameras.push_back(cam);
+	}
+	params_host.depth_min = cameras[0].depth_min * 0.6f;   // APD.cpp:1109-1110
+	params_host.depth_max = cameras[0].depth_max * 1.2f;
+	params_host.num_images = (int)images.size();
+	num_images = (int)images.size();
+	std::cout << "Read images and camera done\n";
+	std::cout << "Depth range: " << params_host.depth_min << " " << params_host.depth_max << std::endl;
+	std::cout << "Num images: " << params_host.num_images << std::endl;
+	if (problem.scale_size != 1) {   // APD.cpp:1119-1143
+		for (int i = 0; i < num_images; ++i) {
+			const float factor = 1.0f / (float)(problem.scale_size);
+			const int new_cols = (int)std::round(images[i].cols * factor);
+			const int new_rows = (int)std::round(images[i].rows * factor);
+			const float scale_x = new_cols / static_cast<float>(images[i].cols);
+			const float scale_y = new_rows / static_cast<float>(images[i].rows);
+			images[i] = ResizeLinear(images[i], new_cols, new_rows);
+			width = new_cols;
+			height = new_rows;
+			cameras[i].K[0] *= scale_x;
+			cameras[i].K[2] *= scale_x;
+			cameras[i].K[4] *= scale_y;
+			cameras[i].K[5] *= scale_y;
+			cameras[i].width = width;
+			cameras[i].height = height;
+		}
+		std::cout << "Scale images and cameras done\n";
+	}
+	std::cout << "Image size: " << width << " * " << height << std::endl;
+	if (params_host.geom_consistency) {   // APD.cpp:1147-1166
+		depths.clear();
+		Mat ref_depth;
+		ReadBinMat(problem.result_folder / path("depths.dmb"), ref_depth);
+		depths.push_back(ref_depth);
+		for (const auto& src_idx : problem.src_image_ids) {
+			Mat src_depth;
+			ReadBinMat(problem.dense_folder / path("APD") / path(ToFormatIndex(src_idx)) / path("depths.dmb"), src_depth);
+			depths.push_back(src_depth);
+		}
+		for (auto& depth : depths) {
+			if (depth.empty()) depth = Mat::zeros(height, width, CV_32FC1);
+			if (depth.cols != width || depth.rows != height) RescaleMatToTargetSize<float>(depth, depth, width, height);
+		}
+	}
+	if (params_host.use_APD) {            // APD.cpp:1169-1195
+		path weak_info_path = problem.result_folder / path("weak.bin");
+		if (!std::filesystem::exists(weak_info_path)) {
+			std::cerr << "Can't find weak info file: " << weak_info_path.string() << std::endl;
+			exit(EXIT_FAILURE);
+		}
+		ReadBinMat(weak_info_path, weak_info_host);
+		if (weak_info_host.cols != width || weak_info_host.rows != height) {
+			std::cerr << "Weak info doesn't match the images' size!\n";
+			RescaleMatToTargetSize<uint8_t>(weak_info_host, weak_info_host, width, height);
+			std::cout << "Scale done\n";
+		}
+		weak_count = 0;
+		for (int r = 0; r < height; ++r)
+			for (int c = 0; c < width; ++c)
+				if (weak_info_host.at<uint8_t>(r, c) == WEAK) weak_count++;
+		std::cout << "Weak count: " << weak_count << " / " << width * height << " = " << (float)weak_count / (float)(width * height) * 100 << "%" << std::endl;
+	} else {                              // APD.cpp:1196-1204
+		weak_info_host = Mat::zeros(height, width, CV_8UC1);
+		weak_count = 0;
+		for (int r = 0; r < height; ++r)
+			for (int c = 0; c < width; ++c) weak_info_host.at<uint8_t>(r, c) = STRONG;
+	}
+	plane_hypotheses_host = new float4[(size_t)width * height];
+	std::memset(plane_hypotheses_host, 0, sizeof(float4) * (size_t)width * height);
+	// FIRST_INIT: the reference builds a plane prior from Depth-Anything maps (dep/<id>.dmb,
+	// sfm/<id>.txt, APD.cpp:1210-1424).  Not restated yet: planes stay zero (.w out of range), so
+	// RandomInitialization draws random planes (APD.cu:1289-1291).
+	selected_views_host = Mat::zeros(height, width, CV_32SC1);
+	if (params_host.state != FIRST_INIT) {   // APD.cpp:1428-1456
+		Mat depth, normal;
+		ReadBinMat(problem.result_folder / path("depths.dmb"), depth);
+		ReadBinMat(problem.result_folder / path("APD_normals.dmb"), normal);
+		if (depth.cols != width || depth.rows != height || normal.cols != width || normal.rows != height) {
+			std::cerr << "Depth and Normal doesn't match the images' size!\n";
+			RescaleMatToTargetSize<float>(depth, depth, width, height);
+			RescaleMatToTargetSize<Vec3f>(normal, normal, width, height);
+		}
+		for (int col = 0; col < width; ++col)
+			for (int row = 0; row < height; ++row) {
+				const int center = row * width + col;
+				plane_hypotheses_host[center].w = depth.at<float>(row, col);
+				plane_hypotheses_host[center].x = normal.at<Vec3f>(row, col)[0];
+				plane_hypotheses_host[center].y = normal.at<Vec3f>(row, col)[1];
+				plane_hypotheses_host[center].z = normal.at<Vec3f>(row, col)[2];
+			}
+		ReadBinMat(problem.result_folder / path("selected_views.bin"), selected_views_host);
+		if (selected_views_host.cols != width || selected_views_host.rows != height) {
+			std::cerr << "Select view doesn't match the images' size!\n";
+			RescaleMatToTargetSize<unsigned int>(selected_views_host, selected_views_host, width, height);
+		}
+	}
+}
+
+// APD.cpp:1615-1668
+void APD::SupportInitialization() {
+	int scale = 0;
+	while ((1 << scale) < problem.scale_size) scale++;
+	if (problem.params.use_edge || problem.params.use_limit) {
+		path edge_path = problem.result_folder / path("edges_" + std::to_string(scale) + ".dmb");
+		if (!std::filesystem::exists(edge_path) || !ReadBinMat(edge_path, edge_host) || edge_host.cols != width || edge_host.rows != height) {
+			// the Canny front end (GetProblemEdges, main.cpp:193-246) is not part of this build yet:
+			// without a cached edges_<s>.dmb the edge map is empty (no edge pixels)
+			edge_host = Mat::zeros(height, width, CV_8UC1);
+		}
+	}
+	if (problem.params.use_label) {
+		// the shipped reference only fills label_host when MVS4/<id>.dmb needs rescaling
+		// (APD.cpp:1636-1645) and uploads it regardless; here: load if present, else zeros
+		Mat ref_dep;
+		path p = problem.dense_folder / path("MVS4") / path(ToFormatIndex(problem.ref_image_id) + ".dmb");
+		label_host = Mat::zeros(height, width, CV_32SC1);
+		if (std::filesystem::exists(p) && ReadBinMat(p, ref_dep) && (ref_dep.cols != width || ref_dep.rows != height)) {
+			Mat tmp;
+			RescaleMatToTargetSize<float>(ref_dep, tmp, width, height);
+			std::memcpy(label_host.data, tmp.data, (size_t)width * height * 4);   // float bits reinterpreted, as the reference does
+		}
+	}
+	if (problem.params.use_radius) {
+		const int strong_radius = problem.params.strong_radius;
+		if (problem.params.state == FIRST_INIT) {
+			radius_host = Mat::zeros(height, width, CV_32S);
+			for (int r = 0; r < height; r++)
+				for (int c = 0; c < width; c++) radius_host.at<int>(r, c) = strong_radius;
+		} else {
+			ReadBinMat(problem.result_folder / path("radius.bin"), radius_host);
+		}
+		if (radius_host.cols != width || radius_host.rows != height) {
+			std::cerr << "Radius map doesn't match the images' size!\n";
+			RescaleMatToTargetSize<int>(radius_host, radius_host, width, height);
+		}
+		for (int r = 0; r < height; r++)
+			for (int c = 0; c < width; c++)
+				if (weak_info_host.at<uint8_t>(r, c) == UNKNOWN) radius_host.at<int>(r, c) = strong_radius;
+	}
+}
+
+// APD.cpp:1497-1613: every cudaMalloc/cudaMemcpy/texture creation becomes one C-ABI upload
+void APD::CudaSpaceInitialization() {
+	if (dvp_ctx_create(g_device, width, height, num_images, &ctx) != 0) {
+		fprintf(stderr, "dvp_ctx_create failed: %s\n", dvp_last_error(nullptr));
+		exit(EXIT_FAILURE);
+	}
+	std::vector<const float*> ptrs(num_images);
+	for (int i = 0; i < num_images; ++i) ptrs[i] = images[i].ptr<float>(0);
+	DVP_SAFE_CALL(ctx, dvp_upload_images(ctx, ptrs.data(), width));
+	if (params_host.geom_consistency) {
+		for (int i = 0; i < num_images; ++i) ptrs[i] = depths[i].ptr<float>(0);
+		DVP_SAFE_CALL(ctx, dvp_upload_depths(ctx, ptrs.data(), width));
+	}
+	DVP_SAFE_CALL(ctx, dvp_upload_cameras(ctx, reinterpret_cast<const DvpCamera*>(cameras.data()), num_images));
+	DVP_SAFE_CALL(ctx, dvp_upload_state(ctx, reinterpret_cast<const float*>(plane_hypotheses_host),
+		selected_views_host.ptr<uint32_t>(0), weak_info_host.ptr<uint8_t>(0),
+		(problem.params.use_edge || problem.params.use_limit) ? edge_host.ptr<uint8_t>(0) : nullptr,
+		problem.params.use_label ? label_host.ptr<int32_t>(0) : nullptr,
+		problem.params.use_radius ? radius_host.ptr<int32_t>(0) : nullptr));
+}
+
+// APD.cpp:1670-1704: the DataPassHelper lives inside the context; what is left is params + seed
+void APD::SetDataPassHelperInCuda() {
+	DVP_SAFE_CALL(ctx, dvp_set_params(ctx, reinterpret_cast<const DvpParams*>(&params_host)));
+	DVP_SAFE_CALL(ctx, dvp_set_seed(ctx, g_seed + (uint64_t)problem.ref_image_id * 1000003ull + (uint64_t)problem.iteration));
+}
+
+// APD.cu:4406-4532
+void APD::RunPatchMatch() {
+	DVP_SAFE_CALL(ctx, dvp_run_patchmatch(ctx));
+	if (!problem.params.use_radius) radius_host = Mat::zeros(height, width, CV_32S);
+	DVP_SAFE_CALL(ctx, dvp_download_state(ctx, reinterpret_cast<float*>(plane_hypotheses_host), selected_views_host.ptr<uint32_t>(0),
+		weak_info_host.ptr<uint8_t>(0), problem.params.use_radius ? radius_host.ptr<int32_t>(0) : nullptr));
+	DVP_SAFE_CALL(ctx, dvp_get_timings(ctx, &timings));
+}
+
+float4 APD::GetPlaneHypothesis(int r, int c) { return plane_hypotheses_host[c + r * width]; }   // APD.cpp:1706-1708
+int APD::GetPixelSelectedViews(int r, int c) { return selected_views_host.at<int>(r, c); }
+void APD::SetPixelSelectedViews(int r, int c, int v) { selected_views_host.at<int>(r, c) = v; }
+Mat APD::GetEdge() { return edge_host; }
+Mat APD::GetPixelStates() { return weak_info_host; }
+Mat APD::GetSelectedViews() { return selected_views_host; }
+Mat APD::GetRadiusMap() { return radius_host; }
+int APD::GetWidth() { return width; }
+int APD::GetHeight() { return height; }
+float APD::GetDepthMin() { return params_host.depth_min; }
+float APD::GetDepthMax() { return params_host.depth_max; }

@@ -1,0 +1,78 @@
+// APD.h — C++ host mirror of the reference's per-view pipeline API (/root/reference/APD.h:11-54,
+// 94-199): same class name, method names (including the `InuputInitialization` spelling), call
+// order and free functions, with the CUDA runtime replaced by the engine's C ABI
+// (include/dvp_mvs.h), cv::Mat by Mat and boost::filesystem by std::filesystem.
+// A `main.cpp`-style caller (ProcessProblem, /root/reference/main.cpp:267-419) compiles against
+// this header unchanged apart from the include set.
+#ifndef _APD_H_
+#define _APD_H_
+#include "main.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+// ---- free functions (APD.h:11-54) ------------------------------------------------------------------
+void Connect(const Mat& dstImage, Mat& label_mask, std::vector<int>& label_cnt);      // APD.cpp:233-346
+void Label_Update(Mat& label_mask, std::vector<int>& label_cnt);                       // APD.cpp:192-230
+bool ReadBinMat(const path& mat_path, Mat& mat);                                       // APD.cpp:548-573
+bool WriteBinMat(const path& mat_path, const Mat& mat);                                // APD.cpp:630-649
+int writeDepthDmb(const path& mat_path, const Mat& depth);                             // APD.cpp:575-600
+int writeNormalDmb(const path& mat_path, const Mat& normal);                           // APD.cpp:603-628
+bool ReadCamera(const path& cam_path, Camera& cam);                                    // APD.cpp:651-692
+bool ExportPointCloud(const path& point_cloud_path, std::vector<PointList>& pointcloud);   // APD.cpp:842-882
+std::string ToFormatIndex(int index);                                                  // APD.cpp:978-982
+template <typename TYPE>
+void RescaleMatToTargetSize(const Mat& src, Mat& dst, int target_width, int target_height);   // APD.cpp:1773-1795
+void RunFusion(const path& dense_folder, const std::vector<Problem>& problems);        // APD.cpp:1809-1960
+// image I/O without OpenCV: images/<id>.pgm|.ppm (binary P5/P6) next to / instead of <id>.jpg
+// (tools/jpg2pnm.py converts); returns an empty Mat if nothing readable is found.
+Mat ReadImageGray(const path& image_path_jpg);      // stands in for cv::imread(IMREAD_GRAYSCALE), APD.cpp:1057
+Mat ReadImageColor(const path& image_path_jpg);     // cv::imread(IMREAD_COLOR) (BGR), APD.cpp:1842
+Mat ResizeLinear(const Mat& src_f32, int new_cols, int new_rows);   // cv::resize(INTER_LINEAR), APD.cpp:1129
+// error convention of the reference (CudaSafeCall, APD.cpp:943-951): message on stderr + exit
+void DvpSafeCall(int rc, dvp_ctx* ctx, const char* what, const char* file, int line);
+#define DVP_SAFE_CALL(ctx, expr) DvpSafeCall((expr), (ctx), #expr, __FILE__, __LINE__)
+
+class APD {
+public:
+	APD(const Problem& problem);
+	~APD();
+
+	void InuputInitialization();
+	void CudaSpaceInitialization();     // name kept; allocates/uploads through the HIP engine
+	void SupportInitialization();
+	void SetDataPassHelperInCuda();
+	void RunPatchMatch();
+	float4 GetPlaneHypothesis(int r, int c);
+	int GetPixelSelectedViews(int r, int c);
+	void SetPixelSelectedViews(int r, int c, int temp_selected_views);
+	Mat GetEdge();
+	Mat GetPixelStates();
+	Mat GetSelectedViews();
+	Mat GetRadiusMap();
+	int GetWidth();
+	int GetHeight();
+	float GetDepthMin();
+	float GetDepthMax();
+	// extensions (not in the reference): device selection, explicit seed, in-memory inputs
+	static void SetDevice(int device);
+	static void SetSeed(uint64_t seed);
+	const DvpTimings& GetTimings() const { return timings; }
+
+private:
+	int num_images = 0;
+	int width = 0, height = 0;
+	Problem problem;
+	std::vector<Mat> images;
+	std::vector<Mat> depths;
+	std::vector<Camera> cameras;
+	int weak_count = 0;
+	Mat weak_info_host;
+	float4* plane_hypotheses_host = nullptr;
+	Mat edge_host, radius_host, label_host, selected_views_host;
+	PatchMatchParams params_host;
+	dvp_ctx* ctx = nullptr;
+	DvpTimings timings{};
+};
+#endif

@@ -1,0 +1,47 @@
+// Mat.h — minimal owning 2-D array standing in for the cv::Mat the reference's API returns
+// (APD.h:105-115).  Only what the PatchMatch path and its callers use: rows/cols/type()/data/step,
+// at<T>(r,c), ptr<T>(r), zeros(), clone(), empty().  Type codes are OpenCV's (they are written
+// into the BinMat headers on disk, APD.cpp:630-649): CV_8UC1=0, CV_32SC1=4, CV_32FC1=5, CV_32FC3=21.
+#ifndef DVP_MAT_H_
+#define DVP_MAT_H_
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+enum { CV_8UC1 = 0, CV_8U = 0, CV_8UC3 = 16, CV_32SC1 = 4, CV_32S = 4, CV_32FC1 = 5, CV_32F = 5, CV_32FC3 = 21 };
+
+struct Vec3f { float v[3]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
+
+class Mat {
+public:
+	int rows = 0, cols = 0;
+	size_t step = 0;
+	uint8_t* data = nullptr;
+	Mat() {}
+	Mat(int r, int c, int type) { create(r, c, type); }
+	static size_t elem_size(int type) {
+		const int depth = type & 7, ch = (type >> 3) + 1;
+		static const int sz[8] = { 1, 1, 2, 2, 4, 4, 8, 2 };
+		return (size_t)sz[depth] * ch;
+	}
+	void create(int r, int c, int type) {
+		rows = r; cols = c; type_ = type;
+		step = (size_t)c * elem_size(type);
+		buf_ = std::shared_ptr<uint8_t[]>(new uint8_t[step * (size_t)(r > 0 ? r : 1) + 8]);
+		data = buf_.get();
+	}
+	static Mat zeros(int r, int c, int type) { Mat m(r, c, type); std::memset(m.data, 0, m.step * r); return m; }
+	Mat clone() const { Mat m(rows, cols, type_); if (data) std::memcpy(m.data, data, step * rows); return m; }
+	int type() const { return type_; }
+	bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+	size_t total() const { return (size_t)rows * cols; }
+	template <class T> T& at(int r, int c) { return *reinterpret_cast<T*>(data + step * r + sizeof(T) * c); }
+	template <class T> const T& at(int r, int c) const { return *reinterpret_cast<const T*>(data + step * r + sizeof(T) * c); }
+	template <class T> T* ptr(int r = 0) { return reinterpret_cast<T*>(data + step * r); }
+	template <class T> const T* ptr(int r = 0) const { return reinterpret_cast<const T*>(data + step * r); }
+private:
+	int type_ = 0;
+	std::shared_ptr<uint8_t[]> buf_;
+};
+#endif

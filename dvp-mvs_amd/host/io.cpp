@@ -1,0 +1,223 @@
+// io.cpp — on-disk formats of the reference's per-view pipeline, OpenCV/Boost-free.
+// BinMat (APD.cpp:548-573, 630-649), ACMM dmb (APD.cpp:575-628), MVSNet camera text
+// (APD.cpp:651-692), binary PLY (APD.cpp:842-882), PNM images, bilinear resize, nearest rescale.
+#include "APD.h"
+#include <cstdio>
+#include <cstdlib>
+
+bool ReadBinMat(const path& mat_path, Mat& mat) {
+	std::ifstream in(mat_path, std::ios_base::binary);
+	if (!in.good()) {
+		std::cerr << "Error opening file: " << mat_path << std::endl;
+		return false;
+	}
+	int32_t version, rows, cols, type;
+	in.read((char*)(&version), sizeof(int32_t));
+	in.read((char*)(&rows), sizeof(int32_t));
+	in.read((char*)(&cols), sizeof(int32_t));
+	in.read((char*)(&type), sizeof(int32_t));
+	if (!in.good() || version != 1) {
+		std::cerr << "Version error: " << mat_path << std::endl;
+		return false;
+	}
+	mat = Mat(rows, cols, type);
+	in.read((char*)mat.data, (std::streamsize)(mat.step * mat.rows));
+	return true;
+}
+
+bool WriteBinMat(const path& mat_path, const Mat& mat) {
+	std::ofstream out(mat_path, std::ios_base::binary);
+	if (!out.good()) {
+		std::cout << "Error opening file: " << mat_path << std::endl;
+		return false;
+	}
+	int32_t version = 1, rows = mat.rows, cols = mat.cols, type = mat.type();
+	out.write((char*)&version, sizeof(int32_t));
+	out.write((char*)&rows, sizeof(int32_t));
+	out.write((char*)&cols, sizeof(int32_t));
+	out.write((char*)&type, sizeof(int32_t));
+	out.write((char*)mat.data, (std::streamsize)(mat.step * mat.rows));
+	return out.good();
+}
+
+static int write_dmb(const path& p, const Mat& m, int32_t nb) {
+	FILE* f = fopen(p.string().c_str(), "wb");
+	if (!f) {
+		std::cout << "Error opening file " << p << std::endl;
+		return -1;
+	}
+	int32_t type = 1, h = m.rows, w = m.cols;
+	fwrite(&type, sizeof(int32_t), 1, f);
+	fwrite(&h, sizeof(int32_t), 1, f);
+	fwrite(&w, sizeof(int32_t), 1, f);
+	fwrite(&nb, sizeof(int32_t), 1, f);
+	fwrite(m.data, sizeof(float), (size_t)w * h * nb, f);
+	fclose(f);
+	return 0;
+}
+int writeDepthDmb(const path& mat_path, const Mat& depth) { return write_dmb(mat_path, depth, 1); }
+int writeNormalDmb(const path& mat_path, const Mat& normal) { return write_dmb(mat_path, normal, 3); }
+
+bool ReadCamera(const path& cam_path, Camera& cam) {
+	std::ifstream in(cam_path);
+	if (!in.good()) return false;
+	std::string line;
+	in >> line;   // "extrinsic"
+	for (int i = 0; i < 3; ++i) in >> cam.R[3 * i + 0] >> cam.R[3 * i + 1] >> cam.R[3 * i + 2] >> cam.t[i];
+	float tmp[4];
+	in >> tmp[0] >> tmp[1] >> tmp[2] >> tmp[3];
+	in >> line;   // "intrinsic"
+	for (int i = 0; i < 3; ++i) in >> cam.K[3 * i + 0] >> cam.K[3 * i + 1] >> cam.K[3 * i + 2];
+	const auto& R = cam.R;
+	const auto& t = cam.t;
+	for (int j = 0; j < 3; ++j)   // camera centre in world coordinates, in double (APD.cpp:673-677)
+		cam.c[j] = -float(double(R[0 + j]) * double(t[0]) + double(R[3 + j]) * double(t[1]) + double(R[6 + j]) * double(t[2]));
+	float depth_num, interval;   // TAT & ETH layout: depth_min interval depth_num depth_max (APD.cpp:680-682)
+	in >> cam.depth_min >> interval >> depth_num >> cam.depth_max;
+	return true;
+}
+
+bool ExportPointCloud(const path& point_cloud_path, std::vector<PointList>& pointcloud) {
+	std::ofstream out(point_cloud_path, std::ios::binary);
+	if (!out.good()) return false;
+	out << "ply\n" << "format binary_little_endian 1.0\n" << "element vertex " << int(pointcloud.size()) << "\n"
+	    << "property float x\n" << "property float y\n" << "property float z\n"
+	    << "property uchar diffuse_blue\n" << "property uchar diffuse_green\n" << "property uchar diffuse_red\n" << "end_header\n";
+	for (size_t idx = 0; idx < pointcloud.size(); idx++) {
+		float p[3] = { pointcloud[idx].coord.x, pointcloud[idx].coord.y, pointcloud[idx].coord.z };
+		unsigned char c[3] = { static_cast<unsigned char>(pointcloud[idx].color.x), static_cast<unsigned char>(pointcloud[idx].color.y),
+		                       static_cast<unsigned char>(pointcloud[idx].color.z) };
+		out.write((char*)p, 12);
+		out.write((char*)c, 3);
+	}
+	return out.good();
+}
+
+std::string ToFormatIndex(int index) {
+	std::stringstream ss;
+	ss << std::setw(8) << std::setfill('0') << index;
+	return ss.str();
+}
+
+// nearest-neighbour rescale with the reference's swapped scale factors (APD.cpp:1787-1788): kept
+template <typename TYPE>
+void RescaleMatToTargetSize(const Mat& src, Mat& dst, int tw, int th) {
+	if (src.cols == tw && src.rows == th) return;
+	const float scale_x = tw / static_cast<float>(src.cols);
+	const float scale_y = th / static_cast<float>(src.rows);
+	Mat src_clone = src.clone();
+	Mat out = Mat::zeros(th, tw, src.type());
+	for (int r = 0; r < th; ++r)
+		for (int c = 0; c < tw; ++c) {
+			int o_r = static_cast<int>(r / scale_x);
+			int o_c = static_cast<int>(c / scale_y);
+			if (o_r < 0 || o_c < 0 || o_r >= src_clone.rows || o_c >= src_clone.cols) continue;
+			out.at<TYPE>(r, c) = src_clone.at<TYPE>(o_r, o_c);
+		}
+	dst = out;
+}
+template void RescaleMatToTargetSize<float>(const Mat&, Mat&, int, int);
+template void RescaleMatToTargetSize<uint8_t>(const Mat&, Mat&, int, int);
+template void RescaleMatToTargetSize<int>(const Mat&, Mat&, int, int);
+template void RescaleMatToTargetSize<unsigned int>(const Mat&, Mat&, int, int);
+template void RescaleMatToTargetSize<Vec3f>(const Mat&, Mat&, int, int);
+
+// ---- PNM ---------------------------------------------------------------------------------------------
+static bool read_pnm(const path& p, int want_channels, Mat& out) {
+	FILE* f = fopen(p.string().c_str(), "rb");
+	if (!f) return false;
+	char magic[3] = { 0 };
+	int w = 0, h = 0, maxv = 0;
+	auto next_int = [&](int* v) {
+		int c = fgetc(f);
+		while (c == '#' || c == ' ' || c == '\n' || c == '\r' || c == '\t') {
+			if (c == '#') while (c != '\n' && c != EOF) c = fgetc(f);
+			c = fgetc(f);
+		}
+		int x = 0;
+		while (c >= '0' && c <= '9') { x = x * 10 + (c - '0'); c = fgetc(f); }
+		*v = x;
+	};
+	if (fread(magic, 1, 2, f) != 2) { fclose(f); return false; }
+	const int ch = (magic[1] == '5') ? 1 : (magic[1] == '6' ? 3 : 0);
+	if (magic[0] != 'P' || ch == 0) { fclose(f); return false; }
+	next_int(&w); next_int(&h); next_int(&maxv);
+	if (w <= 0 || h <= 0 || maxv != 255) { fclose(f); return false; }
+	std::vector<unsigned char> buf((size_t)w * h * ch);
+	if (fread(buf.data(), 1, buf.size(), f) != buf.size()) { fclose(f); return false; }
+	fclose(f);
+	if (want_channels == 1) {
+		out = Mat(h, w, CV_8UC1);
+		for (size_t i = 0; i < (size_t)w * h; ++i) {
+			if (ch == 1) out.data[i] = buf[i];
+			else {   // RGB -> gray with OpenCV's fixed-point weights (R 0.299, G 0.587, B 0.114)
+				const int r = buf[3 * i], g = buf[3 * i + 1], b = buf[3 * i + 2];
+				out.data[i] = (unsigned char)((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14);
+			}
+		}
+	} else {
+		out = Mat(h, w, CV_8UC3);   // BGR like cv::imread
+		for (size_t i = 0; i < (size_t)w * h; ++i) {
+			if (ch == 1) out.data[3 * i] = out.data[3 * i + 1] = out.data[3 * i + 2] = buf[i];
+			else { out.data[3 * i] = buf[3 * i + 2]; out.data[3 * i + 1] = buf[3 * i + 1]; out.data[3 * i + 2] = buf[3 * i]; }
+		}
+	}
+	return true;
+}
+static Mat read_image(const path& jpg, int channels) {
+	Mat m;
+	path p = jpg;
+	for (const char* ext : { ".pgm", ".ppm" }) {
+		p.replace_extension(ext);
+		if (std::filesystem::exists(p) && read_pnm(p, channels, m)) return m;
+	}
+	if (std::filesystem::exists(jpg))
+		std::cerr << "No JPEG decoder in this build (no OpenCV/libjpeg): convert " << jpg << " with tools/jpg2pnm.py\n";
+	return Mat();
+}
+Mat ReadImageGray(const path& p) { return read_image(p, 1); }
+Mat ReadImageColor(const path& p) { return read_image(p, 3); }
+
+// cv::resize(src, dst, Size(new_cols,new_rows), 0, 0, INTER_LINEAR) for CV_32FC1: pixel-centre
+// aligned bilinear (src = (dst + 0.5) * scale - 0.5), border replicated, horizontal pass then
+// vertical pass in float.  Third-party arithmetic (OpenCV >= 3.3), restated from its documentation.
+Mat ResizeLinear(const Mat& src, int new_cols, int new_rows) {
+	Mat dst(new_rows, new_cols, CV_32FC1);
+	const double sx = (double)src.cols / new_cols, sy = (double)src.rows / new_rows;
+	std::vector<int> x0(new_cols);
+	std::vector<float> ax(new_cols);
+	for (int dx = 0; dx < new_cols; ++dx) {
+		float fx = (float)((dx + 0.5) * sx - 0.5);
+		int ix = (int)std::floor(fx);
+		fx -= ix;
+		if (ix < 0) { ix = 0; fx = 0; }
+		if (ix >= src.cols - 1) { ix = src.cols - 1; fx = 0; }
+		x0[dx] = ix;
+		ax[dx] = fx;
+	}
+	for (int dy = 0; dy < new_rows; ++dy) {
+		float fy = (float)((dy + 0.5) * sy - 0.5);
+		int iy = (int)std::floor(fy);
+		fy -= iy;
+		if (iy < 0) { iy = 0; fy = 0; }
+		if (iy >= src.rows - 1) { iy = src.rows - 1; fy = 0; }
+		const float* r0 = src.ptr<float>(iy);
+		const float* r1 = src.ptr<float>(std::min(iy + 1, src.rows - 1));
+		float* o = dst.ptr<float>(dy);
+		for (int dx = 0; dx < new_cols; ++dx) {
+			const int ix = x0[dx], ix1 = std::min(ix + 1, src.cols - 1);
+			const float a = ax[dx];
+			const float h0 = r0[ix] * (1.f - a) + r0[ix1] * a;
+			const float h1 = r1[ix] * (1.f - a) + r1[ix1] * a;
+			o[dx] = h0 * (1.f - fy) + h1 * fy;
+		}
+	}
+	return dst;
+}
+
+void DvpSafeCall(int rc, dvp_ctx* ctx, const char* what, const char* file, int line) {
+	if (rc != 0) {
+		fprintf(stderr, "DvpSafeCall() failed at %s:%i : %s : %s\n", file, line, what, dvp_last_error(ctx));
+		exit(EXIT_FAILURE);
+	}
+}

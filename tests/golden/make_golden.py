@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/golden_small.npz from the CPU oracle (the reference itself cannot be built
+or run in this image: it needs CUDA, OpenCV and Boost).  These are regression anchors for the
+oracle + engine pair: inputs (seeded synthetic scene, KAT pixel/plane pairs) and expected outputs
+(cost vectors, final planes / views / pixel states of a 2-iteration FIRST_INIT pass)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import synth, make_params, first_pass_state   # noqa: E402
+from oracle import oracle as O   # noqa: E402
+
+W, H, S, seed = 96, 64, 3, 4242
+sc = synth.make_scene(W, H, S)
+p = make_params(S + 1, max_iterations=2, state=synth.FIRST_INIT, use_APD=0)
+o = O.from_scene(sc, p, seed=seed)
+o.upload_state(**first_pass_state(sc))
+rng = np.random.default_rng(11)
+n = 512
+px = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], 1).astype(np.int32)
+depth = rng.uniform(1.5, 7.8, n).astype(np.float32)
+nrm = rng.normal(size=(n, 3)).astype(np.float32)
+nrm[:, 2] = -np.abs(nrm[:, 2]) - 0.3
+nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+K = sc["cameras"][0]["K"]
+d = -(nrm[:, 0] * depth * (px[:, 0] - K[2]) / K[0] + nrm[:, 1] * depth * (px[:, 1] - K[5]) / K[4] + nrm[:, 2] * depth)
+planes = np.concatenate([nrm, d[:, None]], 1).astype(np.float32)
+costs = o.eval_cost_vectors(px, planes)
+o.run_patchmatch()
+np.savez_compressed(os.path.join(os.path.dirname(__file__), "golden_small.npz"), W=W, H=H, S=S, seed=seed,
+                    images=sc["images"], kat_px=px, kat_planes=planes, kat_costs=costs, planes=o.get("planes"),
+                    selected_views=o.get("selected_views"), weak_info=o.get("weak_info"))
+print("written")

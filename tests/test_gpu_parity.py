@@ -193,3 +193,32 @@ def test_size_independent_properties_at_bench_size():
     assert views.max() < (1 << S)
     t = g.timings()
     assert t["total_ms"] > 0 and t["stage_launches"]["strong_update"] == 4
+
+
+def test_golden_fixtures_on_gpu():
+    """the committed vectors (tests/golden/golden_small.npz) through the C ABI"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_small.npz"))
+    W, H, S = int(g["W"]), int(g["H"]), int(g["S"])
+    sc = synth.make_scene(W, H, S)
+    p = make_params(S + 1, max_iterations=2, state=synth.FIRST_INIT, use_APD=0)
+    b = capi().from_scene(sc, p, seed=int(g["seed"]))
+    b.upload_state(**first_pass_state(sc))
+    assert count_diff(b.eval_cost_vectors(g["kat_px"], g["kat_planes"]), g["kat_costs"]) == 0
+    b.run_patchmatch()
+    planes, views, weak, radius = b.download_state()
+    assert count_diff(planes, g["planes"]) == 0
+    assert np.array_equal(views, g["selected_views"]) and np.array_equal(weak, g["weak_info"])
+
+
+def test_reset_state_equals_fresh_context():
+    W, H, S = 96, 64, 3
+    sc = synth.make_scene(W, H, S)
+    p = make_params(S + 1, max_iterations=1, state=synth.FIRST_INIT, use_APD=0)
+    g = capi().from_scene(sc, p, seed=9)
+    g.upload_state(**first_pass_state(sc))
+    g.run_patchmatch()
+    first = g.get("planes")
+    g.reset_state()
+    g.run_patchmatch()
+    assert count_diff(first, g.get("planes")) == 0

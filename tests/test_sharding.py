@@ -1,0 +1,73 @@
+"""Multi-GPU path on CPU: views shard round-robin over ranks with no data-path collective; the
+union over ranks equals the 1-rank result.  world_size-2 `gloo` processes each run the CPU oracle on
+their own views of one scene (stand-in for one GPU each) and rank 0 gathers checksums."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import ROOT, pkg
+
+sharding = pkg("sharding")
+
+
+def test_round_robin_partition():
+    for nv in (1, 2, 7, 13, 35):
+        for ws in (1, 2, 4, 8):
+            parts = [sharding.views_for_rank(nv, r, ws) for r in range(ws)]
+            flat = sorted(v for p in parts for v in p)
+            assert flat == list(range(nv))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+            for r, p in enumerate(parts):
+                assert all(sharding.owner_of(v, ws) == r for v in p)
+
+
+WORKER = r'''
+import os, sys, hashlib, importlib
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from conftest import synth, make_params, first_pass_state
+from oracle import oracle as O
+sharding = importlib.import_module("dvp-mvs_amd.sharding")
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+NV, W, H, S = 5, 48, 40, 2
+sc = synth.make_scene(W, H, S)
+p = make_params(S + 1, max_iterations=1, state=synth.FIRST_INIT, use_APD=0)
+mine = {}
+for v in sharding.views_for_rank(NV, rank, world):
+    o = O.from_scene(sc, p, seed=1000 + v)          # one "view" = one seed over the shared scene
+    o.upload_state(**first_pass_state(sc))
+    o.run_patchmatch()
+    mine[v] = hashlib.sha1(o.get("planes").tobytes()).hexdigest()
+gathered = [None] * world
+dist.all_gather_object(gathered, mine)
+if rank == 0:
+    allv = {}
+    for g in gathered: allv.update(g)
+    print("RESULT", sorted(allv.items()))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _run(world):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + world + (os.getpid() % 200)), "-c", WORKER, ROOT]
+    # torchrun has no -c: write the worker to a temp file
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(WORKER)
+        path = f.name
+    cmd = cmd[:-3] + [path, ROOT]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    os.unlink(path)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0]
+    return line
+
+
+def test_two_ranks_equal_one_rank():
+    assert _run(2) == _run(1)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Write a synthetic scene as an MVSNet-layout dense folder the `apd` driver can consume
+(layout of /root/reference/colmap2mvsnet.py:424-469): images/%08d.pgm (+ .ppm), cams/%08d_cam.txt,
+pair.txt.  usage: make_dataset.py OUT W H NUM_VIEWS [SRC_PER_VIEW]"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def write_cam(path, cam):
+    R = cam["R"].reshape(3, 3)
+    t = cam["t"]
+    K = cam["K"].reshape(3, 3)
+    with open(path, "w") as f:
+        f.write("extrinsic\n")
+        for i in range(3):
+            f.write("%.9g %.9g %.9g %.9g\n" % (R[i, 0], R[i, 1], R[i, 2], t[i]))
+        f.write("0.0 0.0 0.0 1.0\n\nintrinsic\n")
+        for i in range(3):
+            f.write("%.9g %.9g %.9g\n" % tuple(K[i]))
+        dmin, dmax = float(cam["depth_min"]), float(cam["depth_max"])
+        f.write("\n%.9g %.9g %d %.9g\n" % (dmin, (dmax - dmin) / 192.0, 192, dmax))
+
+
+def main():
+    out, W, H, NV = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    nsrc = int(sys.argv[5]) if len(sys.argv) > 5 else min(NV - 1, 4)
+    synth = importlib.import_module("dvp-mvs_amd.synth")
+    sc = synth.make_scene(W, H, NV - 1)
+    os.makedirs(os.path.join(out, "images"), exist_ok=True)
+    os.makedirs(os.path.join(out, "cams"), exist_ok=True)
+    for i in range(NV):
+        img = sc["images"][i].astype(np.uint8)
+        with open(os.path.join(out, "images", "%08d.pgm" % i), "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (W, H))
+            f.write(img.tobytes())
+        write_cam(os.path.join(out, "cams", "%08d_cam.txt" % i), sc["cameras"][i])
+    with open(os.path.join(out, "pair.txt"), "w") as f:
+        f.write("%d\n" % NV)
+        for i in range(NV):
+            c = sc["cameras"]["c"]
+            d = np.linalg.norm(c - c[i], axis=1)
+            order = [j for j in np.argsort(d) if j != i][:nsrc]
+            f.write("%d\n%d " % (i, len(order)) + " ".join("%d %.3f" % (j, 100.0 / (1.0 + d[j])) for j in order) + "\n")
+    np.save(os.path.join(out, "depth_gt.npy"), sc["depth_gt"])
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    main()
