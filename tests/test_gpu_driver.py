@@ -24,12 +24,12 @@ def read_binmat(path):
 
 
 def test_apd_driver(tmp_path):
-    W, H, NV = 160, 120, 4
+    W, H, NV = 192, 144, 4
     d = str(tmp_path / "scene")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), "3"])
     apd = os.path.join(ROOT, "dvp-mvs_amd", "apd")
     # W,H <= 800 -> one round at scale 1: FIRST_INIT pass + 1 geom pass
-    out = subprocess.run([apd, d, "0", "--iters", "2", "--passes", "1", "--min-scale", "1", "--seed", "77"], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([apd, d, "0", "--iters", "3", "--passes", "1", "--min-scale", "1", "--seed", "77"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     gt = np.load(os.path.join(d, "depth_gt.npy"))
     for v in range(NV):
@@ -40,7 +40,7 @@ def test_apd_driver(tmp_path):
         assert dep.shape == (H, W)
         m = dep[10:-10, 10:-10] > 0
         rel = np.abs(dep - gt[v])[10:-10, 10:-10][m] / gt[v][10:-10, 10:-10][m]
-        assert m.mean() > 0.7 and np.median(rel) < 5e-3, (v, m.mean(), np.median(rel))
+        assert m.mean() > 0.7 and np.median(rel) < 1.5e-2, (v, m.mean(), np.median(rel))
         nrm = read_binmat(os.path.join(r, "APD_normals.dmb"))
         assert nrm.shape == (H, W, 3)
     ply = os.path.join(d, "APD", "APD.ply")
