@@ -47,8 +47,9 @@ struct ViewConst {
 // The buffer bundle every kernel receives (the engine's DataPassHelper, APD.h:60-92).
 struct Dev {
 	int width, height, num_images;
-	int pitch;                 // floats per image row (multiple of 64 -> 256 B aligned rows)
-	size_t plane_stride;       // floats per image plane
+	int pitch;                 // floats per padded image row (multiple of 64 -> 256 B aligned rows)
+	int org;                   // element offset of pixel (0,0) inside a padded plane (= PAD*pitch + PAD)
+	size_t plane_stride;       // floats per padded image plane ((H + 2*PAD) * pitch)
 	int sampler;               // 0 = 8-bit interpolation weights, 1 = exact
 	int weak_count;
 	uint64_t seed;
@@ -56,8 +57,8 @@ struct Dev {
 	// uniform constants derived from params on the host (GenNeighbours, APD.cu:3375-3380)
 	float nb_cos, nb_sin, nb_thresh;
 	int nb_shift_range;
-	const float* images;       // [num_images][height][pitch]
-	const float* depths;       // [num_images][height][pitch] (geom_consistency only)
+	const float* images;       // [num_images][H + 2*PAD][pitch], border replicated (== clamp addressing)
+	const float* depths;       // same layout (geom_consistency only)
 	const DvpCamera* cameras;  // [num_images]
 	const ViewConst* views;    // [num_images] (index 0 unused)
 	const uint8_t* sector_lut; // [(2r+1)^2], r = weak_radius: 30-degree sector of offset (i,j) (APD.cu:797-821)
@@ -135,33 +136,66 @@ struct Rng {
 };
 
 // ---- software texture unit (gfx950 has no tex2D path; semantics of APD.cpp:1501-1517) --------
+// Image planes carry kImgPad replicated border pixels on every side: reading the padded plane at
+// an unclamped coordinate in [-kImgPad, W-1+kImgPad] IS clamp-to-edge addressing, so the bilinear
+// footprint needs no integer clamps and its two x-neighbours are always adjacent in memory.
+constexpr int kImgPad = 2;
+
 DVP_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-DVP_HD float tex_texel(const float* img, int pitch, int W, int H, int ix, int iy) {
-	return img[(size_t)clampi(iy, 0, H - 1) * pitch + clampi(ix, 0, W - 1)];
+// tex2D(img, ix + 0.5f, iy + 0.5f): exact texel, clamp-to-edge (arbitrary integer coordinates)
+DVP_HD float tex_texel(const float* img, int org, int pitch, int W, int H, int ix, int iy) {
+	return img[org + clampi(iy, 0, H - 1) * pitch + clampi(ix, 0, W - 1)];
 }
 
-// x, y are the texture coordinates the reference passes to tex2D (pixel + 0.5)
-DVP_HD float tex_linear(const float* img, int pitch, int W, int H, float x, float y, int sampler) {
+// two adjacent floats at a 4-byte aligned address: one global_load_dwordx2 with a 32-bit byte
+// offset from a wave-uniform base (SGPR base + VGPR offset addressing)
+DVP_HD void load_pair(const float* base, unsigned byte_off, float* a, float* b) {
+#if defined(__HIPCC__)
+	typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+	const f2u t = *reinterpret_cast<const f2u*>(reinterpret_cast<const char*>(base) + byte_off);
+	*a = t.x;
+	*b = t.y;
+#else
+	const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+	*a = p[0];
+	*b = p[1];
+#endif
+}
+DVP_HD unsigned mul24(unsigned a, unsigned b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __umul24(a, b);
+#else
+	return a * b;
+#endif
+}
+
+// tex2D(img, x, y), cudaFilterModeLinear, unnormalised coordinates, clamp; x, y are the texture
+// coordinates the reference passes (pixel + 0.5).  SMP 0: fractions rounded to 8 bits, 1: exact.
+template <int SMP>
+DVP_HD float tex_linear_t(const float* img, int pitch, int W, int H, float x, float y) {
 	float xb = x - 0.5f, yb = y - 0.5f;
-	xb = fminf(fmaxf(xb, -1.0f), (float)W);
+	xb = fminf(fmaxf(xb, -1.0f), (float)W);   // also maps NaN to -1
 	yb = fminf(fmaxf(yb, -1.0f), (float)H);
 	const float fx = floorf(xb), fy = floorf(yb);
 	float a = xb - fx, b = yb - fy;
-	if (sampler == 0) {
+	if (SMP == 0) {
 		a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
 		b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
 	}
-	const int i0 = (int)fx, j0 = (int)fy;
-	const int x0 = clampi(i0, 0, W - 1), x1 = clampi(i0 + 1, 0, W - 1);
-	const int y0 = clampi(j0, 0, H - 1), y1 = clampi(j0 + 1, 0, H - 1);
-	const float* r0 = img + (size_t)y0 * pitch;
-	const float* r1 = img + (size_t)y1 * pitch;
-	const float t00 = r0[x0], t10 = r0[x1];
-	const float t01 = r1[x0], t11 = r1[x1];
+	// floor results are in [-1, W] / [-1, H]: the footprint [i0, i0+1] x [j0, j0+1] lies inside
+	// the padded plane
+	const unsigned ip = (unsigned)((int)fx + kImgPad), jp = (unsigned)((int)fy + kImgPad);
+	const unsigned off = (mul24(jp, (unsigned)pitch) + ip) * 4u;
+	float t00, t10, t01, t11;
+	load_pair(img, off, &t00, &t10);
+	load_pair(img, off + (unsigned)pitch * 4u, &t01, &t11);
 	const float top = fmaf(a, t10 - t00, t00);
 	const float bot = fmaf(a, t11 - t01, t01);
 	return fmaf(b, bot - top, top);
+}
+DVP_HD float tex_linear(const float* img, int pitch, int W, int H, float x, float y, int sampler) {
+	return sampler == 0 ? tex_linear_t<0>(img, pitch, W, H, x, y) : tex_linear_t<1>(img, pitch, W, H, x, y);
 }
 
 // ---- small geometry helpers (APD.cu:181-194, 331-422, 467-499, 750-768) ----------------------

@@ -20,21 +20,25 @@ struct LaunchArgs {
 	int tiles_x, tiles, chunk, rows, half, colour, iter;
 };
 
-template <int STAGE>
+template <int STAGE, int SMP>
 __device__ __forceinline__ void stage_body(const Dev& d, const LaunchArgs& a) {
 	const int lane = threadIdx.x & 63;
 	const int wave = threadIdx.x >> 6;
 	int px, py;
 	unsigned long long n = 0;
 	if (block_to_pixel(blockIdx.x, lane, wave, a.tiles_x, a.tiles, a.chunk, a.rows, a.half, a.colour, d.width, d.height, &px, &py))
-		run_pixel<STAGE>(d, px, py, a.iter, d.eval_counter ? &n : nullptr);
+		run_pixel<STAGE, SMP>(d, px, py, a.iter, d.eval_counter ? &n : nullptr);
 	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
 }
 
 // One named kernel per launch site so that rocprofv3 --kernel-trace shows the reference's names.
-#define DVP_KERNEL(NAME, STAGE, MINW)                                                              \
-	extern "C" __global__ void __launch_bounds__(256, MINW) NAME(const Dev d, const LaunchArgs a) { \
-		stage_body<STAGE>(d, a);                                                                    \
+// NAME: sampler 0 (8-bit interpolation weights, default); NAME_exact: sampler 1.
+#define DVP_KERNEL(NAME, STAGE, MINW)                                                                      \
+	extern "C" __global__ void __launch_bounds__(256, MINW) NAME(const Dev d, const LaunchArgs a) {         \
+		stage_body<STAGE, 0>(d, a);                                                                         \
+	}                                                                                                       \
+	extern "C" __global__ void __launch_bounds__(256, MINW) NAME##_exact(const Dev d, const LaunchArgs a) { \
+		stage_body<STAGE, 1>(d, a);                                                                         \
 	}
 
 DVP_KERNEL(dvp_gen_edge_inform, DVP_ST_GEN_EDGE_INFORM, 1)
@@ -57,6 +61,30 @@ DVP_KERNEL(dvp_filter_strong, DVP_ST_FILTER_STRONG, 1)
 DVP_KERNEL(dvp_depth_to_weak, DVP_ST_DEPTH_TO_WEAK, DVP_LB_HEAVY)
 DVP_KERNEL(dvp_local_refine, DVP_ST_LOCAL_REFINE, DVP_LB_HEAVY)
 
+// replicate the image border into the kImgPad-wide frame of a padded plane set
+extern "C" __global__ void dvp_pad_replicate(float* planes, int W, int H, int pitch, size_t plane_stride, int n_planes) {
+	const int PW = W + 2 * kImgPad, PH = H + 2 * kImgPad;
+	const int frame = 2 * kImgPad * PW + 2 * kImgPad * H;   // border cells per plane
+	const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= (long long)frame * n_planes) return;
+	const int pl = (int)(t / frame);
+	int k = (int)(t - (long long)pl * frame);
+	int x, y;
+	if (k < 2 * kImgPad * PW) {           // top and bottom bands
+		y = k / PW;
+		x = k - y * PW;
+		if (y >= kImgPad) y += H;
+	} else {                              // left and right bands of the interior rows
+		k -= 2 * kImgPad * PW;
+		y = kImgPad + k / (2 * kImgPad);
+		x = k % (2 * kImgPad);
+		if (x >= kImgPad) x += W;
+	}
+	float* p = planes + (size_t)pl * plane_stride;
+	const int sx = clampi(x - kImgPad, 0, W - 1) + kImgPad, sy = clampi(y - kImgPad, 0, H - 1) + kImgPad;
+	p[(size_t)y * pitch + x] = p[(size_t)sy * pitch + sx];
+}
+
 extern "C" __global__ void dvp_prepare_views(const DvpCamera* cams, ViewConst* views, int n) {
 	const int v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= 1 && v < n) compute_view_const(cams[0], cams[v], &views[v]);
@@ -74,7 +102,7 @@ extern "C" __global__ void __launch_bounds__(256) dvp_cost_vectors(const Dev d, 
 	patch_geometry(d, x + y * d.width, &radius, &inc);
 	build_patch_ctx(d, x, y, radius, inc, 0, &c);
 	const f4 pl = planes[i];
-	for (int v = 0; v < S; ++v) out[(size_t)i * S + v] = ncc_old(d, c, x, y, v + 1, pl);
+	for (int v = 0; v < S; ++v) out[(size_t)i * S + v] = d.sampler ? ncc_old<1>(d, c, x, y, v + 1, pl) : ncc_old<0>(d, c, x, y, v + 1, pl);
 }
 
 // same computation on every pixel with its current plane (camera frame); writes the view-mean
@@ -90,7 +118,7 @@ extern "C" __global__ void __launch_bounds__(256) dvp_cost_all_pixels(const Dev 
 	build_patch_ctx(d, px, py, radius, inc, 0, &c);
 	const f4 pl = d.planes[center];
 	float acc = 0.0f;
-	for (int v = 0; v < S; ++v) acc += ncc_old(d, c, px, py, v + 1, pl);
+	for (int v = 0; v < S; ++v) acc += ncc_old<0>(d, c, px, py, v + 1, pl);
 	out[center] = acc / S;
 }
 
@@ -155,7 +183,8 @@ static int dalloc(dvp_ctx* c, T** p, size_t count, bool zero = true) {
 static void sync_dev_struct(dvp_ctx* c) {
 	Dev& d = c->d;
 	d.width = c->W; d.height = c->H; d.num_images = c->NI; d.pitch = c->pitch;
-	d.plane_stride = (size_t)c->pitch * c->H;
+	d.org = kImgPad * c->pitch + kImgPad;
+	d.plane_stride = (size_t)c->pitch * (c->H + 2 * kImgPad);
 	d.images = c->images; d.depths = c->depths; d.cameras = c->cameras; d.views = c->views; d.sector_lut = c->lut;
 	d.planes = c->planes; d.planes_snap = c->planes_snap; d.costs = c->costs; d.costs_snap = c->costs_snap;
 	d.selected_views = c->selected_views; d.view_weight = c->view_weight; d.weak_info = c->weak_info;
@@ -182,12 +211,12 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	}
 	dvp_ctx* c = new dvp_ctx();
 	c->device = device; c->W = width; c->H = height; c->NI = num_images;
-	c->pitch = (width + 63) / 64 * 64;
+	c->pitch = (width + 2 * kImgPad + 63) / 64 * 64;
 	c->L = (size_t)width * height;
 	auto fail = [&](int) { g_create_error = c->error; dvp_ctx_destroy(c); return 1; };
 	if (set_device(c)) return fail(0);
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->error = "hipStreamCreate failed"; return fail(0); }
-	const size_t L = c->L, S = (size_t)num_images - 1, plane = (size_t)c->pitch * height;
+	const size_t L = c->L, S = (size_t)num_images - 1, plane = (size_t)c->pitch * (height + 2 * kImgPad);
 	int r = 0;
 	r |= dalloc(c, &c->images, plane * num_images);
 	r |= dalloc(c, &c->cameras, (size_t)num_images);
@@ -250,10 +279,16 @@ const char* dvp_last_error(const dvp_ctx* c) { return c ? c->error.c_str() : g_c
 static int upload_planes(dvp_ctx* c, float* dst, const float* const* src, int pitch_floats, hipMemcpyKind kind) {
 	if (set_device(c)) return 1;
 	if (pitch_floats < c->W) { c->error = "pitch_floats < width"; return 1; }
+	const size_t stride = (size_t)c->pitch * (c->H + 2 * kImgPad);
 	for (int i = 0; i < c->NI; ++i) {
 		if (!src[i]) { c->error = "null image pointer"; return 1; }
-		HIP_TRY(c, hipMemcpy2DAsync(dst + (size_t)i * c->pitch * c->H, (size_t)c->pitch * 4, src[i], (size_t)pitch_floats * 4,
-		                            (size_t)c->W * 4, (size_t)c->H, kind, c->stream));
+		HIP_TRY(c, hipMemcpy2DAsync(dst + (size_t)i * stride + (size_t)kImgPad * c->pitch + kImgPad, (size_t)c->pitch * 4, src[i],
+		                            (size_t)pitch_floats * 4, (size_t)c->W * 4, (size_t)c->H, kind, c->stream));
+	}
+	{   // border replication == clamp-to-edge addressing (APD.cpp:1511-1515)
+		const long long cells = (long long)(2 * kImgPad * (c->W + 2 * kImgPad) + 2 * kImgPad * c->H) * c->NI;
+		hipLaunchKernelGGL(dvp_pad_replicate, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, c->stream, dst, c->W, c->H, c->pitch, stride, c->NI);
+		HIP_TRY(c, hipGetLastError());
 	}
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	return 0;
@@ -266,7 +301,7 @@ int dvp_upload_images_device(dvp_ctx* c, const float* const* images, int pitch_f
 }
 static int ensure_depths(dvp_ctx* c) {
 	if (!c->depths) {
-		if (dalloc(c, &c->depths, (size_t)c->pitch * c->H * c->NI)) return 1;
+		if (dalloc(c, &c->depths, (size_t)c->pitch * (c->H + 2 * kImgPad) * c->NI)) return 1;
 		sync_dev_struct(c);
 	}
 	c->have_depths = true;
@@ -397,18 +432,18 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 	HIP_TRY(c, hipEventRecord(ep.a, c->stream));
 	const dim3 grid(g.grid()), block(256);
 	switch (stage) {
-	case DVP_ST_GEN_EDGE_INFORM: hipLaunchKernelGGL(dvp_gen_edge_inform, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_FIND_NEAREST_STRONG: hipLaunchKernelGGL(dvp_find_nearest_strong, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_GEN_NEIGHBOURS: hipLaunchKernelGGL(dvp_gen_neighbours, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(dvp_neighbour_update, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_RANDOM_INIT: hipLaunchKernelGGL(dvp_random_init, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_STRONG_UPDATE: hipLaunchKernelGGL(dvp_strong_update, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(dvp_ransac_fit_plane, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_WEAK_UPDATE: hipLaunchKernelGGL(dvp_weak_update, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_GET_DEPTH_NORMAL: hipLaunchKernelGGL(dvp_get_depth_normal, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_FILTER_STRONG: hipLaunchKernelGGL(dvp_filter_strong, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_DEPTH_TO_WEAK: hipLaunchKernelGGL(dvp_depth_to_weak, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_LOCAL_REFINE: hipLaunchKernelGGL(dvp_local_refine, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_GEN_EDGE_INFORM: hipLaunchKernelGGL(c->d.sampler ? dvp_gen_edge_inform_exact : dvp_gen_edge_inform, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_FIND_NEAREST_STRONG: hipLaunchKernelGGL(c->d.sampler ? dvp_find_nearest_strong_exact : dvp_find_nearest_strong, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_GEN_NEIGHBOURS: hipLaunchKernelGGL(c->d.sampler ? dvp_gen_neighbours_exact : dvp_gen_neighbours, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(c->d.sampler ? dvp_neighbour_update_exact : dvp_neighbour_update, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_RANDOM_INIT: hipLaunchKernelGGL(c->d.sampler ? dvp_random_init_exact : dvp_random_init, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_STRONG_UPDATE: hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_exact : dvp_strong_update, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(c->d.sampler ? dvp_ransac_fit_plane_exact : dvp_ransac_fit_plane, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_WEAK_UPDATE: hipLaunchKernelGGL(c->d.sampler ? dvp_weak_update_exact : dvp_weak_update, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_GET_DEPTH_NORMAL: hipLaunchKernelGGL(c->d.sampler ? dvp_get_depth_normal_exact : dvp_get_depth_normal, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_FILTER_STRONG: hipLaunchKernelGGL(c->d.sampler ? dvp_filter_strong_exact : dvp_filter_strong, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_DEPTH_TO_WEAK: hipLaunchKernelGGL(c->d.sampler ? dvp_depth_to_weak_exact : dvp_depth_to_weak, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_LOCAL_REFINE: hipLaunchKernelGGL(c->d.sampler ? dvp_local_refine_exact : dvp_local_refine, grid, block, 0, c->stream, c->d, a); break;
 	}
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipEventRecord(ep.b, c->stream));

@@ -53,7 +53,7 @@ DVP_HD void build_patch_ctx(const Dev& d, int px, int py, int radius, int inc, i
 	c->inc = inc;
 	c->fast = (inc > 0 && (2 * radius) / inc + 1 == kTaps) ? 1 : 0;
 	if (!c->fast) return;
-	const float cpix = tex_texel(ref, P, W, H, px, py);
+	const float cpix = tex_texel(ref, d.org, P, W, H, px, py);
 	const float sig_s = d.params.sigma_spatial, sig_c = d.params.sigma_color;
 	float sr = 0.0f, srr = 0.0f, ws = 0.0f;
 #pragma unroll
@@ -63,7 +63,7 @@ DVP_HD void build_patch_ctx(const Dev& d, int px, int py, int radius, int inc, i
 #pragma unroll
 		for (int tj = 0; tj < kTaps; ++tj) {
 			const int j = -radius + tj * inc;
-			const float a = tex_texel(ref, P, W, H, px + i, py + j);
+			const float a = tex_texel(ref, d.org, P, W, H, px + i, py + j);
 			const float w = bilateral_weight((float)i, (float)j, a, cpix, sig_s, sig_c, colour_only);
 			const float wa = w * a;
 			c->w[ti * kTaps + tj] = w;
@@ -103,13 +103,13 @@ DVP_HD float ncc_from_sums(float sum_ref, float sum_ref_ref, float sum_src, floa
 DVP_HD float ncc_patch_generic(const Dev& d, const float* H, const float* src, int px, int py, int radius, int inc, int colour_only) {
 	const float* ref = d.images;
 	const int W = d.width, Hh = d.height, P = d.pitch;
-	const float cpix = tex_texel(ref, P, W, Hh, px, py);
+	const float cpix = tex_texel(ref, d.org, P, W, Hh, px, py);
 	float s_r = 0.0f, s_rr = 0.0f, s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f, s_w = 0.0f;
 	if (inc <= 0) inc = 1;
 	for (int i = -radius; i <= radius; i += inc) {
 		float r_r = 0.0f, r_rr = 0.0f, r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f, r_w = 0.0f;
 		for (int j = -radius; j <= radius; j += inc) {
-			const float a = tex_texel(ref, P, W, Hh, px + i, py + j);
+			const float a = tex_texel(ref, d.org, P, W, Hh, px + i, py + j);
 			const f2 sp = apply_homography(H, px + i, py + j);
 			const float b = tex_linear(src, P, W, Hh, sp.x + 0.5f, sp.y + 0.5f, d.sampler);
 			const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, colour_only);
@@ -125,7 +125,9 @@ DVP_HD float ncc_patch_generic(const Dev& d, const float* H, const float* src, i
 	return ncc_from_sums(s_r, s_rr, s_s, s_ss, s_rs, s_w);
 }
 
-// 36-tap patch with the hoisted context.  H is the pixel->source homography.
+// 36-tap patch with the hoisted context.  H is the pixel->source homography.  The sampler mode is
+// a template parameter so that the unrolled tap body is one branch-free basic block.
+template <int SMP>
 DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, const float* src, int px, int py) {
 	const int W = d.width, Hh = d.height, P = d.pitch;
 	// H[k]*x and H[k]*y products for the 6 distinct tap columns / rows: same products the
@@ -147,7 +149,7 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 			const float x = hx0[ti] + hy1[tj] + H[2];
 			const float y = hx3[ti] + hy4[tj] + H[5];
 			const float z = hx6[ti] + hy7[tj] + H[8];
-			const float b = tex_linear(src, P, W, Hh, x / z + 0.5f, y / z + 0.5f, d.sampler);
+			const float b = tex_linear_t<SMP>(src, P, W, Hh, x / z + 0.5f, y / z + 0.5f);
 			const float wb = c.w[ti * kTaps + tj] * b;
 			r_s += wb;
 			r_ss += wb * b;
@@ -161,6 +163,7 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 }
 
 // ComputeBilateralNCCOld (APD.cu:1023-1113) for source view `v` (1-based image index).
+template <int SMP>
 DVP_HD float ncc_old(const Dev& d, const PatchCtx& c, int px, int py, int v, const f4 plane) {
 	const DvpCamera& rc = d.cameras[0];
 	const DvpCamera& sc = d.cameras[v];
@@ -169,7 +172,7 @@ DVP_HD float ncc_old(const Dev& d, const PatchCtx& c, int px, int py, int v, con
 	const f2 pt = apply_homography(H, px, py);
 	if (pt.x >= sc.width || pt.x < 0.0f || pt.y >= sc.height || pt.y < 0.0f) return 2.0f;
 	const float* src = d.images + (size_t)v * d.plane_stride;
-	if (c.fast) return ncc_patch_fast(d, c, H, src, px, py);
+	if (c.fast) return ncc_patch_fast<SMP>(d, c, H, src, px, py);
 	return ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 0);
 }
 
@@ -185,7 +188,7 @@ DVP_HD float geom_cost(const Dev& d, int px, int py, int v, const f4 plane) {
 	project_on_camera(fwd, sc, &sp, &sd);
 	const float cx = fminf(fmaxf(sp.x, -1.0f), (float)d.width);
 	const float cy = fminf(fmaxf(sp.y, -1.0f), (float)d.height);
-	const float src_depth = tex_texel(dimg, d.pitch, d.width, d.height, (int)cx, (int)cy);
+	const float src_depth = tex_texel(dimg, d.org, d.pitch, d.width, d.height, (int)cx, (int)cy);
 	if (src_depth == 0.0f) return 3.0f;
 	const f3 back = point_on_world(sp.x, sp.y, src_depth, sc);
 	f2 bp;

@@ -43,7 +43,7 @@ DVP_HD f4 random_normal_yzl(const Dev& d, int px, int py, Rng& rng, float depth)
 		float src_depth = 1.0f;   // reference leaves it uninitialised outside the image (APD.cu:526)
 		if (d.params.geom_consistency) {
 			if (ix >= 0 && ix < W && iy >= 0 && iy < H)
-				src_depth = tex_texel(d.depths + (size_t)v * d.plane_stride, d.pitch, W, H, (int)sx, (int)sy);
+				src_depth = tex_texel(d.depths + (size_t)v * d.plane_stride, d.org, d.pitch, W, H, (int)sx, (int)sy);
 		}
 		const f4 dir = view_direction(sc, ix, iy, src_depth);
 		// R_c = R_ref * R_src^T ; R_f = R_c * {x, y, x} with row 2 using R_c[7] twice (APD.cu:14-18, 540-544)
@@ -87,6 +87,7 @@ DVP_HD f4 random_normal_yzl(const Dev& d, int px, int py, Rng& rng, float depth)
 }
 
 // RandomInitialization (APD.cu:1273-1309)
+template <int SMP>
 DVP_HD void random_init_px(const Dev& d, int px, int py, unsigned long long* nevals) {
 	const int center = py * d.width + px;
 	const DvpParams& P = d.params;
@@ -112,7 +113,7 @@ DVP_HD void random_init_px(const Dev& d, int px, int py, unsigned long long* nev
 		float cv[32], cvs[32];
 		int valid = 0;
 		for (int v = 0; v < S; ++v) {
-			const float cst = ncc_old(d, c, px, py, v + 1, plane);
+			const float cst = ncc_old<SMP>(d, c, px, py, v + 1, plane);
 			cv[v] = cst;
 			cvs[v] = cst;
 			if (cst < 2.0f) valid++;
@@ -143,7 +144,7 @@ DVP_HD void random_init_px(const Dev& d, int px, int py, unsigned long long* nev
 		float acc = 0.0f;
 		for (int v = 0; v < S; ++v) {
 			if (!is_set(sel, v)) continue;
-			const float cst = ncc_old(d, c, px, py, v + 1, plane);
+			const float cst = ncc_old<SMP>(d, c, px, py, v + 1, plane);
 			if (nevals) *nevals += 1;
 			if (cst < 2.0f) { cnt++; acc += cst; }
 			else unset_bit_ref(&sel, v);
@@ -241,6 +242,7 @@ DVP_HD int strong_sample_search(const Dev& d, int px, int py, int k, int pass) {
 // prologue picks the plane and the views to evaluate, an epilogue consumes the cost vector.
 // After view selection only views with non-zero weight are evaluated: the reference evaluates all
 // S and multiplies the others by a zero weight, which is the same value.
+template <int SMP>
 DVP_HD void strong_update_px(const Dev& d, int px, int py, int iter, unsigned long long* nevals) {
 	const int W = d.width;
 	const int center = py * W + px;
@@ -330,7 +332,7 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, int iter, unsigned lo
 		if (mask) {
 			for (int v = 0; v < S; ++v) {
 				if ((mask >> v) & 1) {
-					cv[v] = ncc_old(d, c, px, py, v + 1, plane);
+					cv[v] = ncc_old<SMP>(d, c, px, py, v + 1, plane);
 					if (nevals) *nevals += 1;
 				}
 			}
@@ -466,14 +468,16 @@ struct SweepCtx {
 	uint32_t sel;
 };
 
+template <int SMP>
 DVP_HD float sweep_cost_view(const Dev& d, const PatchCtx& c, int px, int py, int v, const f4 pl, unsigned long long* nevals) {
-	float cst = ncc_old(d, c, px, py, v + 1, pl);
+	float cst = ncc_old<SMP>(d, c, px, py, v + 1, pl);
 	if (nevals) *nevals += 1;
 	if (d.params.geom_consistency) cst += d.params.geom_factor * geom_cost(d, px, py, v + 1, pl);
 	return cst;
 }
 
 // DepthToWeak (APD.cu:3892-4051)
+template <int SMP>
 DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, unsigned long long* nevals) {
 	const int W = d.width, H = d.height;
 	const int center = px + py * W;
@@ -520,7 +524,7 @@ DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, unsigned long long* n
 			if (!is_set(sel, v)) continue;
 			// a selected view with zero weight contributes cost*0 = +0: skipped (finite cost)
 			if (vw[v] == 0) continue;
-			const float tc = 0.0f + sweep_cost_view(d, c, px, py, v, pl, nevals);
+			const float tc = 0.0f + sweep_cost_view<SMP>(d, c, px, py, v, pl, nevals);
 			pc += tc * vw[v];
 		}
 		pc /= weight_normal;
@@ -555,6 +559,7 @@ DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, unsigned long long* n
 }
 
 // LocalRefine (APD.cu:4053-4139)
+template <int SMP>
 DVP_HD void local_refine_px(const Dev& d, int px, int py, unsigned long long* nevals) {
 	const int W = d.width;
 	const int center = px + py * W;
@@ -600,7 +605,7 @@ DVP_HD void local_refine_px(const Dev& d, int px, int py, unsigned long long* ne
 		for (int v = 0; v < S; ++v) {
 			if (!is_set(sel, v)) continue;
 			if (vw[v] == 0) continue;   // contributes +0 (finite costs)
-			const float ncc = ncc_old(d, c, px, py, v + 1, pl);
+			const float ncc = ncc_old<SMP>(d, c, px, py, v + 1, pl);
 			if (nevals) *nevals += 1;
 			const float gc = P.geom_consistency ? geom_cost(d, px, py, v + 1, pl) : 0.0f;
 			if (pd == -6) {   // (ncc + factor*geom) * w, APD.cu:4085-4089

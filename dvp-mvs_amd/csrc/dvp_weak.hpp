@@ -19,7 +19,7 @@ DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
 	const DvpParams& P = d.params;
 	const int S = P.num_images - 1;
 	const float* ref = d.images;
-	const float cpix = tex_texel(ref, d.pitch, W, H, px, py);
+	const float cpix = tex_texel(ref, d.org, d.pitch, W, H, px, py);
 
 	for (int v = 0; v < S; ++v) {
 		float bw[12];
@@ -33,7 +33,7 @@ DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
 				const int x = px + i, y = py + j;
 				if (!(x >= 0 && x < W && y >= 0 && y < H)) continue;
 				if (!is_set(d.selected_views[x + y * W], v)) continue;
-				const float a = tex_texel(ref, d.pitch, W, H, x, y);
+				const float a = tex_texel(ref, d.org, d.pitch, W, H, x, y);
 				const float w = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
 				const int r = d.sector_lut[(i + radius) * (2 * radius + 1) + (j + radius)];   // host-built for this radius
 				if (r >= 12) continue;
@@ -563,6 +563,7 @@ DVP_HD void ransac_fit_plane_px(const Dev& d, int px, int py, int iter) {
 
 // ---- ComputeBilateralNCCNew (APD.cu:835-1021) ---------------------------------------------------
 // `c` = centre-patch context built with colour-only weights (ComputeBilateralWeight_YZL).
+template <int SMP>
 DVP_HD float ncc_new(const Dev& d, const PatchCtx& c, int px, int py, int v, const f4 plane) {
 	const DvpCamera& rc = d.cameras[0];
 	const DvpCamera& sc = d.cameras[v];
@@ -575,9 +576,9 @@ DVP_HD float ncc_new(const Dev& d, const PatchCtx& c, int px, int py, int v, con
 	const float* ref = d.images;
 	const float* src = d.images + (size_t)v * d.plane_stride;
 	const int center = px + py * W;
-	const float cpix = tex_texel(ref, Pt, W, Hh, px, py);
+	const float cpix = tex_texel(ref, d.org, Pt, W, Hh, px, py);
 	// k == 0: the pixel's own patch (neighbours[0] is the pixel itself, APD.cu:3365)
-	const float center_cost = c.fast ? ncc_patch_fast(d, c, H, src, px, py)
+	const float center_cost = c.fast ? ncc_patch_fast<SMP>(d, c, H, src, px, py)
 	                                 : ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
 	float strong_cost = 0.0f;
 	int strong_count = 0;
@@ -606,7 +607,7 @@ DVP_HD float ncc_new(const Dev& d, const PatchCtx& c, int px, int py, int v, con
 					j = rj[t];
 				}
 				const int rx = nb.x + i, ry = nb.y + j;
-				const float a = tex_texel(ref, Pt, W, Hh, rx, ry);
+				const float a = tex_texel(ref, d.org, Pt, W, Hh, rx, ry);
 				const f2 sp = apply_homography(H, rx, ry);
 				const float b = tex_linear(src, Pt, W, Hh, sp.x + 0.5f, sp.y + 0.5f, d.sampler);
 				const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
@@ -631,6 +632,7 @@ DVP_HD float ncc_new(const Dev& d, const PatchCtx& c, int px, int py, int v, con
 // ---- CheckerboardPropagationWeak + PlaneHypothesisRefinementWeak (APD.cu:2739-3089, 1897-2008) --
 // 16 slots with one inlined copy of ncc_new: 8 anchor planes, the current plane, the RANSAC fit
 // plane, 6 refinement hypotheses.
+template <int SMP>
 DVP_HD void weak_update_px(const Dev& d, int px, int py, int iter, unsigned long long* nevals) {
 	const int W = d.width;
 	const int center = py * W + px;
@@ -728,7 +730,7 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, int iter, unsigned long
 		if (mask) {
 			for (int v = 0; v < S; ++v) {
 				if ((mask >> v) & 1) {
-					cv[v] = ncc_new(d, c, px, py, v + 1, plane);
+					cv[v] = ncc_new<SMP>(d, c, px, py, v + 1, plane);
 					if (nevals) *nevals += 1;
 				}
 			}
@@ -816,7 +818,7 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, int iter, unsigned long
 	float cn = 0.0f;
 	for (int v = 0; v < S; ++v) {
 		if (vw[v] == 0) continue;
-		cn += vw[v] * ncc_old(d, c2, px, py, v + 1, final_plane);
+		cn += vw[v] * ncc_old<SMP>(d, c2, px, py, v + 1, final_plane);
 		if (nevals) *nevals += 1;
 	}
 	d.costs[center] = cn / weight_norm;

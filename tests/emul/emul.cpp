@@ -33,7 +33,8 @@ struct Emu {
 void refresh(Emu& e) {
 	Dev& d = e.d;
 	d.width = e.W; d.height = e.H; d.num_images = e.NI; d.pitch = e.pitch;
-	d.plane_stride = (size_t)e.pitch * e.H;
+	d.org = kImgPad * e.pitch + kImgPad;
+	d.plane_stride = (size_t)e.pitch * (e.H + 2 * kImgPad);
 	d.images = e.images.data();
 	d.depths = e.depths.data();
 	d.cameras = e.cameras.data();
@@ -70,7 +71,8 @@ void launch(Emu& e, int iter, int colour) {
 				int px, py;
 				if (!block_to_pixel(b, lane, wave, g.tiles_x, g.tiles, g.chunk, g.rows, g.half ? 1 : 0, colour, e.W, e.H, &px, &py)) continue;
 				unsigned long long n = 0;
-				run_pixel<STAGE>(e.d, px, py, iter, e.count ? &n : nullptr);
+				if (e.d.sampler) run_pixel<STAGE, 1>(e.d, px, py, iter, e.count ? &n : nullptr);
+				else run_pixel<STAGE, 0>(e.d, px, py, iter, e.count ? &n : nullptr);
 				total += n;
 			}
 	e.evals += total;
@@ -83,11 +85,11 @@ extern "C" {
 void* emu_create(int W, int H, int NI) {
 	Emu* e = new Emu();
 	e->W = W; e->H = H; e->NI = NI;
-	e->pitch = (W + 63) / 64 * 64;
+	e->pitch = (W + 2 * kImgPad + 63) / 64 * 64;
 	const size_t L = (size_t)W * H;
 	const int S = NI - 1;
-	e->images.assign((size_t)e->pitch * H * NI, 0.0f);
-	e->depths.assign((size_t)e->pitch * H * NI, 0.0f);
+	e->images.assign((size_t)e->pitch * (H + 2 * kImgPad) * NI, 0.0f);
+	e->depths.assign((size_t)e->pitch * (H + 2 * kImgPad) * NI, 0.0f);
 	e->cameras.resize(NI);
 	e->views.resize(NI);
 	e->planes.assign(L, mk4(0, 0, 0, 0));
@@ -115,13 +117,19 @@ void* emu_create(int W, int H, int NI) {
 	return e;
 }
 void emu_destroy(void* c) { delete (Emu*)c; }
+// padded plane with replicated borders (== clamp addressing)
+static void fill_plane(Emu& e, float* plane, const float* data) {
+	for (int y = -kImgPad; y < e.H + kImgPad; ++y)
+		for (int x = -kImgPad; x < e.W + kImgPad; ++x)
+			plane[(size_t)(y + kImgPad) * e.pitch + (x + kImgPad)] = data[(size_t)clampi(y, 0, e.H - 1) * e.W + clampi(x, 0, e.W - 1)];
+}
 void emu_set_image(void* c, int idx, const float* data) {
 	Emu& e = *(Emu*)c;
-	for (int y = 0; y < e.H; ++y) std::memcpy(&e.images[((size_t)idx * e.H + y) * e.pitch], data + (size_t)y * e.W, e.W * 4);
+	fill_plane(e, &e.images[(size_t)idx * e.d.plane_stride], data);
 }
 void emu_set_depth(void* c, int idx, const float* data) {
 	Emu& e = *(Emu*)c;
-	for (int y = 0; y < e.H; ++y) std::memcpy(&e.depths[((size_t)idx * e.H + y) * e.pitch], data + (size_t)y * e.W, e.W * 4);
+	fill_plane(e, &e.depths[(size_t)idx * e.d.plane_stride], data);
 }
 void emu_set_cameras(void* c, const DvpCamera* cams, int n) {
 	Emu& e = *(Emu*)c;
@@ -251,7 +259,7 @@ void emu_eval_cost_vectors(void* c, const int* px, const float* planes, int n, f
 		patch_geometry(e.d, x + y * e.W, &radius, &inc);
 		build_patch_ctx(e.d, x, y, radius, inc, 0, &pc);
 		for (int v = 0; v < S; ++v)
-			out[(size_t)i * S + v] = ncc_old(e.d, pc, x, y, v + 1, mk4(planes[4 * i], planes[4 * i + 1], planes[4 * i + 2], planes[4 * i + 3]));
+			out[(size_t)i * S + v] = (e.d.sampler ? ncc_old<1> : ncc_old<0>)(e.d, pc, x, y, v + 1, mk4(planes[4 * i], planes[4 * i + 1], planes[4 * i + 2], planes[4 * i + 3]));
 	}
 }
 
