@@ -283,16 +283,21 @@ DVP_HD void compute_view_const(const DvpCamera& ref, const DvpCamera& src, ViewC
 
 // plane-dependent part of ComputeHomography (APD.cu:709-738)
 DVP_HD void homography(const DvpCamera& ref, const DvpCamera& src, const ViewConst& vc, const f4 pl, float* H) {
+	// a/b -> a * (1/b) with one correctly rounded reciprocal per divisor (numerics contract:
+	// nvcc --use_fast_math lowers these divisions to a*rcp(b))
 	float Hh[9], tmp[9];
+	const float inv_w = 1.0f / pl.w;
+	const float inv_k0 = 1.0f / ref.K[0];
+	const float inv_k4 = 1.0f / ref.K[4];
 	for (int i = 0; i < 3; ++i) {
-		Hh[3 * i + 0] = vc.Rrel[3 * i + 0] - vc.trel[i] * pl.x / pl.w;
-		Hh[3 * i + 1] = vc.Rrel[3 * i + 1] - vc.trel[i] * pl.y / pl.w;
-		Hh[3 * i + 2] = vc.Rrel[3 * i + 2] - vc.trel[i] * pl.z / pl.w;
+		Hh[3 * i + 0] = vc.Rrel[3 * i + 0] - vc.trel[i] * pl.x * inv_w;
+		Hh[3 * i + 1] = vc.Rrel[3 * i + 1] - vc.trel[i] * pl.y * inv_w;
+		Hh[3 * i + 2] = vc.Rrel[3 * i + 2] - vc.trel[i] * pl.z * inv_w;
 	}
 	for (int i = 0; i < 3; ++i) {
-		tmp[3 * i + 0] = Hh[3 * i + 0] / ref.K[0];
-		tmp[3 * i + 1] = Hh[3 * i + 1] / ref.K[4];
-		tmp[3 * i + 2] = -Hh[3 * i + 0] * ref.K[2] / ref.K[0] - Hh[3 * i + 1] * ref.K[5] / ref.K[4] + Hh[3 * i + 2];
+		tmp[3 * i + 0] = Hh[3 * i + 0] * inv_k0;
+		tmp[3 * i + 1] = Hh[3 * i + 1] * inv_k4;
+		tmp[3 * i + 2] = -Hh[3 * i + 0] * ref.K[2] * inv_k0 - Hh[3 * i + 1] * ref.K[5] * inv_k4 + Hh[3 * i + 2];
 	}
 	H[0] = src.K[0] * tmp[0] + src.K[2] * tmp[6];
 	H[1] = src.K[0] * tmp[1] + src.K[2] * tmp[7];
@@ -308,7 +313,8 @@ DVP_HD f2 apply_homography(const float* H, int px, int py) {   // ComputeCorresp
 	const float x = H[0] * px + H[1] * py + H[2];
 	const float y = H[3] * px + H[4] * py + H[5];
 	const float z = H[6] * px + H[7] * py + H[8];
-	return mk2(x / z, y / z);
+	const float inv_z = 1.0f / z;
+	return mk2(x * inv_z, y * inv_z);
 }
 
 }  // namespace dvp

@@ -149,7 +149,8 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 			const float x = hx0[ti] + hy1[tj] + H[2];
 			const float y = hx3[ti] + hy4[tj] + H[5];
 			const float z = hx6[ti] + hy7[tj] + H[8];
-			const float b = tex_linear_t<SMP>(src, P, W, Hh, x / z + 0.5f, y / z + 0.5f);
+			const float iz = 1.0f / z;   // x/z, y/z as x*rcp(z), y*rcp(z) (numerics contract)
+			const float b = tex_linear_t<SMP>(src, P, W, Hh, x * iz + 0.5f, y * iz + 0.5f);
 			const float wb = c.w[ti * kTaps + tj] * b;
 			r_s += wb;
 			r_ss += wb * b;

@@ -281,6 +281,10 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, int iter, unsigned lo
 
 	float cv[32];
 	for (int slot = 0; slot < 23; ++slot) {
+		// hypotheses 3 and 4 of the refinement are the same plane (both GeneratePerturbedNormal calls
+		// return the input normal, APD.cu:1354-1360): the second one can never be accepted after the
+		// first was tested (same cost, strict `<`), so it is not evaluated.
+		if (slot == 21) continue;
 		// ---- prologue: which plane, which views ----
 		f4 plane = mk4(0, 0, 1, 1);
 		uint32_t mask = 0;

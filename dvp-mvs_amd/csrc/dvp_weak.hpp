@@ -668,6 +668,7 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, int iter, unsigned long
 	float cv[32];
 
 	for (int slot = 0; slot < 16; ++slot) {
+		if (slot == 14) continue;   // refinement hypothesis 4 == hypothesis 3 (see strong_update_px)
 		f4 plane = mk4(0, 0, 1, 1);
 		uint32_t mask = 0;
 		if (slot < 8) {

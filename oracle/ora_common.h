@@ -17,6 +17,10 @@
 //    (build with -ffp-contract=off); division and sqrt are correctly rounded.  The reference was
 //    built with nvcc --use_fast_math (CMakeLists.txt:21), whose approximate div/exp/rsqrt are
 //    NVIDIA-specific and not reproducible; IEEE evaluation of the same expressions is the anchor.
+//  * exception, mirroring nvcc's lowering under --use_fast_math (-prec-div=false: a/b = a*rcp(b)):
+//    the divisions of ComputeHomography (by plane.w, K[0], K[4]) and ComputeCorrespondingPoint
+//    (by the projective z) are evaluated as a * (1.0f / b) with a correctly rounded reciprocal,
+//    one reciprocal per distinct divisor.  Every other division is a correctly rounded a / b.
 //  * exp() is the polynomial dvp_expf below (<= 1 ulp on the ranges used).
 //  * rsqrtf(x) is restated as 1.0f / sqrtf(x).
 //  * cuRAND XORWOW seeded by clock64() (APD.cu:1270) is replaced by a counter-based generator
