@@ -181,6 +181,9 @@ def main():
             "iter_loop_value": round(float(W) * H * iters * args.steps / (tm["iter_loop_ms"] * 1e-3) / 1e6, 3) if tm["iter_loop_ms"] > 0 else None,
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in tm["stage_ms"].items() if v > 0},
             "evals_per_px_iter_strong": round(evals["ncc_evals"]["strong_update"] / (float(W) * H * iters), 2),
+            "ncc_evals_per_step": {k: int(v) for k, v in evals["ncc_evals"].items() if v > 0},
+            "Gevals_per_s": {k: round(evals["ncc_evals"][k] / (tm["stage_ms"][k] / args.steps * 1e-3) / 1e9, 3)
+                             for k in evals["ncc_evals"] if evals["ncc_evals"][k] > 0 and tm["stage_ms"][k] > 0},
         }
         if args.micro:
             ms, ev = ctx.bench_cost_kernel(3)

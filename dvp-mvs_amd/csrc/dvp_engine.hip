@@ -26,8 +26,11 @@ __device__ __forceinline__ void stage_body(const Dev& d, const LaunchArgs& a) {
 	const int wave = threadIdx.x >> 6;
 	int px, py;
 	unsigned long long n = 0;
+	// per-lane (w, w*ref) table of the hoisted patch context: [tap][lane] in LDS (72 KiB / workgroup)
+	__shared__ f2 lds_tab[stage_uses_tab(STAGE) ? kTaps * kTaps * 256 : 1];
+	const PatchTab tab{&lds_tab[stage_uses_tab(STAGE) ? threadIdx.x : 0], 256};
 	if (block_to_pixel(blockIdx.x, lane, wave, a.tiles_x, a.tiles, a.chunk, a.rows, a.half, a.colour, d.width, d.height, &px, &py))
-		run_pixel<STAGE, SMP>(d, px, py, a.iter, d.eval_counter ? &n : nullptr);
+		run_pixel<STAGE, SMP>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, tab);
 	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
 }
 
@@ -50,7 +53,7 @@ DVP_KERNEL(dvp_neighbour_update, DVP_ST_NEIGHBOUR_UPDATE, 1)
 // 1 -> 64 ms per strong-update launch, 2 -> 110 ms, 3 -> 135 ms, 4 -> 154 ms: the fully unrolled
 // 36-tap evaluation wants the whole 512-entry register file (144 gathers in flight per lane);
 // any tighter bound spills the weight table to scratch inside the tap loop.
-#define DVP_LB_HEAVY 1
+#define DVP_LB_HEAVY 2
 #endif
 DVP_KERNEL(dvp_random_init, DVP_ST_RANDOM_INIT, DVP_LB_HEAVY)
 DVP_KERNEL(dvp_strong_update, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY)
@@ -98,9 +101,10 @@ extern "C" __global__ void __launch_bounds__(256) dvp_cost_vectors(const Dev d, 
 	const int x = px[2 * i], y = px[2 * i + 1];
 	const int S = d.num_images - 1;
 	PatchCtx c;
+	__shared__ f2 lds_tab[kTaps * kTaps * 256];
 	int radius, inc;
 	patch_geometry(d, x + y * d.width, &radius, &inc);
-	build_patch_ctx(d, x, y, radius, inc, 0, &c);
+	build_patch_ctx(d, x, y, radius, inc, 0, PatchTab{&lds_tab[threadIdx.x], 256}, &c);
 	const f4 pl = planes[i];
 	for (int v = 0; v < S; ++v) out[(size_t)i * S + v] = d.sampler ? ncc_old<1>(d, c, x, y, v + 1, pl) : ncc_old<0>(d, c, x, y, v + 1, pl);
 }
@@ -113,9 +117,10 @@ extern "C" __global__ void __launch_bounds__(256) dvp_cost_all_pixels(const Dev 
 	const int center = px + py * d.width;
 	const int S = d.num_images - 1;
 	PatchCtx c;
+	__shared__ f2 lds_tab[kTaps * kTaps * 256];
 	int radius, inc;
 	patch_geometry(d, center, &radius, &inc);
-	build_patch_ctx(d, px, py, radius, inc, 0, &c);
+	build_patch_ctx(d, px, py, radius, inc, 0, PatchTab{&lds_tab[threadIdx.x], 256}, &c);
 	const f4 pl = d.planes[center];
 	float acc = 0.0f;
 	for (int v = 0; v < S; ++v) acc += ncc_old<0>(d, c, px, py, v + 1, pl);

@@ -19,9 +19,19 @@ namespace dvp {
 
 constexpr int kTaps = 6;   // taps per axis on the fast path (radius 5k, increment 2k)
 
+// Per-lane table of the 36 (w, w*ref) pairs.  On the GPU it lives in LDS, laid out [tap][lane]
+// (8-byte entries, lane-contiguous: conflict-free ds_read_b64), 72 KiB per 256-thread workgroup,
+// which frees 72 VGPRs per lane and lets two waves share a SIMD without spilling.  The host
+// emulation points it at a per-thread array (stride 1).
+struct PatchTab {
+	f2* p;
+	int stride;
+	DVP_HD f2 get(int t) const { return p[t * stride]; }
+	DVP_HD void set(int t, f2 v) const { p[t * stride] = v; }
+};
+
 struct PatchCtx {
-	float w[kTaps * kTaps];    // bilateral weight of tap (ti, tj), index ti*6+tj (ti = x offset index)
-	float wa[kTaps * kTaps];   // w * ref_pix
+	PatchTab tab;              // (bilateral weight w, w * ref_pix) of tap (ti, tj) at index ti*6+tj (ti = x offset index)
 	float sum_ref, sum_ref_ref, wsum;   // un-normalised reference sums (row-then-total order)
 	int radius, inc;
 	int fast;                  // 1: exactly 6 taps per axis (register path); 0: generic loops
@@ -46,7 +56,8 @@ DVP_HD void patch_geometry(const Dev& d, int center, int* radius, int* inc) {
 	*inc = s;
 }
 
-DVP_HD void build_patch_ctx(const Dev& d, int px, int py, int radius, int inc, int colour_only, PatchCtx* c) {
+DVP_HD void build_patch_ctx(const Dev& d, int px, int py, int radius, int inc, int colour_only, PatchTab tab, PatchCtx* c) {
+	c->tab = tab;
 	const float* ref = d.images;
 	const int W = d.width, H = d.height, P = d.pitch;
 	c->radius = radius;
@@ -66,8 +77,7 @@ DVP_HD void build_patch_ctx(const Dev& d, int px, int py, int radius, int inc, i
 			const float a = tex_texel(ref, d.org, P, W, H, px + i, py + j);
 			const float w = bilateral_weight((float)i, (float)j, a, cpix, sig_s, sig_c, colour_only);
 			const float wa = w * a;
-			c->w[ti * kTaps + tj] = w;
-			c->wa[ti * kTaps + tj] = wa;
+			tab.set(ti * kTaps + tj, mk2(w, wa));
 			sr_row += wa;
 			srr_row += wa * a;
 			ws_row += w;
@@ -151,10 +161,11 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 			const float z = hx6[ti] + hy7[tj] + H[8];
 			const float iz = 1.0f / z;   // x/z, y/z as x*rcp(z), y*rcp(z) (numerics contract)
 			const float b = tex_linear_t<SMP>(src, P, W, Hh, x * iz + 0.5f, y * iz + 0.5f);
-			const float wb = c.w[ti * kTaps + tj] * b;
+			const f2 t = c.tab.get(ti * kTaps + tj);
+			const float wb = t.x * b;
 			r_s += wb;
 			r_ss += wb * b;
-			r_rs += c.wa[ti * kTaps + tj] * b;
+			r_rs += t.y * b;
 		}
 		s_s += r_s;
 		s_ss += r_ss;

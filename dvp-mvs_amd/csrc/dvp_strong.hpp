@@ -88,7 +88,7 @@ DVP_HD f4 random_normal_yzl(const Dev& d, int px, int py, Rng& rng, float depth)
 
 // RandomInitialization (APD.cu:1273-1309)
 template <int SMP>
-DVP_HD void random_init_px(const Dev& d, int px, int py, unsigned long long* nevals) {
+DVP_HD void random_init_px(const Dev& d, int px, int py, PatchTab tab, unsigned long long* nevals) {
 	const int center = py * d.width + px;
 	const DvpParams& P = d.params;
 	const DvpCamera& rc = d.cameras[0];
@@ -97,7 +97,7 @@ DVP_HD void random_init_px(const Dev& d, int px, int py, unsigned long long* nev
 	PatchCtx c;
 	int radius, inc;
 	patch_geometry(d, center, &radius, &inc);
-	build_patch_ctx(d, px, py, radius, inc, 0, &c);
+	build_patch_ctx(d, px, py, radius, inc, 0, tab, &c);
 
 	if (P.state == DVP_FIRST_INIT) {
 		if (plane.w > P.depth_max || plane.w < P.depth_min) {
@@ -243,7 +243,7 @@ DVP_HD int strong_sample_search(const Dev& d, int px, int py, int k, int pass) {
 // After view selection only views with non-zero weight are evaluated: the reference evaluates all
 // S and multiplies the others by a zero weight, which is the same value.
 template <int SMP>
-DVP_HD void strong_update_px(const Dev& d, int px, int py, int iter, unsigned long long* nevals) {
+DVP_HD void strong_update_px(const Dev& d, int px, int py, PatchTab tab, int iter, unsigned long long* nevals) {
 	const int W = d.width;
 	const int center = py * W + px;
 	const DvpParams& P = d.params;
@@ -255,7 +255,7 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, int iter, unsigned lo
 	{
 		int radius, inc;
 		patch_geometry(d, center, &radius, &inc);
-		build_patch_ctx(d, px, py, radius, inc, 0, &c);
+		build_patch_ctx(d, px, py, radius, inc, 0, tab, &c);
 	}
 	float cost_array[8 * 32];
 	for (int i = 0; i < 8 * 32; ++i) cost_array[i] = 0.0f;
@@ -482,7 +482,7 @@ DVP_HD float sweep_cost_view(const Dev& d, const PatchCtx& c, int px, int py, in
 
 // DepthToWeak (APD.cu:3892-4051)
 template <int SMP>
-DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, unsigned long long* nevals) {
+DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, PatchTab tab, unsigned long long* nevals) {
 	const int W = d.width, H = d.height;
 	const int center = px + py * W;
 	const DvpParams& P = d.params;
@@ -499,7 +499,7 @@ DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, unsigned long long* n
 	{
 		int radius, inc;
 		patch_geometry(d, center, &radius, &inc);
-		build_patch_ctx(d, px, py, radius, inc, 0, &c);
+		build_patch_ctx(d, px, py, radius, inc, 0, tab, &c);
 	}
 	float base_line = 0, weight_normal = 0.0f;
 	int valid = 0;
@@ -564,7 +564,7 @@ DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, unsigned long long* n
 
 // LocalRefine (APD.cu:4053-4139)
 template <int SMP>
-DVP_HD void local_refine_px(const Dev& d, int px, int py, unsigned long long* nevals) {
+DVP_HD void local_refine_px(const Dev& d, int px, int py, PatchTab tab, unsigned long long* nevals) {
 	const int W = d.width;
 	const int center = px + py * W;
 	const DvpParams& P = d.params;
@@ -591,7 +591,7 @@ DVP_HD void local_refine_px(const Dev& d, int px, int py, unsigned long long* ne
 	{
 		int radius, inc;
 		patch_geometry(d, center, &radius, &inc);
-		build_patch_ctx(d, px, py, radius, inc, 0, &c);
+		build_patch_ctx(d, px, py, radius, inc, 0, tab, &c);
 	}
 	base_line /= valid;
 	const float disp = rc.K[0] * base_line / origin_depth;

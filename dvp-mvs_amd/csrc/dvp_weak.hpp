@@ -633,7 +633,7 @@ DVP_HD float ncc_new(const Dev& d, const PatchCtx& c, int px, int py, int v, con
 // 16 slots with one inlined copy of ncc_new: 8 anchor planes, the current plane, the RANSAC fit
 // plane, 6 refinement hypotheses.
 template <int SMP>
-DVP_HD void weak_update_px(const Dev& d, int px, int py, int iter, unsigned long long* nevals) {
+DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter, unsigned long long* nevals) {
 	const int W = d.width;
 	const int center = py * W + px;
 	const DvpParams& P = d.params;
@@ -646,7 +646,7 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, int iter, unsigned long
 	{
 		int radius, inc;
 		patch_geometry(d, center, &radius, &inc);
-		build_patch_ctx(d, px, py, radius, inc, 1, &c);
+		build_patch_ctx(d, px, py, radius, inc, 1, tab, &c);
 	}
 	float cost_array[8 * 32];
 	for (int i = 0; i < 8 * 32; ++i) cost_array[i] = 0.0f;
@@ -814,7 +814,7 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, int iter, unsigned long
 	{
 		int r = P.strong_radius, inc = P.strong_increment;
 		if (P.use_radius) inc = DVP_MAX(2, (int)(2.0 * r / 5.0));
-		build_patch_ctx(d, px, py, r, inc, 0, &c2);
+		build_patch_ctx(d, px, py, r, inc, 0, tab, &c2);
 	}
 	float cn = 0.0f;
 	for (int v = 0; v < S; ++v) {

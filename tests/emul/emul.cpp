@@ -71,8 +71,10 @@ void launch(Emu& e, int iter, int colour) {
 				int px, py;
 				if (!block_to_pixel(b, lane, wave, g.tiles_x, g.tiles, g.chunk, g.rows, g.half ? 1 : 0, colour, e.W, e.H, &px, &py)) continue;
 				unsigned long long n = 0;
-				if (e.d.sampler) run_pixel<STAGE, 1>(e.d, px, py, iter, e.count ? &n : nullptr);
-				else run_pixel<STAGE, 0>(e.d, px, py, iter, e.count ? &n : nullptr);
+				f2 tab_mem[kTaps * kTaps];
+				const PatchTab tab{tab_mem, 1};
+				if (e.d.sampler) run_pixel<STAGE, 1>(e.d, px, py, iter, e.count ? &n : nullptr, tab);
+				else run_pixel<STAGE, 0>(e.d, px, py, iter, e.count ? &n : nullptr, tab);
 				total += n;
 			}
 	e.evals += total;
@@ -255,9 +257,10 @@ void emu_eval_cost_vectors(void* c, const int* px, const float* planes, int n, f
 	for (int i = 0; i < n; ++i) {
 		const int x = px[2 * i], y = px[2 * i + 1];
 		PatchCtx pc;
+		f2 tab_mem[kTaps * kTaps];
 		int radius, inc;
 		patch_geometry(e.d, x + y * e.W, &radius, &inc);
-		build_patch_ctx(e.d, x, y, radius, inc, 0, &pc);
+		build_patch_ctx(e.d, x, y, radius, inc, 0, PatchTab{tab_mem, 1}, &pc);
 		for (int v = 0; v < S; ++v)
 			out[(size_t)i * S + v] = (e.d.sampler ? ncc_old<1> : ncc_old<0>)(e.d, pc, x, y, v + 1, mk4(planes[4 * i], planes[4 * i + 1], planes[4 * i + 2], planes[4 * i + 3]));
 	}
