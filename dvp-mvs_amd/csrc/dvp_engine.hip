@@ -88,6 +88,11 @@ extern "C" __global__ void dvp_pad_replicate(float* planes, int W, int H, int pi
 	p[(size_t)y * pitch + x] = p[(size_t)sy * pitch + sx];
 }
 
+// line-scan pre-pass of GenEdgeInform: nearest edge pixel in 8 directions (blockIdx.y = direction)
+extern "C" __global__ void __launch_bounds__(256) dvp_edge_rays(const Dev d) {
+	edge_ray_line(d, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 extern "C" __global__ void dvp_prepare_views(const DvpCamera* cams, ViewConst* views, int n) {
 	const int v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= 1 && v < n) compute_view_const(cams[0], cams[v], &views[v]);
@@ -436,6 +441,10 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 	if (c->profiling) HIP_TRY(c, hipMemsetAsync(c->eval_counter, 0, 8, c->stream));
 	HIP_TRY(c, hipEventRecord(ep.a, c->stream));
 	const dim3 grid(g.grid()), block(256);
+	if (stage == DVP_ST_GEN_EDGE_INFORM && c->d.params.use_edge) {
+		hipLaunchKernelGGL(dvp_edge_rays, dim3((c->W + c->H + 255) / 256, 8), dim3(256), 0, c->stream, c->d);
+		HIP_TRY(c, hipGetLastError());
+	}
 	switch (stage) {
 	case DVP_ST_GEN_EDGE_INFORM: hipLaunchKernelGGL(c->d.sampler ? dvp_gen_edge_inform_exact : dvp_gen_edge_inform, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_FIND_NEAREST_STRONG: hipLaunchKernelGGL(c->d.sampler ? dvp_find_nearest_strong_exact : dvp_find_nearest_strong, grid, block, 0, c->stream, c->d, a); break;

@@ -223,13 +223,21 @@ DVP_HD int strong_sample_search(const Dev& d, int px, int py, int k, int pass) {
 	if (k > 4) { if (k % 2) fx = dx; else fy = dy; }
 	int best = -1;
 	float min_cost = FLT_MAX;
-	for (int step = 0; step < step_num; ++step) {
+	// step_num <= 22: fixed trip count with predicated loads so that all samples are in flight at
+	// once instead of one dependent L2 round trip per sample
+	float cs[22];
+	int pcs[22];
+#pragma unroll
+	for (int step = 0; step < 22; ++step) {
 		const int tx = px + 5 * dx + step * step_len * dx + fx;
 		const int ty = py + 5 * dy + step * step_len * dy + fy;
-		if (!(tx >= 0 && ty >= 0 && tx < W && ty < H)) continue;
-		const int pc = tx + ty * W;
-		const float cst = d.costs_snap[pc];
-		if (min_cost > cst) { best = pc; min_cost = cst; }
+		const bool ok = step < step_num && tx >= 0 && ty >= 0 && tx < W && ty < H;
+		pcs[step] = ok ? tx + ty * W : -1;
+		cs[step] = ok ? d.costs_snap[tx + ty * W] : 0.0f;
+	}
+#pragma unroll
+	for (int step = 0; step < 22; ++step) {
+		if (pcs[step] >= 0 && min_cost > cs[step]) { best = pcs[step]; min_cost = cs[step]; }
 	}
 	return (min_cost < FLT_MAX) ? best : -1;
 }

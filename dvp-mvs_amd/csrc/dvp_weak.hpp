@@ -13,62 +13,101 @@ namespace dvp {
 // per offset, bubble-sorts each sector and then the 12 winners (24-byte structs in scratch).
 // Here the sector of an offset comes from a 121-entry table and each sector keeps a running
 // arg-max; the stable descending sort of the 12 winners is kept.
+// Nearest edge pixel in each of the 8 directions (APD.cu:3799-3824).  The reference marches a ray
+// per pixel and direction (up to max(W,H) steps each: O(L*(W+H)) reads).  Here one thread owns
+// one image line of one direction and walks it once AGAINST the direction, carrying the last edge
+// pixel seen: O(L) reads per direction, same result.
+DVP_HD int edge_ray_lines(int W, int H, int k) { return k < 2 ? W : (k < 4 ? H : W + H - 1); }
+DVP_HD void edge_ray_line(const Dev& d, int k, int line) {
+	const int W = d.width, H = d.height;
+	const int dxs[8] = { 0, 0, -1, 1, -1, 1, -1, 1 };
+	const int dys[8] = { -1, 1, 0, 0, -1, 1, 1, -1 };
+	const int dx = dxs[k], dy = dys[k];
+	if (line >= edge_ray_lines(W, H, k)) return;
+	// first pixel of the line in walking order (-d): the pixel whose +d neighbour is outside
+	int x, y;
+	if (dx == 0) { x = line; y = dy < 0 ? 0 : H - 1; }
+	else if (dy == 0) { x = dx < 0 ? 0 : W - 1; y = line; }
+	else {
+		const int xb = dx < 0 ? 0 : W - 1, yb = dy < 0 ? 0 : H - 1;
+		if (line < H) { x = xb; y = line; }
+		else { const int t = line - H; x = (xb == 0) ? t + 1 : t; y = yb; }
+	}
+	s2 last = mks2(-1, -1);
+	while (x >= 0 && x < W && y >= 0 && y < H) {
+		const int c = x + y * W;
+		d.edge_neigh[(size_t)c * 8 + k] = last;
+		if (d.edge[c]) last = mks2(x, y);
+		x -= dx;
+		y -= dy;
+	}
+}
+
 DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
 	const int W = d.width, H = d.height;
 	const int center = px + py * W;
 	const DvpParams& P = d.params;
 	const int S = P.num_images - 1;
+	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
 	const float* ref = d.images;
 	const float cpix = tex_texel(ref, d.org, d.pitch, W, H, px, py);
 
-	for (int v = 0; v < S; ++v) {
-		float bw[12];
-		int bi[12], bj[12];
-		for (int r = 0; r < 12; ++r) { bw[r] = 0.0f; bi[r] = 0; bj[r] = 0; }
-		uint32_t has = 0;
+	// visibility-prior tap candidates (APD.cu:3746-3794).  The reference loops views outermost and
+	// recomputes every tap weight per view; the weight does not depend on the view, so taps are
+	// the outer loop here (one selected_views word, one exp per tap) and each set view bit updates
+	// that view's running per-sector arg-max.  Visit order per (view, sector) is unchanged.
+	{
+		float bw[32 * 12];
+		short bi[32 * 12], bj[32 * 12];
+		uint32_t has[32];
+		for (int v = 0; v < S; ++v) {
+			has[v] = 0;
+			for (int r = 0; r < 12; ++r) { bw[v * 12 + r] = 0.0f; bi[v * 12 + r] = 0; bj[v * 12 + r] = 0; }
+		}
 		const int radius = P.weak_radius;
 		for (int i = -radius; i <= radius; i++) {
 			for (int j = -radius; j <= radius; j++) {
 				if (i == 0 && j == 0) continue;
 				const int x = px + i, y = py + j;
 				if (!(x >= 0 && x < W && y >= 0 && y < H)) continue;
-				if (!is_set(d.selected_views[x + y * W], v)) continue;
-				const float a = tex_texel(ref, d.org, d.pitch, W, H, x, y);
-				const float w = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
+				uint32_t sv = d.selected_views[x + y * W] & all_views;
+				if (!sv) continue;
 				const int r = d.sector_lut[(i + radius) * (2 * radius + 1) + (j + radius)];   // host-built for this radius
 				if (r >= 12) continue;
-				if (!((has >> r) & 1) || w > bw[r]) {   // first maximum wins (stable bubble sort, APD.cu:823-833)
-					has |= 1u << r;
-					bw[r] = w; bi[r] = i; bj[r] = j;
+				const float a = tex_texel(ref, d.org, d.pitch, W, H, x, y);
+				const float w = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
+				for (int v = 0; v < S; ++v) {
+					if (!((sv >> v) & 1)) continue;
+					if (!((has[v] >> r) & 1) || w > bw[v * 12 + r]) {   // first maximum wins (stable bubble sort, APD.cu:823-833)
+						has[v] |= 1u << r;
+						bw[v * 12 + r] = w; bi[v * 12 + r] = (short)i; bj[v * 12 + r] = (short)j;
+					}
 				}
 			}
 		}
-		// stable descending sort of the 12 sector winners (empty sectors: weight 0, offset (0,0))
-		for (int a = 1; a < 12; ++a) {
-			const float tw = bw[a];
-			const int ti = bi[a], tj = bj[a];
-			int b = a;
-			for (; b >= 1 && bw[b - 1] < tw; --b) { bw[b] = bw[b - 1]; bi[b] = bi[b - 1]; bj[b] = bj[b - 1]; }
-			bw[b] = tw; bi[b] = ti; bj[b] = tj;
+		for (int v = 0; v < S; ++v) {
+			// stable descending sort of the 12 sector winners (empty sectors: weight 0, offset (0,0))
+			float* w_ = bw + v * 12;
+			short* i_ = bi + v * 12;
+			short* j_ = bj + v * 12;
+			if (has[v]) {
+				for (int a = 1; a < 12; ++a) {
+					const float tw = w_[a];
+					const short ti = i_[a], tj = j_[a];
+					int b = a;
+					for (; b >= 1 && w_[b - 1] < tw; --b) { w_[b] = w_[b - 1]; i_[b] = i_[b - 1]; j_[b] = j_[b - 1]; }
+					w_[b] = tw; i_[b] = ti; j_[b] = tj;
+				}
+			}
+			s2* cand = d.candidate + ((size_t)center * S + v) * 8;
+			for (int k = 0; k < 8; ++k) cand[k] = mks2(i_[k], j_[k]);
 		}
-		s2* cand = d.candidate + ((size_t)center * S + v) * 8;
-		for (int k = 0; k < 8; ++k) cand[k] = mks2(bi[k], bj[k]);
 	}
 
 	const int dxs[8] = { 0, 0, -1, 1, -1, 1, -1, 1 };
 	const int dys[8] = { -1, 1, 0, 0, -1, 1, 1, -1 };
 	if (P.use_edge) {
-		s2* en = d.edge_neigh + (size_t)center * 8;
-		for (int k = 0; k < 8; k++) {
-			s2 e = mks2(-1, -1);
-			int nx = px + dxs[k], ny = py + dys[k];
-			while (!(nx < 0 || nx >= W || ny < 0 || ny >= H)) {
-				if (d.edge[nx + ny * W]) { e = mks2(nx, ny); break; }
-				nx += dxs[k];
-				ny += dys[k];
-			}
-			en[k] = e;
-		}
+		// edge_neigh is filled by the line-scan pre-pass (edge_ray_line) of the same launch site
 		if (d.weak_info[center] == DVP_WEAK) {
 			const int radius = P.strong_radius;
 			int edge_pix = 0, tot_pix = 0;

@@ -205,7 +205,14 @@ int emu_weak_count(void* c) { return ((Emu*)c)->d.weak_count; }
 int emu_run_stage(void* c, int stage, int iter, int colour) {
 	Emu& e = *(Emu*)c;
 	switch (stage) {
-	case DVP_ST_GEN_EDGE_INFORM: launch<DVP_ST_GEN_EDGE_INFORM>(e, iter, colour); break;
+	case DVP_ST_GEN_EDGE_INFORM:
+		if (e.d.params.use_edge) {
+#pragma omp parallel for schedule(dynamic, 16) collapse(2)
+			for (int k = 0; k < 8; ++k)
+				for (int line = 0; line < e.W + e.H; ++line) edge_ray_line(e.d, k, line);
+		}
+		launch<DVP_ST_GEN_EDGE_INFORM>(e, iter, colour);
+		break;
 	case DVP_ST_FIND_NEAREST_STRONG: launch<DVP_ST_FIND_NEAREST_STRONG>(e, iter, colour); break;
 	case DVP_ST_GEN_NEIGHBOURS: launch<DVP_ST_GEN_NEIGHBOURS>(e, iter, colour); break;
 	case DVP_ST_NEIGHBOUR_UPDATE: launch<DVP_ST_NEIGHBOUR_UPDATE>(e, iter, colour); break;
