@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--src", type=int, default=5)
     ap.add_argument("--iters", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-size", type=str, default="256x192")
+    ap.add_argument("--cpu-size", type=str, default="auto", help="WxH of the CPU-baseline view (auto: scaled to the core count)")
     ap.add_argument("--micro", action="store_true", help="also time the stand-alone cost-vector kernel")
     return ap.parse_args()
 
@@ -47,7 +47,18 @@ def cpu_baseline(synth, args, S, iters):
     """The oracle ("port") timed on this host's cores on a bounded sample of the same workload:
     same scene generator, same S / iterations / params, a 256x192 view."""
     from oracle import oracle as O
-    w, h = [int(v) for v in args.cpu_size.split("x")]
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:
+        ncores = os.cpu_count() or 1
+    if args.cpu_size == "auto":
+        # ~0.004 Mpx*iter/s/core (SURVEY.md §6): ~2000 px per core keeps the sample at 10-30 s and
+        # gives every OpenMP thread a few rows
+        px = max(192 * 144, 2000 * ncores)
+        h = int(round((px * 3 / 4) ** 0.5 / 8)) * 8
+        w = h * 4 // 3
+    else:
+        w, h = [int(v) for v in args.cpu_size.split("x")]
     sc = synth.make_scene(w, h, S)
     p = bench_params(synth, S, iters)
     o = O.from_scene(sc, p)
