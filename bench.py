@@ -95,8 +95,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # DVP_BENCH_FORCE_DIST=1 exercises the RCCL path (init, broadcast, all_reduce) with one rank
+    use_dist = world > 1 or os.environ.get("DVP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     pkg = importlib.import_module("dvp-mvs_amd")
     synth, capi = pkg.synth, pkg.get_capi()
     W, H, S, iters = args.width, args.height, args.src, args.iters
@@ -112,7 +116,7 @@ def main():
         dev_imgs.copy_(torch.from_numpy(sc["images"]))
         cams_t.copy_(torch.from_numpy(np.frombuffer(sc["cameras"].tobytes(), np.uint8).copy()))
         edge_t.copy_(torch.from_numpy(sc["edge"]))
-    if world > 1:
+    if use_dist:
         dist.broadcast(dev_imgs, 0)
         dist.broadcast(cams_t, 0)
         dist.broadcast(edge_t, 0)
@@ -136,7 +140,7 @@ def main():
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     # ---- warm-up (first warm-up step also counts NCC evaluations: deterministic per seed) ---------
@@ -158,7 +162,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tm = ctx.timings()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -202,7 +206,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth, args, S, iters)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
