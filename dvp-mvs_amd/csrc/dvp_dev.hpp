@@ -81,6 +81,10 @@ struct Dev {
 	s2* label_boundary;        // 8 per WEAK pixel
 	float* complex_;           // per WEAK pixel
 	int* radius;
+	// WEAK pixels compacted: pixel indices in raster order, black ((x+y) even) first, then red;
+	// the weak-path kernels launch one lane per list entry instead of one lane per image pixel
+	const int* weak_list;
+	int weak_black, weak_red;
 	unsigned long long* eval_counter;   // profiling builds only (may be null)
 };
 

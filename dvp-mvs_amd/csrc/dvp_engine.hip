@@ -34,6 +34,32 @@ __device__ __forceinline__ void stage_body(const Dev& d, const LaunchArgs& a) {
 	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
 }
 
+// Compacted launch for the weak-pixel path: lane t owns the t-th WEAK pixel of the list segment.
+// WEAK pixels are 1-30 % of a view; a lane-per-image-pixel launch leaves 70-99 % of the lanes idle.
+struct ListArgs { int base, count, iter, covered_rows; };
+template <int STAGE, int SMP>
+__device__ __forceinline__ void stage_body_list(const Dev& d, const ListArgs& a) {
+	__shared__ f2 lds_tab[stage_uses_tab(STAGE) ? kTaps * kTaps * 256 : 1];
+	const PatchTab tab{&lds_tab[stage_uses_tab(STAGE) ? threadIdx.x : 0], 256};
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	unsigned long long n = 0;
+	if (t < a.count) {
+		const int center = d.weak_list[a.base + t];
+		const int py = center / d.width, px = center - py * d.width;
+		// red/black launches never reach rows beyond the reference's half grid (APD.cu:4421-4424)
+		if (!stage_is_half_c(STAGE) || py < a.covered_rows)
+			run_pixel<STAGE, SMP>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, tab);
+	}
+	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
+}
+#define DVP_KERNEL_LIST(NAME, STAGE, MINW)                                                                \
+	extern "C" __global__ void __launch_bounds__(256, MINW) NAME(const Dev d, const ListArgs a) {         \
+		stage_body_list<STAGE, 0>(d, a);                                                                   \
+	}                                                                                                      \
+	extern "C" __global__ void __launch_bounds__(256, MINW) NAME##_exact(const Dev d, const ListArgs a) { \
+		stage_body_list<STAGE, 1>(d, a);                                                                   \
+	}
+
 // One named kernel per launch site so that rocprofv3 --kernel-trace shows the reference's names.
 // NAME: sampler 0 (8-bit interpolation weights, default); NAME_exact: sampler 1.
 #define DVP_KERNEL(NAME, STAGE, MINW)                                                                      \
@@ -65,6 +91,12 @@ DVP_KERNEL(dvp_depth_to_weak, DVP_ST_DEPTH_TO_WEAK, DVP_LB_HEAVY)
 DVP_KERNEL(dvp_local_refine, DVP_ST_LOCAL_REFINE, DVP_LB_HEAVY)
 
 // replicate the image border into the kImgPad-wide frame of a padded plane set
+DVP_KERNEL_LIST(dvp_find_nearest_strong_list, DVP_ST_FIND_NEAREST_STRONG, 1)
+DVP_KERNEL_LIST(dvp_gen_neighbours_list, DVP_ST_GEN_NEIGHBOURS, 1)
+DVP_KERNEL_LIST(dvp_neighbour_update_list, DVP_ST_NEIGHBOUR_UPDATE, 1)
+DVP_KERNEL_LIST(dvp_ransac_fit_plane_list, DVP_ST_RANSAC_FIT, 1)
+DVP_KERNEL_LIST(dvp_weak_update_list, DVP_ST_WEAK_UPDATE, 1)
+
 extern "C" __global__ void dvp_pad_replicate(float* planes, int W, int H, int pitch, size_t plane_stride, int n_planes) {
 	const int PW = W + 2 * kImgPad, PH = H + 2 * kImgPad;
 	const int frame = 2 * kImgPad * PW + 2 * kImgPad * H;   // border cells per plane
@@ -156,6 +188,8 @@ struct dvp_ctx {
 	unsigned long long* eval_counter = nullptr;
 	float* scratch_out = nullptr;
 	size_t weak_alloc = 0;       // capacity (in WEAK pixels) of the per-WEAK buffers
+	int* weak_list = nullptr;    // compacted WEAK pixel indices (black first, then red)
+	size_t weak_list_alloc = 0;
 	int lut_radius = -1;
 	bool have_depths = false;
 	bool profiling = false;
@@ -202,6 +236,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.neighbours_map = c->neighbours_map; d.neighbours = c->neighbours; d.fit_planes = c->fit_planes;
 	d.candidate = c->candidate; d.edge = c->edge; d.edge_neigh = c->edge_neigh; d.label = c->label;
 	d.label_boundary = c->label_boundary; d.complex_ = c->complex_; d.radius = c->radius;
+	d.weak_list = c->weak_list;
 	d.eval_counter = c->profiling ? c->eval_counter : nullptr;
 }
 
@@ -374,6 +409,26 @@ int dvp_upload_state(dvp_ctx* c, const float* planes, const uint32_t* views, con
 	for (size_t i = 0; i < L; ++i)
 		if (wi[i] == DVP_WEAK) map[i] = wc++;
 	c->d.weak_count = wc;
+	{
+		// compacted pixel lists per checkerboard colour; rows the reference's half grid never
+		// reaches (APD.cu:4421-4424) are left out like in the full-grid launch
+		std::vector<int> list;
+		list.reserve((size_t)wc);
+		int nb = 0;
+		for (int colour = 0; colour < 2; ++colour) {
+			for (int y = 0; y < c->H; ++y)
+				for (int x = 0; x < c->W; ++x)
+					if (wi[(size_t)y * c->W + x] == DVP_WEAK && ((x + y) & 1) == colour) list.push_back(y * c->W + x);
+			if (colour == 0) nb = (int)list.size();
+		}
+		if (list.size() > c->weak_list_alloc) {
+			if (dalloc(c, &c->weak_list, list.size(), false)) return 1;
+			c->weak_list_alloc = list.size();
+		}
+		if (!list.empty()) HIP_TRY(c, hipMemcpyAsync(c->weak_list, list.data(), list.size() * 4, hipMemcpyHostToDevice, c->stream));
+		c->d.weak_black = nb;
+		c->d.weak_red = (int)list.size() - nb;
+	}
 	HIP_TRY(c, hipMemcpyAsync(c->neighbours_map, map.data(), L * 4, hipMemcpyHostToDevice, c->stream));
 	if (ensure_weak_buffers(c, (size_t)wc)) return 1;
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -393,6 +448,7 @@ int dvp_reset_state(dvp_ctx* c) {
 	HIP_TRY(c, hipMemsetAsync(c->neighbours_map, 0, L * 4, c->stream));
 	HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->radius, c->d.params.strong_radius, L, c->stream));
 	c->d.weak_count = 0;
+	c->d.weak_black = c->d.weak_red = 0;
 	if (ensure_weak_buffers(c, 0)) return 1;
 	sync_dev_struct(c);
 	return 0;
@@ -441,6 +497,32 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 	if (c->profiling) HIP_TRY(c, hipMemsetAsync(c->eval_counter, 0, 8, c->stream));
 	HIP_TRY(c, hipEventRecord(ep.a, c->stream));
 	const dim3 grid(g.grid()), block(256);
+	const bool list_stage = stage == DVP_ST_FIND_NEAREST_STRONG || stage == DVP_ST_GEN_NEIGHBOURS || stage == DVP_ST_NEIGHBOUR_UPDATE ||
+	                        stage == DVP_ST_RANSAC_FIT || stage == DVP_ST_WEAK_UPDATE;
+	if (list_stage) {
+		// weak-path launch sites: lane-per-WEAK-pixel.  Non-WEAK pixels' outputs of these kernels are
+		// constants / copies and are produced by plain fills: weak_nearest_strong = (-1,-1)
+		// (APD.cu:4169-4173), fit plane = plane (APD.cu:4208-4211).
+		if (stage == DVP_ST_FIND_NEAREST_STRONG) HIP_TRY(c, hipMemsetAsync(c->weak_nearest_strong, 0xFF, c->L * sizeof(s2), c->stream));
+		if (stage == DVP_ST_RANSAC_FIT) HIP_TRY(c, hipMemcpyAsync(c->fit_planes, c->planes, c->L * 16, hipMemcpyDeviceToDevice, c->stream));
+		ListArgs la;
+		la.iter = iter;
+		la.covered_rows = 2 * make_geom(c->W, c->H, true).rows;
+		la.base = (stage == DVP_ST_WEAK_UPDATE && colour == 1) ? c->d.weak_black : 0;
+		la.count = (stage == DVP_ST_WEAK_UPDATE) ? (colour == 0 ? c->d.weak_black : c->d.weak_red) : c->d.weak_black + c->d.weak_red;
+		if (la.count > 0) {
+			const dim3 lg((la.count + 255) / 256);
+			const bool ex = c->d.sampler != 0;
+			switch (stage) {
+			case DVP_ST_FIND_NEAREST_STRONG: hipLaunchKernelGGL(ex ? dvp_find_nearest_strong_list_exact : dvp_find_nearest_strong_list, lg, block, 0, c->stream, c->d, la); break;
+			case DVP_ST_GEN_NEIGHBOURS: hipLaunchKernelGGL(ex ? dvp_gen_neighbours_list_exact : dvp_gen_neighbours_list, lg, block, 0, c->stream, c->d, la); break;
+			case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(ex ? dvp_neighbour_update_list_exact : dvp_neighbour_update_list, lg, block, 0, c->stream, c->d, la); break;
+			case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(ex ? dvp_ransac_fit_plane_list_exact : dvp_ransac_fit_plane_list, lg, block, 0, c->stream, c->d, la); break;
+			case DVP_ST_WEAK_UPDATE: hipLaunchKernelGGL(ex ? dvp_weak_update_list_exact : dvp_weak_update_list, lg, block, 0, c->stream, c->d, la); break;
+			}
+			HIP_TRY(c, hipGetLastError());
+		}
+	} else {
 	if (stage == DVP_ST_GEN_EDGE_INFORM && c->d.params.use_edge) {
 		hipLaunchKernelGGL(dvp_edge_rays, dim3((c->W + c->H + 255) / 256, 8), dim3(256), 0, c->stream, c->d);
 		HIP_TRY(c, hipGetLastError());
@@ -460,6 +542,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 	case DVP_ST_LOCAL_REFINE: hipLaunchKernelGGL(c->d.sampler ? dvp_local_refine_exact : dvp_local_refine, grid, block, 0, c->stream, c->d, a); break;
 	}
 	HIP_TRY(c, hipGetLastError());
+	}
 	HIP_TRY(c, hipEventRecord(ep.b, c->stream));
 	c->events.push_back(ep);
 	if (c->profiling) {

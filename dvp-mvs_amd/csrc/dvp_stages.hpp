@@ -74,6 +74,9 @@ constexpr bool stage_uses_tab(int stage) {
 	return stage == DVP_ST_RANDOM_INIT || stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_WEAK_UPDATE ||
 	       stage == DVP_ST_DEPTH_TO_WEAK || stage == DVP_ST_LOCAL_REFINE;
 }
+constexpr bool stage_is_half_c(int stage) {
+	return stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_WEAK_UPDATE || stage == DVP_ST_FILTER_STRONG;
+}
 inline bool stage_is_half(int stage) {
 	return stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_WEAK_UPDATE || stage == DVP_ST_FILTER_STRONG;
 }

@@ -154,16 +154,25 @@ DVP_HD void find_nearest_strong_px(const Dev& d, int px, int py) {
 	const int center = px + py * W;
 	s2 res = mks2(-1, -1);
 	if (d.weak_info[center] == DVP_WEAK) {
+		// The reference scans the whole (2r+1)^2 square of every ring and skips the interior
+		// (APD.cu:4176-4179): O(r^3).  Only the perimeter is visited here, in the same order
+		// (x ascending; for the two outer columns every y, otherwise y = -r then y = +r).
 		bool found = false;
-		for (int radius = 0; radius <= 100 && !found; ++radius)
-			for (int x = -radius; x <= radius && !found; ++x)
-				for (int y = -radius; y <= radius; ++y) {
-					const int ax = x < 0 ? -x : x, ay = y < 0 ? -y : y;
-					if (ax != radius && ay != radius) continue;
+		for (int radius = 0; radius <= 100 && !found; ++radius) {
+			for (int x = -radius; x <= radius && !found; ++x) {
+				const bool full = (x == -radius || x == radius);
+				const int ystep = full ? 1 : 2 * radius;   // radius >= 1 whenever !full
+				for (int y = -radius; y <= radius; y += ystep) {
 					const int nx = px + x, ny = py + y;
-					if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
-					if (d.weak_info[nx + ny * W] == DVP_STRONG) { res = mks2(nx, ny); found = true; break; }
+					if (!(nx < 0 || ny < 0 || nx >= W || ny >= H) && d.weak_info[nx + ny * W] == DVP_STRONG) {
+						res = mks2(nx, ny);
+						found = true;
+						break;
+					}
+					if (ystep == 0) break;   // radius == 0: single point
 				}
+			}
+		}
 	}
 	d.weak_nearest_strong[center] = res;
 }
@@ -601,63 +610,111 @@ DVP_HD void ransac_fit_plane_px(const Dev& d, int px, int py, int iter) {
 }
 
 // ---- ComputeBilateralNCCNew (APD.cu:835-1021) ---------------------------------------------------
+// The deformable NCC of a WEAK pixel = its own 36-tap patch (colour-only weights) + up to 11 anchor
+// sub-patches of 9 visibility-prior taps.  For a given (pixel, view) the anchors, their tap
+// positions, the reference texels, the weights and the three reference sums do not depend on the
+// plane hypothesis; the reference recomputes them (99 exp + 99 texel reads + the candidate
+// offsets) for each of the ~15 hypotheses.  AnchorTab holds that half once per (pixel, view).
+struct AnchorTab {
+	float w[99], wa[99];              // tap weight, weight * ref texel
+	s2 xy[99];                        // tap pixel
+	float s_r[11], s_rr[11], s_w[11]; // reference sums per anchor (tap order 0..8)
+	s2 nb[11];                        // anchor pixel
+	uint8_t state[11];                // 0 absent, 1 visible in this view, 2 not visible
+};
+
+DVP_HD void build_anchor_tab(const Dev& d, int center, int v, float cpix, AnchorTab* T) {
+	const int W = d.width, Hh = d.height, Pt = d.pitch;
+	const int S = d.params.num_images - 1;
+	const float* ref = d.images;
+	const s2* nbs = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
+	for (int k = 1; k < DVP_NEIGHBOUR_NUM; ++k) {
+		const s2 nb = nbs[k];
+		T->nb[k - 1] = nb;
+		if (nb.x == -1 || nb.y == -1) { T->state[k - 1] = 0; continue; }
+		const int nbc = nb.x + nb.y * W;
+		const int visible = is_set(d.selected_views[nbc], v - 1);
+		T->state[k - 1] = visible ? 1 : 2;
+		if (!visible) continue;
+		const s2* cand = d.candidate + ((size_t)nbc * S + (v - 1)) * 8;
+		s2 off[9];
+#pragma unroll
+		for (int t = 0; t < 8; ++t) off[t] = cand[t];
+		off[8] = mks2(0, 0);
+		float av[9], wv[9];
+#pragma unroll
+		for (int t = 0; t < 9; t++) {
+			int i = off[t].x, j = off[t].y;
+			if (i == 0 && j == 0 && t < 8) {   // default +-5 ring (APD.cu:943-952)
+				const int ri[8] = { -5, -5, -5, 0, 0, 5, 5, 5 };
+				const int rj[8] = { -5, 0, 5, -5, 5, -5, 0, 5 };
+				i = ri[t < 8 ? t : 0];
+				j = rj[t < 8 ? t : 0];
+			}
+			const int rx = nb.x + i, ry = nb.y + j;
+			T->xy[(k - 1) * 9 + t] = mks2(rx, ry);
+			av[t] = tex_texel(ref, d.org, Pt, W, Hh, rx, ry);
+			wv[t] = bilateral_weight((float)i, (float)j, av[t], cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
+		}
+		float s_r = 0.0f, s_rr = 0.0f, s_w = 0.0f;
+#pragma unroll
+		for (int t = 0; t < 9; t++) {
+			const float wa = wv[t] * av[t];
+			T->w[(k - 1) * 9 + t] = wv[t];
+			T->wa[(k - 1) * 9 + t] = wa;
+			s_r += wa;
+			s_rr += wa * av[t];
+			s_w += wv[t];
+		}
+		T->s_r[k - 1] = s_r;
+		T->s_rr[k - 1] = s_rr;
+		T->s_w[k - 1] = s_w;
+	}
+}
+
 // `c` = centre-patch context built with colour-only weights (ComputeBilateralWeight_YZL).
 template <int SMP>
-DVP_HD float ncc_new(const Dev& d, const PatchCtx& c, int px, int py, int v, const f4 plane) {
+DVP_HD float ncc_new(const Dev& d, const PatchCtx& c, const AnchorTab& T, int px, int py, int v, const f4 plane) {
 	const DvpCamera& rc = d.cameras[0];
 	const DvpCamera& sc = d.cameras[v];
 	const int W = d.width, Hh = d.height, Pt = d.pitch;
-	const int S = d.params.num_images - 1;
 	float H[9];
 	homography(rc, sc, d.views[v], plane, H);
 	const f2 pt = apply_homography(H, px, py);
 	if (pt.x >= sc.width || pt.x < 0.0f || pt.y >= sc.height || pt.y < 0.0f) return 2.0f;
-	const float* ref = d.images;
 	const float* src = d.images + (size_t)v * d.plane_stride;
-	const int center = px + py * W;
-	const float cpix = tex_texel(ref, d.org, Pt, W, Hh, px, py);
 	// k == 0: the pixel's own patch (neighbours[0] is the pixel itself, APD.cu:3365)
 	const float center_cost = c.fast ? ncc_patch_fast<SMP>(d, c, H, src, px, py)
 	                                 : ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
 	float strong_cost = 0.0f;
 	int strong_count = 0;
-	const s2* nbs = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
-	for (int k = 1; k < DVP_NEIGHBOUR_NUM; ++k) {
-		const s2 nb = nbs[k];
-		if (nb.x == -1 || nb.y == -1) continue;
+	for (int k = 0; k < DVP_NEIGHBOUR_NUM - 1; ++k) {
+		const int st = T.state[k];
+		if (st == 0) continue;
+		const s2 nb = T.nb[k];
 		const f2 nsp = apply_homography(H, nb.x, nb.y);
-		const int nbc = nb.x + nb.y * W;
-		const int visible = is_set(d.selected_views[nbc], v - 1);
 		if (nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh) {
-			if (visible) { strong_cost += 2.0f; strong_count++; }
+			if (st == 1) { strong_cost += 2.0f; strong_count++; }
 			continue;
 		}
 		float temp_cost = 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
-		if (visible) {
-			float s_r = 0.0f, s_rr = 0.0f, s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f, s_w = 0.0f;
-			const s2* cand = d.candidate + ((size_t)nbc * S + (v - 1)) * 8;
+		if (st == 1) {
+			float bv[9];
+#pragma unroll
 			for (int t = 0; t < 9; t++) {
-				int i = 0, j = 0;
-				if (t != 8) { i = cand[t].x; j = cand[t].y; }
-				if (i == 0 && j == 0 && t < 8) {   // default +-5 ring (APD.cu:943-952)
-					const int ri[8] = { -5, -5, -5, 0, 0, 5, 5, 5 };
-					const int rj[8] = { -5, 0, 5, -5, 5, -5, 0, 5 };
-					i = ri[t];
-					j = rj[t];
-				}
-				const int rx = nb.x + i, ry = nb.y + j;
-				const float a = tex_texel(ref, d.org, Pt, W, Hh, rx, ry);
-				const f2 sp = apply_homography(H, rx, ry);
-				const float b = tex_linear(src, Pt, W, Hh, sp.x + 0.5f, sp.y + 0.5f, d.sampler);
-				const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
-				s_r += w * a;
-				s_rr += w * a * a;
-				s_s += w * b;
-				s_ss += w * b * b;
-				s_rs += w * a * b;
-				s_w += w;
+				const s2 q = T.xy[k * 9 + t];
+				const f2 sp = apply_homography(H, q.x, q.y);
+				bv[t] = tex_linear_t<SMP>(src, Pt, W, Hh, sp.x + 0.5f, sp.y + 0.5f);
 			}
-			temp_cost = ncc_from_sums(s_r, s_rr, s_s, s_ss, s_rs, s_w);
+			float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+#pragma unroll
+			for (int t = 0; t < 9; t++) {
+				const float wb = T.w[k * 9 + t] * bv[t];
+				s_s += wb;
+				s_ss += wb * bv[t];
+				s_rs += T.wa[k * 9 + t] * bv[t];
+			}
+			temp_cost = ncc_from_sums(T.s_r[k], T.s_rr[k], s_s, s_ss, s_rs, T.s_w[k]);
 		}
 		strong_cost += temp_cost;
 		strong_count++;
@@ -669,17 +726,21 @@ DVP_HD float ncc_new(const Dev& d, const PatchCtx& c, int px, int py, int v, con
 }
 
 // ---- CheckerboardPropagationWeak + PlaneHypothesisRefinementWeak (APD.cu:2739-3089, 1897-2008) --
-// 16 slots with one inlined copy of ncc_new: 8 anchor planes, the current plane, the RANSAC fit
-// plane, 6 refinement hypotheses.
+// Three view-major phases through ONE inlined copy of ncc_new, so that the anchor table of a view
+// is built once per phase instead of once per hypothesis:
+//   phase 0: the planes of the <= 8 STRONG anchors x all views            -> view selection
+//   phase 1: the current plane and the RANSAC fit plane x selected views  -> adoption, fit test
+//   phase 2: 5 refinement hypotheses x selected views                     -> sequential acceptance
 template <int SMP>
 DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter, unsigned long long* nevals) {
-	const int W = d.width;
+	const int W = d.width, Hh = d.height;
 	const int center = py * W + px;
 	const DvpParams& P = d.params;
 	const DvpCamera& rc = d.cameras[0];
 	const int S = P.num_images - 1;
 	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
 	const s2* nbs = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
+	const float cpix = tex_texel(d.images, d.org, d.pitch, W, Hh, px, py);
 
 	PatchCtx c;
 	{
@@ -701,24 +762,29 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter,
 	int min_cost_idx = 0;
 	float cost_now = 0.0f, costs_center = 0.0f, depth_now = 0.0f;
 	f4 plane_now = mk4(0, 0, 0, 0);
-	float ref_depths[6];
-	f4 ref_normals[6];
 	bool skip_refine = false;
-	float cv[32];
 
-	for (int slot = 0; slot < 16; ++slot) {
-		if (slot == 14) continue;   // refinement hypothesis 4 == hypothesis 3 (see strong_update_px)
-		f4 plane = mk4(0, 0, 1, 1);
-		uint32_t mask = 0;
-		if (slot < 8) {
-			const s2 nb = nbs[slot + 1];
-			if (!(nb.x == -1 || nb.y == -1) && d.weak_info[nb.x + nb.y * W] == DVP_STRONG) {
-				positions[slot] = nb.x + nb.y * W;
-				flag |= 1u << slot;
-				plane = d.planes[positions[slot]];
-				mask = all_views;
+	f4 pl[8];            // planes evaluated by the current phase
+	float ev[8 * 32];    // their cost vectors [plane][view]
+	AnchorTab T;
+
+	for (int phase = 0; phase < 3; ++phase) {
+		// ---- prologue: the planes of this phase --------------------------------------------------
+		uint32_t pmask = 0;    // which pl[] entries are live
+		uint32_t vmask = 0;    // which views are evaluated
+		if (phase == 0) {
+			for (int k = 0; k < 8; ++k) {
+				const s2 nb = nbs[k + 1];
+				if (!(nb.x == -1 || nb.y == -1) && d.weak_info[nb.x + nb.y * W] == DVP_STRONG) {
+					positions[k] = nb.x + nb.y * W;
+					flag |= 1u << k;
+					pl[k] = d.planes[positions[k]];
+				}
 			}
-		} else if (slot == 8) {
+			pmask = flag;
+			vmask = all_views;
+		} else if (phase == 1) {
+			// joint view selection (APD.cu:2781-2850) and the weighted candidate costs (:2852-2874)
 			float priors[32];
 			for (int i = 0; i < 32; ++i) priors[i] = 0.0f;
 			for (int i = 0; i < 8; ++i) {
@@ -750,46 +816,66 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter,
 				for (int k = 1; k < 8; ++k)
 					if (final_costs[k] <= mc) { mc = final_costs[k]; min_cost_idx = k; }
 			}
-			plane = d.planes[center];
-			mask = sel_mask;
-		} else if (slot == 9) {
-			// the RANSAC fit plane is tried first (APD.cu:1920-1949); an all-zero fit plane makes
-			// the reference return from the whole refinement (:1923-1925)
+			pl[0] = d.planes[center];
+			pmask = 1u;
+			// the RANSAC fit plane is tried first by the refinement (APD.cu:1920-1949); an all-zero
+			// fit plane makes the reference return from the whole refinement (:1923-1925)
 			const f4 fp = d.fit_planes[center];
 			if (fp.x == 0 && fp.y == 0 && fp.z == 0) skip_refine = true;
-			else { plane = fp; mask = sel_mask; }
+			else { pl[1] = fp; pmask |= 2u; }
+			vmask = sel_mask;
 		} else {
-			if (!skip_refine) {
-				const int i = slot - 10;
-				plane = ref_normals[i];
-				plane.w = distance_to_origin(rc, px, py, ref_depths[i], plane);
-				mask = sel_mask;
+			if (skip_refine) break;
+			// random refinement hypotheses from the state after the fit-plane test (APD.cu:1952-1979);
+			// hypothesis 4 equals hypothesis 3 and is never accepted after it: not evaluated
+			Rng rd(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_DEPTH_RAND));
+			Rng rn(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_NORMAL));
+			Rng rp(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_DEPTH_PERT));
+			const float depth_rand = rd.uniform() * (P.depth_max - P.depth_min) + P.depth_min;
+			const f4 n_rand = random_normal_yzl(d, px, py, rn, depth_now);
+			const float dmin_p = (1 - 0.02f) * depth_now, dmax_p = (1 + 0.02f) * depth_now;
+			const float depth_pert = rp.uniform() * (dmax_p - dmin_p) + dmin_p;
+			f4 n_pert = plane_now;
+			normalize3(&n_pert);
+			const float rdep[5] = { depth_rand, depth_now, depth_rand, depth_now, depth_pert };
+			const f4 rnrm[5] = { plane_now, n_rand, n_rand, n_pert, plane_now };
+			for (int i = 0; i < 5; ++i) {
+				pl[i] = rnrm[i];
+				pl[i].w = distance_to_origin(rc, px, py, rdep[i], pl[i]);
 			}
+			pmask = 0x1Fu;
+			vmask = sel_mask;
 		}
 
-		if (mask) {
+		// ---- evaluate: view-major, anchor table built once per view ------------------------------
+		if (pmask) {
 			for (int v = 0; v < S; ++v) {
-				if ((mask >> v) & 1) {
-					cv[v] = ncc_new<SMP>(d, c, px, py, v + 1, plane);
+				if (!((vmask >> v) & 1)) continue;
+				build_anchor_tab(d, center, v + 1, cpix, &T);
+				for (int q = 0; q < 8; ++q) {
+					if (!((pmask >> q) & 1)) continue;
+					ev[q * 32 + v] = ncc_new<SMP>(d, c, T, px, py, v + 1, pl[q]);
 					if (nevals) *nevals += 1;
 				}
 			}
 		}
 
-		if (slot < 8) {
-			if ((flag >> slot) & 1)
-				for (int v = 0; v < S; ++v) cost_array[slot * 32 + v] = cv[v];
-		} else if (slot == 8) {
+		// ---- epilogue ------------------------------------------------------------------------------
+		if (phase == 0) {
+			for (int k = 0; k < 8; ++k)
+				if ((flag >> k) & 1)
+					for (int v = 0; v < S; ++v) cost_array[k * 32 + v] = ev[k * 32 + v];
+		} else if (phase == 1) {
 			float cn = 0.0f;
 			for (int v = 0; v < S; ++v) {
 				if (vw[v] > 0) {
-					if (P.geom_consistency) cn += vw[v] * (cv[v] + P.geom_factor * geom_cost(d, px, py, v + 1, plane));
-					else cn += vw[v] * cv[v];
+					if (P.geom_consistency) cn += vw[v] * (ev[v] + P.geom_factor * geom_cost(d, px, py, v + 1, pl[0]));
+					else cn += vw[v] * ev[v];
 				}
 			}
 			cost_now = cn / weight_norm;
 			costs_center = cost_now;
-			plane_now = plane;
+			plane_now = pl[0];
 			depth_now = depth_from_plane(rc, plane_now, px, py);
 			if ((flag >> min_cost_idx) & 1) {
 				const f4 cand = d.planes[positions[min_cost_idx]];
@@ -801,41 +887,38 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter,
 					d.selected_views[center] = sel_mask;
 				}
 			}
-		} else {
-			const bool active = (slot == 9) ? !skip_refine : !skip_refine;
-			if (active) {
+			if (!skip_refine) {   // fit-plane test
 				float tc = 0.0f;
 				for (int j = 0; j < S; ++j) {
 					if (vw[j] > 0) {
-						if (P.geom_consistency) tc += vw[j] * (cv[j] + P.geom_factor * geom_cost(d, px, py, j + 1, plane));
-						else tc += vw[j] * cv[j];
+						if (P.geom_consistency) tc += vw[j] * (ev[32 + j] + P.geom_factor * geom_cost(d, px, py, j + 1, pl[1]));
+						else tc += vw[j] * ev[32 + j];
 					}
 				}
 				tc /= weight_norm;
-				const float db = depth_from_plane(rc, plane, px, py);
+				const float db = depth_from_plane(rc, pl[1], px, py);
 				if (db >= P.depth_min && db <= P.depth_max && tc < cost_now) {
 					depth_now = db;
-					plane_now = plane;
+					plane_now = pl[1];
 					cost_now = tc;
 				}
 			}
-			if (slot == 9 && !skip_refine) {
-				// random refinement hypotheses are built from the state after the fit-plane test
-				Rng rd(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_DEPTH_RAND));
-				Rng rn(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_NORMAL));
-				Rng rp(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_DEPTH_PERT));
-				const float depth_rand = rd.uniform() * (P.depth_max - P.depth_min) + P.depth_min;
-				const f4 n_rand = random_normal_yzl(d, px, py, rn, depth_now);
-				const float dmin_p = (1 - 0.02f) * depth_now, dmax_p = (1 + 0.02f) * depth_now;
-				const float depth_pert = rp.uniform() * (dmax_p - dmin_p) + dmin_p;
-				f4 n_pert = plane_now;
-				normalize3(&n_pert);
-				ref_depths[0] = depth_rand; ref_normals[0] = plane_now;
-				ref_depths[1] = depth_now;  ref_normals[1] = n_rand;
-				ref_depths[2] = depth_rand; ref_normals[2] = n_rand;
-				ref_depths[3] = depth_now;  ref_normals[3] = n_pert;
-				ref_depths[4] = depth_now;  ref_normals[4] = n_pert;
-				ref_depths[5] = depth_pert; ref_normals[5] = plane_now;
+		} else {
+			for (int i = 0; i < 5; ++i) {
+				float tc = 0.0f;
+				for (int j = 0; j < S; ++j) {
+					if (vw[j] > 0) {
+						if (P.geom_consistency) tc += vw[j] * (ev[i * 32 + j] + P.geom_factor * geom_cost(d, px, py, j + 1, pl[i]));
+						else tc += vw[j] * ev[i * 32 + j];
+					}
+				}
+				tc /= weight_norm;
+				const float db = depth_from_plane(rc, pl[i], px, py);
+				if (db >= P.depth_min && db <= P.depth_max && tc < cost_now) {
+					depth_now = db;
+					plane_now = pl[i];
+					cost_now = tc;
+				}
 			}
 		}
 	}
