@@ -25,6 +25,8 @@ std::string ToFormatIndex(int index);                                           
 template <typename TYPE>
 void RescaleMatToTargetSize(const Mat& src, Mat& dst, int target_width, int target_height);   // APD.cpp:1773-1795
 void RunFusion(const path& dense_folder, const std::vector<Problem>& problems);        // APD.cpp:1809-1960
+Mat EdgeSegment(const int scale, const Mat& srcImage, int mode = 0, bool useCanny = false);   // APD.cpp:348-499 (mode 0 + Canny only)
+void GetProblemEdges(const Problem& problem);                                           // main.cpp:193-246 (edge part)
 // image I/O without OpenCV: images/<id>.pgm|.ppm (binary P5/P6) next to / instead of <id>.jpg
 // (tools/jpg2pnm.py converts); returns an empty Mat if nothing readable is found.
 Mat ReadImageGray(const path& image_path_jpg);      // stands in for cv::imread(IMREAD_GRAYSCALE), APD.cpp:1057

@@ -183,7 +183,10 @@ int main(int argc, char** argv) {
 			params.geom_consistency = false;
 			params.max_iterations = iters;
 			params.weak_peak_radius = 6;
-			if (problem.index % world == rank) ProcessProblem(problem);
+			if (problem.index % world == rank) {
+				GetProblemEdges(problem);   // main.cpp:480
+				ProcessProblem(problem);
+			}
 		}
 		PassBarrier(sync_dir, pass++, rank, world);
 		iteration_index++;

@@ -90,6 +90,23 @@ int main(int argc, char** argv) {
 		std::vector<char> rest((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
 		CHECK(rest.size() == 2 * 15);
 	}
+	// Canny edge front end (EdgeSegment mode 0): a vertical step must give one thin vertical edge
+	{
+		Mat img(40, 60, CV_8UC1);
+		for (int r = 0; r < 40; ++r) for (int c = 0; c < 60; ++c) img.at<uint8_t>(r, c) = c < 30 ? 60 : 180;
+		Mat e = EdgeSegment(0, img, 0, true);
+		CHECK(e.rows == 40 && e.cols == 60);
+		int on_step = 0, elsewhere = 0;
+		for (int r = 2; r < 38; ++r)
+			for (int c = 0; c < 60; ++c)
+				if (e.at<uint8_t>(r, c)) { if (c == 29 || c == 30) on_step++; else elsewhere++; }
+		CHECK(on_step == 36 && elsewhere == 0);
+		Mat flat = Mat::zeros(20, 20, CV_8UC1);
+		Mat e2 = EdgeSegment(0, flat, 0, true);
+		int any = 0;
+		for (int i = 0; i < 400; ++i) any += e2.data[i];
+		CHECK(any == 0);
+	}
 	static_assert(sizeof(Camera) == 112 && sizeof(PatchMatchParams) == 76, "POD layouts");
 	printf("host tests ok\n");
 	return 0;
