@@ -14,9 +14,11 @@ namespace {
 
 template <class F>
 void launch_full(Ctx& h, F f) {   // grid_size_full / block 16x16 (APD.cu:4412-4419): every pixel once
-#pragma omp parallel for schedule(dynamic, 1)
+	const int xb = (h.width + 31) / 32;
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
 	for (int y = 0; y < h.height; ++y)
-		for (int x = 0; x < h.width; ++x) f(make_int2(x, y));
+		for (int b = 0; b < xb; ++b)
+			for (int x = b * 32; x < h.width && x < b * 32 + 32; ++x) f(make_int2(x, y));
 }
 
 // grid_size_half / block 32x16 (APD.cu:4421-4428) with the pixel map of APD.cu:3093-3100:
@@ -25,13 +27,15 @@ void launch_full(Ctx& h, F f) {   // grid_size_full / block 16x16 (APD.cu:4412-4
 template <class F>
 void launch_half(Ctx& h, int colour /*0 = black, 1 = red*/, F f) {
 	const int rows_half = ((h.height / 2) + 15) / 16 * 16;
-#pragma omp parallel for schedule(dynamic, 1)
+	const int xb = (h.width + 31) / 32;
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
 	for (int yh = 0; yh < rows_half; ++yh)
-		for (int x = 0; x < h.width; ++x) {
-			int y = 2 * yh + ((x & 1) ^ colour);
-			if (y >= h.height) continue;
-			f(make_int2(x, y));
-		}
+		for (int b = 0; b < xb; ++b)
+			for (int x = b * 32; x < h.width && x < b * 32 + 32; ++x) {
+				int y = 2 * yh + ((x & 1) ^ colour);
+				if (y >= h.height) continue;
+				f(make_int2(x, y));
+			}
 }
 
 void alloc_state(Ctx& h) {
