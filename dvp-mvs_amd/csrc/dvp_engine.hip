@@ -300,8 +300,8 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	c->d.params.num_images = num_images;
 	c->d.params.strong_radius = 5; c->d.params.strong_increment = 2; c->d.params.weak_radius = 5; c->d.params.weak_increment = 5;
 	c->d.params.rotate_time = 4;
-	hipEventCreate(&c->ev_total_a); hipEventCreate(&c->ev_total_b);
-	hipEventCreate(&c->ev_iter_a); hipEventCreate(&c->ev_iter_b);
+	if (hipEventCreate(&c->ev_total_a) != hipSuccess || hipEventCreate(&c->ev_total_b) != hipSuccess ||
+		hipEventCreate(&c->ev_iter_a) != hipSuccess || hipEventCreate(&c->ev_iter_b) != hipSuccess) { c->error = "hipEventCreate failed"; return fail(0); }
 	sync_dev_struct(c);
 	*out = c;
 	return 0;
@@ -309,12 +309,14 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 
 int dvp_ctx_destroy(dvp_ctx* c) {
 	if (!c) return 0;
-	hipSetDevice(c->device);
-	if (c->stream) hipStreamSynchronize(c->stream);
-	for (auto& e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-	if (c->ev_total_a) { hipEventDestroy(c->ev_total_a); hipEventDestroy(c->ev_total_b); hipEventDestroy(c->ev_iter_a); hipEventDestroy(c->ev_iter_b); }
-	for (void* p : c->allocs) hipFree(p);
-	if (c->stream) hipStreamDestroy(c->stream);
+	// teardown: errors are not actionable here
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+	for (hipEvent_t e : { c->ev_total_a, c->ev_total_b, c->ev_iter_a, c->ev_iter_b })
+		if (e) (void)hipEventDestroy(e);
+	for (void* p : c->allocs) (void)hipFree(p);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return 0;
 }
@@ -490,6 +492,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 		HIP_TRY(c, hipMemcpyAsync(c->planes_snap, c->planes, c->L * 16, hipMemcpyDeviceToDevice, c->stream));
 		HIP_TRY(c, hipMemcpyAsync(c->costs_snap, c->costs, c->L * 4, hipMemcpyDeviceToDevice, c->stream));
 	}
+	if (c->events.size() >= 2048 && dvp_get_timings(c, nullptr)) return 1;   // fold pending timings: bounds the event pool
 	EventPair ep;
 	ep.stage = stage;
 	HIP_TRY(c, hipEventCreate(&ep.a));
@@ -659,8 +662,8 @@ int dvp_get_timings(dvp_ctx* c, DvpTimings* out) {
 		HIP_TRY(c, hipEventElapsedTime(&ms, e.a, e.b));
 		c->timings.stage_ms[e.stage] += ms;
 		c->timings.stage_launches[e.stage] += 1;
-		hipEventDestroy(e.a);
-		hipEventDestroy(e.b);
+		(void)hipEventDestroy(e.a);
+		(void)hipEventDestroy(e.b);
 	}
 	c->events.clear();
 	if (c->total_pending) {
@@ -681,50 +684,61 @@ int dvp_reset_timings(dvp_ctx* c) {
 }
 
 // ---- KAT / micro-benchmark ---------------------------------------------------------------------
+namespace {
+struct DevBuf {   // hipMalloc'ed scratch released on every exit path
+	void* p = nullptr;
+	~DevBuf() { if (p) (void)hipFree(p); }
+};
+struct EventPairGuard {
+	hipEvent_t a = nullptr, b = nullptr;
+	~EventPairGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+}  // namespace
+
 int dvp_eval_cost_vectors(dvp_ctx* c, const int32_t* px, const float* planes, int n, float* out, float* kernel_ms) {
 	if (set_device(c)) return 1;
 	if (!c->lut) { c->error = "dvp_set_params must be called first"; return 1; }
 	if (n <= 0) return 0;
 	const size_t S = (size_t)c->NI - 1;
-	int* dpx = nullptr; f4* dpl = nullptr; float* dout = nullptr;
-	HIP_TRY(c, hipMalloc((void**)&dpx, (size_t)n * 8));
-	HIP_TRY(c, hipMalloc((void**)&dpl, (size_t)n * 16));
-	HIP_TRY(c, hipMalloc((void**)&dout, (size_t)n * S * 4));
-	HIP_TRY(c, hipMemcpyAsync(dpx, px, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(dpl, planes, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-	hipEvent_t a, b;
-	hipEventCreate(&a); hipEventCreate(&b);
-	hipEventRecord(a, c->stream);
-	hipLaunchKernelGGL(dvp_cost_vectors, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, dpx, dpl, n, dout);
-	hipEventRecord(b, c->stream);
+	DevBuf dpx, dpl, dout;
+	EventPairGuard ev;
+	HIP_TRY(c, hipMalloc(&dpx.p, (size_t)n * 8));
+	HIP_TRY(c, hipMalloc(&dpl.p, (size_t)n * 16));
+	HIP_TRY(c, hipMalloc(&dout.p, (size_t)n * S * 4));
+	HIP_TRY(c, hipMemcpyAsync(dpx.p, px, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(dpl.p, planes, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipEventCreate(&ev.a));
+	HIP_TRY(c, hipEventCreate(&ev.b));
+	HIP_TRY(c, hipEventRecord(ev.a, c->stream));
+	hipLaunchKernelGGL(dvp_cost_vectors, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, (const int*)dpx.p, (const f4*)dpl.p, n, (float*)dout.p);
 	HIP_TRY(c, hipGetLastError());
-	HIP_TRY(c, hipMemcpyAsync(out, dout, (size_t)n * S * 4, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipEventRecord(ev.b, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(out, dout.p, (size_t)n * S * 4, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	if (kernel_ms) hipEventElapsedTime(kernel_ms, a, b);
-	hipEventDestroy(a); hipEventDestroy(b);
-	hipFree(dpx); hipFree(dpl); hipFree(dout);
+	if (kernel_ms) HIP_TRY(c, hipEventElapsedTime(kernel_ms, ev.a, ev.b));
 	return 0;
 }
 
 int dvp_bench_cost_kernel(dvp_ctx* c, int repeat, float* mean_kernel_ms, uint64_t* evals_per_launch) {
 	if (set_device(c)) return 1;
 	if (!c->lut) { c->error = "dvp_set_params must be called first"; return 1; }
+	if (repeat < 1) repeat = 1;
 	const LaunchGeom g = make_geom(c->W, c->H, false);
 	LaunchArgs a;
 	a.tiles_x = g.tiles_x; a.tiles = g.tiles; a.chunk = g.chunk; a.rows = g.rows; a.half = 0; a.colour = 0; a.iter = 0;
-	hipEvent_t e0, e1;
-	hipEventCreate(&e0); hipEventCreate(&e1);
+	EventPairGuard ev;
+	HIP_TRY(c, hipEventCreate(&ev.a));
+	HIP_TRY(c, hipEventCreate(&ev.b));
 	hipLaunchKernelGGL(dvp_cost_all_pixels, dim3(g.grid()), dim3(256), 0, c->stream, c->d, a, c->scratch_out);   // warm-up
-	hipEventRecord(e0, c->stream);
+	HIP_TRY(c, hipEventRecord(ev.a, c->stream));
 	for (int i = 0; i < repeat; ++i)
 		hipLaunchKernelGGL(dvp_cost_all_pixels, dim3(g.grid()), dim3(256), 0, c->stream, c->d, a, c->scratch_out);
-	hipEventRecord(e1, c->stream);
+	HIP_TRY(c, hipEventRecord(ev.b, c->stream));
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	float ms = 0.0f;
-	hipEventElapsedTime(&ms, e0, e1);
-	hipEventDestroy(e0); hipEventDestroy(e1);
-	if (mean_kernel_ms) *mean_kernel_ms = ms / (repeat > 0 ? repeat : 1);
+	HIP_TRY(c, hipEventElapsedTime(&ms, ev.a, ev.b));
+	if (mean_kernel_ms) *mean_kernel_ms = ms / repeat;
 	if (evals_per_launch) *evals_per_launch = (uint64_t)c->L * (uint64_t)(c->NI - 1);
 	return 0;
 }
