@@ -1,97 +1,81 @@
-// main.h — host-side types of the reference's public API (/root/reference/main.h:39-124),
-// without OpenCV / Boost / CUDA: boost::filesystem::path -> std::filesystem::path, cv::Mat -> Mat
-// (Mat.h).  Layouts of Camera and PatchMatchParams are byte-identical to the reference's PODs and
-// to the C ABI's DvpCamera / DvpParams (include/dvp_mvs.h).
-#ifndef _MAIN_H_
-#define _MAIN_H_
+// main.h — host-side vocabulary of the reference's public API (/root/reference/main.h:39-124)
+// expressed on top of the C ABI (include/dvp_mvs.h) instead of OpenCV / Boost / CUDA headers:
+//   Camera            is the ABI's DvpCamera itself (same field names, 112 bytes);
+//   PatchMatchParams  is the ABI's DvpParams plus the reference's default values, so an
+//                     APD can hand `&params` straight to dvp_set_params();
+//   path              is std::filesystem::path (the reference uses boost::filesystem);
+//   cv::Mat           is replaced by the small Mat of Mat.h.
+// Names are the reference's so that code written against it compiles unchanged.
+#ifndef DVP_HOST_MAIN_H_
+#define DVP_HOST_MAIN_H_
 
-#include <vector>
-#include <string>
-#include <iostream>
-#include <fstream>
-#include <sstream>
 #include <algorithm>
 #include <chrono>
-#include <iomanip>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <filesystem>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
 
 #include "../../include/dvp_mvs.h"
 #include "Mat.h"
 
-#define MAX_IMAGES 32
-#define NEIGHBOUR_NUM 12
-#define NUM_IMAGES 4
-#define EDGE_NEIGH_NUM 8
-#define LAB_BOUNDARY_NUM 8
-#define MAX_SEARCH_RADIUS 4096
+// Capacity constants (main.h:39-45).  The first four are fixed by the engine's buffer layouts.
+constexpr int MAX_IMAGES = DVP_MAX_IMAGES;
+constexpr int NEIGHBOUR_NUM = DVP_NEIGHBOUR_NUM;
+constexpr int EDGE_NEIGH_NUM = DVP_EDGE_NEIGH_NUM;
+constexpr int LAB_BOUNDARY_NUM = DVP_LAB_BOUNDARY_NUM;
+constexpr int NUM_IMAGES = 4;                // default top_k
+constexpr int MAX_SEARCH_RADIUS = 4096;
 
-using std::filesystem::path;
+using path = std::filesystem::path;
 
-struct float4 { float x, y, z, w; };
-struct float3 { float x, y, z; };
+// CUDA's vector PODs, as the reference's host code uses them.
 struct float2 { float x, y; };
+struct float3 { float x, y, z; };
+struct float4 { float x, y, z, w; };
 struct int2 { int x, y; };
 
-struct Camera {          // main.h:58-67
-	float K[9];
-	float R[9];
-	float t[3];
-	float c[3];
-	int height;
-	int width;
-	float depth_min;
-	float depth_max;
+using Camera = DvpCamera;                    // main.h:58-67: K R t c height width depth_min depth_max
+
+// main.h:74-84; numeric values are the ABI's.
+enum RunState { FIRST_INIT = DVP_FIRST_INIT, REFINE_INIT = DVP_REFINE_INIT, REFINE_ITER = DVP_REFINE_ITER };
+enum PixelState { WEAK = DVP_WEAK, STRONG = DVP_STRONG, UNKNOWN = DVP_UNKNOWN };
+
+// main.h:86-112.  The flag members are uint8_t in the ABI (C has no bool); they convert to and
+// from bool implicitly, `state` to and from RunState.
+struct PatchMatchParams : DvpParams {
+	PatchMatchParams() : DvpParams{} {
+		max_iterations = 3;       num_images = 5;           top_k = NUM_IMAGES;
+		sigma_spatial = 5.0f;     sigma_color = 3.0f;
+		depth_min = 0.0f;         depth_max = 1.0f;
+		strong_radius = 5;        strong_increment = 2;
+		weak_radius = 5;          weak_increment = 5;
+		weak_peak_radius = 2;     rotate_time = 4;
+		ransac_threshold = 0.005f; geom_factor = 0.2f;
+		geom_consistency = false; use_detail = false;
+		use_APD = use_edge = use_limit = use_label = use_radius = true;
+		state = FIRST_INIT;
+	}
 };
-static_assert(sizeof(Camera) == sizeof(DvpCamera) && sizeof(Camera) == 112, "Camera layout");
+static_assert(sizeof(PatchMatchParams) == sizeof(DvpParams) && sizeof(DvpParams) == 76, "params layout");
+static_assert(sizeof(Camera) == 112, "camera layout");
 
-struct PointList {       // main.h:69-72
-	float3 coord;
-	float3 color;
-};
+struct PointList { float3 coord, color; };   // main.h:69-72, one fused point of the .ply
 
-enum RunState { FIRST_INIT, REFINE_INIT, REFINE_ITER };   // main.h:74-78
-enum PixelState { WEAK, STRONG, UNKNOWN };                // main.h:80-84
-
-struct PatchMatchParams {   // main.h:86-112
-	int max_iterations = 3;
-	int num_images = 5;
-	float sigma_spatial = 5.0f;
-	float sigma_color = 3.0f;
-	int top_k = 4;
-	float depth_min = 0.0f;
-	float depth_max = 1.0f;
-	bool geom_consistency = false;
-	int strong_radius = 5;
-	int strong_increment = 2;
-	int weak_radius = 5;
-	int weak_increment = 5;
-	bool use_APD = true;
-	bool use_edge = true;
-	bool use_limit = true;
-	bool use_label = true;
-	bool use_detail = false;
-	bool use_radius = true;
-	int weak_peak_radius = 2;
-	int rotate_time = 4;
-	float ransac_threshold = 0.005f;
-	float geom_factor = 0.2f;
-	RunState state;
-};
-static_assert(sizeof(PatchMatchParams) == sizeof(DvpParams) && sizeof(PatchMatchParams) == 76, "PatchMatchParams layout");
-
-struct Problem {         // main.h:114-124
-	int index;
-	int ref_image_id;
+// One reference view's work item (main.h:114-124).
+struct Problem {
+	int index = 0, ref_image_id = 0, iteration = 0;
 	std::vector<int> src_image_ids;
-	path dense_folder;
-	path result_folder;
+	path dense_folder, result_folder;
 	int scale_size = 1;
-	PatchMatchParams params;
 	bool show_medium_result = true;
-	int iteration;
+	PatchMatchParams params;
 };
 
 #endif
