@@ -31,7 +31,7 @@ struct PatchTab {
 };
 
 struct PatchCtx {
-	PatchTab tab;              // (bilateral weight w, w * ref_pix) of tap (ti, tj) at index ti*6+tj (ti = x offset index)
+	PatchTab tab;              // (bilateral weight w, w * ref_pix) of tap (tx, ty) at index ty*6+tx (row-major: ty = y offset index)
 	float sum_ref, sum_ref_ref, wsum;   // un-normalised reference sums (row-then-total order)
 	int radius, inc;
 	int fast;                  // 1: exactly 6 taps per axis (register path); 0: generic loops
@@ -68,16 +68,16 @@ DVP_HD void build_patch_ctx(const Dev& d, int px, int py, int radius, int inc, i
 	const float sig_s = d.params.sigma_spatial, sig_c = d.params.sigma_color;
 	float sr = 0.0f, srr = 0.0f, ws = 0.0f;
 #pragma unroll
-	for (int ti = 0; ti < kTaps; ++ti) {
-		const int i = -radius + ti * inc;
+	for (int ty = 0; ty < kTaps; ++ty) {          // rows outer, columns inner (tap order)
+		const int j = -radius + ty * inc;
 		float sr_row = 0.0f, srr_row = 0.0f, ws_row = 0.0f;
 #pragma unroll
-		for (int tj = 0; tj < kTaps; ++tj) {
-			const int j = -radius + tj * inc;
+		for (int tx = 0; tx < kTaps; ++tx) {
+			const int i = -radius + tx * inc;
 			const float a = tex_texel(ref, d.org, P, W, H, px + i, py + j);
 			const float w = bilateral_weight((float)i, (float)j, a, cpix, sig_s, sig_c, colour_only);
 			const float wa = w * a;
-			tab.set(ti * kTaps + tj, mk2(w, wa));
+			tab.set(ty * kTaps + tx, mk2(w, wa));
 			sr_row += wa;
 			srr_row += wa * a;
 			ws_row += w;
@@ -108,17 +108,17 @@ DVP_HD float ncc_from_sums(float sum_ref, float sum_ref_ref, float sum_src, floa
 	return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
 }
 
-// Generic (non-hoisted) patch loop for tap counts other than 6 per axis; direct restatement of
-// APD.cu:1059-1089 with the weight variant selected by `colour_only`.
+// Generic (non-hoisted) patch loop for tap counts other than 6 per axis; restatement of
+// APD.cu:1059-1089 with the weight variant selected by `colour_only` (taps visited row by row).
 DVP_HD float ncc_patch_generic(const Dev& d, const float* H, const float* src, int px, int py, int radius, int inc, int colour_only) {
 	const float* ref = d.images;
 	const int W = d.width, Hh = d.height, P = d.pitch;
 	const float cpix = tex_texel(ref, d.org, P, W, Hh, px, py);
 	float s_r = 0.0f, s_rr = 0.0f, s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f, s_w = 0.0f;
 	if (inc <= 0) inc = 1;
-	for (int i = -radius; i <= radius; i += inc) {
+	for (int j = -radius; j <= radius; j += inc) {        // rows outer, columns inner
 		float r_r = 0.0f, r_rr = 0.0f, r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f, r_w = 0.0f;
-		for (int j = -radius; j <= radius; j += inc) {
+		for (int i = -radius; i <= radius; i += inc) {
 			const float a = tex_texel(ref, d.org, P, W, Hh, px + i, py + j);
 			const f2 sp = apply_homography(H, px + i, py + j);
 			const float b = tex_linear(src, P, W, Hh, sp.x + 0.5f, sp.y + 0.5f, d.sampler);
@@ -152,16 +152,19 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 	}
 	float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
 #pragma unroll
-	for (int ti = 0; ti < kTaps; ++ti) {
+	for (int ty = 0; ty < kTaps; ++ty) {
+		// one patch row: the 6 taps land on the same two source rows (for the usual near-upright
+		// homographies), so a lane whose hypothesis is unrelated to its neighbours' (random draws)
+		// touches 2-3 cache lines per row instead of 12 per column
 		float r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f;
 #pragma unroll
-		for (int tj = 0; tj < kTaps; ++tj) {
-			const float x = hx0[ti] + hy1[tj] + H[2];
-			const float y = hx3[ti] + hy4[tj] + H[5];
-			const float z = hx6[ti] + hy7[tj] + H[8];
+		for (int tx = 0; tx < kTaps; ++tx) {
+			const float x = hx0[tx] + hy1[ty] + H[2];
+			const float y = hx3[tx] + hy4[ty] + H[5];
+			const float z = hx6[tx] + hy7[ty] + H[8];
 			const float iz = 1.0f / z;   // x/z, y/z as x*rcp(z), y*rcp(z) (numerics contract)
 			const float b = tex_linear_t<SMP>(src, P, W, Hh, x * iz + 0.5f, y * iz + 0.5f);
-			const f2 t = c.tab.get(ti * kTaps + tj);
+			const f2 t = c.tab.get(ty * kTaps + tx);
 			const float wb = t.x * b;
 			r_s += wb;
 			r_ss += wb * b;

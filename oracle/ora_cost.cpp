@@ -36,10 +36,12 @@ float ComputeBilateralNCCOld(const int2 p, const int src_idx, const float4 plane
 		float bilateral_weight_sum = 0.0f;
 		const float ref_center_pix = tex_texel(ref_image, W, Hh, p.x, p.y);
 
-		for (int i = -radius; i <= radius; i += increment) {
+		// taps are visited row by row (j = y offset outer, i = x offset inner) with per-row partial
+		// sums; the reference walks columns in one chain (APD.cu:1059-1061) — DESIGN.md §Numerics
+		for (int j = -radius; j <= radius; j += increment) {
 			float sum_ref_row = 0.0f, sum_src_row = 0.0f, sum_ref_ref_row = 0.0f;
 			float sum_src_src_row = 0.0f, sum_ref_src_row = 0.0f, bilateral_weight_sum_row = 0.0f;
-			for (int j = -radius; j <= radius; j += increment) {
+			for (int i = -radius; i <= radius; i += increment) {
 				const int2 ref_pt = make_int2(p.x + i, p.y + j);
 				const float ref_pix = tex_texel(ref_image, W, Hh, ref_pt.x, ref_pt.y);
 				float2 src_pt = ComputeCorrespondingPoint(H, ref_pt);
@@ -129,10 +131,10 @@ float ComputeBilateralNCCNew(const int2 p, const int src_idx, const float4 plane
 			increment = ORA_MAX(2, (int)(2.0 * radius / 5.0));
 		}
 		if (k == 0) {
-			for (int i = -radius; i <= radius; i += increment) {
+			for (int j = -radius; j <= radius; j += increment) {      // row by row, as in the Old variant above
 				float sum_ref_row = 0.0f, sum_src_row = 0.0f, sum_ref_ref_row = 0.0f;
 				float sum_src_src_row = 0.0f, sum_ref_src_row = 0.0f, bilateral_weight_sum_row = 0.0f;
-				for (int j = -radius; j <= radius; j += increment) {
+				for (int i = -radius; i <= radius; i += increment) {
 					const int2 ref_pt = make_int2(neighbour_pt.x + i, neighbour_pt.y + j);
 					const float ref_pix = tex_texel(ref_image, width, height, ref_pt.x, ref_pt.y);
 					float2 src_pt = ComputeCorrespondingPoint(H, ref_pt);
