@@ -20,7 +20,7 @@ APD::~APD() {                        // APD.cpp:989-1043
 	if (ctx) dvp_ctx_destroy(ctx);
 }
 
-// APD.cpp:1045-1495 (without the Depth-Anything prior block :1210-1424, see DESIGN.md "next")
+// APD.cpp:1045-1495 (the Depth-Anything prior block :1210-1424 lives in prior.cpp)
 void APD::InuputInitialization() {
 	images.clear();
 	cameras.clear();
@@ -141,9 +141,13 @@ void APD::InuputInitialization() {
 	}
 	plane_hypotheses_host = new float4[(size_t)width * height];
 	std::memset(plane_hypotheses_host, 0, sizeof(float4) * (size_t)width * height);
-	// FIRST_INIT: the reference builds a plane prior from Depth-Anything maps (dep/<id>.dmb,
-	// sfm/<id>.txt, APD.cpp:1210-1424).  Not restated yet: planes stay zero (.w out of range), so
-	// RandomInitialization draws random planes (APD.cu:1289-1291).
+	// FIRST_INIT: plane prior from the Depth-Anything map + sparse SfM points (dep/<id>.dmb,
+	// sfm/<id>.txt, APD.cpp:1210-1424; host/prior.cpp).  Without those inputs the planes stay zero
+	// (.w out of range) and RandomInitialization draws random planes (APD.cu:1289-1291).
+	if (params_host.state == FIRST_INIT) {
+		if (BuildPlanePrior(problem, cameras[0], width, height, plane_hypotheses_host)) std::cout << "Plane prior from dep/ and sfm/\n";
+		else std::cout << "No dep/ + sfm/ prior: random plane initialisation\n";
+	}
 	selected_views_host = Mat::zeros(height, width, CV_32SC1);
 	if (params_host.state != FIRST_INIT) {   // APD.cpp:1428-1456
 		Mat depth, normal;
@@ -177,8 +181,8 @@ void APD::SupportInitialization() {
 	if (problem.params.use_edge || problem.params.use_limit) {
 		path edge_path = problem.result_folder / path("edges_" + std::to_string(scale) + ".dmb");
 		if (!std::filesystem::exists(edge_path) || !ReadBinMat(edge_path, edge_host) || edge_host.cols != width || edge_host.rows != height) {
-			// the Canny front end (GetProblemEdges, main.cpp:193-246) is not part of this build yet:
-			// without a cached edges_<s>.dmb the edge map is empty (no edge pixels)
+			// edges_<s>.dmb is written by GetProblemEdges (edges.cpp) before the first pass; a caller
+			// that skipped it gets an empty edge map (no edge pixels)
 			edge_host = Mat::zeros(height, width, CV_8UC1);
 		}
 	}

@@ -27,6 +27,13 @@ void RescaleMatToTargetSize(const Mat& src, Mat& dst, int target_width, int targ
 void RunFusion(const path& dense_folder, const std::vector<Problem>& problems);        // APD.cpp:1809-1960
 Mat EdgeSegment(const int scale, const Mat& srcImage, int mode = 0, bool useCanny = false);   // APD.cpp:348-499 (mode 0 + Canny only)
 void GetProblemEdges(const Problem& problem);                                           // main.cpp:193-246 (edge part)
+// Depth-Anything plane prior of a FIRST_INIT pass (APD.cpp:1210-1424), host/prior.cpp
+std::vector<Triangle> DelaunayTriangulation(int cols, int rows, const Rect boundRC, std::vector<float2> xy_temps, std::vector<float> rates);   // APD.cpp:51-80
+double calculateZ(const double A[3], const double B[3], const double C[3], double X, double Y);   // APD.cpp:30-49
+void ProjectCamera(const float3 PointX, const Camera camera, float2& point, float& depth);          // APD.cpp:536-546
+bool MetricDepthFromPrior(Mat& dep, const std::vector<float2>& xy, const std::vector<float3>& xyz, const Camera& cam);   // APD.cpp:1221-1356
+void PlanesFromDepth(const Mat& dep, const Camera& cam, float4* planes);                              // APD.cpp:1365-1422
+bool BuildPlanePrior(const Problem& problem, const Camera& scaled_ref_camera, int width, int height, float4* planes);
 // image I/O without OpenCV: images/<id>.pgm|.ppm (binary P5/P6) next to / instead of <id>.jpg
 // (tools/jpg2pnm.py converts); returns an empty Mat if nothing readable is found.
 Mat ReadImageGray(const path& image_path_jpg);      // stands in for cv::imread(IMREAD_GRAYSCALE), APD.cpp:1057

@@ -11,6 +11,13 @@
 
 enum { CV_8UC1 = 0, CV_8U = 0, CV_8UC3 = 16, CV_32SC1 = 4, CV_32S = 4, CV_32FC1 = 5, CV_32F = 5, CV_32FC3 = 21 };
 
+struct Point { int x = 0, y = 0; Point() {} Point(int _x, int _y) : x(_x), y(_y) {} };   // cv::Point
+struct Rect {                                                                           // cv::Rect
+	int x = 0, y = 0, width = 0, height = 0;
+	Rect() {}
+	Rect(int _x, int _y, int w, int h) : x(_x), y(_y), width(w), height(h) {}
+	bool contains(const Point& p) const { return x <= p.x && p.x < x + width && y <= p.y && p.y < y + height; }
+};
 struct Vec3f { float v[3]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
 
 class Mat {

@@ -17,15 +17,7 @@ static float3 Get3DPointonWorld(const int x, const int y, const float depth, con
 	pointX.z = tmpX.z + camera.c[2];
 	return pointX;
 }
-static void ProjectCamera(const float3 PointX, const Camera& camera, float2& point, float& depth) {   // APD.cpp:536-546
-	float3 tmp;
-	tmp.x = camera.R[0] * PointX.x + camera.R[1] * PointX.y + camera.R[2] * PointX.z + camera.t[0];
-	tmp.y = camera.R[3] * PointX.x + camera.R[4] * PointX.y + camera.R[5] * PointX.z + camera.t[1];
-	tmp.z = camera.R[6] * PointX.x + camera.R[7] * PointX.y + camera.R[8] * PointX.z + camera.t[2];
-	depth = camera.K[6] * tmp.x + camera.K[7] * tmp.y + camera.K[8] * tmp.z;
-	point.x = (camera.K[0] * tmp.x + camera.K[1] * tmp.y + camera.K[2] * tmp.z) / depth;
-	point.y = (camera.K[3] * tmp.x + camera.K[4] * tmp.y + camera.K[5] * tmp.z) / depth;
-}
+// ProjectCamera (APD.cpp:536-546) is defined in prior.cpp
 static float GetAngle(const Vec3f& v1, const Vec3f& v2) {   // APD.cpp:1797-1806
 	float dot_product = v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2];
 	float angle = acosf(dot_product);

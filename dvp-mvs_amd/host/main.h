@@ -68,6 +68,13 @@ static_assert(sizeof(Camera) == 112, "camera layout");
 
 struct PointList { float3 coord, color; };   // main.h:69-72, one fused point of the .ply
 
+// A Delaunay triangle of the sparse-point prior with the depth ratio at each corner (main.h:126-130).
+struct Triangle {
+	Point pt1, pt2, pt3;
+	float rate1 = 0, rate2 = 0, rate3 = 0;
+	Triangle(const Point a, const Point b, const Point c) : pt1(a), pt2(b), pt3(c) {}
+};
+
 // One reference view's work item (main.h:114-124).
 struct Problem {
 	int index = 0, ref_image_id = 0, iteration = 0;

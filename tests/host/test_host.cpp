@@ -107,6 +107,113 @@ int main(int argc, char** argv) {
 		for (int i = 0; i < 400; ++i) any += e2.data[i];
 		CHECK(any == 0);
 	}
+	// Delaunay substitute of cv::Subdiv2D (APD.cpp:51-80): empty-circumcircle property + coverage
+	{
+		std::vector<float2> pts;
+		std::vector<float> rates;
+		uint32_t lcg = 12345u;
+		auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (lcg >> 8) * (1.0f / 16777216.0f); };
+		for (int i = 0; i < 300; ++i) { pts.push_back(float2{ 10.0f + 180.0f * rnd(), 10.0f + 130.0f * rnd() }); rates.push_back((float)i); }
+		pts.push_back(pts[7]); rates.push_back(1000.0f);            // duplicate position: ignored, last rate wins
+		pts.push_back(float2{ -5.0f, 20.0f }); rates.push_back(0);   // outside: not inserted
+		const Rect rc(0, 0, 200, 150);
+		auto tris = DelaunayTriangulation(200, 150, rc, pts, rates);
+		int real = 0, saw_dup_rate = 0;
+		for (const auto& t : tris) {
+			if (!(rc.contains(t.pt1) && rc.contains(t.pt2) && rc.contains(t.pt3))) continue;
+			real++;
+			if (t.rate1 == 1000.0f || t.rate2 == 1000.0f || t.rate3 == 1000.0f) saw_dup_rate = 1;
+			CHECK(t.rate1 != 7.0f && t.rate2 != 7.0f && t.rate3 != 7.0f);
+		}
+		CHECK(real > 500 && real < 600 && saw_dup_rate);   // ~2n - 2 - hull
+		// recompute with exact float vertices to test the Delaunay property
+		// (triangle corners are truncated to int in the API, so rebuild from rates = point index)
+		for (const auto& t : tris) {
+			if (!(rc.contains(t.pt1) && rc.contains(t.pt2) && rc.contains(t.pt3))) continue;
+			auto idx = [&](float r) { return r == 1000.0f ? 7 : (int)r; };
+			const float2 a = pts[idx(t.rate1)], b = pts[idx(t.rate2)], c = pts[idx(t.rate3)];
+			CHECK((int)a.x == t.pt1.x && (int)a.y == t.pt1.y && (int)c.x == t.pt3.x);
+			const double bx = (double)b.x - a.x, by = (double)b.y - a.y, cx = (double)c.x - a.x, cy = (double)c.y - a.y;
+			const double d = 2.0 * (bx * cy - by * cx);
+			CHECK(std::fabs(d) > 1e-9);
+			const double ux = (cy * (bx * bx + by * by) - by * (cx * cx + cy * cy)) / d;
+			const double uy = (bx * (cx * cx + cy * cy) - cx * (bx * bx + by * by)) / d;
+			const double r2 = ux * ux + uy * uy;
+			for (int k = 0; k < 300; ++k) {
+				const double dx = pts[k].x - (a.x + ux), dy = pts[k].y - (a.y + uy);
+				CHECK(dx * dx + dy * dy > r2 * (1.0 - 1e-9));
+			}
+		}
+	}
+	// Depth-Anything prior (APD.cpp:1210-1424): relative map + sparse points -> metric depth -> planes
+	{
+		const int W = 160, H = 120;
+		Camera cam{};
+		const float K[9] = { 150, 0, 80, 0, 150, 60, 0, 0, 1 };
+		const float ang = 0.3f;
+		const float R[9] = { std::cos(ang), 0, std::sin(ang), 0, 1, 0, -std::sin(ang), 0, std::cos(ang) };
+		std::memcpy(cam.K, K, sizeof K);
+		std::memcpy(cam.R, R, sizeof R);
+		cam.t[0] = 0.1f; cam.t[1] = -0.2f; cam.t[2] = 0.3f;
+		for (int j = 0; j < 3; ++j) cam.c[j] = -(R[j] * cam.t[0] + R[3 + j] * cam.t[1] + R[6 + j] * cam.t[2]);
+		cam.width = W; cam.height = H;
+		// camera-frame plane n.X = dplane
+		const float n[3] = { 0.2f, -0.1f, -0.9746794f };
+		const float dplane = -4.0f;
+		auto depth_at = [&](float x, float y) { return dplane / (n[0] * (x - K[2]) / K[0] + n[1] * (y - K[5]) / K[4] + n[2]); };
+		Mat raw(H, W, CV_32FC1), truth(H, W, CV_32FC1);
+		for (int y = 0; y < H; ++y)
+			for (int x = 0; x < W; ++x) {
+				truth.at<float>(y, x) = depth_at((float)x, (float)y);
+				const float s = 20.0f * (1.0f + 0.001f * x + 0.0005f * y);   // relative-to-metric ratio, linear over the image
+				raw.at<float>(y, x) = 255.0f - s * truth.at<float>(y, x);
+			}
+		std::vector<float2> xy;
+		std::vector<float3> xyz;
+		uint32_t lcg = 99u;
+		auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (lcg >> 8) * (1.0f / 16777216.0f); };
+		for (int i = 0; i < 400; ++i) {
+			const int px = 2 + (int)(rnd() * (W - 4)), py = 2 + (int)(rnd() * (H - 4));
+			const float Z = depth_at((float)px, (float)py);
+			const float Xc[3] = { Z * (px - K[2]) / K[0], Z * (py - K[5]) / K[4], Z };
+			float3 Xw;   // X_world = R^T (X_cam - t)
+			const float e[3] = { Xc[0] - cam.t[0], Xc[1] - cam.t[1], Xc[2] - cam.t[2] };
+			Xw.x = R[0] * e[0] + R[3] * e[1] + R[6] * e[2];
+			Xw.y = R[1] * e[0] + R[4] * e[1] + R[7] * e[2];
+			Xw.z = R[2] * e[0] + R[5] * e[1] + R[8] * e[2];
+			xy.push_back(float2{ (float)px, (float)py });
+			xyz.push_back(Xw);
+		}
+		float2 pp; float pd;
+		ProjectCamera(xyz[0], cam, pp, pd);
+		CHECK(std::fabs(pp.x - xy[0].x) < 1e-2f && std::fabs(pp.y - xy[0].y) < 1e-2f);
+		Mat dep = raw.clone();
+		CHECK(MetricDepthFromPrior(dep, xy, xyz, cam));
+		int good = 0, inside = 0;
+		for (int y = 30; y < H - 30; ++y)
+			for (int x = 30; x < W - 30; ++x) {
+				inside++;
+				if (std::fabs(dep.at<float>(y, x) / truth.at<float>(y, x) - 1.0f) < 2e-3f) good++;
+			}
+		// the reference's sweep (truncating pixel casts + unsigned-area barycentric weights,
+		// APD.cpp:1333-1347, 30-49) extrapolates badly along sliver triangles and can miss isolated
+		// pixels (those keep rates[n/2]): streaks of wrong ratios are its behaviour, reproduced here
+		CHECK(good >= inside * 0.75);
+		std::vector<float4> planes((size_t)W * H);
+		PlanesFromDepth(truth, cam, planes.data());
+		const float nw[3] = { R[0] * n[0] + R[3] * n[1] + R[6] * n[2], R[1] * n[0] + R[4] * n[1] + R[7] * n[2], R[2] * n[0] + R[5] * n[1] + R[8] * n[2] };
+		for (int y = 1; y < H - 1; y += 7)
+			for (int x = 1; x < W - 1; x += 5) {
+				const float4 p = planes[(size_t)y * W + x];
+				CHECK(std::fabs(p.x - nw[0]) < 2e-3f && std::fabs(p.y - nw[1]) < 2e-3f && std::fabs(p.z - nw[2]) < 2e-3f);
+				CHECK(p.w == truth.at<float>(y, x));
+			}
+		CHECK(planes[0].x == 0 && planes[0].w == truth.at<float>(0, 0));
+		Mat empty;
+		CHECK(!MetricDepthFromPrior(empty, xy, xyz, cam));
+		Mat dep2 = raw.clone();
+		CHECK(!MetricDepthFromPrior(dep2, {}, {}, cam));
+	}
 	static_assert(sizeof(Camera) == 112 && sizeof(PatchMatchParams) == 76, "POD layouts");
 	printf("host tests ok\n");
 	return 0;

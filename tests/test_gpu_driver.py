@@ -50,6 +50,28 @@ def test_apd_driver(tmp_path):
     assert npts > 1000
 
 
+def test_apd_with_depth_prior(tmp_path):
+    """FIRST_INIT with dep/ + sfm/ inputs (APD.cpp:1210-1424): the prior planes are kept by
+    RandomInitialization when their depth is in range, so after a single iteration the depth map is
+    already far closer to the truth than from random planes."""
+    W, H, NV = 128, 96, 3
+    med = {}
+    for tag, extra in (("prior", ["--prior"]), ("random", [])):
+        d = str(tmp_path / tag)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), "2"] + extra)
+        out = subprocess.run([os.path.join(ROOT, "dvp-mvs_amd", "apd"), d, "0", "--iters", "1", "--passes", "0", "--min-scale", "1",
+                              "--seed", "9", "--no-fusion"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-1500:]
+        assert ("Plane prior from dep/ and sfm/" in out.stdout) == (tag == "prior"), out.stdout[-800:]
+        gt = np.load(os.path.join(d, "depth_gt.npy"))
+        dep = read_binmat(os.path.join(d, "APD", "00000000", "depths.dmb"))
+        m = dep[8:-8, 8:-8] > 0
+        rel = np.abs(dep - gt[0])[8:-8, 8:-8][m] / gt[0][8:-8, 8:-8][m]
+        med[tag] = (float(np.mean(rel < 1e-2)), float(np.mean(rel < 1e-3)), float(m.mean()))
+    print(med)
+    assert med["prior"][0] > 0.7 and med["prior"][0] >= med["random"][0] and med["prior"][1] > med["random"][1] + 0.15, med
+
+
 def test_apd_first_pass_equals_capi(tmp_path):
     """class APD is a thin layer: its FIRST_INIT pass on view 0 must be bit-identical to driving the
     C ABI directly with the same images / cameras / seed."""
