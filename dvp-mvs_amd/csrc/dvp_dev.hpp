@@ -49,7 +49,7 @@ struct Dev {
 	int width, height, num_images;
 	int pitch;                 // floats per padded image row (multiple of 64 -> 256 B aligned rows)
 	int org;                   // element offset of pixel (0,0) inside a padded plane (= PAD*pitch + PAD)
-	size_t plane_stride;       // floats per padded image plane ((H + 2*PAD) * pitch)
+	size_t plane_stride;       // floats per padded depth plane ((H + 2*PAD) * pitch); an image plane is 2x that (row pairs)
 	int sampler;               // 0 = 8-bit interpolation weights, 1 = exact
 	int weak_count;
 	uint64_t seed;
@@ -57,7 +57,7 @@ struct Dev {
 	// uniform constants derived from params on the host (GenNeighbours, APD.cu:3375-3380)
 	float nb_cos, nb_sin, nb_thresh;
 	int nb_shift_range;
-	const float* images;       // [num_images][H + 2*PAD][pitch], border replicated (== clamp addressing)
+	const float* images;       // [num_images][H + 2*PAD][pitch][2] row-pair planes {I(x,y), I(x,y+1)}, border replicated (== clamp addressing)
 	const float* depths;       // same layout (geom_consistency only)
 	const DvpCamera* cameras;  // [num_images]
 	const ViewConst* views;    // [num_images] (index 0 unused)
@@ -142,28 +142,37 @@ struct Rng {
 // ---- software texture unit (gfx950 has no tex2D path; semantics of APD.cpp:1501-1517) --------
 // Image planes carry kImgPad replicated border pixels on every side: reading the padded plane at
 // an unclamped coordinate in [-kImgPad, W-1+kImgPad] IS clamp-to-edge addressing, so the bilinear
-// footprint needs no integer clamps and its two x-neighbours are always adjacent in memory.
+// footprint needs no integer clamps.
 constexpr int kImgPad = 2;
 
 DVP_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// tex2D(img, ix + 0.5f, iy + 0.5f): exact texel, clamp-to-edge (arbitrary integer coordinates)
+// tex2D(map, ix + 0.5f, iy + 0.5f): exact texel, clamp-to-edge (arbitrary integer coordinates).
+// Plain planes (the depth maps of the geometric-consistency term).
 DVP_HD float tex_texel(const float* img, int org, int pitch, int W, int H, int ix, int iy) {
 	return img[org + clampi(iy, 0, H - 1) * pitch + clampi(ix, 0, W - 1)];
 }
 
-// two adjacent floats at a 4-byte aligned address: one global_load_dwordx2 with a 32-bit byte
+// Image planes are stored as ROW PAIRS: element (x, y) of a plane is the float2 {I(x,y), I(x,y+1)}.
+// The 2x2 bilinear footprint {I(x,y), I(x,y+1), I(x+1,y), I(x+1,y+1)} is then 16 contiguous bytes:
+// ONE global_load_dwordx4 per tap instead of two dwordx2 loads on two image rows, i.e. half the
+// load instructions and — for lanes whose hypotheses are unrelated (random draws, propagated planes
+// of far-away pixels, anchor sub-patches) — half the cache lines the texture path has to look up.
+// Costs 2x the image bytes in HBM (each texel is stored in its own row pair and in the one above).
+DVP_HD float img_texel(const float* img, int org, int pitch, int W, int H, int ix, int iy) {
+	return img[(size_t)(org + clampi(iy, 0, H - 1) * pitch + clampi(ix, 0, W - 1)) * 2];
+}
+
+// four adjacent floats at an 8-byte aligned address: one global_load_dwordx4 with a 32-bit byte
 // offset from a wave-uniform base (SGPR base + VGPR offset addressing)
-DVP_HD void load_pair(const float* base, unsigned byte_off, float* a, float* b) {
+DVP_HD void load_quad(const float* base, unsigned byte_off, float* a, float* b, float* c, float* e) {
 #if defined(__HIPCC__)
-	typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-	const f2u t = *reinterpret_cast<const f2u*>(reinterpret_cast<const char*>(base) + byte_off);
-	*a = t.x;
-	*b = t.y;
+	typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+	const f4u t = *reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(base) + byte_off);
+	*a = t.x; *b = t.y; *c = t.z; *e = t.w;
 #else
 	const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
-	*a = p[0];
-	*b = p[1];
+	*a = p[0]; *b = p[1]; *c = p[2]; *e = p[3];
 #endif
 }
 DVP_HD unsigned mul24(unsigned a, unsigned b) {
@@ -190,10 +199,9 @@ DVP_HD float tex_linear_t(const float* img, int pitch, int W, int H, float x, fl
 	// floor results are in [-1, W] / [-1, H]: the footprint [i0, i0+1] x [j0, j0+1] lies inside
 	// the padded plane
 	const unsigned ip = (unsigned)((int)fx + kImgPad), jp = (unsigned)((int)fy + kImgPad);
-	const unsigned off = (mul24(jp, (unsigned)pitch) + ip) * 4u;
+	const unsigned off = (mul24(jp, (unsigned)pitch) + ip) * 8u;
 	float t00, t10, t01, t11;
-	load_pair(img, off, &t00, &t10);
-	load_pair(img, off + (unsigned)pitch * 4u, &t01, &t11);
+	load_quad(img, off, &t00, &t01, &t10, &t11);   // {I(i,j), I(i,j+1)} {I(i+1,j), I(i+1,j+1)}
 	const float top = fmaf(a, t10 - t00, t00);
 	const float bot = fmaf(a, t11 - t01, t01);
 	return fmaf(b, bot - top, top);

@@ -120,6 +120,19 @@ extern "C" __global__ void dvp_pad_replicate(float* planes, int W, int H, int pi
 	p[(size_t)y * pitch + x] = p[(size_t)sy * pitch + sx];
 }
 
+// plain padded planes -> row-pair planes: out[(y*pitch + x)*2 + {0,1}] = {in[y][x], in[y+1][x]}
+// (the last padded row pairs with itself; the sampler never reads its second component)
+extern "C" __global__ void dvp_interleave_rows(const float* __restrict__ in, float* __restrict__ out, int PH, int pitch, size_t plane_stride, int n_planes) {
+	const int x = blockIdx.x * blockDim.x + threadIdx.x;
+	const int y = blockIdx.y;
+	const int pl = blockIdx.z;
+	if (x >= pitch) return;
+	const float* p = in + (size_t)pl * plane_stride;
+	const int y1 = y + 1 < PH ? y + 1 : y;
+	const float2 v = make_float2(p[(size_t)y * pitch + x], p[(size_t)y1 * pitch + x]);
+	reinterpret_cast<float2*>(out + (size_t)pl * plane_stride * 2)[(size_t)y * pitch + x] = v;
+}
+
 // line-scan pre-pass of GenEdgeInform: nearest edge pixel in 8 directions (blockIdx.y = direction)
 extern "C" __global__ void __launch_bounds__(256) dvp_edge_rays(const Dev d) {
 	edge_ray_line(d, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
@@ -177,7 +190,9 @@ struct dvp_ctx {
 	Dev d{};
 	std::vector<void*> allocs;
 	// named device buffers
-	float* images = nullptr; float* depths = nullptr;
+	float* images = nullptr;        // row-pair planes (dvp_dev.hpp: img_texel / load_quad)
+	float* image_stage = nullptr;   // plain padded planes the uploads land in before dvp_interleave_rows
+	float* depths = nullptr;
 	DvpCamera* cameras = nullptr; ViewConst* views = nullptr; uint8_t* lut = nullptr;
 	f4* planes = nullptr; f4* planes_snap = nullptr; f4* fit_planes = nullptr;
 	float* costs = nullptr; float* costs_snap = nullptr; float* complex_ = nullptr;
@@ -263,7 +278,8 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->error = "hipStreamCreate failed"; return fail(0); }
 	const size_t L = c->L, S = (size_t)num_images - 1, plane = (size_t)c->pitch * (height + 2 * kImgPad);
 	int r = 0;
-	r |= dalloc(c, &c->images, plane * num_images);
+	r |= dalloc(c, &c->images, plane * num_images * 2);
+	r |= dalloc(c, &c->image_stage, plane * num_images);
 	r |= dalloc(c, &c->cameras, (size_t)num_images);
 	r |= dalloc(c, &c->views, (size_t)num_images);
 	r |= dalloc(c, &c->planes, L);
@@ -323,7 +339,8 @@ int dvp_ctx_destroy(dvp_ctx* c) {
 
 const char* dvp_last_error(const dvp_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
 
-static int upload_planes(dvp_ctx* c, float* dst, const float* const* src, int pitch_floats, hipMemcpyKind kind) {
+// `pairs` != nullptr: `dst` is the staging set and the row-pair planes are produced from it
+static int upload_planes(dvp_ctx* c, float* dst, const float* const* src, int pitch_floats, hipMemcpyKind kind, float* pairs = nullptr) {
 	if (set_device(c)) return 1;
 	if (pitch_floats < c->W) { c->error = "pitch_floats < width"; return 1; }
 	const size_t stride = (size_t)c->pitch * (c->H + 2 * kImgPad);
@@ -337,14 +354,20 @@ static int upload_planes(dvp_ctx* c, float* dst, const float* const* src, int pi
 		hipLaunchKernelGGL(dvp_pad_replicate, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, c->stream, dst, c->W, c->H, c->pitch, stride, c->NI);
 		HIP_TRY(c, hipGetLastError());
 	}
+	if (pairs) {
+		const int PH = c->H + 2 * kImgPad;
+		hipLaunchKernelGGL(dvp_interleave_rows, dim3((unsigned)((c->pitch + 255) / 256), (unsigned)PH, (unsigned)c->NI), dim3(256), 0, c->stream,
+		                   dst, pairs, PH, c->pitch, stride, c->NI);
+		HIP_TRY(c, hipGetLastError());
+	}
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	return 0;
 }
 int dvp_upload_images(dvp_ctx* c, const float* const* images, int pitch_floats) {
-	return upload_planes(c, c->images, images, pitch_floats, hipMemcpyHostToDevice);
+	return upload_planes(c, c->image_stage, images, pitch_floats, hipMemcpyHostToDevice, c->images);
 }
 int dvp_upload_images_device(dvp_ctx* c, const float* const* images, int pitch_floats) {
-	return upload_planes(c, c->images, images, pitch_floats, hipMemcpyDeviceToDevice);
+	return upload_planes(c, c->image_stage, images, pitch_floats, hipMemcpyDeviceToDevice, c->images);
 }
 static int ensure_depths(dvp_ctx* c) {
 	if (!c->depths) {

@@ -64,7 +64,7 @@ DVP_HD void build_patch_ctx(const Dev& d, int px, int py, int radius, int inc, i
 	c->inc = inc;
 	c->fast = (inc > 0 && (2 * radius) / inc + 1 == kTaps) ? 1 : 0;
 	if (!c->fast) return;
-	const float cpix = tex_texel(ref, d.org, P, W, H, px, py);
+	const float cpix = img_texel(ref, d.org, P, W, H, px, py);
 	const float sig_s = d.params.sigma_spatial, sig_c = d.params.sigma_color;
 	float sr = 0.0f, srr = 0.0f, ws = 0.0f;
 #pragma unroll
@@ -74,7 +74,7 @@ DVP_HD void build_patch_ctx(const Dev& d, int px, int py, int radius, int inc, i
 #pragma unroll
 		for (int tx = 0; tx < kTaps; ++tx) {
 			const int i = -radius + tx * inc;
-			const float a = tex_texel(ref, d.org, P, W, H, px + i, py + j);
+			const float a = img_texel(ref, d.org, P, W, H, px + i, py + j);
 			const float w = bilateral_weight((float)i, (float)j, a, cpix, sig_s, sig_c, colour_only);
 			const float wa = w * a;
 			tab.set(ty * kTaps + tx, mk2(w, wa));
@@ -113,13 +113,13 @@ DVP_HD float ncc_from_sums(float sum_ref, float sum_ref_ref, float sum_src, floa
 DVP_HD float ncc_patch_generic(const Dev& d, const float* H, const float* src, int px, int py, int radius, int inc, int colour_only) {
 	const float* ref = d.images;
 	const int W = d.width, Hh = d.height, P = d.pitch;
-	const float cpix = tex_texel(ref, d.org, P, W, Hh, px, py);
+	const float cpix = img_texel(ref, d.org, P, W, Hh, px, py);
 	float s_r = 0.0f, s_rr = 0.0f, s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f, s_w = 0.0f;
 	if (inc <= 0) inc = 1;
 	for (int j = -radius; j <= radius; j += inc) {        // rows outer, columns inner
 		float r_r = 0.0f, r_rr = 0.0f, r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f, r_w = 0.0f;
 		for (int i = -radius; i <= radius; i += inc) {
-			const float a = tex_texel(ref, d.org, P, W, Hh, px + i, py + j);
+			const float a = img_texel(ref, d.org, P, W, Hh, px + i, py + j);
 			const f2 sp = apply_homography(H, px + i, py + j);
 			const float b = tex_linear(src, P, W, Hh, sp.x + 0.5f, sp.y + 0.5f, d.sampler);
 			const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, colour_only);
@@ -186,7 +186,7 @@ DVP_HD float ncc_old(const Dev& d, const PatchCtx& c, int px, int py, int v, con
 	homography(rc, sc, d.views[v], plane, H);
 	const f2 pt = apply_homography(H, px, py);
 	if (pt.x >= sc.width || pt.x < 0.0f || pt.y >= sc.height || pt.y < 0.0f) return 2.0f;
-	const float* src = d.images + (size_t)v * d.plane_stride;
+	const float* src = d.images + (size_t)v * d.plane_stride * 2;
 	if (c.fast) return ncc_patch_fast<SMP>(d, c, H, src, px, py);
 	return ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 0);
 }

@@ -50,7 +50,7 @@ DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
 	const int S = P.num_images - 1;
 	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
 	const float* ref = d.images;
-	const float cpix = tex_texel(ref, d.org, d.pitch, W, H, px, py);
+	const float cpix = img_texel(ref, d.org, d.pitch, W, H, px, py);
 
 	// visibility-prior tap candidates (APD.cu:3746-3794).  The reference loops views outermost and
 	// recomputes every tap weight per view; the weight does not depend on the view, so taps are
@@ -74,7 +74,7 @@ DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
 				if (!sv) continue;
 				const int r = d.sector_lut[(i + radius) * (2 * radius + 1) + (j + radius)];   // host-built for this radius
 				if (r >= 12) continue;
-				const float a = tex_texel(ref, d.org, d.pitch, W, H, x, y);
+				const float a = img_texel(ref, d.org, d.pitch, W, H, x, y);
 				const float w = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
 				for (int v = 0; v < S; ++v) {
 					if (!((sv >> v) & 1)) continue;
@@ -653,7 +653,7 @@ DVP_HD void build_anchor_tab(const Dev& d, int center, int v, float cpix, Anchor
 			}
 			const int rx = nb.x + i, ry = nb.y + j;
 			T->xy[(k - 1) * 9 + t] = mks2(rx, ry);
-			av[t] = tex_texel(ref, d.org, Pt, W, Hh, rx, ry);
+			av[t] = img_texel(ref, d.org, Pt, W, Hh, rx, ry);
 			wv[t] = bilateral_weight((float)i, (float)j, av[t], cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
 		}
 		float s_r = 0.0f, s_rr = 0.0f, s_w = 0.0f;
@@ -682,7 +682,7 @@ DVP_HD float ncc_new(const Dev& d, const PatchCtx& c, const AnchorTab& T, int px
 	homography(rc, sc, d.views[v], plane, H);
 	const f2 pt = apply_homography(H, px, py);
 	if (pt.x >= sc.width || pt.x < 0.0f || pt.y >= sc.height || pt.y < 0.0f) return 2.0f;
-	const float* src = d.images + (size_t)v * d.plane_stride;
+	const float* src = d.images + (size_t)v * d.plane_stride * 2;
 	// k == 0: the pixel's own patch (neighbours[0] is the pixel itself, APD.cu:3365)
 	const float center_cost = c.fast ? ncc_patch_fast<SMP>(d, c, H, src, px, py)
 	                                 : ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
@@ -740,7 +740,7 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter,
 	const int S = P.num_images - 1;
 	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
 	const s2* nbs = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
-	const float cpix = tex_texel(d.images, d.org, d.pitch, W, Hh, px, py);
+	const float cpix = img_texel(d.images, d.org, d.pitch, W, Hh, px, py);
 
 	PatchCtx c;
 	{

@@ -90,7 +90,7 @@ void* emu_create(int W, int H, int NI) {
 	e->pitch = (W + 2 * kImgPad + 63) / 64 * 64;
 	const size_t L = (size_t)W * H;
 	const int S = NI - 1;
-	e->images.assign((size_t)e->pitch * (H + 2 * kImgPad) * NI, 0.0f);
+	e->images.assign((size_t)e->pitch * (H + 2 * kImgPad) * NI * 2, 0.0f);   // row-pair planes
 	e->depths.assign((size_t)e->pitch * (H + 2 * kImgPad) * NI, 0.0f);
 	e->cameras.resize(NI);
 	e->views.resize(NI);
@@ -127,7 +127,15 @@ static void fill_plane(Emu& e, float* plane, const float* data) {
 }
 void emu_set_image(void* c, int idx, const float* data) {
 	Emu& e = *(Emu*)c;
-	fill_plane(e, &e.images[(size_t)idx * e.d.plane_stride], data);
+	std::vector<float> plain(e.d.plane_stride, 0.0f);
+	fill_plane(e, plain.data(), data);
+	const int PH = e.H + 2 * kImgPad;
+	float* out = &e.images[(size_t)idx * e.d.plane_stride * 2];   // {I(x,y), I(x,y+1)} (dvp_interleave_rows)
+	for (int y = 0; y < PH; ++y)
+		for (int x = 0; x < e.pitch; ++x) {
+			out[((size_t)y * e.pitch + x) * 2] = plain[(size_t)y * e.pitch + x];
+			out[((size_t)y * e.pitch + x) * 2 + 1] = plain[(size_t)(y + 1 < PH ? y + 1 : y) * e.pitch + x];
+		}
 }
 void emu_set_depth(void* c, int idx, const float* data) {
 	Emu& e = *(Emu*)c;
