@@ -175,31 +175,57 @@ DVP_HD void load_quad(const float* base, unsigned byte_off, float* a, float* b, 
 	*a = p[0]; *b = p[1]; *c = p[2]; *e = p[3];
 #endif
 }
-DVP_HD unsigned mul24(unsigned a, unsigned b) {
+// clamp(v, lo, hi) with NaN -> lo: fminf(fmaxf(v, lo), hi).  One v_med3_f32 on the device (with a
+// NaN operand the instruction returns min3 of the other two == lo).
+DVP_HD float clampf_nan_lo(float v, float lo, float hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
-	return __umul24(a, b);
+	return __builtin_amdgcn_fmed3f(v, lo, hi);
 #else
-	return a * b;
+	return fminf(fmaxf(v, lo), hi);
+#endif
+}
+// (int)floorf(v) for |v| < 2^31: v_cvt_flr_i32_f32
+DVP_HD int floor_to_int(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	int r;
+	asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+	return r;
+#else
+	return (int)floorf(v);
 #endif
 }
 
-// tex2D(img, x, y), cudaFilterModeLinear, unnormalised coordinates, clamp; x, y are the texture
-// coordinates the reference passes (pixel + 0.5).  SMP 0: fractions rounded to 8 bits, 1: exact.
+// The reference's tex2D(img, x + 0.5f, y + 0.5f) with cudaFilterModeLinear, unnormalised
+// coordinates, clamp addressing (APD.cpp:1501-1517), as a function of the PIXEL coordinate (x, y):
+// the texture unit samples at (coordinate - 0.5), so the +0.5f the callers add cancels (DESIGN.md
+// §Numerics: the float rounding of that add/subtract pair is not reproduced).
+//   SMP 0 ("cuda8"): the coordinate is converted to fixed point with 8 fractional bits, round
+//          half up, as the texture unit does; texel index = integer part, weights = fraction/256.
+//   SMP 1: exact floor / fraction in binary32.
 template <int SMP>
 DVP_HD float tex_linear_t(const float* img, int pitch, int W, int H, float x, float y) {
-	float xb = x - 0.5f, yb = y - 0.5f;
-	xb = fminf(fmaxf(xb, -1.0f), (float)W);   // also maps NaN to -1
-	yb = fminf(fmaxf(yb, -1.0f), (float)H);
-	const float fx = floorf(xb), fy = floorf(yb);
-	float a = xb - fx, b = yb - fy;
+	const float xb = clampf_nan_lo(x, -1.0f, (float)W);
+	const float yb = clampf_nan_lo(y, -1.0f, (float)H);
+	int i0, j0;
+	float a, b;
 	if (SMP == 0) {
-		a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
-		b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
+		const int qx = floor_to_int(fmaf(xb, 256.0f, 0.5f));   // in [-256, 256 W]
+		const int qy = floor_to_int(fmaf(yb, 256.0f, 0.5f));
+		i0 = qx >> 8;
+		j0 = qy >> 8;
+		a = (float)(qx & 255) * (1.0f / 256.0f);
+		b = (float)(qy & 255) * (1.0f / 256.0f);
+	} else {
+		const float fx = floorf(xb), fy = floorf(yb);
+		a = xb - fx;
+		b = yb - fy;
+		i0 = (int)fx;
+		j0 = (int)fy;
 	}
-	// floor results are in [-1, W] / [-1, H]: the footprint [i0, i0+1] x [j0, j0+1] lies inside
-	// the padded plane
-	const unsigned ip = (unsigned)((int)fx + kImgPad), jp = (unsigned)((int)fy + kImgPad);
-	const unsigned off = (mul24(jp, (unsigned)pitch) + ip) * 8u;
+	// i0 in [-1, W], j0 in [-1, H]: the footprint [i0, i0+1] x [j0, j0+1] lies inside the padded
+	// plane; (j0 + PAD) * pitch + (i0 + PAD) >= 0, the PAD terms are a wave-uniform constant
+	const int e = j0 * pitch + i0;
+	const unsigned off = ((unsigned)e << 3) + (unsigned)((kImgPad * pitch + kImgPad) * 8);
 	float t00, t10, t01, t11;
 	load_quad(img, off, &t00, &t01, &t10, &t11);   // {I(i,j), I(i,j+1)} {I(i+1,j), I(i+1,j+1)}
 	const float top = fmaf(a, t10 - t00, t00);
@@ -208,6 +234,22 @@ DVP_HD float tex_linear_t(const float* img, int pitch, int W, int H, float x, fl
 }
 DVP_HD float tex_linear(const float* img, int pitch, int W, int H, float x, float y, int sampler) {
 	return sampler == 0 ? tex_linear_t<0>(img, pitch, W, H, x, y) : tex_linear_t<1>(img, pitch, W, H, x, y);
+}
+
+// Reciprocals of up to 6 projective denominators with ONE correctly rounded division (numerics
+// contract: the projective divide of a patch row is taken six taps at a time).  Prefix products,
+// 1/product, then the factors are peeled off again; every step is a plain binary32 multiply.
+// 15 multiplies + 1 division per 6 taps instead of 6 divisions (an IEEE division is 11 VALU ops).
+DVP_HD void batch_rcp(const float* z, int n, float* iz) {
+	float p[6];
+	p[0] = z[0];
+	for (int k = 1; k < n; ++k) p[k] = p[k - 1] * z[k];
+	float r = 1.0f / p[n - 1];
+	for (int k = n - 1; k >= 1; --k) {
+		iz[k] = r * p[k - 1];
+		r = r * z[k];
+	}
+	iz[0] = r;
 }
 
 // ---- small geometry helpers (APD.cu:181-194, 331-422, 467-499, 750-768) ----------------------

@@ -118,17 +118,29 @@ DVP_HD float ncc_patch_generic(const Dev& d, const float* H, const float* src, i
 	if (inc <= 0) inc = 1;
 	for (int j = -radius; j <= radius; j += inc) {        // rows outer, columns inner
 		float r_r = 0.0f, r_rr = 0.0f, r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f, r_w = 0.0f;
-		for (int i = -radius; i <= radius; i += inc) {
-			const float a = img_texel(ref, d.org, P, W, Hh, px + i, py + j);
-			const f2 sp = apply_homography(H, px + i, py + j);
-			const float b = tex_linear(src, P, W, Hh, sp.x + 0.5f, sp.y + 0.5f, d.sampler);
-			const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, colour_only);
-			r_r += w * a;
-			r_rr += w * a * a;
-			r_s += w * b;
-			r_ss += w * b * b;
-			r_rs += w * a * b;
-			r_w += w;
+		for (int i0 = -radius; i0 <= radius; i0 += 6 * inc) {   // projective divide: six taps at a time
+			float X[6], Y[6], Z[6], IZ[6];
+			int n = 0;
+			for (int i = i0; i <= radius && n < 6; i += inc, ++n) {
+				const int qx = px + i, qy = py + j;
+				X[n] = H[0] * qx + H[1] * qy + H[2];
+				Y[n] = H[3] * qx + H[4] * qy + H[5];
+				Z[n] = H[6] * qx + H[7] * qy + H[8];
+			}
+			batch_rcp(Z, n, IZ);
+			for (int k = 0; k < n; ++k) {
+				const int i = i0 + k * inc;
+				const float a = img_texel(ref, d.org, P, W, Hh, px + i, py + j);
+				const float b = tex_linear(src, P, W, Hh, X[k] * IZ[k], Y[k] * IZ[k], d.sampler);
+				const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, colour_only);
+				const float wa = w * a, wb = w * b;
+				r_r += wa;
+				r_rr += wa * a;
+				r_s += wb;
+				r_ss = fmaf(wb, b, r_ss);
+				r_rs = fmaf(wa, b, r_rs);
+				r_w += w;
+			}
 		}
 		s_r += r_r; s_rr += r_rr; s_s += r_s; s_ss += r_ss; s_rs += r_rs; s_w += r_w;
 	}
@@ -153,22 +165,26 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 	float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
 #pragma unroll
 	for (int ty = 0; ty < kTaps; ++ty) {
-		// one patch row: the 6 taps land on the same two source rows (for the usual near-upright
+		// one patch row: the 6 taps land on the same source row pair (for the usual near-upright
 		// homographies), so a lane whose hypothesis is unrelated to its neighbours' (random draws)
-		// touches 2-3 cache lines per row instead of 12 per column
+		// touches 1-2 cache lines per row; one division serves the row's six projective divides
+		float X[kTaps], Y[kTaps], Z[kTaps], IZ[kTaps];
+#pragma unroll
+		for (int tx = 0; tx < kTaps; ++tx) {
+			X[tx] = hx0[tx] + hy1[ty] + H[2];
+			Y[tx] = hx3[tx] + hy4[ty] + H[5];
+			Z[tx] = hx6[tx] + hy7[ty] + H[8];
+		}
+		batch_rcp(Z, kTaps, IZ);
 		float r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f;
 #pragma unroll
 		for (int tx = 0; tx < kTaps; ++tx) {
-			const float x = hx0[tx] + hy1[ty] + H[2];
-			const float y = hx3[tx] + hy4[ty] + H[5];
-			const float z = hx6[tx] + hy7[ty] + H[8];
-			const float iz = 1.0f / z;   // x/z, y/z as x*rcp(z), y*rcp(z) (numerics contract)
-			const float b = tex_linear_t<SMP>(src, P, W, Hh, x * iz + 0.5f, y * iz + 0.5f);
+			const float b = tex_linear_t<SMP>(src, P, W, Hh, X[tx] * IZ[tx], Y[tx] * IZ[tx]);
 			const f2 t = c.tab.get(ty * kTaps + tx);
 			const float wb = t.x * b;
 			r_s += wb;
-			r_ss += wb * b;
-			r_rs += t.y * b;
+			r_ss = fmaf(wb, b, r_ss);
+			r_rs = fmaf(t.y, b, r_rs);
 		}
 		s_s += r_s;
 		s_ss += r_ss;

@@ -704,15 +704,15 @@ DVP_HD float ncc_new(const Dev& d, const PatchCtx& c, const AnchorTab& T, int px
 			for (int t = 0; t < 9; t++) {
 				const s2 q = T.xy[k * 9 + t];
 				const f2 sp = apply_homography(H, q.x, q.y);
-				bv[t] = tex_linear_t<SMP>(src, Pt, W, Hh, sp.x + 0.5f, sp.y + 0.5f);
+				bv[t] = tex_linear_t<SMP>(src, Pt, W, Hh, sp.x, sp.y);
 			}
 			float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
 #pragma unroll
 			for (int t = 0; t < 9; t++) {
 				const float wb = T.w[k * 9 + t] * bv[t];
 				s_s += wb;
-				s_ss += wb * bv[t];
-				s_rs += T.wa[k * 9 + t] * bv[t];
+				s_ss = fmaf(wb, bv[t], s_ss);
+				s_rs = fmaf(T.wa[k * 9 + t], bv[t], s_rs);
 			}
 			temp_cost = ncc_from_sums(T.s_r[k], T.s_rr[k], s_s, s_ss, s_rs, T.s_w[k]);
 		}

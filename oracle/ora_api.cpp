@@ -90,6 +90,8 @@ void ora_set_cameras(void* c, const Camera* cams, int n) { Ctx& h = *(Ctx*)c; fo
 void ora_set_params(void* c, const PatchMatchParams* p) { Ctx& h = *(Ctx*)c; h.params = *p; }
 void ora_set_seed(void* c, uint64_t seed) { ((Ctx*)c)->seed = seed; }
 void ora_set_sampler(void* c, int sampler) { ((Ctx*)c)->sampler = sampler; }
+// 0 = numerics contract (default), 1 = literal per-operator evaluation of the NCC expressions (KAT cross-check)
+void ora_set_numerics(void* c, int numerics) { ((Ctx*)c)->numerics = numerics; }
 void ora_count_evals(void* c, int on) { Ctx& h = *(Ctx*)c; h.count_evals = on != 0; h.ncc_evals = 0; }
 long long ora_get_evals(void* c) { return ((Ctx*)c)->ncc_evals; }
 

@@ -14,6 +14,7 @@ struct Ctx {
 	int width = 0, height = 0;
 	int num_images = 0;
 	int sampler = 0;   // 0 = cuda8 (8-bit fractional weights), 1 = exact
+	int numerics = 0;  // 0 = the numerics contract (ora_common.h); 1 = literal per-operator evaluation of the reference's NCC expressions (KAT cross-check only)
 	uint64_t seed = 0;
 	PatchMatchParams params{};
 	Camera cameras[MAX_IMAGES];
@@ -55,8 +56,43 @@ inline float tex_texel(const float* img, int W, int H, int ix, int iy) {
 	return img[clampi(iy, 0, H - 1) * W + clampi(ix, 0, W - 1)];
 }
 
-// tex2D(img, x, y) with cudaFilterModeLinear, unnormalised coordinates, clamp
+// The reference's tex2D(img, x + 0.5f, y + 0.5f) with cudaFilterModeLinear, unnormalised
+// coordinates, clamp (APD.cpp:1501-1517), as a function of the PIXEL coordinate (x, y): the texture
+// unit samples at (coordinate - 0.5), which cancels the +0.5f of the call sites (contract item in
+// ora_common.h).  sampler 0 ("cuda8"): coordinate -> fixed point with 8 fractional bits, round
+// half up (CUDA Programming Guide, "Linear Filtering": 9-bit fixed point with 8 bits of fraction);
+// sampler 1: exact floor / fraction.
 inline float tex_linear(const float* img, int W, int H, float x, float y, int sampler) {
+	const float xb = fminf(fmaxf(x, -1.0f), (float)W);   // also maps NaN to -1
+	const float yb = fminf(fmaxf(y, -1.0f), (float)H);
+	int i0, j0;
+	float a, b;
+	if (sampler == 0) {
+		const int qx = (int)floorf(fmaf(xb, 256.0f, 0.5f));
+		const int qy = (int)floorf(fmaf(yb, 256.0f, 0.5f));
+		i0 = qx >> 8;   // arithmetic shift: floor division by 256
+		j0 = qy >> 8;
+		a = (float)(qx & 255) * (1.0f / 256.0f);
+		b = (float)(qy & 255) * (1.0f / 256.0f);
+	} else {
+		const float fx = floorf(xb), fy = floorf(yb);
+		a = xb - fx;
+		b = yb - fy;
+		i0 = (int)fx;
+		j0 = (int)fy;
+	}
+	const int x0 = clampi(i0, 0, W - 1), x1 = clampi(i0 + 1, 0, W - 1);
+	const int y0 = clampi(j0, 0, H - 1), y1 = clampi(j0 + 1, 0, H - 1);
+	const float t00 = img[y0 * W + x0], t10 = img[y0 * W + x1];
+	const float t01 = img[y1 * W + x0], t11 = img[y1 * W + x1];
+	const float top = fmaf(a, t10 - t00, t00);
+	const float bot = fmaf(a, t11 - t01, t01);
+	return fmaf(b, bot - top, top);
+}
+
+// Literal variant used by numerics == 1: the call sites' (x + 0.5f), the unit's (coordinate - 0.5f),
+// both rounded in binary32, fractions rounded to 8 bits after the floor.
+inline float tex_linear_literal(const float* img, int W, int H, float x, float y, int sampler) {
 	float xb = x - 0.5f, yb = y - 0.5f;
 	xb = fminf(fmaxf(xb, -1.0f), (float)W);
 	yb = fminf(fmaxf(yb, -1.0f), (float)H);
@@ -74,6 +110,21 @@ inline float tex_linear(const float* img, int W, int H, float x, float y, int sa
 	const float top = fmaf(a, t10 - t00, t00);
 	const float bot = fmaf(a, t11 - t01, t01);
 	return fmaf(b, bot - top, top);
+}
+
+// Reciprocals of up to 6 projective denominators with ONE correctly rounded division (contract:
+// the projective divide of a patch row is taken six taps at a time): prefix products, 1/product,
+// then peel the factors off again.  Every step is a plain binary32 multiply.
+inline void batch_rcp(const float* z, int n, float* iz) {
+	float p[6];
+	p[0] = z[0];
+	for (int k = 1; k < n; ++k) p[k] = p[k - 1] * z[k];
+	float r = 1.0f / p[n - 1];
+	for (int k = n - 1; k >= 1; --k) {
+		iz[k] = r * p[k - 1];
+		r = r * z[k];
+	}
+	iz[0] = r;
 }
 
 // ---- small helpers (APD.cu:3-499) -------------------------------------------------------------

@@ -4,6 +4,68 @@
 
 namespace ora {
 
+// Weighted moments of one square patch around `c` (the tap loops of APD.cu:1059-1089 and 905-935).
+//   numerics 0 (contract): taps row by row (y offset outer, x offset inner) with per-row partial
+//     sums; the projective divide of a row is taken six taps at a time (batch_rcp); the three
+//     source-side sums use one fused multiply-add per tap; the sampler takes pixel coordinates.
+//   numerics 1 (literal): the reference's own order — x offset outer, y offset inner, one running
+//     sum per moment, one division per tap, tex2D(x + 0.5f, y + 0.5f) — every operator rounded once.
+struct PatchSums { float ref, ref_ref, src, src_src, ref_src, w; };
+template <class WeightFn>
+static PatchSums patch_sums(const Ctx& h, const float* ref_image, const float* src_image, const float* H, const int2 c,
+                            int radius, int increment, WeightFn weight_of) {
+	const int W = h.width, Hh = h.height;
+	PatchSums s = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+	if (h.numerics == 1) {
+		for (int i = -radius; i <= radius; i += increment) {
+			for (int j = -radius; j <= radius; j += increment) {
+				const int2 ref_pt = make_int2(c.x + i, c.y + j);
+				const float ref_pix = tex_texel(ref_image, W, Hh, ref_pt.x, ref_pt.y);
+				const float2 src_pt = ComputeCorrespondingPoint(H, ref_pt);
+				const float src_pix = tex_linear_literal(src_image, W, Hh, src_pt.x + 0.5f, src_pt.y + 0.5f, h.sampler);
+				const float weight = weight_of((float)i, (float)j, ref_pix);
+				s.ref += weight * ref_pix;
+				s.ref_ref += weight * ref_pix * ref_pix;
+				s.src += weight * src_pix;
+				s.src_src += weight * src_pix * src_pix;
+				s.ref_src += weight * ref_pix * src_pix;
+				s.w += weight;
+			}
+		}
+		return s;
+	}
+	for (int j = -radius; j <= radius; j += increment) {
+		PatchSums r = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+		for (int i0 = -radius; i0 <= radius; i0 += 6 * increment) {
+			float X[6], Y[6], Z[6], IZ[6];
+			int off[6];
+			int n = 0;
+			for (int i = i0; i <= radius && n < 6; i += increment, ++n) {
+				const int2 q = make_int2(c.x + i, c.y + j);
+				X[n] = H[0] * q.x + H[1] * q.y + H[2];   // ComputeCorrespondingPoint, APD.cu:744-746
+				Y[n] = H[3] * q.x + H[4] * q.y + H[5];
+				Z[n] = H[6] * q.x + H[7] * q.y + H[8];
+				off[n] = i;
+			}
+			batch_rcp(Z, n, IZ);
+			for (int k = 0; k < n; ++k) {
+				const float ref_pix = tex_texel(ref_image, W, Hh, c.x + off[k], c.y + j);
+				const float src_pix = tex_linear(src_image, W, Hh, X[k] * IZ[k], Y[k] * IZ[k], h.sampler);
+				const float weight = weight_of((float)off[k], (float)j, ref_pix);
+				const float wa = weight * ref_pix, wb = weight * src_pix;
+				r.ref += wa;
+				r.ref_ref += wa * ref_pix;
+				r.src += wb;
+				r.src_src = fmaf(wb, src_pix, r.src_src);
+				r.ref_src = fmaf(wa, src_pix, r.ref_src);
+				r.w += weight;
+			}
+		}
+		s.ref += r.ref; s.ref_ref += r.ref_ref; s.src += r.src; s.src_src += r.src_src; s.ref_src += r.ref_src; s.w += r.w;
+	}
+	return s;
+}
+
 // APD.cu:1023-1113
 float ComputeBilateralNCCOld(const int2 p, const int src_idx, const float4 plane_hypothesis, Ctx& h) {
 	const float* ref_image = h.images[0].data();
@@ -36,31 +98,11 @@ float ComputeBilateralNCCOld(const int2 p, const int src_idx, const float4 plane
 		float bilateral_weight_sum = 0.0f;
 		const float ref_center_pix = tex_texel(ref_image, W, Hh, p.x, p.y);
 
-		// taps are visited row by row (j = y offset outer, i = x offset inner) with per-row partial
-		// sums; the reference walks columns in one chain (APD.cu:1059-1061) — DESIGN.md §Numerics
-		for (int j = -radius; j <= radius; j += increment) {
-			float sum_ref_row = 0.0f, sum_src_row = 0.0f, sum_ref_ref_row = 0.0f;
-			float sum_src_src_row = 0.0f, sum_ref_src_row = 0.0f, bilateral_weight_sum_row = 0.0f;
-			for (int i = -radius; i <= radius; i += increment) {
-				const int2 ref_pt = make_int2(p.x + i, p.y + j);
-				const float ref_pix = tex_texel(ref_image, W, Hh, ref_pt.x, ref_pt.y);
-				float2 src_pt = ComputeCorrespondingPoint(H, ref_pt);
-				const float src_pix = tex_linear(src_image, W, Hh, src_pt.x + 0.5f, src_pt.y + 0.5f, h.sampler);
-				float weight = ComputeBilateralWeight((float)i, (float)j, ref_pix, ref_center_pix, h.params.sigma_spatial, h.params.sigma_color);
-				sum_ref_row += weight * ref_pix;
-				sum_ref_ref_row += weight * ref_pix * ref_pix;
-				sum_src_row += weight * src_pix;
-				sum_src_src_row += weight * src_pix * src_pix;
-				sum_ref_src_row += weight * ref_pix * src_pix;
-				bilateral_weight_sum_row += weight;
-			}
-			sum_ref += sum_ref_row;
-			sum_ref_ref += sum_ref_ref_row;
-			sum_src += sum_src_row;
-			sum_src_src += sum_src_src_row;
-			sum_ref_src += sum_ref_src_row;
-			bilateral_weight_sum += bilateral_weight_sum_row;
-		}
+		const float sigma_spatial = h.params.sigma_spatial, sigma_color = h.params.sigma_color;
+		const PatchSums ps = patch_sums(h, ref_image, src_image, H, p, radius, increment,
+			[&](float xd, float yd, float pix) { return ComputeBilateralWeight(xd, yd, pix, ref_center_pix, sigma_spatial, sigma_color); });
+		sum_ref = ps.ref; sum_ref_ref = ps.ref_ref; sum_src = ps.src; sum_src_src = ps.src_src; sum_ref_src = ps.ref_src;
+		bilateral_weight_sum = ps.w;
 		const float inv_bilateral_weight_sum = 1.0f / bilateral_weight_sum;
 		sum_ref *= inv_bilateral_weight_sum;
 		sum_ref_ref *= inv_bilateral_weight_sum;
@@ -131,29 +173,10 @@ float ComputeBilateralNCCNew(const int2 p, const int src_idx, const float4 plane
 			increment = ORA_MAX(2, (int)(2.0 * radius / 5.0));
 		}
 		if (k == 0) {
-			for (int j = -radius; j <= radius; j += increment) {      // row by row, as in the Old variant above
-				float sum_ref_row = 0.0f, sum_src_row = 0.0f, sum_ref_ref_row = 0.0f;
-				float sum_src_src_row = 0.0f, sum_ref_src_row = 0.0f, bilateral_weight_sum_row = 0.0f;
-				for (int i = -radius; i <= radius; i += increment) {
-					const int2 ref_pt = make_int2(neighbour_pt.x + i, neighbour_pt.y + j);
-					const float ref_pix = tex_texel(ref_image, width, height, ref_pt.x, ref_pt.y);
-					float2 src_pt = ComputeCorrespondingPoint(H, ref_pt);
-					const float src_pix = tex_linear(src_image, width, height, src_pt.x + 0.5f, src_pt.y + 0.5f, h.sampler);
-					float weight = ComputeBilateralWeight_YZL((float)i, (float)j, ref_pix, ref_center_pix, params.sigma_spatial, params.sigma_color);
-					sum_ref_row += weight * ref_pix;
-					sum_ref_ref_row += weight * ref_pix * ref_pix;
-					sum_src_row += weight * src_pix;
-					sum_src_src_row += weight * src_pix * src_pix;
-					sum_ref_src_row += weight * ref_pix * src_pix;
-					bilateral_weight_sum_row += weight;
-				}
-				sum_ref += sum_ref_row;
-				sum_ref_ref += sum_ref_ref_row;
-				sum_src += sum_src_row;
-				sum_src_src += sum_src_src_row;
-				sum_ref_src += sum_ref_src_row;
-				bilateral_weight_sum += bilateral_weight_sum_row;
-			}
+			const PatchSums ps = patch_sums(h, ref_image, src_image, H, make_int2(neighbour_pt.x, neighbour_pt.y), radius, increment,
+				[&](float xd, float yd, float pix) { return ComputeBilateralWeight_YZL(xd, yd, pix, ref_center_pix, params.sigma_spatial, params.sigma_color); });
+			sum_ref = ps.ref; sum_ref_ref = ps.ref_ref; sum_src = ps.src; sum_src_src = ps.src_src; sum_ref_src = ps.ref_src;
+			bilateral_weight_sum = ps.w;
 		} else {
 			if (isSet(h.selected_views[neighbour_pt.x + neighbour_pt.y * width], src_idx - 1) == 1) {
 				int nei_center = neighbour_pt.x + neighbour_pt.y * width;
@@ -179,15 +202,25 @@ float ComputeBilateralNCCNew(const int2 p, const int src_idx, const float4 plane
 					const int2 ref_pt = make_int2(neighbour_pt.x + i, neighbour_pt.y + j);
 					const float ref_pix = tex_texel(ref_image, width, height, ref_pt.x, ref_pt.y);
 					float2 src_pt = ComputeCorrespondingPoint(H, ref_pt);
-					const float src_pix = tex_linear(src_image, width, height, src_pt.x + 0.5f, src_pt.y + 0.5f, h.sampler);
 					float weight = ComputeBilateralWeight_YZL((float)i, (float)j, ref_pix, ref_center_pix, params.sigma_spatial, params.sigma_color);
-					// one-element "rows" (APD.cu:953-976): 0 + x is exact, so plain accumulation
-					sum_ref += (0.0f + weight * ref_pix);
-					sum_ref_ref += (0.0f + weight * ref_pix * ref_pix);
-					sum_src += (0.0f + weight * src_pix);
-					sum_src_src += (0.0f + weight * src_pix * src_pix);
-					sum_ref_src += (0.0f + weight * ref_pix * src_pix);
-					bilateral_weight_sum += (0.0f + weight);
+					if (h.numerics == 1) {
+						const float src_pix = tex_linear_literal(src_image, width, height, src_pt.x + 0.5f, src_pt.y + 0.5f, h.sampler);
+						sum_ref += weight * ref_pix;
+						sum_ref_ref += weight * ref_pix * ref_pix;
+						sum_src += weight * src_pix;
+						sum_src_src += weight * src_pix * src_pix;
+						sum_ref_src += weight * ref_pix * src_pix;
+						bilateral_weight_sum += weight;
+					} else {   // contract: fused multiply-adds on the source-side sums (one division per tap here)
+						const float src_pix = tex_linear(src_image, width, height, src_pt.x, src_pt.y, h.sampler);
+						const float wa = weight * ref_pix, wb = weight * src_pix;
+						sum_ref += wa;
+						sum_ref_ref += wa * ref_pix;
+						sum_src += wb;
+						sum_src_src = fmaf(wb, src_pix, sum_src_src);
+						sum_ref_src = fmaf(wa, src_pix, sum_ref_src);
+						bilateral_weight_sum += weight;
+					}
 				}
 			}
 		}

@@ -137,6 +137,13 @@ class Oracle:
     def set_sampler(self, s):
         self.L.ora_set_sampler(self.h, s)
 
+    def set_numerics(self, n):
+        """0 = the numerics contract (default); 1 = literal per-operator evaluation of the reference's
+        NCC expressions (column-major single-chain sums, one division per tap, tex2D(x+0.5) with the
+        add/subtract pair rounded).  Oracle only: a cross-check of how far the contract is from it."""
+        self.L.ora_set_numerics.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self.L.ora_set_numerics(self.h, n)
+
     def upload_state(self, planes=None, views=None, weak=None, edge=None, label=None, radius=None):
         c = lambda a, dt: None if a is None else np.ascontiguousarray(a, dt)
         args = [c(planes, np.float32), c(views, np.uint32), c(weak, np.uint8), c(edge, np.uint8), c(label, np.int32), c(radius, np.int32)]
