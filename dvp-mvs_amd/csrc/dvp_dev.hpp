@@ -184,6 +184,12 @@ DVP_HD float clampf_nan_lo(float v, float lo, float hi) {
 	return fminf(fmaxf(v, lo), hi);
 #endif
 }
+// keeps the instruction scheduler from moving anything across this point (no code is emitted)
+DVP_HD void sched_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+	__builtin_amdgcn_sched_barrier(0);
+#endif
+}
 // (int)floorf(v) for |v| < 2^31: v_cvt_flr_i32_f32
 DVP_HD int floor_to_int(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -202,35 +208,58 @@ DVP_HD int floor_to_int(float v) {
 //   SMP 0 ("cuda8"): the coordinate is converted to fixed point with 8 fractional bits, round
 //          half up, as the texture unit does; texel index = integer part, weights = fraction/256.
 //   SMP 1: exact floor / fraction in binary32.
-template <int SMP>
-DVP_HD float tex_linear_t(const float* img, int pitch, int W, int H, float x, float y) {
-	const float xb = clampf_nan_lo(x, -1.0f, (float)W);
-	const float yb = clampf_nan_lo(y, -1.0f, (float)H);
-	int i0, j0;
-	float a, b;
-	if (SMP == 0) {
-		const int qx = floor_to_int(fmaf(xb, 256.0f, 0.5f));   // in [-256, 256 W]
-		const int qy = floor_to_int(fmaf(yb, 256.0f, 0.5f));
-		i0 = qx >> 8;
-		j0 = qy >> 8;
-		a = (float)(qx & 255) * (1.0f / 256.0f);
-		b = (float)(qy & 255) * (1.0f / 256.0f);
-	} else {
-		const float fx = floorf(xb), fy = floorf(yb);
-		a = xb - fx;
-		b = yb - fy;
-		i0 = (int)fx;
-		j0 = (int)fy;
-	}
+// Three pieces so that a caller can issue many fetches before consuming any of them:
+//   tex_coord : coordinate -> byte offset of the footprint + the two interpolation weights
+//   load_quad : the 16-byte fetch
+//   tex_lerp  : the bilinear blend
+// interpolation weights of one footprint as they wait for the fetch: SMP 0 keeps the two 8-bit
+// fractions packed in one register, SMP 1 the two exact fractions
+template <int SMP> struct TapW;
+template <> struct TapW<0> { unsigned pk; };
+template <> struct TapW<1> { float a, b; };
+DVP_HD void tap_weights(const TapW<0>& w, float* a, float* b) {
+	*a = (float)(w.pk & 255u) * (1.0f / 256.0f);          // v_cvt_f32_ubyte0
+	*b = (float)((w.pk >> 8) & 255u) * (1.0f / 256.0f);   // v_cvt_f32_ubyte1
+}
+DVP_HD void tap_weights(const TapW<1>& w, float* a, float* b) { *a = w.a; *b = w.b; }
+
+DVP_HD unsigned tex_offset(int pitch, int i0, int j0) {
 	// i0 in [-1, W], j0 in [-1, H]: the footprint [i0, i0+1] x [j0, j0+1] lies inside the padded
 	// plane; (j0 + PAD) * pitch + (i0 + PAD) >= 0, the PAD terms are a wave-uniform constant
 	const int e = j0 * pitch + i0;
-	const unsigned off = ((unsigned)e << 3) + (unsigned)((kImgPad * pitch + kImgPad) * 8);
-	float t00, t10, t01, t11;
-	load_quad(img, off, &t00, &t01, &t10, &t11);   // {I(i,j), I(i,j+1)} {I(i+1,j), I(i+1,j+1)}
+	return ((unsigned)e << 3) + (unsigned)((kImgPad * pitch + kImgPad) * 8);
+}
+DVP_HD void tex_coord(int pitch, int W, int H, float x, float y, unsigned* off, TapW<0>* w) {
+	const float xb = clampf_nan_lo(x, -1.0f, (float)W);
+	const float yb = clampf_nan_lo(y, -1.0f, (float)H);
+	const int qx = floor_to_int(fmaf(xb, 256.0f, 0.5f));   // in [-256, 256 W]
+	const int qy = floor_to_int(fmaf(yb, 256.0f, 0.5f));
+	w->pk = ((unsigned)qx & 255u) | ((unsigned)qy << 8);    // bits 8..15 = fraction of y
+	*off = tex_offset(pitch, qx >> 8, qy >> 8);
+}
+DVP_HD void tex_coord(int pitch, int W, int H, float x, float y, unsigned* off, TapW<1>* w) {
+	const float xb = clampf_nan_lo(x, -1.0f, (float)W);
+	const float yb = clampf_nan_lo(y, -1.0f, (float)H);
+	const float fx = floorf(xb), fy = floorf(yb);
+	w->a = xb - fx;
+	w->b = yb - fy;
+	*off = tex_offset(pitch, (int)fx, (int)fy);
+}
+// q = {I(i,j), I(i,j+1), I(i+1,j), I(i+1,j+1)}
+DVP_HD float tex_lerp(float a, float b, float t00, float t01, float t10, float t11) {
 	const float top = fmaf(a, t10 - t00, t00);
 	const float bot = fmaf(a, t11 - t01, t01);
 	return fmaf(b, bot - top, top);
+}
+template <int SMP>
+DVP_HD float tex_linear_t(const float* img, int pitch, int W, int H, float x, float y) {
+	unsigned off;
+	TapW<SMP> w;
+	float a, b, t00, t01, t10, t11;
+	tex_coord(pitch, W, H, x, y, &off, &w);
+	load_quad(img, off, &t00, &t01, &t10, &t11);
+	tap_weights(w, &a, &b);
+	return tex_lerp(a, b, t00, t01, t10, t11);
 }
 DVP_HD float tex_linear(const float* img, int pitch, int W, int H, float x, float y, int sampler) {
 	return sampler == 0 ? tex_linear_t<0>(img, pitch, W, H, x, y) : tex_linear_t<1>(img, pitch, W, H, x, y);

@@ -154,42 +154,71 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 	const int W = d.width, Hh = d.height, P = d.pitch;
 	// H[k]*x and H[k]*y products for the 6 distinct tap columns / rows: same products the
 	// reference forms per tap (H[0]*p.x + H[1]*p.y + H[2], APD.cu:744-746), formed once.
-	float hx0[kTaps], hx3[kTaps], hx6[kTaps], hy1[kTaps], hy4[kTaps], hy7[kTaps];
+	float hx0[kTaps], hx3[kTaps], hx6[kTaps];
 #pragma unroll
 	for (int t = 0; t < kTaps; ++t) {
 		const float fx = (float)(px - c.radius + t * c.inc);
-		const float fy = (float)(py - c.radius + t * c.inc);
 		hx0[t] = H[0] * fx; hx3[t] = H[3] * fx; hx6[t] = H[6] * fx;
-		hy1[t] = H[1] * fy; hy4[t] = H[4] * fy; hy7[t] = H[7] * fy;
 	}
+	// Software pipeline over the three row PAIRS of the patch (12 taps each):
+	//   coords(p): 2 batched reciprocals + 12 footprint addresses / weights
+	//   issue(p) : 12 sixteen-byte gathers
+	//   consume(p): 12 blends + the row sums, rows in order (row-then-total accumulation)
+	// ordered  coords0 issue0 | coords1 | consume0 issue1 | coords2 | consume1 issue2 | consume2:
+	// the 12 gathers of a pair are issued back to back and fly while the next pair's addresses are
+	// computed (two IEEE divisions + 12 footprints).  Taps of one row land on the same source
+	// row pair (near-upright homographies): a lane with a hypothesis unrelated to its neighbours'
+	// touches 1-2 cache lines per row.
+	constexpr int kPair = 2 * kTaps;
+	unsigned off[2][kPair];
+	TapW<SMP> tw[2][kPair];
+	float q[2][kPair][4];
 	float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
-#pragma unroll
-	for (int ty = 0; ty < kTaps; ++ty) {
-		// one patch row: the 6 taps land on the same source row pair (for the usual near-upright
-		// homographies), so a lane whose hypothesis is unrelated to its neighbours' (random draws)
-		// touches 1-2 cache lines per row; one division serves the row's six projective divides
-		float X[kTaps], Y[kTaps], Z[kTaps], IZ[kTaps];
-#pragma unroll
-		for (int tx = 0; tx < kTaps; ++tx) {
-			X[tx] = hx0[tx] + hy1[ty] + H[2];
-			Y[tx] = hx3[tx] + hy4[ty] + H[5];
-			Z[tx] = hx6[tx] + hy7[ty] + H[8];
-		}
-		batch_rcp(Z, kTaps, IZ);
-		float r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f;
-#pragma unroll
-		for (int tx = 0; tx < kTaps; ++tx) {
-			const float b = tex_linear_t<SMP>(src, P, W, Hh, X[tx] * IZ[tx], Y[tx] * IZ[tx]);
-			const f2 t = c.tab.get(ty * kTaps + tx);
-			const float wb = t.x * b;
-			r_s += wb;
-			r_ss = fmaf(wb, b, r_ss);
-			r_rs = fmaf(t.y, b, r_rs);
-		}
-		s_s += r_s;
-		s_ss += r_ss;
-		s_rs += r_rs;
+#define DVP_COORDS(PR, BUF)                                                                         \
+	_Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                 \
+		const float fy = (float)(py - c.radius + (2 * (PR) + r) * c.inc);                           \
+		const float hy1 = H[1] * fy, hy4 = H[4] * fy, hy7 = H[7] * fy;                              \
+		float X[kTaps], Y[kTaps], Z[kTaps], IZ[kTaps];                                              \
+		_Pragma("unroll") for (int tx = 0; tx < kTaps; ++tx) {                                      \
+			X[tx] = hx0[tx] + hy1 + H[2];                                                           \
+			Y[tx] = hx3[tx] + hy4 + H[5];                                                           \
+			Z[tx] = hx6[tx] + hy7 + H[8];                                                           \
+		}                                                                                           \
+		batch_rcp(Z, kTaps, IZ);                                                                    \
+		_Pragma("unroll") for (int tx = 0; tx < kTaps; ++tx)                                        \
+			tex_coord(P, W, Hh, X[tx] * IZ[tx], Y[tx] * IZ[tx], &off[BUF][r * kTaps + tx],          \
+			          &tw[BUF][r * kTaps + tx]);                                                    \
 	}
+#define DVP_ISSUE(BUF)                                                                              \
+	_Pragma("unroll") for (int k = 0; k < kPair; ++k)                                               \
+		load_quad(src, off[BUF][k], &q[BUF][k][0], &q[BUF][k][1], &q[BUF][k][2], &q[BUF][k][3]);
+#define DVP_CONSUME(PR, BUF)                                                                        \
+	_Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                 \
+		float r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f;                                                 \
+		_Pragma("unroll") for (int tx = 0; tx < kTaps; ++tx) {                                      \
+			const int k = r * kTaps + tx;                                                           \
+			float fa, fb;                                                                           \
+			tap_weights(tw[BUF][k], &fa, &fb);                                                      \
+			const float b = tex_lerp(fa, fb, q[BUF][k][0], q[BUF][k][1], q[BUF][k][2], q[BUF][k][3]); \
+			const f2 t = c.tab.get((2 * (PR) + r) * kTaps + tx);                                    \
+			const float wsb = t.x * b;                                                              \
+			r_s += wsb;                                                                             \
+			r_ss = fmaf(wsb, b, r_ss);                                                              \
+			r_rs = fmaf(t.y, b, r_rs);                                                              \
+		}                                                                                           \
+		s_s += r_s;                                                                                 \
+		s_ss += r_ss;                                                                               \
+		s_rs += r_rs;                                                                               \
+	}
+	DVP_COORDS(0, 0) DVP_ISSUE(0) sched_fence();
+	DVP_COORDS(1, 1) sched_fence();
+	DVP_CONSUME(0, 0) DVP_ISSUE(1) sched_fence();
+	DVP_COORDS(2, 0) sched_fence();
+	DVP_CONSUME(1, 1) DVP_ISSUE(0) sched_fence();
+	DVP_CONSUME(2, 0)
+#undef DVP_COORDS
+#undef DVP_ISSUE
+#undef DVP_CONSUME
 	return ncc_from_sums(c.sum_ref, c.sum_ref_ref, s_s, s_ss, s_rs, c.wsum);
 }
 
