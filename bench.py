@@ -170,7 +170,7 @@ def main():
     if rank == 0:
         total_px_iter = float(W) * H * iters * args.steps * world
         value = total_px_iter / dt / 1e6
-        # dominant kernel: the strong red/black update (dvp_strong_update)
+        # dominant kernel: the strong red/black update (dvp_strong_update; the _v8 instantiation when S <= 8)
         launches = tm["stage_launches"]["strong_update"]
         avg_ms = tm["stage_ms"]["strong_update"] / max(launches, 1)
         ev_launch = evals["ncc_evals"]["strong_update"] / max(evals["stage_launches"]["strong_update"], 1)
@@ -189,7 +189,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE cfg2 stand-in: %dx%d, S=%d source views, %d PatchMatch iterations, FIRST_INIT, geom off, one view per step per GPU" % (W, H, S, iters),
                        "width": W, "height": H, "src_views": S, "iterations": iters, "parallelism": "views round-robin over %d rank(s)" % world},
-            "roofline": {"bound": "hbm", "kernel": "dvp_strong_update", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "dvp_strong_update_v8" if S <= 8 else "dvp_strong_update", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "evals_per_launch": int(ev_launch), "bytes_per_eval": NCC_BYTES, "avg_launch_ms": round(avg_ms, 3),
                          "launches": launches},

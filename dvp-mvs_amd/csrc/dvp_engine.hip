@@ -20,7 +20,7 @@ struct LaunchArgs {
 	int tiles_x, tiles, chunk, rows, half, colour, iter;
 };
 
-template <int STAGE, int SMP>
+template <int STAGE, int SMP, int MV = 32>
 __device__ __forceinline__ void stage_body(const Dev& d, const LaunchArgs& a) {
 	const int lane = threadIdx.x & 63;
 	const int wave = threadIdx.x >> 6;
@@ -30,7 +30,7 @@ __device__ __forceinline__ void stage_body(const Dev& d, const LaunchArgs& a) {
 	__shared__ f2 lds_tab[stage_uses_tab(STAGE) ? kTaps * kTaps * 256 : 1];
 	const PatchTab tab{&lds_tab[stage_uses_tab(STAGE) ? threadIdx.x : 0], 256};
 	if (block_to_pixel(blockIdx.x, lane, wave, a.tiles_x, a.tiles, a.chunk, a.rows, a.half, a.colour, d.width, d.height, &px, &py))
-		run_pixel<STAGE, SMP>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, tab);
+		run_pixel<STAGE, SMP, MV>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, tab);
 	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
 }
 
@@ -70,19 +70,28 @@ __device__ __forceinline__ void stage_body_list(const Dev& d, const ListArgs& a)
 		stage_body<STAGE, 1>(d, a);                                                                         \
 	}
 
+// same launch site, private per-view arrays sized for MV views (strong update with S <= 8)
+#define DVP_KERNEL_MV(NAME, STAGE, MINW, MV)                                                               \
+	extern "C" __global__ void __launch_bounds__(256, MINW) NAME(const Dev d, const LaunchArgs a) {         \
+		stage_body<STAGE, 0, MV>(d, a);                                                                     \
+	}                                                                                                       \
+	extern "C" __global__ void __launch_bounds__(256, MINW) NAME##_exact(const Dev d, const LaunchArgs a) { \
+		stage_body<STAGE, 1, MV>(d, a);                                                                     \
+	}
+
 DVP_KERNEL(dvp_gen_edge_inform, DVP_ST_GEN_EDGE_INFORM, 1)
 DVP_KERNEL(dvp_find_nearest_strong, DVP_ST_FIND_NEAREST_STRONG, 1)
 DVP_KERNEL(dvp_gen_neighbours, DVP_ST_GEN_NEIGHBOURS, 1)
 DVP_KERNEL(dvp_neighbour_update, DVP_ST_NEIGHBOUR_UPDATE, 1)
 #ifndef DVP_LB_HEAVY
-// min waves/SIMD the heavy NCC kernels are compiled for.  Measured on MI355X (3104x2064, S=5):
-// 1 -> 64 ms per strong-update launch, 2 -> 110 ms, 3 -> 135 ms, 4 -> 154 ms: the fully unrolled
-// 36-tap evaluation wants the whole 512-entry register file (144 gathers in flight per lane);
-// any tighter bound spills the weight table to scratch inside the tap loop.
+// min waves/SIMD the NCC kernels are compiled for: 2 = 256 VGPRs per lane (the pipelined 36-tap
+// evaluation keeps 12 sixteen-byte gathers + the next 12 footprints live) and two 72 KiB patch
+// tables per CU in LDS.
 #define DVP_LB_HEAVY 2
 #endif
 DVP_KERNEL(dvp_random_init, DVP_ST_RANDOM_INIT, DVP_LB_HEAVY)
 DVP_KERNEL(dvp_strong_update, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY)
+DVP_KERNEL_MV(dvp_strong_update_v8, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY, kNarrowViews)
 DVP_KERNEL(dvp_ransac_fit_plane, DVP_ST_RANSAC_FIT, 1)
 DVP_KERNEL(dvp_weak_update, DVP_ST_WEAK_UPDATE, 2)
 DVP_KERNEL(dvp_get_depth_normal, DVP_ST_GET_DEPTH_NORMAL, 1)
@@ -559,7 +568,10 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 	case DVP_ST_GEN_NEIGHBOURS: hipLaunchKernelGGL(c->d.sampler ? dvp_gen_neighbours_exact : dvp_gen_neighbours, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(c->d.sampler ? dvp_neighbour_update_exact : dvp_neighbour_update, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_RANDOM_INIT: hipLaunchKernelGGL(c->d.sampler ? dvp_random_init_exact : dvp_random_init, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_STRONG_UPDATE: hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_exact : dvp_strong_update, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_STRONG_UPDATE:
+		if (c->NI - 1 <= kNarrowViews) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v8_exact : dvp_strong_update_v8, grid, block, 0, c->stream, c->d, a);
+		else hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_exact : dvp_strong_update, grid, block, 0, c->stream, c->d, a);
+		break;
 	case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(c->d.sampler ? dvp_ransac_fit_plane_exact : dvp_ransac_fit_plane, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_WEAK_UPDATE: hipLaunchKernelGGL(c->d.sampler ? dvp_weak_update_exact : dvp_weak_update, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_GET_DEPTH_NORMAL: hipLaunchKernelGGL(c->d.sampler ? dvp_get_depth_normal_exact : dvp_get_depth_normal, grid, block, 0, c->stream, c->d, a); break;

@@ -53,7 +53,8 @@ DVP_HD bool block_to_pixel(int block, int lane, int wave, int tiles_x, int tiles
 }
 
 // per-pixel predicate + body of launch site `STAGE` (DVP_ST_*), APD.cu:3091-3165, 3296-3328
-template <int STAGE, int SMP>
+constexpr int kNarrowViews = 8;   // view capacity of the narrow strong-update instantiation
+template <int STAGE, int SMP, int MV = 32>
 DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long* nevals, PatchTab tab) {
 	const int center = px + py * d.width;
 	if (STAGE == DVP_ST_GEN_EDGE_INFORM) gen_edge_inform_px(d, px, py);
@@ -61,7 +62,7 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 	else if (STAGE == DVP_ST_GEN_NEIGHBOURS) gen_neighbours_px(d, px, py);
 	else if (STAGE == DVP_ST_NEIGHBOUR_UPDATE) neighbour_update_px(d, px, py);
 	else if (STAGE == DVP_ST_RANDOM_INIT) random_init_px<SMP>(d, px, py, tab, nevals);
-	else if (STAGE == DVP_ST_STRONG_UPDATE) { if (d.weak_info[center] != DVP_WEAK) strong_update_px<SMP>(d, px, py, tab, iter, nevals); }
+	else if (STAGE == DVP_ST_STRONG_UPDATE) { if (d.weak_info[center] != DVP_WEAK) strong_update_px<SMP, MV>(d, px, py, tab, iter, nevals); }
 	else if (STAGE == DVP_ST_RANSAC_FIT) ransac_fit_plane_px(d, px, py, iter);
 	else if (STAGE == DVP_ST_WEAK_UPDATE) { if (d.weak_info[center] == DVP_WEAK) weak_update_px<SMP>(d, px, py, tab, iter, nevals); }
 	else if (STAGE == DVP_ST_GET_DEPTH_NORMAL) get_depth_normal_px(d, px, py);

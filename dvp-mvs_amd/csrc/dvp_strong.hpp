@@ -155,17 +155,18 @@ DVP_HD void random_init_px(const Dev& d, int px, int py, PatchTab tab, unsigned 
 }
 
 // Multi-hypothesis joint view selection (APD.cu:2483-2530 == 2803-2850)
-DVP_HD void joint_view_selection(const Dev& d, int center, int iter, int phase, const float* cost_array /*[8][32]*/,
-	const float* priors, uint8_t* vw /*[32], zeroed*/, uint32_t* sel_mask, float* weight_norm) {
+template <int MV = 32>   // MV: row stride of cost_array and capacity of priors / vw (>= number of source views)
+DVP_HD void joint_view_selection(const Dev& d, int center, int iter, int phase, const float* cost_array /*[8][MV]*/,
+	const float* priors, uint8_t* vw /*[MV], zeroed*/, uint32_t* sel_mask, float* weight_norm) {
 	const int S = d.params.num_images - 1;
-	float probs[32];
+	float probs[MV];
 	const float thr = (float)(0.8 * dvp_expf((iter) * (iter) / (-90.0f)));
 	for (int i = 0; i < S; i++) {
 		float count = 0;
 		int count_false = 0;
 		float tmpw = 0;
 		for (int j = 0; j < 8; j++) {
-			const float cst = cost_array[j * 32 + i];
+			const float cst = cost_array[j * MV + i];
 			if (cst < thr) { tmpw += dvp_expf(cst * cst / (-0.18f)); count++; }
 			if (cst > 1.2f) count_false++;
 		}
@@ -250,7 +251,10 @@ DVP_HD int strong_sample_search(const Dev& d, int px, int py, int k, int pass) {
 // prologue picks the plane and the views to evaluate, an epilogue consumes the cost vector.
 // After view selection only views with non-zero weight are evaluated: the reference evaluates all
 // S and multiplies the others by a zero weight, which is the same value.
-template <int SMP>
+// MV = capacity of the per-view private arrays (cost_array[8][MV], cv, priors, vw): 32 covers
+// every legal view count; the engine launches the MV = 8 instantiation when S <= 8, which keeps
+// 1.2 KB/lane of zero-filled scratch out of the cache hierarchy (same values either way).
+template <int SMP, int MV = 32>
 DVP_HD void strong_update_px(const Dev& d, int px, int py, PatchTab tab, int iter, unsigned long long* nevals) {
 	const int W = d.width;
 	const int center = py * W + px;
@@ -265,8 +269,8 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, PatchTab tab, int ite
 		patch_geometry(d, center, &radius, &inc);
 		build_patch_ctx(d, px, py, radius, inc, 0, tab, &c);
 	}
-	float cost_array[8 * 32];
-	for (int i = 0; i < 8 * 32; ++i) cost_array[i] = 0.0f;
+	float cost_array[8 * MV];
+	for (int i = 0; i < 8 * MV; ++i) cost_array[i] = 0.0f;
 	cost_array[0] = 2.0f;   // `= { 2.0f }` sets one element (APD.cu:2032)
 	uint32_t flag = 0;      // bit k: direction k has a sample
 	int positions[8];
@@ -274,8 +278,8 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, PatchTab tab, int ite
 	const bool is_edge = d.edge[center] != 0;
 	const float good_thr = 0.8f * dvp_expf((iter) * (iter) / (-90.0f));
 
-	uint8_t vw[32];
-	for (int i = 0; i < 32; ++i) vw[i] = 0;
+	uint8_t vw[MV];
+	for (int i = 0; i < MV; ++i) vw[i] = 0;
 	uint32_t sel_mask = 0;
 	float weight_norm = 0.0f;
 	float final_costs[8];
@@ -287,7 +291,7 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, PatchTab tab, int ite
 	float ref_depths[6];
 	f4 ref_normals[6];
 
-	float cv[32];
+	float cv[MV];
 	for (int slot = 0; slot < 23; ++slot) {
 		// hypotheses 3 and 4 of the refinement are the same plane (both GeneratePerturbedNormal calls
 		// return the input normal, APD.cu:1354-1360): the second one can never be accepted after the
@@ -307,8 +311,8 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, PatchTab tab, int ite
 			}
 		} else if (slot == 16) {
 			// view selection (APD.cu:2462-2530)
-			float priors[32];
-			for (int i = 0; i < 32; ++i) priors[i] = 0.0f;
+			float priors[MV];
+			for (int i = 0; i < MV; ++i) priors[i] = 0.0f;
 			const int nb[4] = { center - W, center + W, center - 1, center + 1 };
 			for (int i = 0; i < 4; ++i) {
 				if ((flag >> (2 * i)) & 1) {   // guards flag[0],[2],[4],[6] (APD.cu:2471)
@@ -316,13 +320,13 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, PatchTab tab, int ite
 					for (int j = 0; j < S; ++j) priors[j] += is_set(sv, j) ? 0.9f : 0.1f;
 				}
 			}
-			joint_view_selection(d, center, iter, PH_STRONG, cost_array, priors, vw, &sel_mask, &weight_norm);
+			joint_view_selection<MV>(d, center, iter, PH_STRONG, cost_array, priors, vw, &sel_mask, &weight_norm);
 			uint8_t* gvw = d.view_weight + (size_t)center * 32;
-			for (int i = 0; i < 32; ++i) gvw[i] = vw[i];
+			for (int i = 0; i < 32; ++i) gvw[i] = i < MV ? vw[i < MV ? i : 0] : (uint8_t)0;
 			for (int k = 0; k < 8; ++k) {
 				float fc = 0.0f;
 				for (int j = 0; j < S; ++j)
-					if (vw[j] > 0) fc += vw[j] * cost_array[k * 32 + j];
+					if (vw[j] > 0) fc += vw[j] * cost_array[k * MV + j];
 				final_costs[k] = fc / weight_norm;
 			}
 			min_cost_idx = 0;   // FindMinCostIndex (ties -> last, APD.cu:155-166)
@@ -355,7 +359,7 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, PatchTab tab, int ite
 			if (pos >= 0) {
 				flag |= 1u << slot;
 				positions[slot] = pos;
-				for (int v = 0; v < S; ++v) cost_array[slot * 32 + v] = cv[v];
+				for (int v = 0; v < S; ++v) cost_array[slot * MV + v] = cv[v];
 			}
 		} else if (slot < 16) {
 			const int k = slot - 8;
@@ -364,7 +368,7 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, PatchTab tab, int ite
 				flag |= 1u << k;
 				int good0 = 0, good1 = 0, bad0 = 0, bad1 = 0;
 				for (int j = 0; j < S; ++j) {
-					const float a = cost_array[k * 32 + j], b = cv[j];
+					const float a = cost_array[k * MV + j], b = cv[j];
 					if (a < good_thr) good0++;
 					if (a > 1.2f) bad0++;
 					if (b < good_thr) good1++;
@@ -372,7 +376,7 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, PatchTab tab, int ite
 				}
 				if (!had || good1 > good0 || (good1 == good0 && bad1 < bad0)) {
 					positions[k] = pos;
-					for (int j = 0; j < S; ++j) cost_array[k * 32 + j] = cv[j];
+					for (int j = 0; j < S; ++j) cost_array[k * MV + j] = cv[j];
 				}
 			}
 		} else if (slot == 16) {

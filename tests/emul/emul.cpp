@@ -73,8 +73,9 @@ void launch(Emu& e, int iter, int colour) {
 				unsigned long long n = 0;
 				f2 tab_mem[kTaps * kTaps];
 				const PatchTab tab{tab_mem, 1};
-				if (e.d.sampler) run_pixel<STAGE, 1>(e.d, px, py, iter, e.count ? &n : nullptr, tab);
-				else run_pixel<STAGE, 0>(e.d, px, py, iter, e.count ? &n : nullptr, tab);
+				const bool narrow = e.NI - 1 <= kNarrowViews;   // the engine's strong-update dispatch
+				if (e.d.sampler) { if (narrow) run_pixel<STAGE, 1, kNarrowViews>(e.d, px, py, iter, e.count ? &n : nullptr, tab); else run_pixel<STAGE, 1>(e.d, px, py, iter, e.count ? &n : nullptr, tab); }
+				else { if (narrow) run_pixel<STAGE, 0, kNarrowViews>(e.d, px, py, iter, e.count ? &n : nullptr, tab); else run_pixel<STAGE, 0>(e.d, px, py, iter, e.count ? &n : nullptr, tab); }
 				total += n;
 			}
 	e.evals += total;
