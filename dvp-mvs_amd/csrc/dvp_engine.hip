@@ -104,7 +104,7 @@ DVP_KERNEL_LIST(dvp_find_nearest_strong_list, DVP_ST_FIND_NEAREST_STRONG, 1)
 DVP_KERNEL_LIST(dvp_gen_neighbours_list, DVP_ST_GEN_NEIGHBOURS, 1)
 DVP_KERNEL_LIST(dvp_neighbour_update_list, DVP_ST_NEIGHBOUR_UPDATE, 1)
 DVP_KERNEL_LIST(dvp_ransac_fit_plane_list, DVP_ST_RANSAC_FIT, 1)
-DVP_KERNEL_LIST(dvp_weak_update_list, DVP_ST_WEAK_UPDATE, 1)
+DVP_KERNEL_LIST(dvp_weak_update_list, DVP_ST_WEAK_UPDATE, 2)
 
 extern "C" __global__ void dvp_pad_replicate(float* planes, int W, int H, int pitch, size_t plane_stride, int n_planes) {
 	const int PW = W + 2 * kImgPad, PH = H + 2 * kImgPad;

@@ -196,7 +196,12 @@ DVP_HD bool point_in_triangle(s2 A, s2 B, s2 C, int px, int py) {
 	return t1 * t2 >= 0 && t1 * t3 >= 0;
 }
 
-// true = the segment B->A crosses an edge pixel (APD.cu:267-311)
+// true = the segment B->A crosses an edge pixel (APD.cu:267-311).
+// The reference walks the line one pixel per loop iteration and tests the edge map after every step
+// (one dependent load per step, up to max(W,H)/30 of them).  The answer is "any visited pixel is
+// an edge pixel", so the walk is done in blocks of 8 steps: eight positions from the integer
+// line state, eight independent byte loads, one OR.  Visited set, step limit and the one-pixel
+// overshoot past the end point (the loop condition is tested after the step) are the reference's.
 DVP_HD bool bresenham_hits_edge(const Dev& d, int Ax, int Ay, int Bx, int By) {
 	const int W = d.width, H = d.height;
 	const int max_step = (int)(DVP_MAX(H, W) / 30.0);
@@ -210,15 +215,27 @@ DVP_HD bool bresenham_hits_edge(const Dev& d, int Ax, int Ay, int Bx, int By) {
 	int erro = (dx > dy ? dx : dy) / 2;
 	int step = 0;
 	bool tagx = true, tagy = true;
-	while (tagx || tagy) {
-		if (x0 == x1) tagx = false;
-		if (y0 == y1) tagy = false;
-		const int e2 = erro;
-		if (e2 > -dx) { erro -= dy; x0 += sx; }
-		if (e2 < dy) { erro += dx; y0 += sy; }
-		if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H && d.edge[x0 + y0 * W]) return true;
-		step += 1;
-		if (step >= max_step) break;
+	bool alive = true;       // the reference's loop would still be running
+	while (alive) {
+		int idx[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			idx[k] = -1;
+			if (alive) {
+				if (x0 == x1) tagx = false;
+				if (y0 == y1) tagy = false;
+				const int e2 = erro;
+				if (e2 > -dx) { erro -= dy; x0 += sx; }
+				if (e2 < dy) { erro += dx; y0 += sy; }
+				if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H) idx[k] = x0 + y0 * W;
+				step += 1;
+				if (step >= max_step || !(tagx || tagy)) alive = false;
+			}
+		}
+		unsigned hit = 0;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) hit |= (unsigned)d.edge[idx[k] < 0 ? 0 : idx[k]] & (idx[k] < 0 ? 0u : 0xFFu);
+		if (hit) return true;
 	}
 	return false;
 }
