@@ -300,9 +300,9 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 							if (np.x == -1 || np.y == -1) continue;
 							npc = np.x + np.y * W;
 						}
-						bool same = false;
+						bool same = false;   // (no early exit: the loads are independent and pipeline)
 						for (int k = 0; k < dir_index; k++)
-							if (strong_points[k].x == np.x && strong_points[k].y == np.y) { same = true; break; }
+							same |= (strong_points[k].x == np.x) & (strong_points[k].y == np.y);
 						if (same) continue;
 						f2 td = mk2((float)(np.x - px), (float)(np.y - py));
 						normalize2(&td);
