@@ -632,12 +632,14 @@ DVP_HD void ransac_fit_plane_px(const Dev& d, int px, int py, int iter) {
 // positions, the reference texels, the weights and the three reference sums do not depend on the
 // plane hypothesis; the reference recomputes them (99 exp + 99 texel reads + the candidate
 // offsets) for each of the ~15 hypotheses.  AnchorTab holds that half once per (pixel, view).
+// One record per tap / per anchor so that an evaluation reads each with a single private-memory
+// load, and the records of anchor k+1 are fetched while anchor k is evaluated.
+struct AnchorTap { float w, wa; s2 xy; };               // tap weight, weight * ref texel, tap pixel
+struct AnchorHead { float s_r, s_rr, s_w; s2 nb; int state; };   // reference sums (tap order 0..8), anchor pixel,
+                                                         // state: 0 absent, 1 visible in this view, 2 not visible
 struct AnchorTab {
-	float w[99], wa[99];              // tap weight, weight * ref texel
-	s2 xy[99];                        // tap pixel
-	float s_r[11], s_rr[11], s_w[11]; // reference sums per anchor (tap order 0..8)
-	s2 nb[11];                        // anchor pixel
-	uint8_t state[11];                // 0 absent, 1 visible in this view, 2 not visible
+	AnchorTap tap[99];
+	AnchorHead head[11];
 };
 
 DVP_HD void build_anchor_tab(const Dev& d, int center, int v, float cpix, AnchorTab* T) {
@@ -647,11 +649,13 @@ DVP_HD void build_anchor_tab(const Dev& d, int center, int v, float cpix, Anchor
 	const s2* nbs = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
 	for (int k = 1; k < DVP_NEIGHBOUR_NUM; ++k) {
 		const s2 nb = nbs[k];
-		T->nb[k - 1] = nb;
-		if (nb.x == -1 || nb.y == -1) { T->state[k - 1] = 0; continue; }
+		AnchorHead& hd = T->head[k - 1];
+		hd.nb = nb;
+		hd.s_r = hd.s_rr = hd.s_w = 0.0f;
+		if (nb.x == -1 || nb.y == -1) { hd.state = 0; continue; }
 		const int nbc = nb.x + nb.y * W;
 		const int visible = is_set(d.selected_views[nbc], v - 1);
-		T->state[k - 1] = visible ? 1 : 2;
+		hd.state = visible ? 1 : 2;
 		if (!visible) continue;
 		const s2* cand = d.candidate + ((size_t)nbc * S + (v - 1)) * 8;
 		s2 off[9];
@@ -669,7 +673,7 @@ DVP_HD void build_anchor_tab(const Dev& d, int center, int v, float cpix, Anchor
 				j = rj[t < 8 ? t : 0];
 			}
 			const int rx = nb.x + i, ry = nb.y + j;
-			T->xy[(k - 1) * 9 + t] = mks2(rx, ry);
+			T->tap[(k - 1) * 9 + t].xy = mks2(rx, ry);
 			av[t] = img_texel(ref, d.org, Pt, W, Hh, rx, ry);
 			wv[t] = bilateral_weight((float)i, (float)j, av[t], cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
 		}
@@ -677,15 +681,15 @@ DVP_HD void build_anchor_tab(const Dev& d, int center, int v, float cpix, Anchor
 #pragma unroll
 		for (int t = 0; t < 9; t++) {
 			const float wa = wv[t] * av[t];
-			T->w[(k - 1) * 9 + t] = wv[t];
-			T->wa[(k - 1) * 9 + t] = wa;
+			T->tap[(k - 1) * 9 + t].w = wv[t];
+			T->tap[(k - 1) * 9 + t].wa = wa;
 			s_r += wa;
 			s_rr += wa * av[t];
 			s_w += wv[t];
 		}
-		T->s_r[k - 1] = s_r;
-		T->s_rr[k - 1] = s_rr;
-		T->s_w[k - 1] = s_w;
+		hd.s_r = s_r;
+		hd.s_rr = s_rr;
+		hd.s_w = s_w;
 	}
 }
 
@@ -705,36 +709,62 @@ DVP_HD float ncc_new(const Dev& d, const PatchCtx& c, const AnchorTab& T, int px
 	                                 : ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
 	float strong_cost = 0.0f;
 	int strong_count = 0;
+	// records of the anchor being evaluated; the next anchor's are loaded at the top of the iteration
+	// and only needed at its bottom, so their latency hides behind this anchor's 9 gathers
+	AnchorHead hc = T.head[0];
+	AnchorTap cur[9];
+#pragma unroll
+	for (int t = 0; t < 9; t++) cur[t] = T.tap[t];
 	for (int k = 0; k < DVP_NEIGHBOUR_NUM - 1; ++k) {
-		const int st = T.state[k];
-		if (st == 0) continue;
-		const s2 nb = T.nb[k];
-		const f2 nsp = apply_homography(H, nb.x, nb.y);
-		if (nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh) {
-			if (st == 1) { strong_cost += 2.0f; strong_count++; }
-			continue;
-		}
-		float temp_cost = 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
-		if (st == 1) {
-			float bv[9];
+		const int kn = k + 1 < DVP_NEIGHBOUR_NUM - 1 ? k + 1 : k;
+		const AnchorHead hn = T.head[kn];
+		AnchorTap nxt[9];
 #pragma unroll
-			for (int t = 0; t < 9; t++) {
-				const s2 q = T.xy[k * 9 + t];
-				const f2 sp = apply_homography(H, q.x, q.y);
-				bv[t] = tex_linear_t<SMP>(src, Pt, W, Hh, sp.x, sp.y);
-			}
-			float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+		for (int t = 0; t < 9; t++) nxt[t] = T.tap[kn * 9 + t];
+		const int st = hc.state;
+		if (st != 0) {
+			const f2 nsp = apply_homography(H, hc.nb.x, hc.nb.y);
+			if (nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh) {
+				if (st == 1) { strong_cost += 2.0f; strong_count++; }
+			} else {
+				float temp_cost = 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
+				if (st == 1) {
+					// footprints of the 9 taps first, then the 9 gathers back to back, then the blends
+					unsigned off[9];
+					TapW<SMP> tw[9];
+					float qd[9][4], bv[9];
 #pragma unroll
-			for (int t = 0; t < 9; t++) {
-				const float wb = T.w[k * 9 + t] * bv[t];
-				s_s += wb;
-				s_ss = fmaf(wb, bv[t], s_ss);
-				s_rs = fmaf(T.wa[k * 9 + t], bv[t], s_rs);
+					for (int t = 0; t < 9; t++) {
+						const f2 sp = apply_homography(H, cur[t].xy.x, cur[t].xy.y);
+						tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t], &tw[t]);
+					}
+					sched_fence();
+#pragma unroll
+					for (int t = 0; t < 9; t++) load_quad(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
+					sched_fence();
+#pragma unroll
+					for (int t = 0; t < 9; t++) {
+						float fa, fb;
+						tap_weights(tw[t], &fa, &fb);
+						bv[t] = tex_lerp(fa, fb, qd[t][0], qd[t][1], qd[t][2], qd[t][3]);
+					}
+					float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+#pragma unroll
+					for (int t = 0; t < 9; t++) {
+						const float wb = cur[t].w * bv[t];
+						s_s += wb;
+						s_ss = fmaf(wb, bv[t], s_ss);
+						s_rs = fmaf(cur[t].wa, bv[t], s_rs);
+					}
+					temp_cost = ncc_from_sums(hc.s_r, hc.s_rr, s_s, s_ss, s_rs, hc.s_w);
+				}
+				strong_cost += temp_cost;
+				strong_count++;
 			}
-			temp_cost = ncc_from_sums(T.s_r[k], T.s_rr[k], s_s, s_ss, s_rs, T.s_w[k]);
 		}
-		strong_cost += temp_cost;
-		strong_count++;
+		hc = hn;
+#pragma unroll
+		for (int t = 0; t < 9; t++) cur[t] = nxt[t];
 	}
 	if (strong_count == 0) return center_cost;
 	strong_cost /= strong_count;
