@@ -192,7 +192,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "dvp_strong_update_v8" if S <= 8 else "dvp_strong_update", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "evals_per_launch": int(ev_launch), "bytes_per_eval": NCC_BYTES, "avg_launch_ms": round(avg_ms, 3),
-                         "launches": launches},
+                         "launches": launches,
+                         # traffic (PMC, profiles/pmc_strong_update.json) over the same launch time: what HBM + Infinity Cache really moved
+                         "physical_gbs": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if (traffic and avg_ms > 0) else None},
             "iter_loop_value": round(float(W) * H * iters * args.steps / (tm["iter_loop_ms"] * 1e-3) / 1e6, 3) if tm["iter_loop_ms"] > 0 else None,
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in tm["stage_ms"].items() if v > 0},
             "evals_per_px_iter_strong": round(evals["ncc_evals"]["strong_update"] / (float(W) * H * iters), 2),

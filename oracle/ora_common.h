@@ -11,25 +11,34 @@
 // restatement is anchored on the reference's source expressions, cited file:line per function,
 // not on outputs of the reference binary.
 //
-// Numerics contract (shared, by specification, with the HIP engine — DESIGN.md §Numerics):
-//  * every reference expression is evaluated in IEEE-754 binary32 (binary64 where the reference
-//    source promotes to double), one rounding per operator, no FMA contraction
-//    (build with -ffp-contract=off); division and sqrt are correctly rounded.  The reference was
-//    built with nvcc --use_fast_math (CMakeLists.txt:21), whose approximate div/exp/rsqrt are
-//    NVIDIA-specific and not reproducible; IEEE evaluation of the same expressions is the anchor.
-//  * exception, mirroring nvcc's lowering under --use_fast_math (-prec-div=false: a/b = a*rcp(b)):
-//    the divisions of ComputeHomography (by plane.w, K[0], K[4]) and ComputeCorrespondingPoint
-//    (by the projective z) are evaluated as a * (1.0f / b) with a correctly rounded reciprocal,
-//    one reciprocal per distinct divisor.  Every other division is a correctly rounded a / b.
+// Numerics contract (shared, by specification, with the HIP engine — DESIGN.md §Numerics).  The
+// reference was built with nvcc --use_fast_math (CMakeLists.txt:21) for NVIDIA's texture unit and
+// cuRAND: its low-order bits cannot be reproduced, so the contract fixes an evaluation order and a
+// rounding for every expression; each item moves results at the ulp level only.
+//  * every expression is evaluated in IEEE-754 binary32 (binary64 where the reference source
+//    promotes to double), one rounding per operator, no FMA contraction (build with
+//    -ffp-contract=off), fused operations written as explicit fmaf(); division and sqrt are
+//    correctly rounded.
+//  * mirroring nvcc's lowering under --use_fast_math (-prec-div=false: a/b = a*rcp(b)): the
+//    divisions of ComputeHomography (by plane.w, K[0], K[4]) and ComputeCorrespondingPoint (by the
+//    projective z) are evaluated as a * (1.0f / b) with a correctly rounded reciprocal, one
+//    reciprocal per distinct divisor.  Every other division is a correctly rounded a / b.
+//  * the NCC tap loops (APD.cu:1059-1089, 905-935) run row by row (y offset outer, x offset inner)
+//    with per-row partial sums added in row order; the projective divide of a row is taken six taps
+//    at a time through ONE division (batch_rcp, ora_core.h); the three source-side moments use one
+//    fmaf per tap.  ctx.numerics = 1 switches these loops (and the sampler) to the literal
+//    per-operator evaluation in the reference's own order; tests/test_oracle_kat.py measures the
+//    distance between the two (NCC costs: 4e-6 median, 5e-4 max).
 //  * exp() is the polynomial dvp_expf below (<= 1 ulp on the ranges used).
 //  * rsqrtf(x) is restated as 1.0f / sqrtf(x).
 //  * cuRAND XORWOW seeded by clock64() (APD.cu:1270) is replaced by a counter-based generator
 //    keyed by (seed, pixel, site, k): every logical sampling site owns a sub-stream, so the
 //    number of draws one site consumes never shifts another site's values.
-//  * tex2D<float> with cudaFilterModeLinear / unnormalised coords / clamp (APD.cpp:1501-1517) is
-//    restated in software: sample at (x-0.5, y-0.5), clamp-to-edge, interpolation weights either
-//    rounded to 8 fractional bits (sampler 0, "cuda8", CUDA Programming Guide "Linear
-//    Filtering") or exact (sampler 1).
+//  * tex2D<float>(x + 0.5f, y + 0.5f) with cudaFilterModeLinear / unnormalised coords / clamp
+//    (APD.cpp:1501-1517) is restated in software as a function of the pixel coordinate (x, y): the
+//    unit samples at coordinate - 0.5, which cancels the call sites' + 0.5f.  Clamp-to-edge;
+//    sampler 0 ("cuda8") converts the coordinate to fixed point with 8 fractional bits, round half
+//    up (CUDA Programming Guide, "Linear Filtering"); sampler 1 uses the exact floor / fraction.
 //  * MIN/MAX are OpenCV's macros (opencv2/core/cvdef.h): MIN(a,b)=((a)>(b)?(b):(a)),
 //    MAX(a,b)=((a)<(b)?(b):(a)); float min/max/fminf/fmaxf in device code are CUDA's
 //    NaN-ignoring fminf/fmaxf.
