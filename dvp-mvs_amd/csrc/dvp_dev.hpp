@@ -226,7 +226,12 @@ DVP_HD void tap_weights(const TapW<1>& w, float* a, float* b) { *a = w.a; *b = w
 DVP_HD unsigned tex_offset(int pitch, int i0, int j0) {
 	// i0 in [-1, W], j0 in [-1, H]: the footprint [i0, i0+1] x [j0, j0+1] lies inside the padded
 	// plane; (j0 + PAD) * pitch + (i0 + PAD) >= 0, the PAD terms are a wave-uniform constant
+	// |j0|, pitch < 2^23: 24-bit multiply (v_mad_i32_i24, full rate; a 32-bit multiply is quarter rate)
+#if defined(__HIP_DEVICE_COMPILE__)
+	const int e = __mul24(j0, pitch) + i0;
+#else
 	const int e = j0 * pitch + i0;
+#endif
 	return ((unsigned)e << 3) + (unsigned)((kImgPad * pitch + kImgPad) * 8);
 }
 DVP_HD void tex_coord(int pitch, int W, int H, float x, float y, unsigned* off, TapW<0>* w) {
