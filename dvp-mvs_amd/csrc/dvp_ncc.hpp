@@ -166,7 +166,8 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 	//   consume(p): 12 blends + the row sums, rows in order (row-then-total accumulation)
 	// ordered  coords0 issue0 | coords1 | consume0 issue1 | coords2 | consume1 issue2 | consume2:
 	// the 12 gathers of a pair are issued back to back and fly while the next pair's addresses are
-	// computed (two IEEE divisions + 12 footprints).  Taps of one row land on the same source
+	// computed (two IEEE divisions + 12 footprints).  (Issuing pair 2 before consume1 costs 40 spilled
+	// registers in the strong update and is slower; the last pair's latency stays exposed.)  Taps of one row land on the same source
 	// row pair (near-upright homographies): a lane with a hypothesis unrelated to its neighbours'
 	// touches 1-2 cache lines per row.
 	constexpr int kPair = 2 * kTaps;
@@ -193,6 +194,9 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 	_Pragma("unroll") for (int k = 0; k < kPair; ++k)                                               \
 		load_quad(src, off[BUF][k], &q[BUF][k][0], &q[BUF][k][1], &q[BUF][k][2], &q[BUF][k][3]);
 #define DVP_CONSUME(PR, BUF)                                                                        \
+	f2 tt##PR[kPair];   /* the pair's 12 table entries: all LDS reads issued before the first use */ \
+	_Pragma("unroll") for (int k = 0; k < kPair; ++k) tt##PR[k] = c.tab.get(2 * (PR) * kTaps + k);  \
+	sched_fence();                                                                                  \
 	_Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                 \
 		float r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f;                                                 \
 		_Pragma("unroll") for (int tx = 0; tx < kTaps; ++tx) {                                      \
@@ -200,7 +204,7 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 			float fa, fb;                                                                           \
 			tap_weights(tw[BUF][k], &fa, &fb);                                                      \
 			const float b = tex_lerp(fa, fb, q[BUF][k][0], q[BUF][k][1], q[BUF][k][2], q[BUF][k][3]); \
-			const f2 t = c.tab.get((2 * (PR) + r) * kTaps + tx);                                    \
+			const f2 t = tt##PR[k];                                                                 \
 			const float wsb = t.x * b;                                                              \
 			r_s += wsb;                                                                             \
 			r_ss = fmaf(wsb, b, r_ss);                                                              \
