@@ -76,6 +76,9 @@ struct Dev {
 	f4* fit_planes;
 	s2* candidate;             // [pixel][view][8]
 	const uint8_t* edge;
+	uint32_t* edge_bits;       // the edge map as 32x32-pixel bit tiles (128 B each), see edge_bit()
+	int edge_tiles_x;
+	uint32_t* strong_bits;     // same tiling, bit = (weak_info == STRONG); valid during GenNeighbours
 	s2* edge_neigh;            // 8 per pixel
 	const int* label;
 	s2* label_boundary;        // 8 per WEAK pixel
@@ -284,6 +287,35 @@ DVP_HD void batch_rcp(const float* z, int n, float* iz) {
 		r = r * z[k];
 	}
 	iz[0] = r;
+}
+
+// Edge map as bit tiles for the line walks of the weak path: tile (tx, ty) = 32 words, word r = row
+// r of the tile, bit b = column b.  A walk of ~100 pixels in any direction touches 4-6 tiles
+// (128 B each; the whole map is W*H/8 bytes and stays in L2) instead of one cache line per step.
+DVP_HD int edge_tiles_x(int W) { return (W + 31) >> 5; }
+DVP_HD size_t edge_bits_words(int W, int H) { return (size_t)edge_tiles_x(W) * ((H + 31) >> 5) * 32; }
+DVP_HD unsigned edge_bit(const Dev& d, int x, int y) {   // 0 <= x < W, 0 <= y < H
+	const unsigned w = d.edge_bits[(size_t)(((y >> 5) * d.edge_tiles_x + (x >> 5)) * 32 + (y & 31))];
+	return (w >> (x & 31)) & 1u;
+}
+DVP_HD unsigned strong_bit(const Dev& d, int x, int y) {
+	const unsigned w = d.strong_bits[(size_t)(((y >> 5) * d.edge_tiles_x + (x >> 5)) * 32 + (y & 31))];
+	return (w >> (x & 31)) & 1u;
+}
+// one word of a bit-tiled map from a byte map (host loop / one thread per word):
+// bit = (byte != 0) when `equals` < 0, else (byte == equals)
+DVP_HD uint32_t pack_edge_word(const uint8_t* edge, int W, int H, int tiles_x, size_t word, int equals = -1) {
+	const int r = (int)(word & 31);
+	const size_t tile = word >> 5;
+	const int ty = (int)(tile / tiles_x), tx = (int)(tile - (size_t)ty * tiles_x);
+	const int y = ty * 32 + r;
+	uint32_t v = 0;
+	if (y < H)
+		for (int b = 0; b < 32; ++b) {
+			const int x = tx * 32 + b;
+			if (x < W && (equals < 0 ? edge[(size_t)y * W + x] != 0 : edge[(size_t)y * W + x] == equals)) v |= 1u << b;
+		}
+	return v;
 }
 
 // ---- small geometry helpers (APD.cu:181-194, 331-422, 467-499, 750-768) ----------------------

@@ -142,6 +142,12 @@ extern "C" __global__ void dvp_interleave_rows(const float* __restrict__ in, flo
 	reinterpret_cast<float2*>(out + (size_t)pl * plane_stride * 2)[(size_t)y * pitch + x] = v;
 }
 
+// byte edge map -> 32x32 bit tiles (one thread per 32-bit word)
+extern "C" __global__ void dvp_pack_edge_bits(const uint8_t* __restrict__ edge, uint32_t* __restrict__ bits, int W, int H, int tiles_x, size_t words, int equals) {
+	const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w < words) bits[w] = pack_edge_word(edge, W, H, tiles_x, w, equals);
+}
+
 // line-scan pre-pass of GenEdgeInform: nearest edge pixel in 8 directions (blockIdx.y = direction)
 extern "C" __global__ void __launch_bounds__(256) dvp_edge_rays(const Dev d) {
 	edge_ray_line(d, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
@@ -202,6 +208,8 @@ struct dvp_ctx {
 	float* images = nullptr;        // row-pair planes (dvp_dev.hpp: img_texel / load_quad)
 	float* image_stage = nullptr;   // plain padded planes the uploads land in before dvp_interleave_rows
 	float* depths = nullptr;
+	uint32_t* edge_bits = nullptr;  // bit-tiled copy of `edge`, rebuilt before the launches that walk lines
+	uint32_t* strong_bits = nullptr; // bit-tiled (weak_info == STRONG), rebuilt before GenNeighbours
 	DvpCamera* cameras = nullptr; ViewConst* views = nullptr; uint8_t* lut = nullptr;
 	f4* planes = nullptr; f4* planes_snap = nullptr; f4* fit_planes = nullptr;
 	float* costs = nullptr; float* costs_snap = nullptr; float* complex_ = nullptr;
@@ -258,7 +266,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.selected_views = c->selected_views; d.view_weight = c->view_weight; d.weak_info = c->weak_info;
 	d.weak_reliable = c->weak_reliable; d.weak_nearest_strong = c->weak_nearest_strong;
 	d.neighbours_map = c->neighbours_map; d.neighbours = c->neighbours; d.fit_planes = c->fit_planes;
-	d.candidate = c->candidate; d.edge = c->edge; d.edge_neigh = c->edge_neigh; d.label = c->label;
+	d.candidate = c->candidate; d.edge = c->edge; d.edge_bits = c->edge_bits; d.strong_bits = c->strong_bits; d.edge_tiles_x = edge_tiles_x(c->W); d.edge_neigh = c->edge_neigh; d.label = c->label;
 	d.label_boundary = c->label_boundary; d.complex_ = c->complex_; d.radius = c->radius;
 	d.weak_list = c->weak_list;
 	d.eval_counter = c->profiling ? c->eval_counter : nullptr;
@@ -304,6 +312,8 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	r |= dalloc(c, &c->neighbours_map, L);
 	r |= dalloc(c, &c->candidate, L * S * 8);
 	r |= dalloc(c, &c->edge, L);
+	r |= dalloc(c, &c->edge_bits, edge_bits_words(width, height));
+	r |= dalloc(c, &c->strong_bits, edge_bits_words(width, height));
 	r |= dalloc(c, &c->edge_neigh, L * 8);
 	r |= dalloc(c, &c->label, L);
 	r |= dalloc(c, &c->radius, L);
@@ -534,6 +544,15 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 	const dim3 grid(g.grid()), block(256);
 	const bool list_stage = stage == DVP_ST_FIND_NEAREST_STRONG || stage == DVP_ST_GEN_NEIGHBOURS || stage == DVP_ST_NEIGHBOUR_UPDATE ||
 	                        stage == DVP_ST_RANSAC_FIT || stage == DVP_ST_WEAK_UPDATE;
+	if (stage == DVP_ST_GEN_NEIGHBOURS || stage == DVP_ST_RANSAC_FIT) {   // the launch sites that walk lines over the edge map
+		const size_t words = edge_bits_words(c->W, c->H);
+		hipLaunchKernelGGL(dvp_pack_edge_bits, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c->stream, c->edge, c->edge_bits, c->W, c->H, edge_tiles_x(c->W), words, -1);
+		HIP_TRY(c, hipGetLastError());
+		if (stage == DVP_ST_GEN_NEIGHBOURS) {   // its anchor search probes "is this pixel STRONG" all over the image
+			hipLaunchKernelGGL(dvp_pack_edge_bits, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c->stream, c->weak_info, c->strong_bits, c->W, c->H, edge_tiles_x(c->W), words, (int)DVP_STRONG);
+			HIP_TRY(c, hipGetLastError());
+		}
+	}
 	if (list_stage) {
 		// weak-path launch sites: lane-per-WEAK-pixel.  Non-WEAK pixels' outputs of these kernels are
 		// constants / copies and are produced by plain fills: weak_nearest_strong = (-1,-1)

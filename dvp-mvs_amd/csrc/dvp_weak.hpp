@@ -200,7 +200,8 @@ DVP_HD bool point_in_triangle(s2 A, s2 B, s2 C, int px, int py) {
 // The reference walks the line one pixel per loop iteration and tests the edge map after every step
 // (one dependent load per step, up to max(W,H)/30 of them).  The answer is "any visited pixel is
 // an edge pixel", so the walk is done in blocks of 8 steps: eight positions from the integer
-// line state, eight independent byte loads, one OR.  Visited set, step limit and the one-pixel
+// line state, eight independent loads from the bit-tiled edge map (dvp_dev.hpp: edge_bit), one OR.
+// Visited set, step limit and the one-pixel
 // overshoot past the end point (the loop condition is tested after the step) are the reference's.
 DVP_HD bool bresenham_hits_edge(const Dev& d, int Ax, int Ay, int Bx, int By) {
 	const int W = d.width, H = d.height;
@@ -209,7 +210,7 @@ DVP_HD bool bresenham_hits_edge(const Dev& d, int Ax, int Ay, int Bx, int By) {
 	const int x1 = Ax, y1 = Ay;
 	const int ABx = Ax - Bx, ABy = Ay - By;
 	if (ABx * ABx + ABy * ABy > 9 * max_step * max_step) return false;
-	if (d.edge[x0 + y0 * W] || d.edge[x1 + y1 * W]) return false;
+	if (edge_bit(d, x0, y0) || edge_bit(d, x1, y1)) return false;
 	const int dx = x1 > x0 ? x1 - x0 : x0 - x1, sx = x0 < x1 ? 1 : -1;
 	const int dy = y1 > y0 ? y1 - y0 : y0 - y1, sy = y0 < y1 ? 1 : -1;
 	int erro = (dx > dy ? dx : dy) / 2;
@@ -217,24 +218,28 @@ DVP_HD bool bresenham_hits_edge(const Dev& d, int Ax, int Ay, int Bx, int By) {
 	bool tagx = true, tagy = true;
 	bool alive = true;       // the reference's loop would still be running
 	while (alive) {
-		int idx[8];
+		int wi[8], sh[8];   // word index in the bit-tiled map (-1: outside the image), bit
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
-			idx[k] = -1;
+			wi[k] = -1;
+			sh[k] = 0;
 			if (alive) {
 				if (x0 == x1) tagx = false;
 				if (y0 == y1) tagy = false;
 				const int e2 = erro;
 				if (e2 > -dx) { erro -= dy; x0 += sx; }
 				if (e2 < dy) { erro += dx; y0 += sy; }
-				if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H) idx[k] = x0 + y0 * W;
+				if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H) {
+					wi[k] = ((y0 >> 5) * d.edge_tiles_x + (x0 >> 5)) * 32 + (y0 & 31);
+					sh[k] = x0 & 31;
+				}
 				step += 1;
 				if (step >= max_step || !(tagx || tagy)) alive = false;
 			}
 		}
 		unsigned hit = 0;
 #pragma unroll
-		for (int k = 0; k < 8; ++k) hit |= (unsigned)d.edge[idx[k] < 0 ? 0 : idx[k]] & (idx[k] < 0 ? 0u : 0xFFu);
+		for (int k = 0; k < 8; ++k) hit |= (d.edge_bits[wi[k] < 0 ? 0 : wi[k]] >> sh[k]) & (wi[k] < 0 ? 0u : 1u);
 		if (hit) return true;
 	}
 	return false;
@@ -295,7 +300,7 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 						s2 np = mks2((int)(px + dir.x * radius), (int)(py + dir.y * radius));
 						if (np.x < min_margin || np.y < min_margin || np.x >= W - min_margin || np.y >= H - min_margin) continue;
 						int npc = np.x + np.y * W;
-						if (d.weak_info[npc] != DVP_STRONG) {
+						if (!strong_bit(d, np.x, np.y)) {   // weak_info[npc] != STRONG, from the L2-resident bit map
 							np = d.weak_nearest_strong[npc];
 							if (np.x == -1 || np.y == -1) continue;
 							npc = np.x + np.y * W;
@@ -358,7 +363,7 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 				s2 np = mks2(px + step * step_len * ldx[i], py + step * step_len * ldy[i]);
 				if (np.x < min_margin || np.y < min_margin || np.x >= W - min_margin || np.y >= H - min_margin) continue;
 				int npc = np.x + np.y * W;
-				if (d.weak_info[npc] != DVP_STRONG) {
+				if (!strong_bit(d, np.x, np.y)) {
 					np = d.weak_nearest_strong[npc];
 					if (np.x == -1 || np.y == -1) continue;
 					npc = np.x + np.y * W;

@@ -23,6 +23,7 @@ struct Emu {
 	std::vector<float> costs, costs_snap, complex_;
 	std::vector<uint32_t> selected_views;
 	std::vector<uint8_t> view_weight, weak_info, weak_reliable, edge;
+	std::vector<uint32_t> edge_bits, strong_bits;
 	std::vector<s2> weak_nearest_strong, neighbours, candidate, edge_neigh, label_boundary;
 	std::vector<int> neighbours_map, label, radius;
 	unsigned long long evals = 0;
@@ -52,6 +53,9 @@ void refresh(Emu& e) {
 	d.fit_planes = e.fit_planes.data();
 	d.candidate = e.candidate.data();
 	d.edge = e.edge.data();
+	d.edge_bits = e.edge_bits.data();
+	d.strong_bits = e.strong_bits.data();
+	d.edge_tiles_x = edge_tiles_x(e.W);
 	d.edge_neigh = e.edge_neigh.data();
 	d.label = e.label.data();
 	d.label_boundary = e.label_boundary.data();
@@ -109,6 +113,8 @@ void* emu_create(int W, int H, int NI) {
 	e->neighbours.assign(DVP_NEIGHBOUR_NUM, mks2(-1, -1));
 	e->candidate.assign(L * (size_t)(S > 0 ? S : 1) * 8, mks2(0, 0));
 	e->edge.assign(L, 0);
+	e->edge_bits.assign(edge_bits_words(W, H), 0u);
+	e->strong_bits.assign(edge_bits_words(W, H), 0u);
 	e->edge_neigh.assign(L * 8, mks2(-1, -1));
 	e->label.assign(L, 0);
 	e->label_boundary.assign(8, mks2(-1, -1));
@@ -211,6 +217,11 @@ int emu_get_buffer(void* c, int id, void* dst) { size_t b; void* p = buf_ptr(*(E
 int emu_set_buffer(void* c, int id, const void* src) { size_t b; void* p = buf_ptr(*(Emu*)c, id, &b); if (!p) return -1; std::memcpy(p, src, b); return 0; }
 int emu_weak_count(void* c) { return ((Emu*)c)->d.weak_count; }
 
+// dvp_pack_edge_bits
+static void pack_edge(Emu& e) {
+	for (size_t w = 0; w < e.edge_bits.size(); ++w) e.edge_bits[w] = pack_edge_word(e.edge.data(), e.W, e.H, edge_tiles_x(e.W), w);
+}
+
 int emu_run_stage(void* c, int stage, int iter, int colour) {
 	Emu& e = *(Emu*)c;
 	switch (stage) {
@@ -223,7 +234,11 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 		launch<DVP_ST_GEN_EDGE_INFORM>(e, iter, colour);
 		break;
 	case DVP_ST_FIND_NEAREST_STRONG: launch<DVP_ST_FIND_NEAREST_STRONG>(e, iter, colour); break;
-	case DVP_ST_GEN_NEIGHBOURS: launch<DVP_ST_GEN_NEIGHBOURS>(e, iter, colour); break;
+	case DVP_ST_GEN_NEIGHBOURS:
+		pack_edge(e);
+		for (size_t w = 0; w < e.strong_bits.size(); ++w) e.strong_bits[w] = pack_edge_word(e.weak_info.data(), e.W, e.H, edge_tiles_x(e.W), w, (int)DVP_STRONG);
+		launch<DVP_ST_GEN_NEIGHBOURS>(e, iter, colour);
+		break;
 	case DVP_ST_NEIGHBOUR_UPDATE: launch<DVP_ST_NEIGHBOUR_UPDATE>(e, iter, colour); break;
 	case DVP_ST_RANDOM_INIT: launch<DVP_ST_RANDOM_INIT>(e, iter, colour); break;
 	case DVP_ST_STRONG_UPDATE:
@@ -232,7 +247,7 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 		refresh(e);
 		launch<DVP_ST_STRONG_UPDATE>(e, iter, colour);
 		break;
-	case DVP_ST_RANSAC_FIT: launch<DVP_ST_RANSAC_FIT>(e, iter, colour); break;
+	case DVP_ST_RANSAC_FIT: pack_edge(e); launch<DVP_ST_RANSAC_FIT>(e, iter, colour); break;
 	case DVP_ST_WEAK_UPDATE: launch<DVP_ST_WEAK_UPDATE>(e, iter, colour); break;
 	case DVP_ST_GET_DEPTH_NORMAL: launch<DVP_ST_GET_DEPTH_NORMAL>(e, iter, colour); break;
 	case DVP_ST_FILTER_STRONG: launch<DVP_ST_FILTER_STRONG>(e, iter, colour); break;
