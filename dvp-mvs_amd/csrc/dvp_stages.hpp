@@ -17,10 +17,10 @@ namespace dvp {
 //    grid covers 16*ceil((H/2)/16) row pairs (APD.cu:4421-4424): for odd H with (H/2)%16 == 0 the
 //    last row is never updated; `rows()` reproduces that.
 struct LaunchGeom {
-	int tiles_x, tiles_y, tiles, chunk;   // chunk = tiles per XCD
+	int tiles_x, tiles_y, tiles, chunk;   // chunk: unused (kept so that LaunchArgs stays layout-compatible)
 	int rows;                             // rows (full) or row pairs (half) covered
 	bool half;
-	int grid() const { return chunk * 8; }
+	int grid() const { return tiles; }
 };
 inline LaunchGeom make_geom(int W, int H, bool half) {
 	LaunchGeom g;
@@ -34,13 +34,28 @@ inline LaunchGeom make_geom(int W, int H, bool half) {
 }
 
 // XCD-aware block -> tile map.  Workgroup b is dispatched to XCD b % 8 (observed placement, a
-// speed matter only): give every XCD one contiguous band of tiles so that neighbouring tiles,
-// which gather overlapping source-image lines, share that XCD's 4 MiB L2.
+// speed matter only).  Tiles are traversed in vertical strips of 8 tile columns: inside a strip
+// XCD j owns column j and walks it top to bottom, so its 64 resident tiles form a 64 x 512-pixel
+// block whose source rows fit its 4 MiB L2, and the eight XCDs work side by side on the same image
+// rows (shared in the Infinity Cache).  The ragged last strip is dealt row-major over all XCDs.
+// Measured (3104x2064, S=5, ms per strong-update launch): one contiguous band of the image per XCD
+// 22.8, plain row-major 20.4, this map 19.3.
 DVP_HD bool block_to_pixel(int block, int lane, int wave, int tiles_x, int tiles, int chunk, int rows, int half, int colour,
 	int W, int H, int* px, int* py) {
-	const int tile = (block & 7) * chunk + (block >> 3);
-	if (tile >= tiles) return false;
-	const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+	if (block >= tiles) return false;
+	const int tiles_y = tiles / tiles_x;
+	const int per_strip = 8 * tiles_y;
+	const int st = block / per_strip;
+	const int rem = block - st * per_strip;
+	const int w_last = tiles_x - st * 8;             // columns left in this strip
+	int ty, tx;
+	if (w_last >= 8) {
+		ty = rem >> 3;
+		tx = st * 8 + (rem & 7);
+	} else {
+		ty = rem / w_last;
+		tx = st * 8 + (rem - ty * w_last);
+	}
 	const int x = tx * 64 + lane;
 	const int r = ty * 4 + wave;
 	if (x >= W || r >= rows) return false;
