@@ -286,18 +286,34 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 			odi++;
 			for (int rot = 0; rot < rotate_time; ++rot) {
 				const int dir_index = odi * 4 + rot;
-				bool found_dir = false;
-				for (int radius = 2; radius <= 4096; radius = DVP_MIN(radius * 2, radius + 25)) {
-					const float tx = px + od.x * radius, ty = py + od.y * radius;
-					if (tx < 0 || ty < 0 || tx >= W || ty >= H) break;
-					for (int ri = 0; ri < 4; ++ri) {
+				// The (radius, try) double loop of APD.cu:3396-3452 as a state machine in two alternating
+				// phases: (A) advance through the tries until one passes the cheap tests, (B) the line walk
+				// of that try for all lanes of the wave together.  Try order and RNG consumption per lane
+				// are unchanged.
+				bool found_dir = false, out = false;
+				int radius = 2, ri = 0;
+				while (!found_dir && !out) {
+					bool cand = false;
+					s2 np = mks2(-1, -1);
+					while (!out) {
+						if (ri == 0) {   // entering a new radius: the ray must still be inside the image
+							const float tx = px + od.x * radius, ty = py + od.y * radius;
+							if (tx < 0 || ty < 0 || tx >= W || ty >= H) { out = true; break; }
+						}
+						const int cur_radius = radius;
+						// advance the state first: the try below may leave the inner loop
+						if (++ri == 4) {
+							ri = 0;
+							radius = DVP_MIN(radius * 2, radius + 25);
+							if (radius > 4096) out = true;
+						}
 						const uint32_t sgx = (r_search.next() % 2 == 0) ? 1u : 0xFFFFFFFFu;
 						const int xs = (int)((sgx * r_search.next()) % (uint32_t)d.nb_shift_range);
 						const uint32_t sgy = (r_search.next() % 2 == 0) ? 1u : 0xFFFFFFFFu;
 						const int ys = (int)((sgy * r_search.next()) % (uint32_t)d.nb_shift_range);
 						f2 dir = mk2(od.x * 20 + xs, od.y * 20 + ys);
 						normalize2(&dir);
-						s2 np = mks2((int)(px + dir.x * radius), (int)(py + dir.y * radius));
+						np = mks2((int)(px + dir.x * cur_radius), (int)(py + dir.y * cur_radius));
 						if (np.x < min_margin || np.y < min_margin || np.x >= W - min_margin || np.y >= H - min_margin) continue;
 						int npc = np.x + np.y * W;
 						if (!strong_bit(d, np.x, np.y)) {   // weak_info[npc] != STRONG, from the L2-resident bit map
@@ -312,14 +328,16 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 						f2 td = mk2((float)(np.x - px), (float)(np.y - py));
 						normalize2(&td);
 						const float cos_a = td.x * od.x + td.y * od.y;
-						if (cos_a > d.nb_thresh && (!edge_limit || !bresenham_hits_edge(d, px, py, np.x, np.y))) {
-							strong_points[dir_index] = np;
-							strong_point_size++;
-							found_dir = true;
-							break;
-						}
+						if (!(cos_a > d.nb_thresh)) continue;
+						cand = true;
+						break;
 					}
-					if (found_dir) break;
+					if (!cand) break;
+					if (!edge_limit || !bresenham_hits_edge(d, px, py, np.x, np.y)) {
+						strong_points[dir_index] = np;
+						strong_point_size++;
+						found_dir = true;
+					}
 				}
 				f2 rd;
 				rd.x = od.x * d.nb_cos - od.y * d.nb_sin;
@@ -410,13 +428,22 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 		float min_cost = FLT_MAX;
 		int max_count = 3;
 		bool has_strong_plane = false;
-		while (iteration > 0 && max_iter > 0) {
-			max_iter--;
-			const int ai = (int)(r_ransac.next() % (uint32_t)valid_count);
-			const int bi = (int)(r_ransac.next() % (uint32_t)valid_count);
-			const int ci = (int)(r_ransac.next() % (uint32_t)valid_count);
-			if (ai == bi || bi == ci || ai == ci) continue;
-			if (!point_in_triangle(spv[ai], spv[bi], spv[ci], px, py)) continue;
+		// two alternating phases (see ransac_fit_plane_px): (A) draws until one survives the cheap
+		// rejections, (B) line walks + plane + inlier count for all lanes that hold a candidate
+		for (;;) {
+			bool cand = false;
+			int ai = 0, bi = 0, ci = 0;
+			while (iteration > 0 && max_iter > 0) {
+				max_iter--;
+				ai = (int)(r_ransac.next() % (uint32_t)valid_count);
+				bi = (int)(r_ransac.next() % (uint32_t)valid_count);
+				ci = (int)(r_ransac.next() % (uint32_t)valid_count);
+				if (ai == bi || bi == ci || ai == ci) continue;
+				if (!point_in_triangle(spv[ai], spv[bi], spv[ci], px, py)) continue;
+				cand = true;
+				break;
+			}
+			if (!cand) break;
 			if (edge_limit) {
 				// the reference memoises these tests in a 25 KB per-thread table (APD.cu:3574); the test
 				// is a pure function of its end points, so it is re-evaluated instead
@@ -536,15 +563,30 @@ DVP_HD void ransac_fit_plane_px(const Dev& d, int px, int py, int iter) {
 	float min_cost = FLT_MAX;
 	f4 best_plane = mk4(0, 0, 0, 0);
 	bool has_best = false;
-	for (int it = 0; it < 50; ++it) {
-		const int ai = (int)(r_ransac.next() % (uint32_t)cnt);
-		const int bi = (int)(r_ransac.next() % (uint32_t)cnt);
-		const int ci = (int)(r_ransac.next() % (uint32_t)cnt);
-		if (ai == bi || bi == ci || ai == ci) continue;
-		const f3 AN = spn[ai], BN = spn[bi], CN = spn[ci];
-		if (AN.x * BN.x + AN.y * BN.y + AN.z * BN.z < 0.9f || AN.x * CN.x + AN.y * CN.y + AN.z * CN.z < 0.9f ||
-			BN.x * CN.x + BN.y * CN.y + BN.z * CN.z < 0.9f) continue;
-		if (!point_in_triangle(sp[ai], sp[bi], sp[ci], px, py)) continue;
+	// The 50 draws (APD.cu:4262-4330) in two alternating phases so that the lanes of a wave do the
+	// expensive part together: (A) each lane advances through its own draws until one survives the
+	// cheap rejections (distinct indices, normals, pixel inside the triangle); (B) every lane that has
+	// a candidate runs the line walks, the plane fit and the residual sum.  Same draws, same order,
+	// same tests per lane — only the interleaving across lanes changes (a draw that fails a cheap
+	// test no longer makes 63 other lanes wait through the walks of the one lane that passed).
+	int it = 0;
+	for (;;) {
+		bool cand = false;
+		int ai = 0, bi = 0, ci = 0;
+		while (it < 50) {
+			++it;
+			ai = (int)(r_ransac.next() % (uint32_t)cnt);
+			bi = (int)(r_ransac.next() % (uint32_t)cnt);
+			ci = (int)(r_ransac.next() % (uint32_t)cnt);
+			if (ai == bi || bi == ci || ai == ci) continue;
+			const f3 AN = spn[ai], BN = spn[bi], CN = spn[ci];
+			if (AN.x * BN.x + AN.y * BN.y + AN.z * BN.z < 0.9f || AN.x * CN.x + AN.y * CN.y + AN.z * CN.z < 0.9f ||
+				BN.x * CN.x + BN.y * CN.y + BN.z * CN.z < 0.9f) continue;
+			if (!point_in_triangle(sp[ai], sp[bi], sp[ci], px, py)) continue;
+			cand = true;
+			break;
+		}
+		if (!cand) break;
 		if (edge_limit) {
 			if (bresenham_hits_edge(d, sp[ai].x, sp[ai].y, sp[bi].x, sp[bi].y) ||
 				bresenham_hits_edge(d, sp[bi].x, sp[bi].y, sp[ci].x, sp[ci].y) ||
