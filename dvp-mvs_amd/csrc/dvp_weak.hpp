@@ -819,6 +819,130 @@ DVP_HD float ncc_new(const Dev& d, const PatchCtx& c, const AnchorTab& T, int px
 	return (float)(0.25 * center_cost + 0.75 * strong_cost);
 }
 
+// ncc_new for ALL live planes of a phase and one view, with the planes innermost per anchor tap.
+// The anchor sub-patches are bandwidth-bound: a 16-byte footprint pulls a 128-byte line nobody else
+// reuses before it is evicted.  The planes of a phase project an anchor tap to neighbouring texels,
+// so evaluating a tap for four planes back to back lets them share the line.  Per plane the
+// arithmetic and its order are exactly those of ncc_new (taps 0..8 per anchor, anchors 1..11).
+//   pass 1: centre patch per live plane (rolled loop, one inlined evaluator)
+//   pass 2: groups of 4 plane slots; per anchor, 3 rounds of (3 taps x 4 planes) = 12 gathers
+template <int SMP>
+DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const AnchorTab& T, int px, int py, int v, const f4* pl /*[8]*/,
+	uint32_t pmask, float* ev /*[8][32], column v-1 written*/) {
+	const DvpCamera& rc = d.cameras[0];
+	const DvpCamera& sc = d.cameras[v];
+	const int W = d.width, Hh = d.height, Pt = d.pitch;
+	const float* src = d.images + (size_t)v * d.plane_stride * 2;
+	float center_cost[8];
+	uint32_t live = 0;   // planes whose centre projects inside the source image
+	for (int q = 0; q < 8; ++q) {
+		if (!((pmask >> q) & 1)) continue;
+		float H[9];
+		homography(rc, sc, d.views[v], pl[q], H);
+		const f2 pt = apply_homography(H, px, py);
+		if (pt.x >= sc.width || pt.x < 0.0f || pt.y >= sc.height || pt.y < 0.0f) { ev[q * 32 + v - 1] = 2.0f; continue; }
+		live |= 1u << q;
+		center_cost[q] = c.fast ? ncc_patch_fast<SMP>(d, c, H, src, px, py) : ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
+	}
+	for (int base = 0; base < 8; base += 4) {
+		const uint32_t gm = (live >> base) & 0xFu;
+		if (!gm) continue;
+		float H[4][9];
+		float scost[4], scnt[4];
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			scost[g] = 0.0f;
+			scnt[g] = 0.0f;
+			if ((gm >> g) & 1) homography(rc, sc, d.views[v], pl[base + g], H[g]);
+			else { for (int i = 0; i < 9; ++i) H[g][i] = 0.0f; H[g][8] = 1.0f; }   // dead slot: maps everything to (0,0)
+		}
+		for (int k = 0; k < DVP_NEIGHBOUR_NUM - 1; ++k) {
+			const AnchorHead hc = T.head[k];
+			const int st = hc.state;
+			if (st == 0) continue;
+			uint32_t act = 0;   // slots whose anchor projects inside the source image
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				if (!((gm >> g) & 1)) continue;
+				const f2 nsp = apply_homography(H[g], hc.nb.x, hc.nb.y);
+				if (nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh) {
+					if (st == 1) { scost[g] += 2.0f; scnt[g] += 1.0f; }
+				} else {
+					act |= 1u << g;
+				}
+			}
+			if (!act) continue;
+			if (st != 1) {   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
+#pragma unroll
+				for (int g = 0; g < 4; ++g)
+					if ((act >> g) & 1) { scost[g] += 2.0f; scnt[g] += 1.0f; }
+				continue;
+			}
+			float s_s[4], s_ss[4], s_rs[4];
+#pragma unroll
+			for (int g = 0; g < 4; ++g) { s_s[g] = 0.0f; s_ss[g] = 0.0f; s_rs[g] = 0.0f; }
+#pragma unroll
+			for (int r3 = 0; r3 < 3; ++r3) {
+				AnchorTap tp[3];
+				unsigned off[3][4];
+				TapW<SMP> tw[3][4];
+				float qd[3][4][4];
+#pragma unroll
+				for (int t = 0; t < 3; ++t) {
+					tp[t] = T.tap[k * 9 + r3 * 3 + t];
+#pragma unroll
+					for (int g = 0; g < 4; ++g) {
+						off[t][g] = 0;
+						tw[t][g] = TapW<SMP>();
+						if (!((act >> g) & 1)) continue;   // slot dead or anchor outside for this plane
+						const f2 sp = apply_homography(H[g], tp[t].xy.x, tp[t].xy.y);
+						tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t][g], &tw[t][g]);
+					}
+				}
+				sched_fence();
+#pragma unroll
+				for (int t = 0; t < 3; ++t)
+#pragma unroll
+					for (int g = 0; g < 4; ++g) {
+						qd[t][g][0] = qd[t][g][1] = qd[t][g][2] = qd[t][g][3] = 0.0f;
+						if ((act >> g) & 1) load_quad(src, off[t][g], &qd[t][g][0], &qd[t][g][1], &qd[t][g][2], &qd[t][g][3]);
+					}
+				sched_fence();
+#pragma unroll
+				for (int t = 0; t < 3; ++t)
+#pragma unroll
+					for (int g = 0; g < 4; ++g) {
+						if (!((act >> g) & 1)) continue;
+						float fa, fb;
+						tap_weights(tw[t][g], &fa, &fb);
+						const float b = tex_lerp(fa, fb, qd[t][g][0], qd[t][g][1], qd[t][g][2], qd[t][g][3]);
+						const float wb = tp[t].w * b;
+						s_s[g] += wb;
+						s_ss[g] = fmaf(wb, b, s_ss[g]);
+						s_rs[g] = fmaf(tp[t].wa, b, s_rs[g]);
+					}
+			}
+#pragma unroll
+			for (int g = 0; g < 4; ++g)
+				if ((act >> g) & 1) {
+					scost[g] += ncc_from_sums(hc.s_r, hc.s_rr, s_s[g], s_ss[g], s_rs[g], hc.s_w);
+					scnt[g] += 1.0f;
+				}
+		}
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			if (!((gm >> g) & 1)) continue;
+			float out = center_cost[base + g];
+			if (scnt[g] > 0.0f) {
+				float sc2 = scost[g] / scnt[g];   // strong_cost /= strong_count (int -> float, exact)
+				sc2 = DVP_MIN(sc2, 2.0f);
+				out = (float)(0.25 * center_cost[base + g] + 0.75 * sc2);
+			}
+			ev[(base + g) * 32 + v - 1] = out;
+		}
+	}
+}
+
 // ---- CheckerboardPropagationWeak + PlaneHypothesisRefinementWeak (APD.cu:2739-3089, 1897-2008) --
 // Three view-major phases through ONE inlined copy of ncc_new, so that the anchor table of a view
 // is built once per phase instead of once per hypothesis:
@@ -946,11 +1070,8 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter,
 			for (int v = 0; v < S; ++v) {
 				if (!((vmask >> v) & 1)) continue;
 				build_anchor_tab(d, center, v + 1, cpix, &T);
-				for (int q = 0; q < 8; ++q) {
-					if (!((pmask >> q) & 1)) continue;
-					ev[q * 32 + v] = ncc_new<SMP>(d, c, T, px, py, v + 1, pl[q]);
-					if (nevals) *nevals += 1;
-				}
+				ncc_new_multi<SMP>(d, c, T, px, py, v + 1, pl, pmask, ev);
+				if (nevals) *nevals += (unsigned long long)__builtin_popcount(pmask);
 			}
 		}
 
