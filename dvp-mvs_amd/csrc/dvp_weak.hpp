@@ -740,90 +740,14 @@ DVP_HD void build_anchor_tab(const Dev& d, int center, int v, float cpix, Anchor
 	}
 }
 
-// `c` = centre-patch context built with colour-only weights (ComputeBilateralWeight_YZL).
-template <int SMP>
-DVP_HD float ncc_new(const Dev& d, const PatchCtx& c, const AnchorTab& T, int px, int py, int v, const f4 plane) {
-	const DvpCamera& rc = d.cameras[0];
-	const DvpCamera& sc = d.cameras[v];
-	const int W = d.width, Hh = d.height, Pt = d.pitch;
-	float H[9];
-	homography(rc, sc, d.views[v], plane, H);
-	const f2 pt = apply_homography(H, px, py);
-	if (pt.x >= sc.width || pt.x < 0.0f || pt.y >= sc.height || pt.y < 0.0f) return 2.0f;
-	const float* src = d.images + (size_t)v * d.plane_stride * 2;
-	// k == 0: the pixel's own patch (neighbours[0] is the pixel itself, APD.cu:3365)
-	const float center_cost = c.fast ? ncc_patch_fast<SMP>(d, c, H, src, px, py)
-	                                 : ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
-	float strong_cost = 0.0f;
-	int strong_count = 0;
-	// records of the anchor being evaluated; the next anchor's are loaded at the top of the iteration
-	// and only needed at its bottom, so their latency hides behind this anchor's 9 gathers
-	AnchorHead hc = T.head[0];
-	AnchorTap cur[9];
-#pragma unroll
-	for (int t = 0; t < 9; t++) cur[t] = T.tap[t];
-	for (int k = 0; k < DVP_NEIGHBOUR_NUM - 1; ++k) {
-		const int kn = k + 1 < DVP_NEIGHBOUR_NUM - 1 ? k + 1 : k;
-		const AnchorHead hn = T.head[kn];
-		AnchorTap nxt[9];
-#pragma unroll
-		for (int t = 0; t < 9; t++) nxt[t] = T.tap[kn * 9 + t];
-		const int st = hc.state;
-		if (st != 0) {
-			const f2 nsp = apply_homography(H, hc.nb.x, hc.nb.y);
-			if (nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh) {
-				if (st == 1) { strong_cost += 2.0f; strong_count++; }
-			} else {
-				float temp_cost = 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
-				if (st == 1) {
-					// footprints of the 9 taps first, then the 9 gathers back to back, then the blends
-					unsigned off[9];
-					TapW<SMP> tw[9];
-					float qd[9][4], bv[9];
-#pragma unroll
-					for (int t = 0; t < 9; t++) {
-						const f2 sp = apply_homography(H, cur[t].xy.x, cur[t].xy.y);
-						tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t], &tw[t]);
-					}
-					sched_fence();
-#pragma unroll
-					for (int t = 0; t < 9; t++) load_quad(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
-					sched_fence();
-#pragma unroll
-					for (int t = 0; t < 9; t++) {
-						float fa, fb;
-						tap_weights(tw[t], &fa, &fb);
-						bv[t] = tex_lerp(fa, fb, qd[t][0], qd[t][1], qd[t][2], qd[t][3]);
-					}
-					float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
-#pragma unroll
-					for (int t = 0; t < 9; t++) {
-						const float wb = cur[t].w * bv[t];
-						s_s += wb;
-						s_ss = fmaf(wb, bv[t], s_ss);
-						s_rs = fmaf(cur[t].wa, bv[t], s_rs);
-					}
-					temp_cost = ncc_from_sums(hc.s_r, hc.s_rr, s_s, s_ss, s_rs, hc.s_w);
-				}
-				strong_cost += temp_cost;
-				strong_count++;
-			}
-		}
-		hc = hn;
-#pragma unroll
-		for (int t = 0; t < 9; t++) cur[t] = nxt[t];
-	}
-	if (strong_count == 0) return center_cost;
-	strong_cost /= strong_count;
-	strong_cost = DVP_MIN(strong_cost, 2.0f);
-	return (float)(0.25 * center_cost + 0.75 * strong_cost);
-}
-
-// ncc_new for ALL live planes of a phase and one view, with the planes innermost per anchor tap.
+// ComputeBilateralNCCNew for ALL live planes of a phase and one view, with the planes innermost per
+// anchor tap.  `c` = centre-patch context built with colour-only weights (ComputeBilateralWeight_YZL);
+// neighbours[0] is the pixel itself (APD.cu:3365), anchors 1..11 come from the table.
 // The anchor sub-patches are bandwidth-bound: a 16-byte footprint pulls a 128-byte line nobody else
 // reuses before it is evicted.  The planes of a phase project an anchor tap to neighbouring texels,
 // so evaluating a tap for four planes back to back lets them share the line.  Per plane the
-// arithmetic and its order are exactly those of ncc_new (taps 0..8 per anchor, anchors 1..11).
+// arithmetic and its order are those of the reference's per-plane loop (taps 0..8 per anchor,
+// anchors 1..11 in order, APD.cu:905-1014).
 //   pass 1: centre patch per live plane (rolled loop, one inlined evaluator)
 //   pass 2: groups of 4 plane slots; per anchor, 3 rounds of (3 taps x 4 planes) = 12 gathers
 template <int SMP>
@@ -944,8 +868,8 @@ DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const AnchorTab& T, i
 }
 
 // ---- CheckerboardPropagationWeak + PlaneHypothesisRefinementWeak (APD.cu:2739-3089, 1897-2008) --
-// Three view-major phases through ONE inlined copy of ncc_new, so that the anchor table of a view
-// is built once per phase instead of once per hypothesis:
+// Three view-major phases through ONE inlined copy of ncc_new_multi, so that the anchor table of a
+// view is built once per phase instead of once per hypothesis:
 //   phase 0: the planes of the <= 8 STRONG anchors x all views            -> view selection
 //   phase 1: the current plane and the RANSAC fit plane x selected views  -> adoption, fit test
 //   phase 2: 5 refinement hypotheses x selected views                     -> sequential acceptance
