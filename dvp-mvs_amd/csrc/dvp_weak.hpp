@@ -428,41 +428,49 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 		float min_cost = FLT_MAX;
 		int max_count = 3;
 		bool has_strong_plane = false;
-		// two alternating phases (see ransac_fit_plane_px): (A) draws until one survives the cheap
-		// rejections, (B) line walks + plane + inlier count for all lanes that hold a candidate
+		// three alternating phases (see ransac_fit_plane_px): (A) draws until one survives the cheap
+		// rejections — distinct indices, pixel inside the triangle, normal length, non-degenerate plane
+		// (all pure tests: their order does not matter) —, (B) the three line walks, back to (A) on an
+		// edge hit, (C) inlier count and bookkeeping for all lanes that hold a survivor
 		for (;;) {
-			bool cand = false;
+			bool ok = false;
 			int ai = 0, bi = 0, ci = 0;
-			while (iteration > 0 && max_iter > 0) {
-				max_iter--;
-				ai = (int)(r_ransac.next() % (uint32_t)valid_count);
-				bi = (int)(r_ransac.next() % (uint32_t)valid_count);
-				ci = (int)(r_ransac.next() % (uint32_t)valid_count);
-				if (ai == bi || bi == ci || ai == ci) continue;
-				if (!point_in_triangle(spv[ai], spv[bi], spv[ci], px, py)) continue;
-				cand = true;
-				break;
-			}
-			if (!cand) break;
-			if (edge_limit) {
+			f3 AN = mk3(0, 0, 0), A = mk3(0, 0, 0);
+			f4 cv = mk4(0, 0, 0, 0);
+			for (;;) {
+				bool cand = false;
+				while (iteration > 0 && max_iter > 0) {
+					max_iter--;
+					ai = (int)(r_ransac.next() % (uint32_t)valid_count);
+					bi = (int)(r_ransac.next() % (uint32_t)valid_count);
+					ci = (int)(r_ransac.next() % (uint32_t)valid_count);
+					if (ai == bi || bi == ci || ai == ci) continue;
+					if (!point_in_triangle(spv[ai], spv[bi], spv[ci], px, py)) continue;
+					AN = spn[ai];   // the reference uses a_index for all three normals (APD.cu:3605-3607)
+					const float nn = AN.x * AN.x + AN.y * AN.y + AN.z * AN.z;
+					if (nn < 0.9f) continue;
+					A = sp3[ai];
+					const f3 B = sp3[bi], C = sp3[ci];
+					const f3 AC = mk3(A.x - C.x, A.y - C.y, A.z - C.z);
+					const f3 BC = mk3(B.x - C.x, B.y - C.y, B.z - C.z);
+					cv.x = AC.y * BC.z - BC.y * AC.z;
+					cv.y = -(AC.x * BC.z - BC.x * AC.z);
+					cv.z = AC.x * BC.y - BC.x * AC.y;
+					cv.w = 0.0f;
+					if ((cv.x == 0 && cv.y == 0 && cv.z == 0) || cv.x != cv.x || cv.y != cv.y || cv.z != cv.z) continue;
+					cand = true;
+					break;
+				}
+				if (!cand) break;
 				// the reference memoises these tests in a 25 KB per-thread table (APD.cu:3574); the test
 				// is a pure function of its end points, so it is re-evaluated instead
-				if (bresenham_hits_edge(d, spv[ai].x, spv[ai].y, spv[bi].x, spv[bi].y) ||
-					bresenham_hits_edge(d, spv[bi].x, spv[bi].y, spv[ci].x, spv[ci].y) ||
-					bresenham_hits_edge(d, spv[ci].x, spv[ci].y, spv[ai].x, spv[ai].y)) continue;
+				if (edge_limit && (bresenham_hits_edge(d, spv[ai].x, spv[ai].y, spv[bi].x, spv[bi].y) ||
+				                   bresenham_hits_edge(d, spv[bi].x, spv[bi].y, spv[ci].x, spv[ci].y) ||
+				                   bresenham_hits_edge(d, spv[ci].x, spv[ci].y, spv[ai].x, spv[ai].y))) continue;
+				ok = true;
+				break;
 			}
-			const f3 AN = spn[ai];   // the reference uses a_index for all three normals (APD.cu:3605-3607)
-			const float nn = AN.x * AN.x + AN.y * AN.y + AN.z * AN.z;
-			if (nn < 0.9f) continue;
-			const f3 A = sp3[ai], B = sp3[bi], C = sp3[ci];
-			const f3 AC = mk3(A.x - C.x, A.y - C.y, A.z - C.z);
-			const f3 BC = mk3(B.x - C.x, B.y - C.y, B.z - C.z);
-			f4 cv;
-			cv.x = AC.y * BC.z - BC.y * AC.z;
-			cv.y = -(AC.x * BC.z - BC.x * AC.z);
-			cv.z = AC.x * BC.y - BC.x * AC.y;
-			cv.w = 0.0f;
-			if ((cv.x == 0 && cv.y == 0 && cv.z == 0) || cv.x != cv.x || cv.y != cv.y || cv.z != cv.z) continue;
+			if (!ok) break;
 			iteration--;
 			normalize3(&cv);
 			cv.w = -(cv.x * A.x + cv.y * A.y + cv.z * A.z);
