@@ -489,6 +489,8 @@ int dvp_reset_state(dvp_ctx* c) {
 	HIP_TRY(c, hipMemsetAsync(c->selected_views, 0, (L + c->W) * 4, c->stream));
 	HIP_TRY(c, hipMemsetAsync(c->view_weight, 0, L * 32, c->stream));
 	HIP_TRY(c, hipMemsetAsync(c->weak_info, DVP_STRONG, L, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->edge, 0, L, c->stream));        // a recycled context must not see the previous view's priors
+	HIP_TRY(c, hipMemsetAsync(c->label, 0, L * 4, c->stream));
 	HIP_TRY(c, hipMemsetAsync(c->neighbours_map, 0, L * 4, c->stream));
 	HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->radius, c->d.params.strong_radius, L, c->stream));
 	c->d.weak_count = 0;

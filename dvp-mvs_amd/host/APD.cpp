@@ -4,6 +4,8 @@
 // files read per pass.
 #include "APD.h"
 #include <cstdlib>
+#include <map>
+#include <tuple>
 
 static int g_device = 0;
 static uint64_t g_seed = 0x5eed5eedULL;
@@ -15,9 +17,26 @@ APD::APD(const Problem& problem) {   // APD.cpp:984-987
 	this->problem = problem;
 }
 
+// The reference allocates and frees ~30 device buffers per view (APD.cpp:1497-1613, 989-1043).  A
+// context whose shape (device, W, H, images) matches the next view's is recycled instead: one pooled
+// context per process, reset on the device (dvp_reset_state) and re-filled by the uploads.
+namespace {
+struct CachedImage { Mat image; int orig_cols = 0, orig_rows = 0; };
+using ImageKey = std::tuple<std::string, int, int, int>;   // file, scale, pad width, pad height
+std::map<ImageKey, CachedImage> g_img_cache;
+struct PooledCtx {
+	dvp_ctx* ctx = nullptr;
+	int device = 0, w = 0, h = 0, ni = 0;
+	~PooledCtx() { if (ctx) dvp_ctx_destroy(ctx); }
+} g_pool;
+}
+
 APD::~APD() {                        // APD.cpp:989-1043
 	delete[] plane_hypotheses_host;
-	if (ctx) dvp_ctx_destroy(ctx);
+	if (!ctx) return;
+	if (g_pool.ctx) dvp_ctx_destroy(g_pool.ctx);
+	g_pool.ctx = ctx;
+	g_pool.device = ctx_device; g_pool.w = width; g_pool.h = height; g_pool.ni = num_images;
 }
 
 // APD.cpp:1045-1495 (the Depth-Anything prior block :1210-1424 lives in prior.cpp)
@@ -26,35 +45,56 @@ void APD::InuputInitialization() {
 	cameras.clear();
 	path image_folder = problem.dense_folder / path("images");
 	path cam_folder = problem.dense_folder / path("cams");
-	auto to_float = [](const Mat& u8) {
-		Mat f(u8.rows, u8.cols, CV_32FC1);
-		for (int r = 0; r < u8.rows; ++r)
-			for (int c = 0; c < u8.cols; ++c) f.at<float>(r, c) = (float)u8.at<uint8_t>(r, c);
-		return f;
-	};
-	{
-		Mat image_uint = ReadImageGray(image_folder / path(ToFormatIndex(problem.ref_image_id) + ".jpg"));
+	// Decoded, padded and rescaled float images are cached per (file, scale, reference size): the
+	// reference re-reads and re-resizes every source image for every view that uses it
+	// (APD.cpp:1055-1143), 5-10x redundantly within a pass.  Same arithmetic, done once.
+	auto load = [&](int image_id, int pad_w, int pad_h, bool is_ref) -> const CachedImage& {
+		const path file = image_folder / path(ToFormatIndex(image_id) + ".jpg");
+		const ImageKey key{ file.string(), problem.scale_size, pad_w, pad_h };
+		auto it = g_img_cache.find(key);
+		if (it != g_img_cache.end()) return it->second;
+		if (!is_ref) {   // the same file cached in its reference role needs no padding when the sizes agree
+			auto ir = g_img_cache.find(ImageKey{ file.string(), problem.scale_size, 0, 0 });
+			if (ir != g_img_cache.end() && ir->second.orig_cols == pad_w && ir->second.orig_rows == pad_h) return ir->second;
+		}
+		if (g_img_cache.size() >= 96) g_img_cache.clear();
+		Mat image_uint = ReadImageGray(file);
 		if (image_uint.empty()) {
-			std::cerr << "Can't read reference image " << problem.ref_image_id << std::endl;
+			std::cerr << "Can't read " << (is_ref ? "reference" : "source") << " image " << image_id << std::endl;
 			exit(EXIT_FAILURE);
 		}
-		Mat image_float = to_float(image_uint);
-		images.push_back(image_float);
-		width = image_float.cols;
-		height = image_float.rows;
+		Mat f(image_uint.rows, image_uint.cols, CV_32FC1);
+		for (int r = 0; r < image_uint.rows; ++r)
+			for (int c = 0; c < image_uint.cols; ++c) f.at<float>(r, c) = (float)image_uint.at<uint8_t>(r, c);
+		if (!is_ref) {   // zero-pad / crop to the reference size (APD.cpp:1071-1079)
+			Mat resized = Mat::zeros(pad_h, pad_w, CV_32FC1);
+			for (int i = 0; i < pad_h; i++)
+				for (int j = 0; j < pad_w; j++)
+					if (i < f.rows && j < f.cols) resized.at<float>(i, j) = f.at<float>(i, j);
+			f = resized;
+		}
+		CachedImage ci;
+		ci.orig_cols = f.cols;
+		ci.orig_rows = f.rows;
+		if (problem.scale_size != 1) {   // APD.cpp:1119-1131
+			const float factor = 1.0f / (float)(problem.scale_size);
+			f = ResizeLinear(f, (int)std::round(f.cols * factor), (int)std::round(f.rows * factor));
+		}
+		ci.image = f;
+		return g_img_cache.emplace(key, ci).first->second;
+	};
+	std::vector<std::pair<int, int>> orig_sizes;   // (cols, rows) before scaling, per image
+	{
+		const CachedImage& ci = load(problem.ref_image_id, 0, 0, true);
+		images.push_back(ci.image);
+		orig_sizes.emplace_back(ci.orig_cols, ci.orig_rows);
+		width = ci.orig_cols;
+		height = ci.orig_rows;
 	}
 	for (const auto& src_idx : problem.src_image_ids) {
-		Mat image_uint = ReadImageGray(image_folder / path(ToFormatIndex(src_idx) + ".jpg"));
-		if (image_uint.empty()) {
-			std::cerr << "Can't read source image " << src_idx << std::endl;
-			exit(EXIT_FAILURE);
-		}
-		Mat image_float = to_float(image_uint);
-		Mat resized = Mat::zeros(height, width, CV_32FC1);   // zero-pad / crop to the reference size (APD.cpp:1071-1079)
-		for (int i = 0; i < height; i++)
-			for (int j = 0; j < width; j++)
-				if (i < image_float.rows && j < image_float.cols) resized.at<float>(i, j) = image_float.at<float>(i, j);
-		images.push_back(resized);
+		const CachedImage& ci = load(src_idx, width, height, false);
+		images.push_back(ci.image);
+		orig_sizes.emplace_back(ci.orig_cols, ci.orig_rows);
 	}
 	if (images.size() > MAX_IMAGES) {
 		std::cerr << "Can't process so much images: " << images.size() << std::endl;
@@ -81,14 +121,11 @@ void APD::InuputInitialization() {
 	std::cout << "Read images and camera done\n";
 	std::cout << "Depth range: " << params_host.depth_min << " " << params_host.depth_max << std::endl;
 	std::cout << "Num images: " << params_host.num_images << std::endl;
-	if (problem.scale_size != 1) {   // APD.cpp:1119-1143
+	if (problem.scale_size != 1) {   // APD.cpp:1119-1143 (the images were rescaled by load())
 		for (int i = 0; i < num_images; ++i) {
-			const float factor = 1.0f / (float)(problem.scale_size);
-			const int new_cols = (int)std::round(images[i].cols * factor);
-			const int new_rows = (int)std::round(images[i].rows * factor);
-			const float scale_x = new_cols / static_cast<float>(images[i].cols);
-			const float scale_y = new_rows / static_cast<float>(images[i].rows);
-			images[i] = ResizeLinear(images[i], new_cols, new_rows);
+			const int new_cols = images[i].cols, new_rows = images[i].rows;
+			const float scale_x = new_cols / static_cast<float>(orig_sizes[i].first);
+			const float scale_y = new_rows / static_cast<float>(orig_sizes[i].second);
 			width = new_cols;
 			height = new_rows;
 			cameras[i].K[0] *= scale_x;
@@ -219,7 +256,13 @@ void APD::SupportInitialization() {
 
 // APD.cpp:1497-1613: every cudaMalloc/cudaMemcpy/texture creation becomes one C-ABI upload
 void APD::CudaSpaceInitialization() {
-	if (dvp_ctx_create(g_device, width, height, num_images, &ctx) != 0) {
+	ctx_device = g_device;
+	if (g_pool.ctx && g_pool.device == g_device && g_pool.w == width && g_pool.h == height && g_pool.ni == num_images) {
+		ctx = g_pool.ctx;
+		g_pool.ctx = nullptr;
+		DVP_SAFE_CALL(ctx, dvp_reset_state(ctx));
+		DVP_SAFE_CALL(ctx, dvp_reset_timings(ctx));
+	} else if (dvp_ctx_create(g_device, width, height, num_images, &ctx) != 0) {
 		fprintf(stderr, "dvp_ctx_create failed: %s\n", dvp_last_error(nullptr));
 		exit(EXIT_FAILURE);
 	}

@@ -82,6 +82,7 @@ private:
 	Mat edge_host, radius_host, label_host, selected_views_host;
 	PatchMatchParams params_host;
 	dvp_ctx* ctx = nullptr;
+	int ctx_device = 0;
 	DvpTimings timings{};
 };
 #endif

@@ -6,6 +6,7 @@
 // processes (one per GPU); passes are separated by a file-system barrier (the per-view result
 // files are the inter-pass API of the reference).
 #include "APD.h"
+#include <cstdlib>
 #include <thread>
 
 static void GenerateSampleList(const path& dense_folder, std::vector<Problem>& problems, int max_src) {   // main.cpp:127-170
@@ -61,18 +62,32 @@ static void ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	std::cout << "Processing image: " << std::setw(8) << std::setfill('0') << problem.ref_image_id << "..." << std::endl;
 	std::cout << "Iteration: " << problem.iteration << std::endl;
 	auto start = std::chrono::steady_clock::now();
+	// DVP_HOST_TIMING=1: wall time of every host step of the view (where the non-GPU time goes)
+	static const bool host_timing = std::getenv("DVP_HOST_TIMING") != nullptr;
+	auto lap_t = start;
+	auto lap = [&](const char* what) {
+		if (!host_timing) return;
+		const auto now = std::chrono::steady_clock::now();
+		std::cout << "  [host] " << what << ": " << std::chrono::duration_cast<std::chrono::microseconds>(now - lap_t).count() / 1000.0 << " ms" << std::endl;
+		lap_t = now;
+	};
 	APD APD(problem);
 	APD.InuputInitialization();
+	lap("InuputInitialization (images, cameras, previous results)");
 	APD.SupportInitialization();
+	lap("SupportInitialization (edges, labels, radius)");
 	APD.CudaSpaceInitialization();
+	lap("CudaSpaceInitialization (context + uploads)");
 	APD.SetDataPassHelperInCuda();
 	APD.RunPatchMatch();
+	lap("RunPatchMatch + download");
 	int width = APD.GetWidth(), height = APD.GetHeight();
 	Mat depth(height, width, CV_32FC1), normal(height, width, CV_32FC3);
 	Mat pixel_states = APD.GetPixelStates();
 	const int nsrc = (int)problem.src_image_ids.size();
 	std::vector<Mat> vis(nsrc);
 	for (int i = 0; i < nsrc; ++i) vis[i] = Mat(height, width, CV_8UC1);
+#pragma omp parallel for schedule(static) num_threads(8)
 	for (int r = 0; r < height; ++r)
 		for (int c = 0; c < width; ++c) {
 			float4 ph = APD.GetPlaneHypothesis(r, c);
@@ -85,9 +100,11 @@ static void ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 			unsigned int views = (unsigned int)APD.GetPixelSelectedViews(r, c);
 			for (int i = 0; i < nsrc; ++i) vis[i].at<uint8_t>(r, c) = ((views >> i) & 1) ? 255 : 0;
 		}
+	lap("unpack planes / view masks");
 	// visibility-mask clean-up: invisible components smaller than 20*(8/scale)^2 px become visible
 	// (main.cpp:323-363)
 	const int thr = 20 * (8 / problem.scale_size) * (8 / problem.scale_size);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nsrc < 8 ? (nsrc > 0 ? nsrc : 1) : 8)   // one source view's mask per thread
 	for (int i = 0; i < nsrc; ++i) {
 		Mat lab_mask(height, width, CV_32S);
 		std::vector<int> label_cnt;
@@ -100,6 +117,7 @@ static void ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 				vis[i].at<uint8_t>(y, x) = big ? 0 : 255;
 			}
 	}
+#pragma omp parallel for schedule(static) num_threads(8)
 	for (int y = 0; y < height; y++)
 		for (int x = 0; x < width; x++) {
 			unsigned int v = 0;
@@ -107,11 +125,13 @@ static void ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 				if (vis[i].at<uint8_t>(y, x) == 255) setBit_YZL(&v, i);
 			APD.SetPixelSelectedViews(y, x, (int)v);
 		}
+	lap("visibility-mask clean-up");
 	WriteBinMat(problem.result_folder / path("depths.dmb"), depth);
 	WriteBinMat(problem.result_folder / path("APD_normals.dmb"), normal);
 	WriteBinMat(problem.result_folder / path("weak.bin"), pixel_states);
 	WriteBinMat(problem.result_folder / path("selected_views.bin"), APD.GetSelectedViews());
 	if (problem.params.use_radius) WriteBinMat(problem.result_folder / path("radius.bin"), APD.GetRadiusMap());
+	lap("write results");
 	auto end = std::chrono::steady_clock::now();
 	const DvpTimings& t = APD.GetTimings();
 	std::cout << "Processing image: " << std::setw(8) << std::setfill('0') << problem.ref_image_id << " done!" << std::endl;
