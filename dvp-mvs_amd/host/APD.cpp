@@ -27,8 +27,14 @@ std::map<ImageKey, CachedImage> g_img_cache;
 struct PooledCtx {
 	dvp_ctx* ctx = nullptr;
 	int device = 0, w = 0, h = 0, ni = 0;
-	~PooledCtx() { if (ctx) dvp_ctx_destroy(ctx); }
+	// no destructor: at static-destruction time the HIP runtime may already be gone; the driver
+	// calls APD::ReleasePooledContext() before it returns
 } g_pool;
+}
+void APD::ReleasePooledContext() {
+	if (g_pool.ctx) dvp_ctx_destroy(g_pool.ctx);
+	g_pool.ctx = nullptr;
+	g_img_cache.clear();
 }
 
 APD::~APD() {                        // APD.cpp:989-1043

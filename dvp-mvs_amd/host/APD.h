@@ -67,6 +67,7 @@ public:
 	// extensions (not in the reference): device selection, explicit seed, in-memory inputs
 	static void SetDevice(int device);
 	static void SetSeed(uint64_t seed);
+	static void ReleasePooledContext();   // frees the recycled engine context and the image cache
 	const DvpTimings& GetTimings() const { return timings; }
 
 private:

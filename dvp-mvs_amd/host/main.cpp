@@ -229,6 +229,7 @@ int main(int argc, char** argv) {
 		}
 		std::cout << "Round: " << i << " done\n";
 	}
+	APD::ReleasePooledContext();
 	if (fusion && rank == 0) RunFusion(dense_folder, problems);
 	std::cout << "All done\n";
 	return EXIT_SUCCESS;
