@@ -17,7 +17,7 @@ using namespace dvp;
 // kernels
 // ------------------------------------------------------------------------------------------------
 struct LaunchArgs {
-	int tiles_x, tiles, chunk, rows, half, colour, iter;
+	int tiles_x, tiles, rows, half, colour, iter;
 };
 
 template <int STAGE, int SMP, int MV = 32>
@@ -29,7 +29,7 @@ __device__ __forceinline__ void stage_body(const Dev& d, const LaunchArgs& a) {
 	// per-lane (w, w*ref) table of the hoisted patch context: [tap][lane] in LDS (72 KiB / workgroup)
 	__shared__ f2 lds_tab[stage_uses_tab(STAGE) ? kTaps * kTaps * 256 : 1];
 	const PatchTab tab{&lds_tab[stage_uses_tab(STAGE) ? threadIdx.x : 0], 256};
-	if (block_to_pixel(blockIdx.x, lane, wave, a.tiles_x, a.tiles, a.chunk, a.rows, a.half, a.colour, d.width, d.height, &px, &py))
+	if (block_to_pixel(blockIdx.x, lane, wave, a.tiles_x, a.tiles, a.rows, a.half, a.colour, d.width, d.height, &px, &py))
 		run_pixel<STAGE, SMP, MV>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, tab);
 	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
 }
@@ -178,7 +178,7 @@ extern "C" __global__ void __launch_bounds__(256) dvp_cost_vectors(const Dev d, 
 extern "C" __global__ void __launch_bounds__(256) dvp_cost_all_pixels(const Dev d, const LaunchArgs a, float* out) {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	int px, py;
-	if (!block_to_pixel(blockIdx.x, lane, wave, a.tiles_x, a.tiles, a.chunk, a.rows, 0, 0, d.width, d.height, &px, &py)) return;
+	if (!block_to_pixel(blockIdx.x, lane, wave, a.tiles_x, a.tiles, a.rows, 0, 0, d.width, d.height, &px, &py)) return;
 	const int center = px + py * d.width;
 	const int S = d.num_images - 1;
 	PatchCtx c;
@@ -528,7 +528,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 	if (c->d.params.geom_consistency && !c->have_depths) { c->error = "geom_consistency is on but no depth maps were uploaded"; return 1; }
 	const LaunchGeom g = make_geom(c->W, c->H, stage_is_half(stage));
 	LaunchArgs a;
-	a.tiles_x = g.tiles_x; a.tiles = g.tiles; a.chunk = g.chunk; a.rows = g.rows; a.half = g.half ? 1 : 0;
+	a.tiles_x = g.tiles_x; a.tiles = g.tiles; a.rows = g.rows; a.half = g.half ? 1 : 0;
 	a.colour = colour; a.iter = iter;
 	if (stage == DVP_ST_STRONG_UPDATE) {
 		// pre-launch snapshot: the direction-4 samples of the strong update are same-colour pixels
@@ -781,7 +781,7 @@ int dvp_bench_cost_kernel(dvp_ctx* c, int repeat, float* mean_kernel_ms, uint64_
 	if (repeat < 1) repeat = 1;
 	const LaunchGeom g = make_geom(c->W, c->H, false);
 	LaunchArgs a;
-	a.tiles_x = g.tiles_x; a.tiles = g.tiles; a.chunk = g.chunk; a.rows = g.rows; a.half = 0; a.colour = 0; a.iter = 0;
+	a.tiles_x = g.tiles_x; a.tiles = g.tiles; a.rows = g.rows; a.half = 0; a.colour = 0; a.iter = 0;
 	EventPairGuard ev;
 	HIP_TRY(c, hipEventCreate(&ev.a));
 	HIP_TRY(c, hipEventCreate(&ev.b));

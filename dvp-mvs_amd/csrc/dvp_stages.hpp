@@ -17,7 +17,7 @@ namespace dvp {
 //    grid covers 16*ceil((H/2)/16) row pairs (APD.cu:4421-4424): for odd H with (H/2)%16 == 0 the
 //    last row is never updated; `rows()` reproduces that.
 struct LaunchGeom {
-	int tiles_x, tiles_y, tiles, chunk;   // chunk: unused (kept so that LaunchArgs stays layout-compatible)
+	int tiles_x, tiles_y, tiles;
 	int rows;                             // rows (full) or row pairs (half) covered
 	bool half;
 	int grid() const { return tiles; }
@@ -29,7 +29,6 @@ inline LaunchGeom make_geom(int W, int H, bool half) {
 	g.tiles_x = (W + 63) / 64;
 	g.tiles_y = (g.rows + 3) / 4;
 	g.tiles = g.tiles_x * g.tiles_y;
-	g.chunk = (g.tiles + 7) / 8;
 	return g;
 }
 
@@ -40,7 +39,7 @@ inline LaunchGeom make_geom(int W, int H, bool half) {
 // rows (shared in the Infinity Cache).  The ragged last strip is dealt row-major over all XCDs.
 // Measured (3104x2064, S=5, ms per strong-update launch): one contiguous band of the image per XCD
 // 22.8, plain row-major 20.4, this map 19.3.
-DVP_HD bool block_to_pixel(int block, int lane, int wave, int tiles_x, int tiles, int chunk, int rows, int half, int colour,
+DVP_HD bool block_to_pixel(int block, int lane, int wave, int tiles_x, int tiles, int rows, int half, int colour,
 	int W, int H, int* px, int* py) {
 	if (block >= tiles) return false;
 	const int tiles_y = tiles / tiles_x;

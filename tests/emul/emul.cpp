@@ -73,7 +73,7 @@ void launch(Emu& e, int iter, int colour) {
 		for (int wave = 0; wave < 4; ++wave)
 			for (int lane = 0; lane < 64; ++lane) {
 				int px, py;
-				if (!block_to_pixel(b, lane, wave, g.tiles_x, g.tiles, g.chunk, g.rows, g.half ? 1 : 0, colour, e.W, e.H, &px, &py)) continue;
+				if (!block_to_pixel(b, lane, wave, g.tiles_x, g.tiles, g.rows, g.half ? 1 : 0, colour, e.W, e.H, &px, &py)) continue;
 				unsigned long long n = 0;
 				f2 tab_mem[kTaps * kTaps];
 				const PatchTab tab{tab_mem, 1};
