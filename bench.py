@@ -194,7 +194,9 @@ def main():
                          "evals_per_launch": int(ev_launch), "bytes_per_eval": NCC_BYTES, "avg_launch_ms": round(avg_ms, 3),
                          "launches": launches,
                          # traffic (PMC, profiles/pmc_strong_update.json) over the same launch time: what HBM + Infinity Cache really moved
-                         "physical_gbs": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if (traffic and avg_ms > 0) else None},
+                         "physical_gbs": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if (traffic and avg_ms > 0) else None,
+                         "note": "achieved = cache-oblivious algorithmic bytes (724 B per NCC evaluation, SURVEY 8d) / launch time: "
+                                 "frac > 1 means L1/L2/Infinity Cache serve the re-reads; physical_gbs is what the PMC counters saw"},
             "iter_loop_value": round(float(W) * H * iters * args.steps / (tm["iter_loop_ms"] * 1e-3) / 1e6, 3) if tm["iter_loop_ms"] > 0 else None,
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in tm["stage_ms"].items() if v > 0},
             "evals_per_px_iter_strong": round(evals["ncc_evals"]["strong_update"] / (float(W) * H * iters), 2),
