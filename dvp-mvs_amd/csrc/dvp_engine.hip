@@ -286,6 +286,13 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 		g_create_error = "dvp_ctx_create: bad dimensions (2 <= num_images <= 32, sizes <= 32767: short2 pixel coordinates)";
 		return 1;
 	}
+	{   // the samplers address a row-pair plane with 32-bit byte offsets
+		const unsigned long long pitch = ((unsigned long long)width + 2 * kImgPad + 63) / 64 * 64;
+		if (pitch * ((unsigned long long)height + 2 * kImgPad) * 8ull >= (1ull << 32)) {
+			g_create_error = "dvp_ctx_create: image too large (a padded row-pair plane must stay below 4 GiB)";
+			return 1;
+		}
+	}
 	dvp_ctx* c = new dvp_ctx();
 	c->device = device; c->W = width; c->H = height; c->NI = num_images;
 	c->pitch = (width + 2 * kImgPad + 63) / 64 * 64;

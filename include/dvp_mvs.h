@@ -122,6 +122,8 @@ typedef struct DvpTimings {
 } DvpTimings;
 
 /* ---- lifetime (APD::APD / ~APD, APD.cpp:984-1043; cudaSetDevice, main.cpp:430-434) ---------- */
+/* limits: 2 <= num_images <= 32 (APD.cpp:1083-1086), width, height <= 32767 (short2 pixel coordinates),
+ * (width+4 rounded up to 64) * (height+4) * 8 bytes < 4 GiB (32-bit offsets into a row-pair plane) */
 int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** out);
 int dvp_ctx_destroy(dvp_ctx* ctx);
 const char* dvp_last_error(const dvp_ctx* ctx);   /* ctx may be NULL: last create error */

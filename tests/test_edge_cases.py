@@ -115,7 +115,7 @@ def test_rejected_inputs_cpu_side():
     import ctypes
     lib = pkg("capi").lib()
     ctx = ctypes.c_void_p()
-    for (w, h, ni) in ((64, 48, 33), (64, 48, 1), (0, 48, 3), (64, -1, 3), (40000, 48, 3)):
+    for (w, h, ni) in ((64, 48, 33), (64, 48, 1), (0, 48, 3), (64, -1, 3), (40000, 48, 3), (30000, 30000, 3)):
         assert lib.dvp_ctx_create(0, w, h, ni, ctypes.byref(ctx)) != 0
         assert not ctx.value
         assert b"dvp_ctx_create" in lib.dvp_last_error(None)
