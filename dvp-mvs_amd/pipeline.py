@@ -74,6 +74,7 @@ class ScenePipeline:
                               weak=np.full(L, synth.STRONG, np.uint8), radius=np.full(L, 5, np.int32)) for v in self.mine}
         self.edges = {v: np.zeros(L, np.uint8) for v in self.mine}
         self.pass_index = 0
+        self._engines = {}   # recycled engines by image count
 
     # ---- collectives -------------------------------------------------------------------------------
     def _device(self):
@@ -130,7 +131,13 @@ class ScenePipeline:
                                      geom_consistency=int(geom), weak_peak_radius=weak_peak_radius, **param_overrides)
             p["depth_min"] = np.float32(self.cameras[v]["depth_min"]) * np.float32(0.6)    # APD.cpp:1109-1110
             p["depth_max"] = np.float32(self.cameras[v]["depth_max"]) * np.float32(1.2)
-            eng = self.make_engine(self.W, self.H, NI)
+            # engines that can be reset on the device are recycled per image count (no re-allocation
+            # of the ~30 device buffers per view); others (the CPU oracle in tests) are created fresh
+            eng = self._engines.pop(NI, None)
+            if eng is None:
+                eng = self.make_engine(self.W, self.H, NI)
+            else:
+                eng.reset_state()
             eng.set_images(self.images[order])
             eng.set_cameras(self.cameras[order])
             eng.set_params(p)
@@ -150,7 +157,9 @@ class ScenePipeline:
             radius[weak == synth.UNKNOWN] = 5   # APD.cpp:1663-1666
             self.state[v] = dict(planes=planes, views=views, weak=weak, radius=radius)
             new_depths[v] = depth.reshape(self.H, self.W)
-            if hasattr(eng, "close"):
+            if hasattr(eng, "reset_state"):
+                self._engines[NI] = eng
+            elif hasattr(eng, "close"):
                 eng.close()
         self._allgather_depths(new_depths)
         self.pass_index += 1
