@@ -2,6 +2,8 @@
 samplers and seeds are drawn from a seeded generator; for every draw the engine must reproduce
 the oracle bit for bit after a full RunPatchMatch.  CPU: host emulation of the kernels; GPU
 (-m gpu): the HIP library through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 
@@ -67,8 +69,9 @@ def test_random_configs_emulated_kernels(case):
     run_pair(lambda sc, p, seed, smp, dep: O.from_scene(sc, p, seed=seed, sampler=smp, depths=dep, cls=E.Emul), rng)
 
 
+# DVP_RANDOM_CASES=N widens the sweep for soak runs (default 10 cases)
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", range(10))
+@pytest.mark.parametrize("case", range(int(os.environ.get("DVP_RANDOM_CASES", "10"))))
 def test_random_configs_gpu(case):
     rng = np.random.default_rng(5000 + case)
     capi = pkg("capi")
