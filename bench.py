@@ -43,7 +43,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(synth, args, S, iters):
+def cpu_baseline(synth, args, S, iters, capi=None, device=0):
     """The oracle ("port") timed on this host's cores on a bounded sample of the same workload:
     same scene generator, same S / iterations / params, a 256x192 view."""
     from oracle import oracle as O
@@ -74,8 +74,19 @@ def cpu_baseline(synth, args, S, iters):
     omp = os.environ.get("OMP_NUM_THREADS")
     if omp:
         cores = min(cores, int(omp))
-    return {"value": round(w * h * iters / dt / 1e6, 5), "unit": "Mpx/s/iter", "cores": cores, "kind": "port",
-            "sample": "%dx%d view, S=%d, %d iters, whole RunPatchMatch, oracle/ (OpenMP over rows), %.1f s" % (w, h, S, iters, dt)}
+    res = {"value": round(w * h * iters / dt / 1e6, 5), "unit": "Mpx/s/iter", "cores": cores, "kind": "port",
+           "sample": "%dx%d view, S=%d, %d iters, whole RunPatchMatch, oracle/ (OpenMP over rows), %.1f s" % (w, h, S, iters, dt)}
+    if capi is not None:
+        # parity of the engine on the very sample the CPU was timed on (oracle used as the checker, outside any timed region)
+        g = capi.from_scene(sc, p, device=device)
+        g.upload_state(planes=np.zeros((w * h, 4), np.float32), edge=sc["edge"], label=sc["label"], radius=np.full(w * h, 5, np.int32))
+        g.run_patchmatch()
+        a, b = o.get("planes"), g.get("planes")
+        diff = (a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))
+        res["gpu_vs_cpu_plane_words_differing"] = int(diff.sum())
+        res["gpu_vs_cpu_states_differing"] = int((o.get("weak_info") != g.get("weak_info")).sum() + (o.get("selected_views") != g.get("selected_views")).sum())
+        g.close()
+    return res
 
 
 def bench_params(synth, S, iters):
@@ -208,7 +219,7 @@ def main():
             ms, ev = ctx.bench_cost_kernel(3)
             out["micro_cost_kernel"] = {"ms": round(ms, 3), "evals": ev, "GBps_algorithmic": round(ev * NCC_BYTES / (ms * 1e-3) / 1e9, 1)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(synth, args, S, iters)
+            out["cpu_baseline"] = cpu_baseline(synth, args, S, iters, capi=capi, device=local_rank)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
