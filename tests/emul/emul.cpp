@@ -217,6 +217,29 @@ int emu_get_buffer(void* c, int id, void* dst) { size_t b; void* p = buf_ptr(*(E
 int emu_set_buffer(void* c, int id, const void* src) { size_t b; void* p = buf_ptr(*(Emu*)c, id, &b); if (!p) return -1; std::memcpy(p, src, b); return 0; }
 int emu_weak_count(void* c) { return ((Emu*)c)->d.weak_count; }
 
+// Launch-geometry property: the block -> tile -> pixel map of a launch visits every pixel it is meant
+// to cover exactly once.  Returns 0 when it does; otherwise 1 + the first offending pixel index.
+long long emu_tile_map_check(int W, int H, int half, int colour) {
+	const LaunchGeom g = make_geom(W, H, half != 0);
+	std::vector<int> hits((size_t)W * H, 0);
+	for (int b = 0; b < g.grid(); ++b)
+		for (int wave = 0; wave < 4; ++wave)
+			for (int lane = 0; lane < 64; ++lane) {
+				int px, py;
+				if (block_to_pixel(b, lane, wave, g.tiles_x, g.tiles, g.rows, half, colour, W, H, &px, &py)) {
+					if (px < 0 || py < 0 || px >= W || py >= H) return -1;
+					hits[(size_t)py * W + px]++;
+				}
+			}
+	for (int y = 0; y < H; ++y)
+		for (int x = 0; x < W; ++x) {
+			int want = 1;
+			if (half) want = (((x & 1) ^ colour) == (y & 1)) && (y / 2) < g.rows ? 1 : 0;   // y = 2*pair + ((x&1)^colour)
+			if (hits[(size_t)y * W + x] != want) return 1 + (long long)y * W + x;
+		}
+	return 0;
+}
+
 // dvp_pack_edge_bits
 static void pack_edge(Emu& e) {
 	for (size_t w = 0; w < e.edge_bits.size(); ++w) e.edge_bits[w] = pack_edge_word(e.edge.data(), e.W, e.H, edge_tiles_x(e.W), w);

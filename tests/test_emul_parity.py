@@ -82,3 +82,16 @@ def test_refine_init_and_generic_radius():
     p3 = make_params(S + 1, max_iterations=1, state=synth.REFINE_INIT, use_APD=1, use_radius=0)
     a, b = _pair(sc, p3, st)
     _run_and_compare(a, b, 1)
+
+
+def test_launch_geometry_covers_every_pixel_once():
+    """block -> tile -> pixel map (csrc/dvp_stages.hpp): strips of 8 tile columns, ragged last strip,
+    full and red/black launches, sizes around the tile and strip boundaries."""
+    import ctypes
+    L = ctypes.CDLL(E.lib()._name) if hasattr(E.lib(), "_name") else E.lib()
+    L.emu_tile_map_check.restype = ctypes.c_longlong
+    L.emu_tile_map_check.argtypes = [ctypes.c_int] * 4
+    for (w, h) in ((1, 1), (16, 12), (63, 9), (64, 8), (65, 33), (511, 40), (512, 64), (513, 31), (1000, 70), (3104, 130)):
+        assert L.emu_tile_map_check(w, h, 0, 0) == 0, (w, h, "full")
+        for colour in (0, 1):
+            assert L.emu_tile_map_check(w, h, 1, colour) == 0, (w, h, "half", colour)
