@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / avg / min / max.
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per (kernel, grid size) calls / total / avg / min /
+max — launches of one kernel at different problem sizes (bench workload vs the small parity sample of
+the cpu_baseline leg) stay on separate rows.
 usage: rocpd_summary.py results.db > profiles/rNN_kernel_stats.txt"""
 import sqlite3
 import sys
@@ -8,7 +10,7 @@ con = sqlite3.connect(sys.argv[1])
 cur = con.cursor()
 rows = list(cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e6, min(end-start)/1e6, "
                         "max(end-start)/1e6, max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(scratch_size), "
-                        "max(lds_size), max(grid_x), max(workgroup_x) from kernels group by name order by 3 desc"))
+                        "max(lds_size), max(grid_x), max(workgroup_x) from kernels group by name, grid_x order by 3 desc"))
 tot = sum(r[2] for r in rows)
 print("%-38s %6s %12s %10s %10s %10s %6s %5s %5s %5s %7s %6s %9s %4s" % (
     "kernel", "calls", "total_ms", "avg_ms", "min_ms", "max_ms", "%", "vgpr", "agpr", "sgpr", "scratch", "lds", "grid_x", "wg"))
