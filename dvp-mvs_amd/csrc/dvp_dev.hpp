@@ -42,6 +42,13 @@ DVP_HD s2 mks2(int x, int y) { s2 r; r.x = (short)x; r.y = (short)y; return r; }
 struct ViewConst {
 	float Rrel[9];
 	float trel[3];
+	// everything else ComputeHomography and the centre test read from the two cameras, so that an
+	// evaluation fetches ONE 96-byte record of wave-uniform data (scalar loads, see load_view)
+	float sK0, sK2, sK4, sK5, sK8;   // source K[0], K[2], K[4], K[5], K[8]
+	float rK2, rK5;                   // reference K[2], K[5]
+	float inv_k0, inv_k4;             // 1.0f / reference K[0], K[4] (one correctly rounded reciprocal per divisor)
+	float fw, fh;                     // source width / height as float (the centre test compares floats)
+	float pad;
 };
 
 // The buffer bundle every kernel receives (the engine's DataPassHelper, APD.h:60-92).
@@ -399,16 +406,39 @@ DVP_HD void compute_view_const(const DvpCamera& ref, const DvpCamera& src, ViewC
 	for (int i = 0; i < 3; ++i) C_rel[i] = ref_C[i] - src_C[i];
 	for (int i = 0; i < 3; ++i)
 		vc->trel[i] = src.R[3 * i] * C_rel[0] + src.R[3 * i + 1] * C_rel[1] + src.R[3 * i + 2] * C_rel[2];
+	vc->sK0 = src.K[0]; vc->sK2 = src.K[2]; vc->sK4 = src.K[4]; vc->sK5 = src.K[5]; vc->sK8 = src.K[8];
+	vc->rK2 = ref.K[2]; vc->rK5 = ref.K[5];
+	vc->inv_k0 = 1.0f / ref.K[0];
+	vc->inv_k4 = 1.0f / ref.K[4];
+	vc->fw = (float)src.width;
+	vc->fh = (float)src.height;
+	vc->pad = 0.0f;
+}
+
+// The per-view record of view `v`, which is the same for every lane that is active at the call site
+// (v is a loop counter): on the device it is fetched through the constant address space with a
+// wave-uniform address, i.e. with scalar loads into SGPRs instead of ~23 vector loads per evaluation
+// (the compiler cannot prove the buffer read-only and emits global_load for a plain `d.views[v]`).
+DVP_HD ViewConst load_view(const Dev& d, int v);
+
+DVP_HD ViewConst load_view(const Dev& d, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	const int vu = __builtin_amdgcn_readfirstlane(v);
+	typedef const __attribute__((address_space(4))) ViewConst* cptr;
+	return *(cptr)(d.views + vu);
+#else
+	return d.views[v];
+#endif
 }
 
 // plane-dependent part of ComputeHomography (APD.cu:709-738)
-DVP_HD void homography(const DvpCamera& ref, const DvpCamera& src, const ViewConst& vc, const f4 pl, float* H) {
+DVP_HD void homography(const ViewConst& vc, const f4 pl, float* H) {
 	// a/b -> a * (1/b) with one correctly rounded reciprocal per divisor (numerics contract:
-	// nvcc --use_fast_math lowers these divisions to a*rcp(b))
+	// nvcc --use_fast_math lowers these divisions to a*rcp(b)); 1/K[0], 1/K[4] come with the record
 	float Hh[9], tmp[9];
 	const float inv_w = 1.0f / pl.w;
-	const float inv_k0 = 1.0f / ref.K[0];
-	const float inv_k4 = 1.0f / ref.K[4];
+	const float inv_k0 = vc.inv_k0;
+	const float inv_k4 = vc.inv_k4;
 	for (int i = 0; i < 3; ++i) {
 		Hh[3 * i + 0] = vc.Rrel[3 * i + 0] - vc.trel[i] * pl.x * inv_w;
 		Hh[3 * i + 1] = vc.Rrel[3 * i + 1] - vc.trel[i] * pl.y * inv_w;
@@ -417,17 +447,17 @@ DVP_HD void homography(const DvpCamera& ref, const DvpCamera& src, const ViewCon
 	for (int i = 0; i < 3; ++i) {
 		tmp[3 * i + 0] = Hh[3 * i + 0] * inv_k0;
 		tmp[3 * i + 1] = Hh[3 * i + 1] * inv_k4;
-		tmp[3 * i + 2] = -Hh[3 * i + 0] * ref.K[2] * inv_k0 - Hh[3 * i + 1] * ref.K[5] * inv_k4 + Hh[3 * i + 2];
+		tmp[3 * i + 2] = -Hh[3 * i + 0] * vc.rK2 * inv_k0 - Hh[3 * i + 1] * vc.rK5 * inv_k4 + Hh[3 * i + 2];
 	}
-	H[0] = src.K[0] * tmp[0] + src.K[2] * tmp[6];
-	H[1] = src.K[0] * tmp[1] + src.K[2] * tmp[7];
-	H[2] = src.K[0] * tmp[2] + src.K[2] * tmp[8];
-	H[3] = src.K[4] * tmp[3] + src.K[5] * tmp[6];
-	H[4] = src.K[4] * tmp[4] + src.K[5] * tmp[7];
-	H[5] = src.K[4] * tmp[5] + src.K[5] * tmp[8];
-	H[6] = src.K[8] * tmp[6];
-	H[7] = src.K[8] * tmp[7];
-	H[8] = src.K[8] * tmp[8];
+	H[0] = vc.sK0 * tmp[0] + vc.sK2 * tmp[6];
+	H[1] = vc.sK0 * tmp[1] + vc.sK2 * tmp[7];
+	H[2] = vc.sK0 * tmp[2] + vc.sK2 * tmp[8];
+	H[3] = vc.sK4 * tmp[3] + vc.sK5 * tmp[6];
+	H[4] = vc.sK4 * tmp[4] + vc.sK5 * tmp[7];
+	H[5] = vc.sK4 * tmp[5] + vc.sK5 * tmp[8];
+	H[6] = vc.sK8 * tmp[6];
+	H[7] = vc.sK8 * tmp[7];
+	H[8] = vc.sK8 * tmp[8];
 }
 DVP_HD f2 apply_homography(const float* H, int px, int py) {   // ComputeCorrespondingPoint, APD.cu:741-748
 	const float x = H[0] * px + H[1] * py + H[2];

@@ -229,12 +229,11 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 // ComputeBilateralNCCOld (APD.cu:1023-1113) for source view `v` (1-based image index).
 template <int SMP>
 DVP_HD float ncc_old(const Dev& d, const PatchCtx& c, int px, int py, int v, const f4 plane) {
-	const DvpCamera& rc = d.cameras[0];
-	const DvpCamera& sc = d.cameras[v];
+	const ViewConst vc = load_view(d, v);
 	float H[9];
-	homography(rc, sc, d.views[v], plane, H);
+	homography(vc, plane, H);
 	const f2 pt = apply_homography(H, px, py);
-	if (pt.x >= sc.width || pt.x < 0.0f || pt.y >= sc.height || pt.y < 0.0f) return 2.0f;
+	if (pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f) return 2.0f;
 	const float* src = d.images + (size_t)v * d.plane_stride * 2;
 	if (c.fast) return ncc_patch_fast<SMP>(d, c, H, src, px, py);
 	return ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 0);

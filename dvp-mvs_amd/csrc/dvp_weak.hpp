@@ -761,8 +761,7 @@ DVP_HD void build_anchor_tab(const Dev& d, int center, int v, float cpix, Anchor
 template <int SMP>
 DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const AnchorTab& T, int px, int py, int v, const f4* pl /*[8]*/,
 	uint32_t pmask, float* ev /*[8][32], column v-1 written*/) {
-	const DvpCamera& rc = d.cameras[0];
-	const DvpCamera& sc = d.cameras[v];
+	const ViewConst vc = load_view(d, v);
 	const int W = d.width, Hh = d.height, Pt = d.pitch;
 	const float* src = d.images + (size_t)v * d.plane_stride * 2;
 	float center_cost[8];
@@ -770,9 +769,9 @@ DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const AnchorTab& T, i
 	for (int q = 0; q < 8; ++q) {
 		if (!((pmask >> q) & 1)) continue;
 		float H[9];
-		homography(rc, sc, d.views[v], pl[q], H);
+		homography(vc, pl[q], H);
 		const f2 pt = apply_homography(H, px, py);
-		if (pt.x >= sc.width || pt.x < 0.0f || pt.y >= sc.height || pt.y < 0.0f) { ev[q * 32 + v - 1] = 2.0f; continue; }
+		if (pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f) { ev[q * 32 + v - 1] = 2.0f; continue; }
 		live |= 1u << q;
 		center_cost[q] = c.fast ? ncc_patch_fast<SMP>(d, c, H, src, px, py) : ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
 	}
@@ -785,7 +784,7 @@ DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const AnchorTab& T, i
 		for (int g = 0; g < 4; ++g) {
 			scost[g] = 0.0f;
 			scnt[g] = 0.0f;
-			if ((gm >> g) & 1) homography(rc, sc, d.views[v], pl[base + g], H[g]);
+			if ((gm >> g) & 1) homography(vc, pl[base + g], H[g]);
 			else { for (int i = 0; i < 9; ++i) H[g][i] = 0.0f; H[g][8] = 1.0f; }   // dead slot: maps everything to (0,0)
 		}
 		for (int k = 0; k < DVP_NEIGHBOUR_NUM - 1; ++k) {
