@@ -431,6 +431,17 @@ DVP_HD ViewConst load_view(const Dev& d, int v) {
 #endif
 }
 
+// A camera record (112 B) by value through the same path; `v` must be wave-uniform (0 or a loop counter).
+DVP_HD DvpCamera load_camera(const Dev& d, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	const int vu = __builtin_amdgcn_readfirstlane(v);
+	typedef const __attribute__((address_space(4))) DvpCamera* cptr;
+	return *(cptr)(d.cameras + vu);
+#else
+	return d.cameras[v];
+#endif
+}
+
 // plane-dependent part of ComputeHomography (APD.cu:709-738)
 DVP_HD void homography(const ViewConst& vc, const f4 pl, float* H) {
 	// a/b -> a * (1/b) with one correctly rounded reciprocal per divisor (numerics contract:

@@ -241,8 +241,8 @@ DVP_HD float ncc_old(const Dev& d, const PatchCtx& c, int px, int py, int v, con
 
 // ComputeGeomConsistencyCost (APD.cu:1218-1256)
 DVP_HD float geom_cost(const Dev& d, int px, int py, int v, const f4 plane) {
-	const DvpCamera& rc = d.cameras[0];
-	const DvpCamera& sc = d.cameras[v];
+	const DvpCamera rc = load_camera(d, 0);
+	const DvpCamera sc = load_camera(d, v);
 	const float* dimg = d.depths + (size_t)v * d.plane_stride;
 	const float depth = depth_from_plane(rc, plane, px, py);
 	const f3 fwd = point_on_world((float)px, (float)py, depth, rc);

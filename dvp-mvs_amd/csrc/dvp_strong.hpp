@@ -22,7 +22,7 @@ DVP_HD void sort_small(float* v, int n) {   // insertion sort, APD.cu:114-123
 DVP_HD f4 random_normal_yzl(const Dev& d, int px, int py, Rng& rng, float depth) {
 	const int W = d.width, H = d.height;
 	const int center = py * W + px;
-	const DvpCamera& rc = d.cameras[0];
+	const DvpCamera rc = load_camera(d, 0);
 	f3 vd[20];
 	{
 		const f4 v0 = view_direction(rc, px, py, depth);
@@ -32,7 +32,7 @@ DVP_HD f4 random_normal_yzl(const Dev& d, int px, int py, Rng& rng, float depth)
 	const uint32_t sel = d.selected_views[center];
 	for (int v = 1; v < d.params.num_images; ++v) {
 		if (!is_set(sel, v - 1)) continue;
-		const DvpCamera& sc = d.cameras[v];
+		const DvpCamera sc = load_camera(d, v);
 		const f3 fwd = point_on_world((float)px, (float)py, depth, rc);
 		f2 sp;
 		float sd;
@@ -91,7 +91,7 @@ template <int SMP>
 DVP_HD void random_init_px(const Dev& d, int px, int py, PatchTab tab, unsigned long long* nevals) {
 	const int center = py * d.width + px;
 	const DvpParams& P = d.params;
-	const DvpCamera& rc = d.cameras[0];
+	const DvpCamera rc = load_camera(d, 0);
 	const int S = P.num_images - 1;
 	f4 plane = d.planes[center];
 	PatchCtx c;
@@ -259,7 +259,7 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, PatchTab tab, int ite
 	const int W = d.width;
 	const int center = py * W + px;
 	const DvpParams& P = d.params;
-	const DvpCamera& rc = d.cameras[0];
+	const DvpCamera rc = load_camera(d, 0);
 	const int S = P.num_images - 1;
 	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
 
@@ -498,7 +498,7 @@ DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, PatchTab tab, unsigne
 	const int W = d.width, H = d.height;
 	const int center = px + py * W;
 	const DvpParams& P = d.params;
-	const DvpCamera& rc = d.cameras[0];
+	const DvpCamera rc = load_camera(d, 0);
 	const int S = P.num_images - 1;
 	if (P.use_radius && d.radius[center] == 0) d.radius[center] = P.strong_radius;
 	if (px < 6 || py < 6 || px >= W - 6 || py >= H - 6) { d.weak_info[center] = DVP_UNKNOWN; return; }
@@ -580,7 +580,7 @@ DVP_HD void local_refine_px(const Dev& d, int px, int py, PatchTab tab, unsigned
 	const int W = d.width;
 	const int center = px + py * W;
 	const DvpParams& P = d.params;
-	const DvpCamera& rc = d.cameras[0];
+	const DvpCamera rc = load_camera(d, 0);
 	const int S = P.num_images - 1;
 	const f4 origin = normal_world_to_cam(rc, d.planes[center]);
 	const float origin_depth = origin.w;

@@ -251,7 +251,7 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 	const int center = px + py * W;
 	if (d.weak_info[center] != DVP_WEAK) return;
 	const DvpParams& P = d.params;
-	const DvpCamera& cam = d.cameras[0];
+	const DvpCamera cam = load_camera(d, 0);
 	const int max_pt_num = 160;
 	const int min_margin = 6;
 	const float depth_diff = P.depth_max - P.depth_min;
@@ -537,7 +537,7 @@ DVP_HD void ransac_fit_plane_px(const Dev& d, int px, int py, int iter) {
 	const int center = px + py * W;
 	const DvpParams& P = d.params;
 	if (d.weak_info[center] != DVP_WEAK) { d.fit_planes[center] = d.planes[center]; return; }
-	const DvpCamera& cam = d.cameras[0];
+	const DvpCamera cam = load_camera(d, 0);
 	Rng r_limit(d.seed, (uint32_t)center, rng_site(PH_RANSAC, iter, SUB_LIMIT));
 	Rng r_ransac(d.seed, (uint32_t)center, rng_site(PH_RANSAC, iter, SUB_RANSAC));
 	bool edge_limit = false;
@@ -885,7 +885,7 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter,
 	const int W = d.width, Hh = d.height;
 	const int center = py * W + px;
 	const DvpParams& P = d.params;
-	const DvpCamera& rc = d.cameras[0];
+	const DvpCamera rc = load_camera(d, 0);
 	const int S = P.num_images - 1;
 	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
 	const s2* nbs = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
