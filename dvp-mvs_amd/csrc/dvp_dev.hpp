@@ -431,6 +431,16 @@ DVP_HD ViewConst load_view(const Dev& d, int v) {
 #endif
 }
 
+// pins a wave-uniform float in an SGPR (an opaque value: the compiler cannot re-load it from memory
+// right before its use, as it does with rematerialisable constant-address-space loads)
+DVP_HD float uniform_f(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+#else
+	return x;
+#endif
+}
+
 // A camera record (112 B) by value through the same path; `v` must be wave-uniform (0 or a loop counter).
 DVP_HD DvpCamera load_camera(const Dev& d, int v) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -230,10 +230,11 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 template <int SMP>
 DVP_HD float ncc_old(const Dev& d, const PatchCtx& c, int px, int py, int v, const f4 plane) {
 	const ViewConst vc = load_view(d, v);
+	const float fw = uniform_f(vc.fw), fh = uniform_f(vc.fh);
 	float H[9];
 	homography(vc, plane, H);
 	const f2 pt = apply_homography(H, px, py);
-	if (pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f) return 2.0f;
+	if (pt.x >= fw || pt.x < 0.0f || pt.y >= fh || pt.y < 0.0f) return 2.0f;
 	const float* src = d.images + (size_t)v * d.plane_stride * 2;
 	if (c.fast) return ncc_patch_fast<SMP>(d, c, H, src, px, py);
 	return ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 0);

@@ -762,6 +762,7 @@ template <int SMP>
 DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const AnchorTab& T, int px, int py, int v, const f4* pl /*[8]*/,
 	uint32_t pmask, float* ev /*[8][32], column v-1 written*/) {
 	const ViewConst vc = load_view(d, v);
+	const float fw = uniform_f(vc.fw), fh = uniform_f(vc.fh);
 	const int W = d.width, Hh = d.height, Pt = d.pitch;
 	const float* src = d.images + (size_t)v * d.plane_stride * 2;
 	float center_cost[8];
@@ -771,7 +772,7 @@ DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const AnchorTab& T, i
 		float H[9];
 		homography(vc, pl[q], H);
 		const f2 pt = apply_homography(H, px, py);
-		if (pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f) { ev[q * 32 + v - 1] = 2.0f; continue; }
+		if (pt.x >= fw || pt.x < 0.0f || pt.y >= fh || pt.y < 0.0f) { ev[q * 32 + v - 1] = 2.0f; continue; }
 		live |= 1u << q;
 		center_cost[q] = c.fast ? ncc_patch_fast<SMP>(d, c, H, src, px, py) : ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
 	}
