@@ -441,6 +441,14 @@ DVP_HD float uniform_f(float x) {
 #endif
 }
 
+DVP_HD int uniform_i(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_amdgcn_readfirstlane(x);
+#else
+	return x;
+#endif
+}
+
 // A camera record (112 B) by value through the same path; `v` must be wave-uniform (0 or a loop counter).
 DVP_HD DvpCamera load_camera(const Dev& d, int v) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -235,7 +235,7 @@ DVP_HD float ncc_old(const Dev& d, const PatchCtx& c, int px, int py, int v, con
 	homography(vc, plane, H);
 	const f2 pt = apply_homography(H, px, py);
 	if (pt.x >= fw || pt.x < 0.0f || pt.y >= fh || pt.y < 0.0f) return 2.0f;
-	const float* src = d.images + (size_t)v * d.plane_stride * 2;
+	const float* src = d.images + (size_t)uniform_i(v) * d.plane_stride * 2;   // wave-uniform base
 	if (c.fast) return ncc_patch_fast<SMP>(d, c, H, src, px, py);
 	return ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 0);
 }

@@ -764,7 +764,7 @@ DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const AnchorTab& T, i
 	const ViewConst vc = load_view(d, v);
 	const float fw = uniform_f(vc.fw), fh = uniform_f(vc.fh);
 	const int W = d.width, Hh = d.height, Pt = d.pitch;
-	const float* src = d.images + (size_t)v * d.plane_stride * 2;
+	const float* src = d.images + (size_t)uniform_i(v) * d.plane_stride * 2;   // wave-uniform base: SGPR base + 32-bit lane offsets
 	float center_cost[8];
 	uint32_t live = 0;   // planes whose centre projects inside the source image
 	for (int q = 0; q < 8; ++q) {
