@@ -66,6 +66,14 @@ DVP_HD void build_patch_ctx(const Dev& d, int px, int py, int radius, int inc, i
 	if (!c->fast) return;
 	const float cpix = img_texel(ref, d.org, P, W, H, px, py);
 	const float sig_s = d.params.sigma_spatial, sig_c = d.params.sigma_color;
+	// the 36 reference texels first (independent loads, all in flight together), then the weights
+	float av[kTaps * kTaps];
+#pragma unroll
+	for (int ty = 0; ty < kTaps; ++ty)
+#pragma unroll
+		for (int tx = 0; tx < kTaps; ++tx)
+			av[ty * kTaps + tx] = img_texel(ref, d.org, P, W, H, px - radius + tx * inc, py - radius + ty * inc);
+	sched_fence();
 	float sr = 0.0f, srr = 0.0f, ws = 0.0f;
 #pragma unroll
 	for (int ty = 0; ty < kTaps; ++ty) {          // rows outer, columns inner (tap order)
@@ -74,7 +82,7 @@ DVP_HD void build_patch_ctx(const Dev& d, int px, int py, int radius, int inc, i
 #pragma unroll
 		for (int tx = 0; tx < kTaps; ++tx) {
 			const int i = -radius + tx * inc;
-			const float a = img_texel(ref, d.org, P, W, H, px + i, py + j);
+			const float a = av[ty * kTaps + tx];
 			const float w = bilateral_weight((float)i, (float)j, a, cpix, sig_s, sig_c, colour_only);
 			const float wa = w * a;
 			tab.set(ty * kTaps + tx, mk2(w, wa));
