@@ -35,3 +35,30 @@ np.savez_compressed(os.path.join(os.path.dirname(__file__), "golden_small.npz"),
                     images=sc["images"], kat_px=px, kat_planes=planes, kat_costs=costs, planes=o.get("planes"),
                     selected_views=o.get("selected_views"), weak_info=o.get("weak_info"))
 print("written")
+
+
+# ---- second fixture: a REFINE_ITER pass with WEAK pixels, priors and geometric consistency -----------
+from conftest import second_pass_inputs   # noqa: E402
+
+W2, H2, S2 = 96, 72, 3
+sc2 = synth.make_scene(W2, H2, S2)
+p1 = make_params(S2 + 1, max_iterations=2, state=synth.FIRST_INIT, use_APD=0)
+o1 = O.from_scene(sc2, p1, seed=777)
+o1.upload_state(**first_pass_state(sc2))
+o1.run_patchmatch()
+st = second_pass_inputs(o1, sc2)
+weak = st["weak"].reshape(H2, W2)
+weak[sc2["flat"] & (weak == synth.STRONG)] = synth.WEAK
+weak[:6, :] = synth.UNKNOWN
+st["weak"] = weak.reshape(-1)
+p2 = make_params(S2 + 1, max_iterations=2, state=synth.REFINE_ITER, use_APD=1, geom_consistency=1,
+                 weak_peak_radius=4, rotate_time=2, ransac_threshold=0.01)
+o2 = O.from_scene(sc2, p2, seed=778, depths=sc2["depth_gt"])
+o2.upload_state(**st)
+o2.run_patchmatch()
+np.savez_compressed(os.path.join(os.path.dirname(__file__), "golden_weak.npz"), W=W2, H=H2, S=S2,
+                    in_planes=st["planes"], in_weak=st["weak"], in_views=st["views"], in_radius=st["radius"],
+                    planes=o2.get("planes"), costs=o2.get("costs"), selected_views=o2.get("selected_views"),
+                    weak_info=o2.get("weak_info"), radius=o2.get("radius"), neighbours=o2.get("neighbours"),
+                    weak_count=o2.weak_count())
+print("written weak fixture, weak_count", o2.weak_count())

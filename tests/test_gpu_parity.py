@@ -222,3 +222,9 @@ def test_reset_state_equals_fresh_context():
     g.reset_state()
     g.run_patchmatch()
     assert count_diff(first, g.get("planes")) == 0
+
+
+def test_golden_weak_pass_engine():
+    """the committed REFINE_ITER / weak-path fixture through the C ABI"""
+    from test_oracle_kat import _golden_weak_pass
+    _golden_weak_pass(lambda sc, p, seed, dep: capi().from_scene(sc, p, seed=seed, depths=dep))
