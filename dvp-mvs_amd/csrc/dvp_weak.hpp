@@ -57,12 +57,12 @@ DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
 	// the outer loop here (one selected_views word, one exp per tap) and each set view bit updates
 	// that view's running per-sector arg-max.  Visit order per (view, sector) is unchanged.
 	{
-		float bw[32 * 12];
-		short bi[32 * 12], bj[32 * 12];
+		struct Best { float w; short i, j; };   // one 8-byte private-memory record per (view, sector)
+		Best best[32 * 12];
 		uint32_t has[32];
 		for (int v = 0; v < S; ++v) {
 			has[v] = 0;
-			for (int r = 0; r < 12; ++r) { bw[v * 12 + r] = 0.0f; bi[v * 12 + r] = 0; bj[v * 12 + r] = 0; }
+			for (int r = 0; r < 12; ++r) best[v * 12 + r] = Best{ 0.0f, 0, 0 };
 		}
 		const int radius = P.weak_radius;
 		for (int i = -radius; i <= radius; i++) {
@@ -78,29 +78,26 @@ DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
 				const float w = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
 				for (int v = 0; v < S; ++v) {
 					if (!((sv >> v) & 1)) continue;
-					if (!((has[v] >> r) & 1) || w > bw[v * 12 + r]) {   // first maximum wins (stable bubble sort, APD.cu:823-833)
+					if (!((has[v] >> r) & 1) || w > best[v * 12 + r].w) {   // first maximum wins (stable bubble sort, APD.cu:823-833)
 						has[v] |= 1u << r;
-						bw[v * 12 + r] = w; bi[v * 12 + r] = (short)i; bj[v * 12 + r] = (short)j;
+						best[v * 12 + r] = Best{ w, (short)i, (short)j };
 					}
 				}
 			}
 		}
 		for (int v = 0; v < S; ++v) {
 			// stable descending sort of the 12 sector winners (empty sectors: weight 0, offset (0,0))
-			float* w_ = bw + v * 12;
-			short* i_ = bi + v * 12;
-			short* j_ = bj + v * 12;
+			Best* b_ = best + v * 12;
 			if (has[v]) {
 				for (int a = 1; a < 12; ++a) {
-					const float tw = w_[a];
-					const short ti = i_[a], tj = j_[a];
+					const Best t = b_[a];
 					int b = a;
-					for (; b >= 1 && w_[b - 1] < tw; --b) { w_[b] = w_[b - 1]; i_[b] = i_[b - 1]; j_[b] = j_[b - 1]; }
-					w_[b] = tw; i_[b] = ti; j_[b] = tj;
+					for (; b >= 1 && b_[b - 1].w < t.w; --b) b_[b] = b_[b - 1];
+					b_[b] = t;
 				}
 			}
 			s2* cand = d.candidate + ((size_t)center * S + v) * 8;
-			for (int k = 0; k < 8; ++k) cand[k] = mks2(i_[k], j_[k]);
+			for (int k = 0; k < 8; ++k) cand[k] = mks2(b_[k].i, b_[k].j);
 		}
 	}
 
