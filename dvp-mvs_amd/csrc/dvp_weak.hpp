@@ -260,7 +260,9 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 	for (int i = 0; i < DVP_NEIGHBOUR_NUM; ++i) neighbours[i] = mks2(-1, -1);
 	neighbours[0] = mks2(px, py);
 	s2 strong_points[max_pt_num];   // (-1,-1) == not valid (the reference's dir_valid[])
-	for (int i = 0; i < max_pt_num; ++i) strong_points[i] = mks2(-1, -1);
+	// only the 32 directional slots can stay empty; label-extension points are appended behind them
+	// and every later loop stops at the last appended one (the reference clears all 160 entries)
+	for (int i = 0; i < 32; ++i) strong_points[i] = mks2(-1, -1);
 	int strong_point_size = 0;
 	const int rotate_time = P.rotate_time;
 
@@ -404,7 +406,7 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 	float X[3];
 	get_3d_point(cam, px, py, d.planes[center].w, X);
 	const float center_z = X[2];
-	for (int i = 0; i < max_pt_num; ++i) {
+	for (int i = 0; i <= extend_index; ++i) {
 		const s2 sp = strong_points[i];
 		if (sp.x == -1) continue;
 		const int spc = sp.x + sp.y * W;
@@ -416,7 +418,7 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 		spn[valid_count] = mk3(n4.x, n4.y, n4.z);
 		valid_count++;
 	}
-	for (int i = valid_count; i < max_pt_num; ++i) spv[i] = mks2(-1, -1);
+	for (int i = valid_count; i < DVP_NEIGHBOUR_NUM - 1; ++i) spv[i] = mks2(-1, -1);   // only spv[0..10] are read beyond valid_count (neighbours[1..11])
 
 	f4 best_plane = mk4(0, 0, 0, 0);
 	bool has_valid_plane = false;
