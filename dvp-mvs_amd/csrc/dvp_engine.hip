@@ -463,22 +463,25 @@ int dvp_upload_state(dvp_ctx* c, const float* planes, const uint32_t* views, con
 	{
 		// compacted pixel lists per checkerboard colour; rows the reference's half grid never
 		// reaches (APD.cu:4421-4424) are left out like in the full-grid launch
-		std::vector<int> list;
+		std::vector<int> list, red;
 		list.reserve((size_t)wc);
-		int nb = 0;
+		red.reserve((size_t)wc / 2 + 1);
 		// Order: 16 x 16 pixel tiles (128 pixels of one colour = two waves when the tile is all WEAK),
 		// row-major inside a tile: the lanes of a wave are neighbours in both directions, so their
 		// anchors (nearest STRONG points per direction) and the lines those touch largely coincide.
 		// Every list kernel is order-independent (a WEAK pixel only reads STRONG pixels' state).
 		constexpr int kTW = 16, kTH = 16;   // measured: 16x16 592.7 ms per REFINE pass, 16x8 599, 32x4 609, row-major 622
-		for (int colour = 0; colour < 2; ++colour) {
-			for (int ty = 0; ty < c->H; ty += kTH)
-				for (int tx = 0; tx < c->W; tx += kTW)
-					for (int y = ty; y < ty + kTH && y < c->H; ++y)
-						for (int x = tx; x < tx + kTW && x < c->W; ++x)
-							if (wi[(size_t)y * c->W + x] == DVP_WEAK && ((x + y) & 1) == colour) list.push_back(y * c->W + x);
-			if (colour == 0) nb = (int)list.size();
-		}
+		for (int ty = 0; wc > 0 && ty < c->H; ty += kTH)   // (no WEAK pixel, e.g. a FIRST_INIT pass: nothing to list)
+			for (int tx = 0; tx < c->W; tx += kTW) {
+				const int y1 = ty + kTH < c->H ? ty + kTH : c->H, x1 = tx + kTW < c->W ? tx + kTW : c->W;
+				for (int y = ty; y < y1; ++y) {
+					const uint8_t* row = wi.data() + (size_t)y * c->W;
+					for (int x = tx; x < x1; ++x)
+						if (row[x] == DVP_WEAK) (((x + y) & 1) ? red : list).push_back(y * c->W + x);
+				}
+			}
+		const int nb = (int)list.size();
+		list.insert(list.end(), red.begin(), red.end());
 		if (list.size() > c->weak_list_alloc) {
 			if (dalloc(c, &c->weak_list, list.size(), false)) return 1;
 			c->weak_list_alloc = list.size();
@@ -487,7 +490,8 @@ int dvp_upload_state(dvp_ctx* c, const float* planes, const uint32_t* views, con
 		c->d.weak_black = nb;
 		c->d.weak_red = (int)list.size() - nb;
 	}
-	HIP_TRY(c, hipMemcpyAsync(c->neighbours_map, map.data(), L * 4, hipMemcpyHostToDevice, c->stream));
+	if (wc > 0) HIP_TRY(c, hipMemcpyAsync(c->neighbours_map, map.data(), L * 4, hipMemcpyHostToDevice, c->stream));
+	else HIP_TRY(c, hipMemsetAsync(c->neighbours_map, 0, L * 4, c->stream));
 	if (ensure_weak_buffers(c, (size_t)wc)) return 1;
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	sync_dev_struct(c);
