@@ -83,6 +83,7 @@ struct Dev {
 	f4* fit_planes;
 	s2* candidate;             // [pixel][view][8]
 	const uint8_t* edge;
+	int* search_pos;           // [16][L]: sample positions of the strong update's 16 propagation slots (strong_search_px)
 	uint32_t* edge_bits;       // the edge map as 32x32-pixel bit tiles (128 B each), see edge_bit()
 	int edge_tiles_x;
 	uint32_t* strong_bits;     // same tiling, bit = (weak_info == STRONG); valid during GenNeighbours

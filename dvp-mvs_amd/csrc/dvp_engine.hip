@@ -148,6 +148,13 @@ extern "C" __global__ void dvp_pack_edge_bits(const uint8_t* __restrict__ edge, 
 	if (w < words) bits[w] = pack_edge_word(edge, W, H, tiles_x, w, equals);
 }
 
+// sample search of the strong update (same red/black launch geometry, no LDS, small register footprint)
+extern "C" __global__ void __launch_bounds__(256) dvp_strong_search(const Dev d, const LaunchArgs a) {
+	int px, py;
+	if (block_to_pixel(blockIdx.x, threadIdx.x & 63, threadIdx.x >> 6, a.tiles_x, a.tiles, a.rows, a.half, a.colour, d.width, d.height, &px, &py))
+		strong_search_px(d, px, py);
+}
+
 // line-scan pre-pass of GenEdgeInform: nearest edge pixel in 8 directions (blockIdx.y = direction)
 extern "C" __global__ void __launch_bounds__(256) dvp_edge_rays(const Dev d) {
 	edge_ray_line(d, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
@@ -212,6 +219,7 @@ struct dvp_ctx {
 	uint32_t* strong_bits = nullptr; // bit-tiled (weak_info == STRONG), rebuilt before GenNeighbours
 	DvpCamera* cameras = nullptr; ViewConst* views = nullptr; uint8_t* lut = nullptr;
 	f4* planes = nullptr; f4* planes_snap = nullptr; f4* fit_planes = nullptr;
+	int* search_pos = nullptr;   // [16][L]
 	float* costs = nullptr; float* costs_snap = nullptr; float* complex_ = nullptr;
 	uint32_t* selected_views = nullptr;
 	uint8_t* view_weight = nullptr; uint8_t* weak_info = nullptr; uint8_t* weak_reliable = nullptr; uint8_t* edge = nullptr;
@@ -262,6 +270,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.org = kImgPad * c->pitch + kImgPad;
 	d.plane_stride = (size_t)c->pitch * (c->H + 2 * kImgPad);
 	d.images = c->images; d.depths = c->depths; d.cameras = c->cameras; d.views = c->views; d.sector_lut = c->lut;
+	d.search_pos = c->search_pos;
 	d.planes = c->planes; d.planes_snap = c->planes_snap; d.costs = c->costs; d.costs_snap = c->costs_snap;
 	d.selected_views = c->selected_views; d.view_weight = c->view_weight; d.weak_info = c->weak_info;
 	d.weak_reliable = c->weak_reliable; d.weak_nearest_strong = c->weak_nearest_strong;
@@ -308,6 +317,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	r |= dalloc(c, &c->views, (size_t)num_images);
 	r |= dalloc(c, &c->planes, L);
 	r |= dalloc(c, &c->planes_snap, L);
+	r |= dalloc(c, &c->search_pos, L * 16);
 	r |= dalloc(c, &c->fit_planes, L);                     // cudaMemset 0, APD.cpp:1571
 	r |= dalloc(c, &c->costs, L);
 	r |= dalloc(c, &c->costs_snap, L);
@@ -608,6 +618,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 	case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(c->d.sampler ? dvp_neighbour_update_exact : dvp_neighbour_update, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_RANDOM_INIT: hipLaunchKernelGGL(c->d.sampler ? dvp_random_init_exact : dvp_random_init, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_STRONG_UPDATE:
+		hipLaunchKernelGGL(dvp_strong_search, grid, block, 0, c->stream, c->d, a);
 		if (c->NI - 1 <= kNarrowViews) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v8_exact : dvp_strong_update_v8, grid, block, 0, c->stream, c->d, a);
 		else hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_exact : dvp_strong_update, grid, block, 0, c->stream, c->d, a);
 		break;

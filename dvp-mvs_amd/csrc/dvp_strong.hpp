@@ -243,6 +243,23 @@ DVP_HD int strong_sample_search(const Dev& d, int px, int py, int k, int pass) {
 	return (min_cost < FLT_MAX) ? best : -1;
 }
 
+// The sample positions of the 16 propagation slots of a pixel (8 edge-adaptive + 8 fixed, -1 = none)
+// depend only on the pre-launch snapshot and the edge priors, so they are found by a separate,
+// light launch (dozens of waves per SIMD hide the two dependent round trips per slot) and the
+// register-starved update kernel reads one word per slot.
+DVP_HD void strong_search_px(const Dev& d, int px, int py) {
+	const int center = py * d.width + px;
+	if (d.weak_info[center] == DVP_WEAK) return;
+	const size_t L = (size_t)d.width * d.height;
+	const bool is_edge = d.edge[center] != 0;
+	for (int slot = 0; slot < 16; ++slot) {
+		int pos = -1;
+		if (slot < 8) pos = strong_sample_search(d, px, py, slot, 0);
+		else if (!is_edge) pos = strong_sample_search(d, px, py, slot - 8, 1);
+		d.search_pos[(size_t)slot * L + center] = pos;
+	}
+}
+
 // CheckerboardPropagationStrong + PlaneHypothesisRefinementStrong
 // (APD.cu:2010-2141, 2462-2567, 2725-2737, 1311-1383), use_edge branch.
 //
@@ -301,14 +318,9 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, PatchTab tab, int ite
 		f4 plane = mk4(0, 0, 1, 1);
 		uint32_t mask = 0;
 		int pos = -1;
-		if (slot < 8) {
-			pos = strong_sample_search(d, px, py, slot, 0);
+		if (slot < 16) {
+			pos = d.search_pos[(size_t)slot * ((size_t)W * d.height) + center];   // strong_search_px (-1 on edge pixels for slots 8-15)
 			if (pos >= 0) { plane = d.planes_snap[pos]; mask = all_views; }
-		} else if (slot < 16) {
-			if (!is_edge) {
-				pos = strong_sample_search(d, px, py, slot - 8, 1);
-				if (pos >= 0) { plane = d.planes_snap[pos]; mask = all_views; }
-			}
 		} else if (slot == 16) {
 			// view selection (APD.cu:2462-2530)
 			float priors[MV];

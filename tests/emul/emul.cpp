@@ -20,6 +20,7 @@ struct Emu {
 	std::vector<ViewConst> views;
 	std::vector<uint8_t> lut;
 	std::vector<f4> planes, planes_snap, fit_planes;
+	std::vector<int> search_pos;
 	std::vector<float> costs, costs_snap, complex_;
 	std::vector<uint32_t> selected_views;
 	std::vector<uint8_t> view_weight, weak_info, weak_reliable, edge;
@@ -41,6 +42,7 @@ void refresh(Emu& e) {
 	d.cameras = e.cameras.data();
 	d.views = e.views.data();
 	d.sector_lut = e.lut.data();
+	d.search_pos = e.search_pos.data();
 	d.planes = e.planes.data(); d.planes_snap = e.planes_snap.data();
 	d.costs = e.costs.data(); d.costs_snap = e.costs_snap.data();
 	d.selected_views = e.selected_views.data();
@@ -101,6 +103,7 @@ void* emu_create(int W, int H, int NI) {
 	e->views.resize(NI);
 	e->planes.assign(L, mk4(0, 0, 0, 0));
 	e->planes_snap = e->planes;
+	e->search_pos.assign(L * 16, -1);
 	e->fit_planes = e->planes;
 	e->costs.assign(L, 0.0f);
 	e->costs_snap = e->costs;
@@ -264,12 +267,22 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 		break;
 	case DVP_ST_NEIGHBOUR_UPDATE: launch<DVP_ST_NEIGHBOUR_UPDATE>(e, iter, colour); break;
 	case DVP_ST_RANDOM_INIT: launch<DVP_ST_RANDOM_INIT>(e, iter, colour); break;
-	case DVP_ST_STRONG_UPDATE:
+	case DVP_ST_STRONG_UPDATE: {
 		e.planes_snap = e.planes;
 		e.costs_snap = e.costs;
 		refresh(e);
+		// dvp_strong_search: same red/black geometry
+		const LaunchGeom g = make_geom(e.W, e.H, true);
+#pragma omp parallel for schedule(dynamic, 1)
+		for (int b = 0; b < g.grid(); ++b)
+			for (int wave = 0; wave < 4; ++wave)
+				for (int lane = 0; lane < 64; ++lane) {
+					int px, py;
+					if (block_to_pixel(b, lane, wave, g.tiles_x, g.tiles, g.rows, 1, colour, e.W, e.H, &px, &py)) strong_search_px(e.d, px, py);
+				}
 		launch<DVP_ST_STRONG_UPDATE>(e, iter, colour);
 		break;
+	}
 	case DVP_ST_RANSAC_FIT: pack_edge(e); launch<DVP_ST_RANSAC_FIT>(e, iter, colour); break;
 	case DVP_ST_WEAK_UPDATE: launch<DVP_ST_WEAK_UPDATE>(e, iter, colour); break;
 	case DVP_ST_GET_DEPTH_NORMAL: launch<DVP_ST_GET_DEPTH_NORMAL>(e, iter, colour); break;
