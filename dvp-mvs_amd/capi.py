@@ -17,6 +17,8 @@ STAGES = dict(gen_edge_inform=0, find_nearest_strong=1, gen_neighbours=2, neighb
               random_init=4, strong_update=5, ransac_fit=6, weak_update=7, get_depth_normal=8,
               filter_strong=9, depth_to_weak=10, local_refine=11)
 STAGE_NAMES = {v: k for k, v in STAGES.items()}
+STAGE_NAMES[12] = "strong_prep"   # timing bucket only (snapshot copies + sample search of every strong_update), not launchable
+N_TIMING = 13
 BUFFERS = dict(planes=(0, np.float32, 4), costs=(1, np.float32, 1), selected_views=(2, np.uint32, 1),
                view_weight=(3, np.uint8, 32), weak_info=(4, np.uint8, 1), weak_reliable=(5, np.uint8, 1),
                weak_nearest_strong=(6, np.int16, 2), neighbours_map=(7, np.int32, 1),
@@ -34,9 +36,9 @@ EXPORTS = ["dvp_ctx_create", "dvp_ctx_destroy", "dvp_last_error", "dvp_upload_im
 
 
 class DvpTimings(ctypes.Structure):
-    _fields_ = [("stage_ms", ctypes.c_double * 12), ("stage_launches", ctypes.c_int32 * 12),
+    _fields_ = [("stage_ms", ctypes.c_double * 13), ("stage_launches", ctypes.c_int32 * 13),
                 ("iter_loop_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
-                ("ncc_evals", ctypes.c_uint64 * 12)]
+                ("ncc_evals", ctypes.c_uint64 * 13)]
 
 
 def build(force=False):
@@ -203,9 +205,9 @@ class Context:
     def timings(self, reset=False):
         t = DvpTimings()
         self._ck(self.L.dvp_get_timings(self.h, ctypes.byref(t)))
-        out = dict(stage_ms={STAGE_NAMES[i]: t.stage_ms[i] for i in range(12)},
-                   stage_launches={STAGE_NAMES[i]: t.stage_launches[i] for i in range(12)},
-                   ncc_evals={STAGE_NAMES[i]: t.ncc_evals[i] for i in range(12)},
+        out = dict(stage_ms={STAGE_NAMES[i]: t.stage_ms[i] for i in range(N_TIMING)},
+                   stage_launches={STAGE_NAMES[i]: t.stage_launches[i] for i in range(N_TIMING)},
+                   ncc_evals={STAGE_NAMES[i]: t.ncc_evals[i] for i in range(N_TIMING)},
                    iter_loop_ms=t.iter_loop_ms, total_ms=t.total_ms)
         if reset:
             self._ck(self.L.dvp_reset_timings(self.h))

@@ -551,20 +551,31 @@ int dvp_set_profiling(dvp_ctx* c, int on) { c->profiling = on != 0; sync_dev_str
 
 // ---- launches ---------------------------------------------------------------------------------
 static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
-	if (stage < 0 || stage >= DVP_ST_COUNT) { c->error = "bad stage id"; return 1; }
+	if (stage < 0 || stage >= DVP_ST_LAUNCHABLE) { c->error = "bad stage id"; return 1; }
 	if (!c->lut) { c->error = "dvp_set_params must be called before running kernels"; return 1; }
 	if (c->d.params.geom_consistency && !c->have_depths) { c->error = "geom_consistency is on but no depth maps were uploaded"; return 1; }
 	const LaunchGeom g = make_geom(c->W, c->H, stage_is_half(stage));
 	LaunchArgs a;
 	a.tiles_x = g.tiles_x; a.tiles = g.tiles; a.rows = g.rows; a.half = g.half ? 1 : 0;
 	a.colour = colour; a.iter = iter;
+	if (c->events.size() >= 2048 && dvp_get_timings(c, nullptr)) return 1;   // fold pending timings: bounds the event pool
 	if (stage == DVP_ST_STRONG_UPDATE) {
 		// pre-launch snapshot: the direction-4 samples of the strong update are same-colour pixels
-		// (APD.cu:2071-2074); every neighbour read of that kernel sees the state before the launch
+		// (APD.cu:2071-2074); every neighbour read of that kernel sees the state before the launch.
+		// Then the light sample-search launch.  Both are timed in their own bucket (DVP_ST_STRONG_PREP)
+		// so that stage_ms[DVP_ST_STRONG_UPDATE] is the update kernel alone.
+		EventPair prep;
+		prep.stage = DVP_ST_STRONG_PREP;
+		HIP_TRY(c, hipEventCreate(&prep.a));
+		HIP_TRY(c, hipEventCreate(&prep.b));
+		HIP_TRY(c, hipEventRecord(prep.a, c->stream));
 		HIP_TRY(c, hipMemcpyAsync(c->planes_snap, c->planes, c->L * 16, hipMemcpyDeviceToDevice, c->stream));
 		HIP_TRY(c, hipMemcpyAsync(c->costs_snap, c->costs, c->L * 4, hipMemcpyDeviceToDevice, c->stream));
+		hipLaunchKernelGGL(dvp_strong_search, dim3(g.grid()), dim3(256), 0, c->stream, c->d, a);
+		HIP_TRY(c, hipGetLastError());
+		HIP_TRY(c, hipEventRecord(prep.b, c->stream));
+		c->events.push_back(prep);
 	}
-	if (c->events.size() >= 2048 && dvp_get_timings(c, nullptr)) return 1;   // fold pending timings: bounds the event pool
 	EventPair ep;
 	ep.stage = stage;
 	HIP_TRY(c, hipEventCreate(&ep.a));
@@ -618,7 +629,6 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 	case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(c->d.sampler ? dvp_neighbour_update_exact : dvp_neighbour_update, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_RANDOM_INIT: hipLaunchKernelGGL(c->d.sampler ? dvp_random_init_exact : dvp_random_init, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_STRONG_UPDATE:
-		hipLaunchKernelGGL(dvp_strong_search, grid, block, 0, c->stream, c->d, a);
 		if (c->NI - 1 <= kNarrowViews) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v8_exact : dvp_strong_update_v8, grid, block, 0, c->stream, c->d, a);
 		else hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_exact : dvp_strong_update, grid, block, 0, c->stream, c->d, a);
 		break;

@@ -85,7 +85,10 @@ enum {
 	DVP_ST_FILTER_STRONG = 9,        /* Black/RedPixelFilterStrong  APD.cu:4497-4499 */
 	DVP_ST_DEPTH_TO_WEAK = 10,       /* DepthToWeak            APD.cu:4502 */
 	DVP_ST_LOCAL_REFINE = 11,        /* LocalRefine            APD.cu:4505 */
-	DVP_ST_COUNT = 12
+	DVP_ST_LAUNCHABLE = 12,          /* ids below this one are launch sites accepted by dvp_run_stage */
+	DVP_ST_STRONG_PREP = 12,         /* timing bucket only: the pre-launch snapshot copies and the sample-search
+	                                    launch issued by every DVP_ST_STRONG_UPDATE (DvpTimings) */
+	DVP_ST_COUNT = 13
 };
 
 /* Device buffers (DataPassHelper members, APD.h:60-92) addressable by dvp_download_buffer /

@@ -26,7 +26,8 @@ def test_pod_layouts():
     assert synth.CAMERA_DTYPE.itemsize == 112       # main.h:58-67
     assert synth.PARAMS_DTYPE.itemsize == 76        # main.h:86-112
     capi = pkg("capi")
-    assert ctypes.sizeof(capi.DvpTimings) == 12 * 8 + 12 * 4 + 8 + 8 + 12 * 8
+    n = 13   # DVP_ST_COUNT: 12 launch sites + the strong_prep timing bucket
+    assert ctypes.sizeof(capi.DvpTimings) == n * 8 + (n * 4 + 4) + 8 + 8 + n * 8   # int32[13] is padded to the next double
     p = synth.default_params(6)
     raw = np.frombuffer(p.tobytes(), np.uint8)
     assert raw[28] == 0 and raw[48] == 1 and raw[49] == 1 and raw[52] == 0 and raw[53] == 1   # bool bytes
