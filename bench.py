@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — Mpixels/s/PatchMatch-iteration of the MI355X PatchMatch engine.
 
-A "step" = one APD::RunPatchMatch (reference: /root/reference/APD.cu:4406-4532) over one
-reference view of synthetic input; the workload at N=1 is BASELINE.json configs[1]
-("half-res, 5 source views, 6 iterations, 1xMI355X"): 3104x2064, S=5, 6 iterations, FIRST_INIT,
-geom off.  With N>1 (torchrun, one rank per GPU) every rank processes its own views — weak
-scaling, no data-path collective; the shared image/camera buffers are broadcast once over RCCL
-before the timed region.  value = W*H*iters*steps*N / wall time of the timed steps (whole
-RunPatchMatch, inputs resident in HBM).
+A "step" = one APD::RunPatchMatch (reference: /root/reference/APD.cu:4406-4532) over one reference
+view of synthetic input.  Default workload (N=1) = BASELINE.json configs[2], the configuration the
+metric is quoted on ("ETH3D full-res"): 6208x4128, 9 source views, a REFINE_ITER pass with
+geometric consistency, use_APD (WEAK pixels) and the edge/label/radius priors on — all twelve launch
+sites live.  Its inputs (planes, selected views, WEAK map, radius map) come from an UNTIMED FIRST_INIT
+pass of the same view on the same engine, handed over the way the reference's driver does between
+passes (main.cpp:298-376 -> APD.cpp:1169-1195,1428-1456); the source depth maps are the scene's
+rendered depths.  `--config cfg2` selects the half-res FIRST_INIT configuration (round-1 bench line).
+
+With N>1 (torchrun, one rank per GPU): rank 0 renders the scene on its GPU, images / depth maps /
+surface maps are broadcast once over RCCL (xGMI); rank r then takes view (r mod NI) of the scene as
+ITS reference view (the other NI-1 as sources) — different content per rank, no data-path collective,
+weak scaling.  value = W*H*iters*steps*N / max-over-ranks wall time of the timed steps (whole
+RunPatchMatch incl. the device-side state restore; inputs resident in HBM).
 
 Prints ONE JSON line (rank 0).
 """
@@ -24,76 +31,139 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-NCC_BYTES = 724          # algorithmic bytes of one bilateral-NCC evaluation
-HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md)
+NCC_BYTES = 724            # algorithmic bytes of one bilateral-NCC evaluation
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+VALU_PEAK_GINST = 1228.8   # wave64 VALU instructions/s: 256 CU x 4 SIMD x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md "Wave scheduling")
+PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_r02.json")
+
+# launch site -> kernel name in a rocprofv3 trace (list launches for the weak path; the narrow
+# strong-update instantiation when S <= 8)
+def kernel_name(stage, S):
+    return {"strong_update": "dvp_strong_update_v8" if S <= 8 else "dvp_strong_update",
+            "weak_update": "dvp_weak_update_list", "gen_neighbours": "dvp_gen_neighbours_list",
+            "ransac_fit": "dvp_ransac_fit_plane_list", "find_nearest_strong": "dvp_find_nearest_strong_list",
+            "neighbour_update": "dvp_neighbour_update_list"}.get(stage, "dvp_" + stage)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=3104)
-    ap.add_argument("--height", type=int, default=2064)
-    ap.add_argument("--src", type=int, default=5)
-    ap.add_argument("--iters", type=int, default=6)
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--src", type=int, default=0)
+    ap.add_argument("--iters", type=int, default=0)
+    ap.add_argument("--weak-frac", type=float, default=0.05, help="share of 32x32 tiles handed over as WEAK (refine configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=str, default="auto", help="WxH of the CPU-baseline view (auto: scaled to the core count)")
-    ap.add_argument("--micro", action="store_true", help="also time the stand-alone cost-vector kernel")
     return ap.parse_args()
 
 
-def cpu_baseline(synth, args, S, iters, capi=None, device=0):
-    """The oracle ("port") timed on this host's cores on a bounded sample of the same workload:
-    same scene generator, same S / iterations / params, a 256x192 view."""
-    from oracle import oracle as O
+def host_cores():
     try:
-        ncores = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
-        ncores = os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    omp = os.environ.get("OMP_NUM_THREADS")
+    return min(n, int(omp)) if omp else n
+
+
+def cpu_baseline(pkg, args, cfg, S, iters, device=0):
+    """The oracle ("port") timed on this host's cores on a bounded sample of the same workload: same
+    scene generator, same S / iterations / parameters / pass structure on a small view; the engine is
+    then run on that very sample and compared with it (oracle = checker, outside any timed region)."""
+    from oracle import oracle as O
+    synth, wl, capi = pkg.synth, pkg.workloads, pkg.get_capi()
+    ncores = host_cores()
     if args.cpu_size == "auto":
-        # ~0.004 Mpx*iter/s/core (SURVEY.md §6): ~2000 px per core keeps the sample at 10-30 s and
-        # gives every OpenMP thread a few rows
-        px = max(192 * 144, 2000 * ncores)
+        # ~0.0006 Mpx*iter/s/core measured (r01): ~1500 px per core keeps the timed pass at 10-30 s
+        px = max(192 * 144, 1500 * ncores)
         h = int(round((px * 3 / 4) ** 0.5 / 8)) * 8
         w = h * 4 // 3
     else:
         w, h = [int(v) for v in args.cpu_size.split("x")]
     sc = synth.make_scene(w, h, S)
-    p = bench_params(synth, S, iters)
-    o = O.from_scene(sc, p)
-    o.upload_state(planes=np.zeros((w * h, 4), np.float32), edge=sc["edge"], label=sc["label"],
-                   radius=np.full(w * h, 5, np.int32))
+    L = w * h
+    p1 = wl.first_init_params(S, iters)
+    first = dict(planes=np.zeros((L, 4), np.float32), edge=sc["edge"], label=sc["label"], radius=np.full(L, 5, np.int32))
+    o = O.from_scene(sc, p1)
+    g = capi.from_scene(sc, p1, device=device)
+    o.upload_state(**first)
+    g.upload_state(**first)
     t0 = time.time()
     o.run_patchmatch()
-    dt = time.time() - t0
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count()
-    omp = os.environ.get("OMP_NUM_THREADS")
-    if omp:
-        cores = min(cores, int(omp))
-    res = {"value": round(w * h * iters / dt / 1e6, 5), "unit": "Mpx/s/iter", "cores": cores, "kind": "port",
-           "sample": "%dx%d view, S=%d, %d iters, whole RunPatchMatch, oracle/ (OpenMP over rows), %.1f s" % (w, h, S, iters, dt)}
-    if capi is not None:
-        # parity of the engine on the very sample the CPU was timed on (oracle used as the checker, outside any timed region)
-        g = capi.from_scene(sc, p, device=device)
-        g.upload_state(planes=np.zeros((w * h, 4), np.float32), edge=sc["edge"], label=sc["label"], radius=np.full(w * h, 5, np.int32))
+    t_first = time.time() - t0
+    g.run_patchmatch()
+    timed, what = t_first, "FIRST_INIT pass"
+    if cfg["refine"]:
+        p2 = wl.refine_iter_params(S, iters)
+        st = wl.hand_over(o.get("planes"), o.get("selected_views"), o.get("weak_info"), o.get("radius"), p1, w, h,
+                          extra_weak=wl.weak_tiles(w, h, args.weak_frac, sc["flat"]))
+        for e in (o, g):
+            e.set_params(p2)
+            e.set_depths(sc["depth_gt"])
+            e.upload_state(planes=st[0], views=st[1], weak=st[2], radius=st[3])
+        t0 = time.time()
+        o.run_patchmatch()
+        timed, what = time.time() - t0, "REFINE_ITER pass (geom, %.1f %% WEAK) after an untimed FIRST_INIT pass" % (100.0 * o.weak_count() / L)
         g.run_patchmatch()
-        a, b = o.get("planes"), g.get("planes")
-        diff = (a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))
-        res["gpu_vs_cpu_plane_words_differing"] = int(diff.sum())
-        res["gpu_vs_cpu_states_differing"] = int((o.get("weak_info") != g.get("weak_info")).sum() + (o.get("selected_views") != g.get("selected_views")).sum())
-        g.close()
+    res = {"value": round(L * iters / timed / 1e6, 5), "unit": "Mpx/s/iter", "cores": ncores, "kind": "port",
+           "sample": "%dx%d view, S=%d, %d iterations, whole RunPatchMatch of the %s, oracle/ (g++ -O3, OpenMP over row blocks), %.1f s" % (w, h, S, iters, what, timed)}
+    a, b = o.get("planes"), g.get("planes")
+    diff = (a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))
+    res["gpu_vs_cpu_plane_words_differing"] = int(diff.sum())
+    res["gpu_vs_cpu_states_differing"] = int((o.get("weak_info") != g.get("weak_info")).sum() + (o.get("selected_views") != g.get("selected_views")).sum())
+    g.close()
     return res
 
 
-def bench_params(synth, S, iters):
-    p = synth.default_params(S + 1, max_iterations=iters, state=synth.FIRST_INIT, use_APD=0)
-    p["depth_min"] = np.float32(2.5) * np.float32(0.6)   # APD.cpp:1109-1110
-    p["depth_max"] = np.float32(6.5) * np.float32(1.2)
-    return p
+def pmc_lookup(kernel, W, H, S):
+    """PMC counters of `kernel` at exactly this problem size (profiles/pmc_r02.json, written by
+    tools/pmc_table.py from separate rocprofv3 --pmc passes of this bench) or None."""
+    try:
+        return json.load(open(PMC_TABLE))["kernels"].get("%s|%dx%d|S%d" % (kernel, W, H, S))
+    except Exception:
+        return None
+
+
+def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
+    """Roofline entry of one launch site.  `bound` = the limiter with the larger fraction of its peak:
+    VALU issue (wave64 VALU instructions / s against 256 CU x 4 SIMD x 2.4 GHz / 2) or physical HBM
+    traffic (PMC FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction) — both <= 1 by construction; they need
+    the PMC table entry of this (kernel, size).  The cache-oblivious algorithmic rate (724 B per NCC
+    evaluation) is reported beside it; it exceeds the HBM peak whenever the caches serve
+    the re-reads, i.e. it is a work rate, not a bound."""
+    k = kernel_name(stage, S)
+    sec = avg_ms * 1e-3
+    alg = evals_per_launch * NCC_BYTES / sec / 1e9 if (sec > 0 and evals_per_launch) else None
+    pmc = pmc_lookup(k, W, H, S)
+    r = {"kernel": k, "avg_launch_ms": round(avg_ms, 3), "evals_per_launch": int(evals_per_launch or 0), "bytes_per_eval": NCC_BYTES,
+         "algorithmic_gbs": round(alg, 1) if alg else None, "algorithmic_frac_of_hbm_peak": round(alg / HBM_PEAK_GBS, 4) if alg else None}
+    if pmc and sec > 0:
+        traffic = pmc.get("hbm_bytes_per_launch")
+        valu = pmc.get("SQ_INSTS_VALU")
+        hbm_gbs = traffic / sec / 1e9 if traffic else None
+        valu_g = valu / sec / 1e9 if valu else None
+        fh = hbm_gbs / HBM_PEAK_GBS if hbm_gbs else 0.0
+        fv = valu_g / VALU_PEAK_GINST if valu_g else 0.0
+        if fv >= fh:
+            r.update(bound="valu", achieved=round(valu_g, 1), peak=VALU_PEAK_GINST, unit="Ginstr/s", frac=round(fv, 4))
+        else:
+            r.update(bound="hbm", achieved=round(hbm_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fh, 4))
+        r.update(traffic=traffic, physical_hbm_gbs=round(hbm_gbs, 1) if hbm_gbs else None, physical_hbm_frac=round(fh, 4),
+                 valu_ginstr_s=round(valu_g, 1) if valu_g else None, valu_issue_frac=round(fv, 4),
+                 valu_instr_per_wave_eval=round(valu * 64.0 / evals_per_launch, 1) if (valu and evals_per_launch) else None,
+                 pmc_source="profiles/pmc_r02.json[%s|%dx%d|S%d]" % (k, W, H, S))
+        for c in ("l2_hit_rate", "wait_any_frac", "valu_busy_frac", "scratch_bytes_per_lane"):
+            if c in pmc:
+                r[c] = pmc[c]
+    else:
+        r.update(bound="hbm", achieved=round(alg, 1) if alg else None, peak=HBM_PEAK_GBS, unit="GB/s",
+                 frac=round(alg / HBM_PEAK_GBS, 4) if alg else None, traffic=None,
+                 note="no PMC entry for this (kernel, size) in profiles/pmc_r02.json: algorithmic rate only (not a bound; can exceed 1)")
+    return r
 
 
 def main():
@@ -106,46 +176,86 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     # DVP_BENCH_FORCE_DIST=1 exercises the RCCL path (init, broadcast, all_reduce) with one rank
     use_dist = world > 1 or os.environ.get("DVP_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     pkg = importlib.import_module("dvp-mvs_amd")
-    synth, capi = pkg.synth, pkg.get_capi()
-    W, H, S, iters = args.width, args.height, args.src, args.iters
-    NI = S + 1
+    importlib.import_module("dvp-mvs_amd.workloads")
+    synth, wl, capi = pkg.synth, pkg.workloads, pkg.get_capi()
+    cfg = dict(wl.CONFIGS[args.config])
+    W, H = args.width or cfg["W"], args.height or cfg["H"]
+    S, iters = args.src or cfg["S"], args.iters or cfg["iters"]
+    NI, L = S + 1, W * H
 
-    # ---- inputs: rank 0 renders the scene; every rank gets it over RCCL (xGMI) --------------------
-    pitch = W
-    dev_imgs = torch.empty((NI, H, W), dtype=torch.float32, device="cuda")
-    cams_t = torch.empty(NI * 112, dtype=torch.uint8, device="cuda")
-    edge_t = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+    # ---- inputs: rank 0 renders the scene on its GPU; every rank gets it over RCCL (xGMI) ----------
+    t_setup = time.time()
+    imgs = torch.empty((NI, H, W), dtype=torch.float32, device=dev)
+    deps = torch.empty((NI, H, W), dtype=torch.float32, device=dev)
+    sids = torch.empty((NI, H, W), dtype=torch.uint8, device=dev)
+    flats = torch.empty((NI, H, W), dtype=torch.bool, device=dev)
+    cams_t = torch.empty(NI * 112, dtype=torch.uint8, device=dev)
     if rank == 0:
-        sc = synth.make_scene(W, H, S)
-        dev_imgs.copy_(torch.from_numpy(sc["images"]))
+        sc = synth.make_scene_torch(W, H, S, dev)
+        imgs.copy_(sc["images"])
+        deps.copy_(sc["depth_gt"])
+        for i in range(NI):
+            sids[i], flats[i] = sc["sids"][i], sc["flats"][i]
         cams_t.copy_(torch.from_numpy(np.frombuffer(sc["cameras"].tobytes(), np.uint8).copy()))
-        edge_t.copy_(torch.from_numpy(sc["edge"]))
+        del sc
     if use_dist:
-        dist.broadcast(dev_imgs, 0)
-        dist.broadcast(cams_t, 0)
-        dist.broadcast(edge_t, 0)
+        for t in (imgs, deps, sids, cams_t):
+            dist.broadcast(t, 0)
+        fl8 = flats.to(torch.uint8)
+        dist.broadcast(fl8, 0)
+        flats = fl8.bool()
     torch.cuda.synchronize()
-    cams = np.frombuffer(cams_t.cpu().numpy().tobytes(), dtype=synth.CAMERA_DTYPE).copy()
-    edge = edge_t.cpu().numpy()
+    cams_all = np.frombuffer(cams_t.cpu().numpy().tobytes(), dtype=synth.CAMERA_DTYPE).copy()
+
+    # ---- this rank's problem: view `ref` is the reference image, the others its sources -------------
+    ref = rank % NI
+    order = [ref] + [i for i in range(NI) if i != ref]
+    cams = cams_all[order].copy()
+    edge_t, label_t = synth.view_priors_torch(sids[ref], flats[ref])
+    edge, label = edge_t.cpu().numpy(), label_t.cpu().numpy()
+    flat = flats[ref].cpu().numpy()
+    del sids, flats, edge_t, label_t
 
     ctx = capi.Context(W, H, NI, device=local_rank)
-    ctx.set_images_device([dev_imgs[i].data_ptr() for i in range(NI)], pitch)
+    ctx.set_images_device([imgs[i].data_ptr() for i in order], W)
     ctx.set_cameras(cams)
-    ctx.set_params(bench_params(synth, S, iters))
-    ctx.upload_state(edge=edge)
-    del dev_imgs
+    p1 = wl.first_init_params(S, iters)
+    ctx.set_params(p1)
+    ctx.set_seed(1234 + rank)
+    ctx.upload_state(planes=np.zeros((L, 4), np.float32), views=np.zeros(L, np.uint32), weak=np.full(L, synth.STRONG, np.uint8),
+                     edge=edge, label=label, radius=np.full(L, 5, np.int32))
+    del imgs
+    weak_frac = 0.0
+    if cfg["refine"]:
+        # untimed FIRST_INIT pass -> hand-over -> the REFINE_ITER pass that is timed
+        ctx.run_patchmatch()
+        planes, views, weak, radius = ctx.download_state()
+        st = wl.hand_over(planes, views, weak, radius, p1, W, H, extra_weak=wl.weak_tiles(W, H, args.weak_frac, flat))
+        del planes, views, weak, radius
+        ctx.set_params(wl.refine_iter_params(S, iters))
+        ctx.set_depths_device([deps[i].data_ptr() for i in order], W)
+        ctx.upload_state(planes=st[0], views=st[1], weak=st[2], radius=st[3])
+        weak_frac = ctx.weak_count() / float(L)
+        del st
+    del deps
+    ctx.save_state()
+    ctx.synchronize()
+    ctx.timings(reset=True)
+    torch.cuda.empty_cache()
+    t_setup = time.time() - t_setup
 
     def one_step(view_index, profile=False):
         ctx.set_seed(1234 + view_index)
         ctx.set_profiling(profile)
-        ctx.reset_state()
+        ctx.restore_state()
         ctx.run_patchmatch()
 
     def barrier():
@@ -154,7 +264,7 @@ def main():
         if use_dist:
             dist.barrier()
 
-    # ---- warm-up (first warm-up step also counts NCC evaluations: deterministic per seed) ---------
+    # ---- warm-up (the first warm-up step also counts NCC evaluations: deterministic per seed) -------
     evals = None
     for w in range(max(args.warmup, 1)):
         one_step(rank, profile=(w == 0))
@@ -165,61 +275,59 @@ def main():
     ctx.synchronize()
     ctx.timings(reset=True)
 
-    # ---- timed region ---------------------------------------------------------------------------------
+    # ---- timed region ------------------------------------------------------------------------------
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
         one_step(rank + s * world)
+    ctx.synchronize()
+    busy = time.perf_counter() - t0          # this rank's own time (before waiting for the others)
     barrier()
     dt = time.perf_counter() - t0
     tm = ctx.timings()
+    busy_all = [busy]
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        bt = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(bt, torch.tensor([busy], dtype=torch.float64, device=dev))
+        busy_all = [float(b.item()) for b in bt]
 
     if rank == 0:
         total_px_iter = float(W) * H * iters * args.steps * world
         value = total_px_iter / dt / 1e6
-        # dominant kernel: the strong red/black update (dvp_strong_update; the _v8 instantiation when S <= 8)
-        launches = tm["stage_launches"]["strong_update"]
-        avg_ms = tm["stage_ms"]["strong_update"] / max(launches, 1)
-        ev_launch = evals["ncc_evals"]["strong_update"] / max(evals["stage_launches"]["strong_update"], 1)
-        achieved = ev_launch * NCC_BYTES / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_strong_update.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        stage_ms = {k: v for k, v in tm["stage_ms"].items() if v > 0}
+        per_launch = {k: stage_ms[k] / max(tm["stage_launches"][k], 1) for k in stage_ms}
+        ev_launch = {k: evals["ncc_evals"][k] / max(evals["stage_launches"][k], 1) for k in stage_ms}
+        ranked = sorted((k for k in stage_ms if k != "strong_prep"), key=lambda k: -stage_ms[k])
+        roofs = {k: roofline_of(k, S, W, H, per_launch[k], ev_launch[k]) for k in ranked[:4]}
+        dom = ranked[0]
+        workload = "BASELINE %s stand-in: %dx%d, S=%d source views, %d PatchMatch iterations, %s" % (
+            args.config if (W, H, S) == (cfg["W"], cfg["H"], cfg["S"]) else "custom(%s-like)" % args.config, W, H, S, iters,
+            ("REFINE_ITER pass, geom_consistency on, use_APD on (%.1f %% WEAK pixels), edge/label/radius priors on, inputs from an untimed FIRST_INIT pass" % (100 * weak_frac))
+            if cfg["refine"] else "FIRST_INIT, geom off")
         out = {
             "metric": "Mpixels/sec/PatchMatch-iteration", "value": round(value, 3), "unit": "Mpx/s/iter",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg2 stand-in: %dx%d, S=%d source views, %d PatchMatch iterations, FIRST_INIT, geom off, one view per step per GPU" % (W, H, S, iters),
-                       "width": W, "height": H, "src_views": S, "iterations": iters, "parallelism": "views round-robin over %d rank(s)" % world},
-            "roofline": {"bound": "hbm", "kernel": "dvp_strong_update_v8" if S <= 8 else "dvp_strong_update", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "evals_per_launch": int(ev_launch), "bytes_per_eval": NCC_BYTES, "avg_launch_ms": round(avg_ms, 3),
-                         "launches": launches,
-                         # traffic (PMC, profiles/pmc_strong_update.json) over the same launch time: what HBM + Infinity Cache really moved
-                         "physical_gbs": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if (traffic and avg_ms > 0) else None,
-                         "note": "achieved = cache-oblivious algorithmic bytes (724 B per NCC evaluation, SURVEY 8d) / launch time: "
-                                 "frac > 1 means L1/L2/Infinity Cache serve the re-reads; physical_gbs is what the PMC counters saw"},
+            "config": {"workload": workload + ", one reference view per step per GPU", "baseline_config": args.config,
+                       "width": W, "height": H, "src_views": S, "iterations": iters, "weak_fraction": round(weak_frac, 4),
+                       "parallelism": "rank r takes view r mod %d of the scene as its reference view; %d rank(s), no data-path collective" % (NI, world)},
+            "roofline": dict(roofs[dom], launch_site=dom, share_of_step=round(stage_ms[dom] / (dt * 1e3), 3)),
+            "rooflines_top_kernels": roofs,
             "iter_loop_value": round(float(W) * H * iters * args.steps / (tm["iter_loop_ms"] * 1e-3) / 1e6, 3) if tm["iter_loop_ms"] > 0 else None,
-            "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in tm["stage_ms"].items() if v > 0},
-            "evals_per_px_iter_strong": round(evals["ncc_evals"]["strong_update"] / (float(W) * H * iters), 2),
+            "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
+            "launches_per_step": {kernel_name(k, S): tm["stage_launches"][k] // args.steps for k in stage_ms if k != "strong_prep"},
             "ncc_evals_per_step": {k: int(v) for k, v in evals["ncc_evals"].items() if v > 0},
             "Gevals_per_s": {k: round(evals["ncc_evals"][k] / (tm["stage_ms"][k] / args.steps * 1e-3) / 1e9, 3)
                              for k in evals["ncc_evals"] if evals["ncc_evals"][k] > 0 and tm["stage_ms"][k] > 0},
+            "rank_busy_ms_per_step": [round(b / args.steps * 1e3, 1) for b in busy_all],
+            "setup_s": round(t_setup, 1),
         }
-        if args.micro:
-            ms, ev = ctx.bench_cost_kernel(3)
-            out["micro_cost_kernel"] = {"ms": round(ms, 3), "evals": ev, "GBps_algorithmic": round(ev * NCC_BYTES / (ms * 1e-3) / 1e9, 1)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(synth, args, S, iters, capi=capi, device=local_rank)
+            out["cpu_baseline"] = cpu_baseline(pkg, args, cfg, S, iters, device=local_rank)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

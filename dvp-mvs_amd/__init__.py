@@ -6,7 +6,7 @@ harness glue: ctypes binding (capi), synthetic scenes (synth), view sharding (sh
 The directory name contains a hyphen, so import it with
     importlib.import_module("dvp-mvs_amd")
 """
-from . import synth, sharding, pipeline  # noqa: F401
+from . import synth, sharding, pipeline, workloads  # noqa: F401
 
 
 def get_capi():

@@ -29,7 +29,7 @@ BUFFERS = dict(planes=(0, np.float32, 4), costs=(1, np.float32, 1), selected_vie
 # every symbol include/dvp_mvs.h declares
 EXPORTS = ["dvp_ctx_create", "dvp_ctx_destroy", "dvp_last_error", "dvp_upload_images", "dvp_upload_depths",
            "dvp_upload_images_device", "dvp_upload_depths_device", "dvp_upload_cameras", "dvp_upload_state",
-           "dvp_reset_state", "dvp_set_params", "dvp_set_seed", "dvp_set_sampler", "dvp_set_profiling", "dvp_run_patchmatch",
+           "dvp_reset_state", "dvp_save_state", "dvp_restore_state", "dvp_set_params", "dvp_set_seed", "dvp_set_sampler", "dvp_set_profiling", "dvp_run_patchmatch",
            "dvp_run_stage", "dvp_synchronize", "dvp_download_state", "dvp_buffer_bytes", "dvp_download_buffer",
            "dvp_upload_buffer", "dvp_weak_count", "dvp_get_timings", "dvp_reset_timings", "dvp_eval_cost_vectors",
            "dvp_bench_cost_kernel"]
@@ -65,6 +65,8 @@ def lib():
         L.dvp_upload_cameras.argtypes = [vp, vp, ci]
         L.dvp_upload_state.argtypes = [vp] * 7
         L.dvp_reset_state.argtypes = [vp]
+        L.dvp_save_state.argtypes = [vp]
+        L.dvp_restore_state.argtypes = [vp]
         L.dvp_set_params.argtypes = [vp, vp]
         L.dvp_set_seed.argtypes = [vp, ctypes.c_uint64]
         L.dvp_set_sampler.argtypes = [vp, ci]
@@ -140,6 +142,10 @@ class Context:
         ptrs = (ctypes.c_void_p * self.NI)(*dev_ptrs)
         self._ck(self.L.dvp_upload_images_device(self.h, ptrs, pitch_floats))
 
+    def set_depths_device(self, dev_ptrs, pitch_floats):
+        ptrs = (ctypes.c_void_p * self.NI)(*dev_ptrs)
+        self._ck(self.L.dvp_upload_depths_device(self.h, ptrs, pitch_floats))
+
     def set_cameras(self, cams):
         a = np.ascontiguousarray(cams)
         assert a.dtype.itemsize == 112
@@ -167,6 +173,12 @@ class Context:
 
     def reset_state(self):
         self._ck(self.L.dvp_reset_state(self.h))
+
+    def save_state(self):
+        self._ck(self.L.dvp_save_state(self.h))
+
+    def restore_state(self):
+        self._ck(self.L.dvp_restore_state(self.h))
 
     def download_state(self):
         L = self.W * self.H

@@ -230,6 +230,9 @@ struct dvp_ctx {
 	size_t weak_alloc = 0;       // capacity (in WEAK pixels) of the per-WEAK buffers
 	int* weak_list = nullptr;    // compacted WEAK pixel indices (black first, then red)
 	size_t weak_list_alloc = 0;
+	// dvp_save_state / dvp_restore_state: device-side copy of the per-pixel input state
+	f4* saved_planes = nullptr; uint32_t* saved_views = nullptr; uint8_t* saved_weak = nullptr; int* saved_radius = nullptr;
+	bool have_saved = false;
 	int lut_radius = -1;
 	bool have_depths = false;
 	bool profiling = false;
@@ -466,6 +469,7 @@ int dvp_upload_state(dvp_ctx* c, const float* planes, const uint32_t* views, con
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
 	}
 	std::vector<int> map(L, 0);
+	std::vector<int> list, red;   // function scope: source of an async copy, alive until the stream sync below
 	int wc = 0;
 	for (size_t i = 0; i < L; ++i)
 		if (wi[i] == DVP_WEAK) map[i] = wc++;
@@ -473,7 +477,6 @@ int dvp_upload_state(dvp_ctx* c, const float* planes, const uint32_t* views, con
 	{
 		// compacted pixel lists per checkerboard colour; rows the reference's half grid never
 		// reaches (APD.cu:4421-4424) are left out like in the full-grid launch
-		std::vector<int> list, red;
 		list.reserve((size_t)wc);
 		red.reserve((size_t)wc / 2 + 1);
 		// Order: 16 x 16 pixel tiles (128 pixels of one colour = two waves when the tile is all WEAK),
@@ -525,6 +528,41 @@ int dvp_reset_state(dvp_ctx* c) {
 	c->d.weak_black = c->d.weak_red = 0;
 	if (ensure_weak_buffers(c, 0)) return 1;
 	sync_dev_struct(c);
+	return 0;
+}
+
+// Device-side snapshot of the per-pixel INPUT state of a pass (what dvp_upload_state delivers:
+// planes, selected_views, weak_info, radius; the WEAK-pixel list and neighbours_map derived from
+// weak_info stay valid because the same weak map comes back) and its restore, which also returns the
+// pass-internal buffers to their freshly-uploaded content.  Lets a caller run the same pass again
+// from identical inputs (bench steps, A/B checks) without a host round trip.
+int dvp_save_state(dvp_ctx* c) {
+	if (set_device(c)) return 1;
+	const size_t L = c->L;
+	if (!c->saved_planes) {
+		if (dalloc(c, &c->saved_planes, L, false) || dalloc(c, &c->saved_views, L, false) ||
+			dalloc(c, &c->saved_weak, L, false) || dalloc(c, &c->saved_radius, L, false)) return 1;
+	}
+	HIP_TRY(c, hipMemcpyAsync(c->saved_planes, c->planes, L * 16, hipMemcpyDeviceToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->saved_views, c->selected_views, L * 4, hipMemcpyDeviceToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->saved_weak, c->weak_info, L, hipMemcpyDeviceToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->saved_radius, c->radius, L * 4, hipMemcpyDeviceToDevice, c->stream));
+	c->have_saved = true;
+	return 0;
+}
+int dvp_restore_state(dvp_ctx* c) {
+	if (set_device(c)) return 1;
+	if (!c->have_saved) { c->error = "dvp_restore_state: no saved state"; return 1; }
+	const size_t L = c->L;
+	HIP_TRY(c, hipMemcpyAsync(c->planes, c->saved_planes, L * 16, hipMemcpyDeviceToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->selected_views, c->saved_views, L * 4, hipMemcpyDeviceToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->weak_info, c->saved_weak, L, hipMemcpyDeviceToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->radius, c->saved_radius, L * 4, hipMemcpyDeviceToDevice, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->fit_planes, 0, L * 16, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->costs, 0, L * 4, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->view_weight, 0, L * 32, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->weak_reliable, 0, L, c->stream));
+	if (ensure_weak_buffers(c, (size_t)c->d.weak_count)) return 1;
 	return 0;
 }
 

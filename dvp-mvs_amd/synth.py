@@ -179,3 +179,79 @@ def make_scene(W, H, num_src, seed=1234, with_step=True, with_flat=True, baselin
     flat = (sid0 == 0) & (Xr > -0.55) & (Xr < -0.15) & (Yr > -0.35) & (Yr < 0.05) if with_flat else np.zeros((H, W), bool)
     return dict(images=np.stack(images), cameras=cams, depth_gt=np.stack(depths), normal_gt=n.astype(np.float32),
                 edge=edge, label=label, flat=flat, width=W, height=H)
+
+
+# ---- the same scene rendered on the GPU (bench.py at full resolution: 10 views of 25.6 Mpx take
+# minutes in numpy).  Same formulas in float64 torch ops; grey levels may differ from the numpy
+# renderer by one level on a few pixels (libm vs device sin/cos), which is irrelevant for a timing
+# workload — parity tests always use the numpy renderer on both sides.
+def render_view_torch(W, H, cam, px_world, device, x_step=0.35, step=0.45, flat=(-0.55, -0.15, -0.35, 0.05)):
+    import torch
+    K = cam["K"].astype(np.float64)
+    C = cam["c"].astype(np.float64)
+    fx, cx, fy, cy = K[0], K[2], K[4], K[5]
+    xs = torch.arange(W, dtype=torch.float64, device=device)
+    ys = torch.arange(H, dtype=torch.float64, device=device)
+    yg, xg = torch.meshgrid(ys, xs, indexing="ij")
+    dx, dy = (xg - cx) / fx, (yg - cy) / fy
+    den = 1.0 - 0.25 * dx - 0.1 * dy
+
+    def hit(z0):
+        return (z0 + 0.25 * C[0] + 0.1 * C[1] - C[2]) / den
+    sA, sB = hit(4.0), hit(4.0 + step)
+    validA = (C[0] + sA * dx) < x_step
+    validB = (C[0] + sB * dx) >= x_step
+    sW = (x_step - C[0]) / dx
+    YW, ZW = C[1] + sW * dy, C[2] + sW
+    zA_w = 4.0 + 0.25 * x_step + 0.1 * YW
+    validW = torch.isfinite(sW) & (sW > 0) & (ZW >= zA_w) & (ZW <= zA_w + step)
+    big = 1e30
+    cA = torch.where(validA, sA, torch.full_like(sA, big))
+    cB = torch.where(validB, sB, torch.full_like(sA, big))
+    cW = torch.where(validW, sW, torch.full_like(sA, big))
+    s = torch.minimum(cA, torch.minimum(cB, cW))
+    sid = torch.where(s == cA, 0, torch.where(s == cB, 1, 2)).to(torch.uint8)
+    s = torch.where(s >= big, sA, s)
+    del cA, cB, cW, sB, sW, YW, ZW, zA_w, validA, validB, validW
+    X, Y, Z = C[0] + s * dx, C[1] + s * dy, C[2] + s
+    U = torch.where(sid == 2, Z * 1.7, X)
+    flat_mask = (sid == 0) & (X > flat[0]) & (X < flat[1]) & (Y > flat[2]) & (Y < flat[3])
+    base = 55.0 * torch.sin(9.0 * U) * torch.cos(7.0 * Y) + 35.0 * torch.sin(23.0 * U + 17.0 * Y) + 20.0 * torch.sin(41.0 * Y - 13.0 * U)
+    k1, k2, k3 = (2.0 * np.pi / (q * px_world) for q in (6.0, 11.0, 23.0))
+    fine = 22.0 * torch.sin(k1 * (0.8 * U + 0.6 * Y)) + 18.0 * torch.sin(k2 * (0.6 * U - 0.8 * Y) + 1.3) \
+        + 14.0 * torch.sin(k3 * (U + 0.3 * Y) + 0.4) * torch.cos(k3 * (0.2 * U - Y))
+    tex = base * 0.6 + fine
+    tex = torch.where(flat_mask, 0.02 * tex, tex)
+    img = torch.clamp(torch.round(127.5 + tex), 0, 255).to(torch.float32)
+    return img, Z.to(torch.float32), sid, flat_mask
+
+
+def make_scene_torch(W, H, num_src, device, seed=1234, baseline=0.4):
+    """make_scene on `device`: dict(images [NI,H,W] f32, depth_gt [NI,H,W] f32, edge [H,W] u8, label
+    [H,W] i32, flat [H,W] bool — torch tensors on `device`; cameras — numpy CAMERA_DTYPE)."""
+    import torch
+    assert 1 <= num_src <= len(_RING)
+    rng = np.random.default_rng(seed)
+    centres = [(0.0, 0.0, 0.0)] + [(baseline * a, baseline * b, 0.02 * float(rng.standard_normal())) for a, b in _RING[:num_src]]
+    cams = np.zeros(num_src + 1, dtype=CAMERA_DTYPE)
+    px_world = 4.0 / (0.9 * W)
+    images = torch.empty((num_src + 1, H, W), dtype=torch.float32, device=device)
+    depths = torch.empty((num_src + 1, H, W), dtype=torch.float32, device=device)
+    sids, flats = [], []
+    for i, c in enumerate(centres):
+        cams[i] = make_camera(W, H, c)
+        images[i], depths[i], sid, fm = render_view_torch(W, H, cams[i], px_world, device)
+        sids.append(sid)
+        flats.append(fm)
+    return dict(images=images, cameras=cams, depth_gt=depths, sids=sids, flats=flats, width=W, height=H)
+
+
+def view_priors_torch(sid, flat):
+    """edge / label maps of one view from its surface-id map (same rule as make_scene)."""
+    import torch
+    edge = torch.zeros_like(sid)
+    edge[:, 1:] |= (sid[:, 1:] != sid[:, :-1]).to(torch.uint8)
+    edge[1:, :] |= (sid[1:, :] != sid[:-1, :]).to(torch.uint8)
+    label = sid.to(torch.int32) + 1
+    label[edge > 0] = -1
+    return edge, label

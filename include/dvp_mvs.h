@@ -155,6 +155,12 @@ int dvp_upload_state(dvp_ctx* ctx, const float* planes_xyzw, const uint32_t* sel
  * (APD.cpp:1571); edge/label maps are kept.  Lets one context process consecutive views without
  * host round trips. */
 int dvp_reset_state(dvp_ctx* ctx);
+/* device-side snapshot of the per-pixel input state (planes, selected_views, weak_info, radius) and
+ * its restore (pass-internal buffers return to their freshly-uploaded content): re-running a pass
+ * from identical inputs without re-uploading — what a fresh APD per view per pass (main.cpp:273,
+ * APD.cpp:984-987) gives the reference for free. */
+int dvp_save_state(dvp_ctx* ctx);
+int dvp_restore_state(dvp_ctx* ctx);
 int dvp_set_params(dvp_ctx* ctx, const DvpParams* params);                     /* APD.cpp:1607-1608 */
 /* The reference seeds cuRAND with clock64() (APD.cu:1270); here the seed is explicit. */
 int dvp_set_seed(dvp_ctx* ctx, uint64_t seed);
