@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Fold the PMC passes of tools/pmc_collect.sh into profiles/pmc_r02.json.
+usage: pmc_table.py OUTDIR [TABLE=profiles/pmc_r02.json]
+
+Per kernel only the launches of the bench's LAST step are averaged (the untimed FIRST_INIT pass and
+the counting warm-up step launch the same kernels earlier): the last `launches_per_step[kernel]`
+dispatches, a number the bench line of the same run states.  Entries are keyed
+"<kernel>|<W>x<H>|S<S>" so that bench.py only ever uses counters taken at its own problem size.
+
+Units and corrections (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE / WRITE_SIZE are KiB derived from the
+L2's fabric-side request counters (Infinity-Cache hits included).  On gfx950 FETCH_SIZE tallies the
+128-byte requests of 16 B/lane reads at 64 bytes: the fetch part is doubled; WRITE_SIZE is
+uncalibrated and reported raw.  SQ_INSTS_* count wave-level instructions; SQ_WAVE_CYCLES / SQ_WAIT_* /
+SQ_ACTIVE_INST_* count quad-cycles."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def per_kernel_last(path, launches_per_step):
+    rows = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0]
+        rows[k][int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    out = {}
+    for k, disp in rows.items():
+        n = launches_per_step.get(k)
+        if not n:
+            continue
+        ids = sorted(disp)[-n:]
+        agg = collections.defaultdict(float)
+        for i in ids:
+            for c, v in disp[i].items():
+                agg[c] += v
+        out[k] = {c: v / len(ids) for c, v in agg.items()}
+        out[k]["launches_averaged"] = len(ids)
+    return out
+
+
+def main():
+    out = sys.argv[1]
+    table_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_r02.json")
+    table = {"notes": __doc__.split("Units and corrections")[1].strip(), "kernels": {}}
+    if os.path.exists(table_path):
+        table = json.load(open(table_path))
+    merged = collections.defaultdict(dict)
+    cfg = None
+    for name in ("fetch", "write", "sq1", "sq2"):
+        js = os.path.join(out, name + ".json")
+        cs = glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True)
+        if not (os.path.exists(js) and cs):
+            print("pass %s missing" % name, file=sys.stderr)
+            continue
+        bench = json.loads(open(js).read().strip().splitlines()[-1])
+        cfg = bench["config"]
+        for k, v in per_kernel_last(cs[0], bench["launches_per_step"]).items():
+            merged[k].update(v)
+    if cfg is None:
+        raise SystemExit("no PMC pass found under " + out)
+    for k, v in merged.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            v["fetch_bytes_per_launch_corrected_x2"] = 2.0 * v["FETCH_SIZE"] * 1024.0
+            v["write_bytes_per_launch"] = v["WRITE_SIZE"] * 1024.0
+            v["hbm_bytes_per_launch"] = v["fetch_bytes_per_launch_corrected_x2"] + v["write_bytes_per_launch"]
+        if v.get("TCC_HIT", 0) + v.get("TCC_MISS", 0) > 0:
+            v["l2_hit_rate"] = round(v["TCC_HIT"] / (v["TCC_HIT"] + v["TCC_MISS"]), 4)
+        if v.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in v:
+            v["wait_any_frac"] = round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 4)
+        if v.get("SQ_WAVE_CYCLES") and "SQ_ACTIVE_INST_VALU" in v:
+            v["valu_active_over_wave_cycles"] = round(v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"], 4)
+        v["workload"] = cfg["workload"]
+        v["command"] = "tools/pmc_collect.sh: rocprofv3 --pmc <group> -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --config %s (separate passes, counters only)" % cfg["baseline_config"]
+        table["kernels"]["%s|%dx%d|S%d" % (k, cfg["width"], cfg["height"], cfg["src_views"])] = v
+    json.dump(table, open(table_path, "w"), indent=1, sort_keys=True)
+    print("wrote %s: %d kernels at %dx%d S=%d" % (table_path, len(merged), cfg["width"], cfg["height"], cfg["src_views"]))
+
+
+if __name__ == "__main__":
+    main()
