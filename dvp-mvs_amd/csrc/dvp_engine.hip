@@ -37,11 +37,24 @@ __device__ __forceinline__ void stage_body(const Dev& d, const LaunchArgs& a) {
 // Compacted launch for the weak-pixel path: lane t owns the t-th WEAK pixel of the list segment.
 // WEAK pixels are 1-30 % of a view; a lane-per-image-pixel launch leaves 70-99 % of the lanes idle.
 struct ListArgs { int base, count, iter, covered_rows; };
+// XCD-aware block -> list-block map.  Workgroup b runs on XCD b % 8 (observed placement, a speed matter
+// only); the list is in super-tile order, so giving every XCD RUNS of kListRun consecutive list blocks
+// (instead of every 8th block) keeps the workgroups that share anchors — and the source-image lines
+// their anchor sub-patches gather — behind one L2.  Bijection on [0, nblocks): whole groups of
+// 8 * kListRun blocks are permuted, the ragged tail keeps its order.
+constexpr int kListRun = 16;
+__device__ __forceinline__ int list_block(int b, int nblocks) {
+	const int group = 8 * kListRun;
+	if (b >= nblocks / group * group) return b;
+	const int g = b / group, r = b - g * group;
+	const int xcd = r & 7, i = r >> 3;
+	return g * group + xcd * kListRun + i;
+}
 template <int STAGE, int SMP>
 __device__ __forceinline__ void stage_body_list(const Dev& d, const ListArgs& a) {
 	__shared__ f2 lds_tab[stage_uses_tab(STAGE) ? kTaps * kTaps * 256 : 1];
 	const PatchTab tab{&lds_tab[stage_uses_tab(STAGE) ? threadIdx.x : 0], 256};
-	const int t = blockIdx.x * 256 + threadIdx.x;
+	const int t = list_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
 	unsigned long long n = 0;
 	if (t < a.count) {
 		const int center = d.weak_list[a.base + t];
@@ -92,6 +105,7 @@ DVP_KERNEL(dvp_neighbour_update, DVP_ST_NEIGHBOUR_UPDATE, 1)
 DVP_KERNEL(dvp_random_init, DVP_ST_RANDOM_INIT, DVP_LB_HEAVY)
 DVP_KERNEL(dvp_strong_update, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY)
 DVP_KERNEL_MV(dvp_strong_update_v8, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY, kNarrowViews)
+DVP_KERNEL_MV(dvp_strong_update_v16, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY, 16)
 DVP_KERNEL(dvp_ransac_fit_plane, DVP_ST_RANSAC_FIT, 1)
 DVP_KERNEL(dvp_weak_update, DVP_ST_WEAK_UPDATE, 2)
 DVP_KERNEL(dvp_get_depth_normal, DVP_ST_GET_DEPTH_NORMAL, 1)
@@ -202,7 +216,8 @@ extern "C" __global__ void __launch_bounds__(256) dvp_cost_all_pixels(const Dev 
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
-struct EventPair { int stage; hipEvent_t a, b; };
+struct EventPair { int stage; hipEvent_t a, b; };   // stage: launch site, or one of the two whole-run timers below
+enum { EV_TOTAL = -1, EV_ITER_LOOP = -2 };
 
 struct dvp_ctx {
 	int device = 0;
@@ -237,8 +252,6 @@ struct dvp_ctx {
 	bool have_depths = false;
 	bool profiling = false;
 	std::vector<EventPair> events;
-	hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr, ev_iter_a = nullptr, ev_iter_b = nullptr;
-	bool total_pending = false;
 	DvpTimings timings{};
 	std::string error;
 };
@@ -355,8 +368,6 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	c->d.params.num_images = num_images;
 	c->d.params.strong_radius = 5; c->d.params.strong_increment = 2; c->d.params.weak_radius = 5; c->d.params.weak_increment = 5;
 	c->d.params.rotate_time = 4;
-	if (hipEventCreate(&c->ev_total_a) != hipSuccess || hipEventCreate(&c->ev_total_b) != hipSuccess ||
-		hipEventCreate(&c->ev_iter_a) != hipSuccess || hipEventCreate(&c->ev_iter_b) != hipSuccess) { c->error = "hipEventCreate failed"; return fail(0); }
 	sync_dev_struct(c);
 	*out = c;
 	return 0;
@@ -368,8 +379,6 @@ int dvp_ctx_destroy(dvp_ctx* c) {
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-	for (hipEvent_t e : { c->ev_total_a, c->ev_total_b, c->ev_iter_a, c->ev_iter_b })
-		if (e) (void)hipEventDestroy(e);
 	for (void* p : c->allocs) (void)hipFree(p);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -479,20 +488,23 @@ int dvp_upload_state(dvp_ctx* c, const float* planes, const uint32_t* views, con
 		// reaches (APD.cu:4421-4424) are left out like in the full-grid launch
 		list.reserve((size_t)wc);
 		red.reserve((size_t)wc / 2 + 1);
-		// Order: 16 x 16 pixel tiles (128 pixels of one colour = two waves when the tile is all WEAK),
-		// row-major inside a tile: the lanes of a wave are neighbours in both directions, so their
-		// anchors (nearest STRONG points per direction) and the lines those touch largely coincide.
+		// Order: 64 x 64 super-tiles (row-major over the image), inside them 16 x 16 tiles, inside those
+		// rows: the lanes of a wave are neighbours in both directions and the ~8 consecutive workgroups of
+		// a super-tile share their anchors (the STRONG points around a WEAK region) and the source lines
+		// those touch; stage_body_list hands such runs of consecutive workgroups to ONE XCD (one L2).
 		// Every list kernel is order-independent (a WEAK pixel only reads STRONG pixels' state).
-		constexpr int kTW = 16, kTH = 16;   // measured: 16x16 592.7 ms per REFINE pass, 16x8 599, 32x4 609, row-major 622
-		for (int ty = 0; wc > 0 && ty < c->H; ty += kTH)   // (no WEAK pixel, e.g. a FIRST_INIT pass: nothing to list)
-			for (int tx = 0; tx < c->W; tx += kTW) {
-				const int y1 = ty + kTH < c->H ? ty + kTH : c->H, x1 = tx + kTW < c->W ? tx + kTW : c->W;
-				for (int y = ty; y < y1; ++y) {
-					const uint8_t* row = wi.data() + (size_t)y * c->W;
-					for (int x = tx; x < x1; ++x)
-						if (row[x] == DVP_WEAK) (((x + y) & 1) ? red : list).push_back(y * c->W + x);
-				}
-			}
+		constexpr int kTW = 16, kTH = 16, kSuper = 64;   // 16x16 vs 16x8 / 32x4 / row-major: 592.7 / 599 / 609 / 622 ms per REFINE pass (r01)
+		for (int sy = 0; wc > 0 && sy < c->H; sy += kSuper)   // (no WEAK pixel, e.g. a FIRST_INIT pass: nothing to list)
+			for (int sx = 0; sx < c->W; sx += kSuper)
+				for (int ty = sy; ty < sy + kSuper && ty < c->H; ty += kTH)
+					for (int tx = sx; tx < sx + kSuper && tx < c->W; tx += kTW) {
+						const int y1 = ty + kTH < c->H ? ty + kTH : c->H, x1 = tx + kTW < c->W ? tx + kTW : c->W;
+						for (int y = ty; y < y1; ++y) {
+							const uint8_t* row = wi.data() + (size_t)y * c->W;
+							for (int x = tx; x < x1; ++x)
+								if (row[x] == DVP_WEAK) (((x + y) & 1) ? red : list).push_back(y * c->W + x);
+						}
+					}
 		const int nb = (int)list.size();
 		list.insert(list.end(), red.begin(), red.end());
 		if (list.size() > c->weak_list_alloc) {
@@ -668,6 +680,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 	case DVP_ST_RANDOM_INIT: hipLaunchKernelGGL(c->d.sampler ? dvp_random_init_exact : dvp_random_init, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_STRONG_UPDATE:
 		if (c->NI - 1 <= kNarrowViews) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v8_exact : dvp_strong_update_v8, grid, block, 0, c->stream, c->d, a);
+		else if (c->NI - 1 <= 16) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v16_exact : dvp_strong_update_v16, grid, block, 0, c->stream, c->d, a);
 		else hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_exact : dvp_strong_update, grid, block, 0, c->stream, c->d, a);
 		break;
 	case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(c->d.sampler ? dvp_ransac_fit_plane_exact : dvp_ransac_fit_plane, grid, block, 0, c->stream, c->d, a); break;
@@ -704,13 +717,17 @@ int dvp_synchronize(dvp_ctx* c) {
 // APD::RunPatchMatch (APD.cu:4406-4532): same launch order; no host sync between launches.
 int dvp_run_patchmatch(dvp_ctx* c) {
 	if (set_device(c)) return 1;
-	HIP_TRY(c, hipEventRecord(c->ev_total_a, c->stream));
+	EventPair tot, itl;
+	tot.stage = EV_TOTAL; itl.stage = EV_ITER_LOOP;
+	HIP_TRY(c, hipEventCreate(&tot.a)); HIP_TRY(c, hipEventCreate(&tot.b));
+	HIP_TRY(c, hipEventCreate(&itl.a)); HIP_TRY(c, hipEventCreate(&itl.b));
+	HIP_TRY(c, hipEventRecord(tot.a, c->stream));
 	if (launch_stage(c, DVP_ST_GEN_EDGE_INFORM, 0, 0)) return 1;
 	if (launch_stage(c, DVP_ST_FIND_NEAREST_STRONG, 0, 0)) return 1;
 	if (launch_stage(c, DVP_ST_GEN_NEIGHBOURS, 0, 0)) return 1;
 	if (launch_stage(c, DVP_ST_NEIGHBOUR_UPDATE, 0, 0)) return 1;
 	if (launch_stage(c, DVP_ST_RANDOM_INIT, 0, 0)) return 1;
-	HIP_TRY(c, hipEventRecord(c->ev_iter_a, c->stream));
+	HIP_TRY(c, hipEventRecord(itl.a, c->stream));
 	for (int i = 0; i < c->d.params.max_iterations; ++i) {
 		if (launch_stage(c, DVP_ST_STRONG_UPDATE, i, 0)) return 1;
 		if (launch_stage(c, DVP_ST_STRONG_UPDATE, i, 1)) return 1;
@@ -720,14 +737,15 @@ int dvp_run_patchmatch(dvp_ctx* c) {
 			if (launch_stage(c, DVP_ST_WEAK_UPDATE, i, 1)) return 1;
 		}
 	}
-	HIP_TRY(c, hipEventRecord(c->ev_iter_b, c->stream));
+	HIP_TRY(c, hipEventRecord(itl.b, c->stream));
 	if (launch_stage(c, DVP_ST_GET_DEPTH_NORMAL, 0, 0)) return 1;
 	if (launch_stage(c, DVP_ST_FILTER_STRONG, 0, 0)) return 1;
 	if (launch_stage(c, DVP_ST_FILTER_STRONG, 0, 1)) return 1;
 	if (launch_stage(c, DVP_ST_DEPTH_TO_WEAK, 0, 0)) return 1;
 	if (launch_stage(c, DVP_ST_LOCAL_REFINE, 0, 0)) return 1;
-	HIP_TRY(c, hipEventRecord(c->ev_total_b, c->stream));
-	c->total_pending = true;
+	HIP_TRY(c, hipEventRecord(tot.b, c->stream));
+	c->events.push_back(tot);
+	c->events.push_back(itl);
 	return 0;
 }
 
@@ -793,20 +811,13 @@ int dvp_get_timings(dvp_ctx* c, DvpTimings* out) {
 	for (auto& e : c->events) {
 		float ms = 0.0f;
 		HIP_TRY(c, hipEventElapsedTime(&ms, e.a, e.b));
-		c->timings.stage_ms[e.stage] += ms;
-		c->timings.stage_launches[e.stage] += 1;
+		if (e.stage == EV_TOTAL) c->timings.total_ms += ms;
+		else if (e.stage == EV_ITER_LOOP) c->timings.iter_loop_ms += ms;
+		else { c->timings.stage_ms[e.stage] += ms; c->timings.stage_launches[e.stage] += 1; }
 		(void)hipEventDestroy(e.a);
 		(void)hipEventDestroy(e.b);
 	}
 	c->events.clear();
-	if (c->total_pending) {
-		float ms = 0.0f;
-		HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_total_a, c->ev_total_b));
-		c->timings.total_ms += ms;
-		HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_iter_a, c->ev_iter_b));
-		c->timings.iter_loop_ms += ms;
-		c->total_pending = false;
-	}
 	if (out) *out = c->timings;
 	return 0;
 }

@@ -83,7 +83,8 @@ def test_cfg1_engine_equals_cpu_path():
 
 # ---- cfg3-shaped parity ---------------------------------------------------------------------------
 def _two_pass(make, sc, S, iters, weak_frac):
-    """FIRST_INIT pass -> hand-over (+ forced WEAK tiles) -> engine ready for the REFINE_ITER pass"""
+    """FIRST_INIT pass -> hand-over (+ forced WEAK tiles) -> a FRESH engine (the reference constructs
+    one APD per view per pass, main.cpp:273) ready for the REFINE_ITER pass"""
     W, H = sc["width"], sc["height"]
     p1 = wl.first_init_params(S, iters)
     e = make(sc, p1)
@@ -91,9 +92,10 @@ def _two_pass(make, sc, S, iters, weak_frac):
     e.run_patchmatch()
     st = wl.hand_over(e.get("planes"), e.get("selected_views"), e.get("weak_info"), e.get("radius"), p1, W, H,
                       extra_weak=wl.weak_tiles(W, H, weak_frac, sc["flat"]))
-    e.set_params(wl.refine_iter_params(S, iters))
+    e.close()
+    e = make(sc, wl.refine_iter_params(S, iters))
     e.set_depths(sc["depth_gt"])
-    e.upload_state(planes=st[0], views=st[1], weak=st[2], radius=st[3])
+    e.upload_state(planes=st[0], views=st[1], weak=st[2], radius=st[3], edge=sc["edge"], label=sc["label"])
     return e
 
 
