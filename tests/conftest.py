@@ -12,6 +12,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.path.exists("/dev/kfd"):
+        # tests that render full-size scenes on the GPU use torch: its HIP runtime must be initialised
+        # before libdvp_mvs_hip.so pulls in /opt/rocm's copy (the order bench.py uses), or torch finds no device
+        try:
+            import torch
+            torch.cuda.init()
+        except Exception:
+            pass
 
 
 def pkg(name=""):
