@@ -50,7 +50,7 @@ __device__ __forceinline__ int list_block(int b, int nblocks) {
 	const int xcd = r & 7, i = r >> 3;
 	return g * group + xcd * kListRun + i;
 }
-template <int STAGE, int SMP>
+template <int STAGE, int SMP, int MV = 32>
 __device__ __forceinline__ void stage_body_list(const Dev& d, const ListArgs& a) {
 	__shared__ f2 lds_tab[stage_uses_tab(STAGE) ? kTaps * kTaps * 256 : 1];
 	const PatchTab tab{&lds_tab[stage_uses_tab(STAGE) ? threadIdx.x : 0], 256};
@@ -61,10 +61,17 @@ __device__ __forceinline__ void stage_body_list(const Dev& d, const ListArgs& a)
 		const int py = center / d.width, px = center - py * d.width;
 		// red/black launches never reach rows beyond the reference's half grid (APD.cu:4421-4424)
 		if (!stage_is_half_c(STAGE) || py < a.covered_rows)
-			run_pixel<STAGE, SMP>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, tab);
+			run_pixel<STAGE, SMP, MV>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, tab);
 	}
 	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
 }
+#define DVP_KERNEL_LIST_MV(NAME, STAGE, MINW, MV)                                                         \
+	extern "C" __global__ void __launch_bounds__(256, MINW) NAME(const Dev d, const ListArgs a) {         \
+		stage_body_list<STAGE, 0, MV>(d, a);                                                               \
+	}                                                                                                      \
+	extern "C" __global__ void __launch_bounds__(256, MINW) NAME##_exact(const Dev d, const ListArgs a) { \
+		stage_body_list<STAGE, 1, MV>(d, a);                                                               \
+	}
 #define DVP_KERNEL_LIST(NAME, STAGE, MINW)                                                                \
 	extern "C" __global__ void __launch_bounds__(256, MINW) NAME(const Dev d, const ListArgs a) {         \
 		stage_body_list<STAGE, 0>(d, a);                                                                   \
@@ -93,9 +100,6 @@ __device__ __forceinline__ void stage_body_list(const Dev& d, const ListArgs& a)
 	}
 
 DVP_KERNEL(dvp_gen_edge_inform, DVP_ST_GEN_EDGE_INFORM, 1)
-DVP_KERNEL(dvp_find_nearest_strong, DVP_ST_FIND_NEAREST_STRONG, 1)
-DVP_KERNEL(dvp_gen_neighbours, DVP_ST_GEN_NEIGHBOURS, 1)
-DVP_KERNEL(dvp_neighbour_update, DVP_ST_NEIGHBOUR_UPDATE, 1)
 #ifndef DVP_LB_HEAVY
 // min waves/SIMD the NCC kernels are compiled for: 2 = 256 VGPRs per lane (the pipelined 36-tap
 // evaluation keeps 12 sixteen-byte gathers + the next 12 footprints live) and two 72 KiB patch
@@ -106,20 +110,20 @@ DVP_KERNEL(dvp_random_init, DVP_ST_RANDOM_INIT, DVP_LB_HEAVY)
 DVP_KERNEL(dvp_strong_update, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY)
 DVP_KERNEL_MV(dvp_strong_update_v8, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY, kNarrowViews)
 DVP_KERNEL_MV(dvp_strong_update_v16, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY, 16)
-DVP_KERNEL(dvp_ransac_fit_plane, DVP_ST_RANSAC_FIT, 1)
-DVP_KERNEL(dvp_weak_update, DVP_ST_WEAK_UPDATE, 2)
 DVP_KERNEL(dvp_get_depth_normal, DVP_ST_GET_DEPTH_NORMAL, 1)
 DVP_KERNEL(dvp_filter_strong, DVP_ST_FILTER_STRONG, 1)
 DVP_KERNEL(dvp_depth_to_weak, DVP_ST_DEPTH_TO_WEAK, DVP_LB_HEAVY)
 DVP_KERNEL(dvp_local_refine, DVP_ST_LOCAL_REFINE, DVP_LB_HEAVY)
 
-// replicate the image border into the kImgPad-wide frame of a padded plane set
+// the weak-path launch sites: one lane per entry of the WEAK-pixel list
 DVP_KERNEL_LIST(dvp_find_nearest_strong_list, DVP_ST_FIND_NEAREST_STRONG, 1)
 DVP_KERNEL_LIST(dvp_gen_neighbours_list, DVP_ST_GEN_NEIGHBOURS, 1)
 DVP_KERNEL_LIST(dvp_neighbour_update_list, DVP_ST_NEIGHBOUR_UPDATE, 1)
 DVP_KERNEL_LIST(dvp_ransac_fit_plane_list, DVP_ST_RANSAC_FIT, 1)
 DVP_KERNEL_LIST(dvp_weak_update_list, DVP_ST_WEAK_UPDATE, 2)
+DVP_KERNEL_LIST_MV(dvp_weak_update_list_v16, DVP_ST_WEAK_UPDATE, 2, 16)
 
+// replicate the image border into the kImgPad-wide frame of a padded plane set
 extern "C" __global__ void dvp_pad_replicate(float* planes, int W, int H, int pitch, size_t plane_stride, int n_planes) {
 	const int PW = W + 2 * kImgPad, PH = H + 2 * kImgPad;
 	const int frame = 2 * kImgPad * PW + 2 * kImgPad * H;   // border cells per plane
@@ -663,7 +667,10 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 			case DVP_ST_GEN_NEIGHBOURS: hipLaunchKernelGGL(ex ? dvp_gen_neighbours_list_exact : dvp_gen_neighbours_list, lg, block, 0, c->stream, c->d, la); break;
 			case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(ex ? dvp_neighbour_update_list_exact : dvp_neighbour_update_list, lg, block, 0, c->stream, c->d, la); break;
 			case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(ex ? dvp_ransac_fit_plane_list_exact : dvp_ransac_fit_plane_list, lg, block, 0, c->stream, c->d, la); break;
-			case DVP_ST_WEAK_UPDATE: hipLaunchKernelGGL(ex ? dvp_weak_update_list_exact : dvp_weak_update_list, lg, block, 0, c->stream, c->d, la); break;
+			case DVP_ST_WEAK_UPDATE:
+				if (c->NI - 1 <= 16) hipLaunchKernelGGL(ex ? dvp_weak_update_list_v16_exact : dvp_weak_update_list_v16, lg, block, 0, c->stream, c->d, la);
+				else hipLaunchKernelGGL(ex ? dvp_weak_update_list_exact : dvp_weak_update_list, lg, block, 0, c->stream, c->d, la);
+				break;
 			}
 			HIP_TRY(c, hipGetLastError());
 		}
@@ -674,17 +681,12 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 	}
 	switch (stage) {
 	case DVP_ST_GEN_EDGE_INFORM: hipLaunchKernelGGL(c->d.sampler ? dvp_gen_edge_inform_exact : dvp_gen_edge_inform, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_FIND_NEAREST_STRONG: hipLaunchKernelGGL(c->d.sampler ? dvp_find_nearest_strong_exact : dvp_find_nearest_strong, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_GEN_NEIGHBOURS: hipLaunchKernelGGL(c->d.sampler ? dvp_gen_neighbours_exact : dvp_gen_neighbours, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(c->d.sampler ? dvp_neighbour_update_exact : dvp_neighbour_update, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_RANDOM_INIT: hipLaunchKernelGGL(c->d.sampler ? dvp_random_init_exact : dvp_random_init, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_STRONG_UPDATE:
 		if (c->NI - 1 <= kNarrowViews) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v8_exact : dvp_strong_update_v8, grid, block, 0, c->stream, c->d, a);
 		else if (c->NI - 1 <= 16) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v16_exact : dvp_strong_update_v16, grid, block, 0, c->stream, c->d, a);
 		else hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_exact : dvp_strong_update, grid, block, 0, c->stream, c->d, a);
 		break;
-	case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(c->d.sampler ? dvp_ransac_fit_plane_exact : dvp_ransac_fit_plane, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_WEAK_UPDATE: hipLaunchKernelGGL(c->d.sampler ? dvp_weak_update_exact : dvp_weak_update, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_GET_DEPTH_NORMAL: hipLaunchKernelGGL(c->d.sampler ? dvp_get_depth_normal_exact : dvp_get_depth_normal, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_FILTER_STRONG: hipLaunchKernelGGL(c->d.sampler ? dvp_filter_strong_exact : dvp_filter_strong, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_DEPTH_TO_WEAK: hipLaunchKernelGGL(c->d.sampler ? dvp_depth_to_weak_exact : dvp_depth_to_weak, grid, block, 0, c->stream, c->d, a); break;

@@ -78,7 +78,7 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 	else if (STAGE == DVP_ST_RANDOM_INIT) random_init_px<SMP>(d, px, py, tab, nevals);
 	else if (STAGE == DVP_ST_STRONG_UPDATE) { if (d.weak_info[center] != DVP_WEAK) strong_update_px<SMP, MV>(d, px, py, tab, iter, nevals); }
 	else if (STAGE == DVP_ST_RANSAC_FIT) ransac_fit_plane_px(d, px, py, iter);
-	else if (STAGE == DVP_ST_WEAK_UPDATE) { if (d.weak_info[center] == DVP_WEAK) weak_update_px<SMP>(d, px, py, tab, iter, nevals); }
+	else if (STAGE == DVP_ST_WEAK_UPDATE) { if (d.weak_info[center] == DVP_WEAK) weak_update_px<SMP, MV>(d, px, py, tab, iter, nevals); }
 	else if (STAGE == DVP_ST_GET_DEPTH_NORMAL) get_depth_normal_px(d, px, py);
 	else if (STAGE == DVP_ST_FILTER_STRONG) { if (d.weak_info[center] != DVP_WEAK) filter_strong_px(d, px, py); }
 	else if (STAGE == DVP_ST_DEPTH_TO_WEAK) depth_to_weak_px<SMP>(d, px, py, tab, nevals);

@@ -685,81 +685,71 @@ DVP_HD void ransac_fit_plane_px(const Dev& d, int px, int py, int iter) {
 // sub-patches of 9 visibility-prior taps.  For a given (pixel, view) the anchors, their tap
 // positions, the reference texels, the weights and the three reference sums do not depend on the
 // plane hypothesis; the reference recomputes them (99 exp + 99 texel reads + the candidate
-// offsets) for each of the ~15 hypotheses.  AnchorTab holds that half once per (pixel, view).
-// One record per tap / per anchor so that an evaluation reads each with a single private-memory
-// load, and the records of anchor k+1 are fetched while anchor k is evaluated.
-struct AnchorTap { float w, wa; s2 xy; };               // tap weight, weight * ref texel, tap pixel
-struct AnchorHead { float s_r, s_rr, s_w; s2 nb; int state; };   // reference sums (tap order 0..8), anchor pixel,
-                                                         // state: 0 absent, 1 visible in this view, 2 not visible
-struct AnchorTab {
-	AnchorTap tap[99];
-	AnchorHead head[11];
-};
+// offsets) for each of the ~15 hypotheses.  Here that half is computed once per (anchor, group of
+// four planes) and lives in REGISTERS for the duration of the anchor's 9 taps.  (Round 1 kept it in a
+// 1.4 KB per-lane table built once per (pixel, view): the table lived in scratch, was written once
+// and read once per plane group, and that traffic — not the gathers — was most of the kernel's
+// 120 GB of fetches per launch.)
+struct AnchorTap { float w, wa; int x, y; };   // tap weight, weight * ref texel, tap pixel
 
-DVP_HD void build_anchor_tab(const Dev& d, int center, int v, float cpix, AnchorTab* T) {
+// reference side of anchor `nb` for view v: 9 taps (8 visibility-prior offsets of the ANCHOR pixel +
+// the anchor itself), weights relative to the centre pixel's grey level, the three reference sums
+// in tap order (APD.cu:905-1000)
+DVP_HD void anchor_ref_side(const Dev& d, s2 nb, int nbc, int v, float cpix, AnchorTap* tp /*[9]*/, float* s_r, float* s_rr, float* s_w) {
 	const int W = d.width, Hh = d.height, Pt = d.pitch;
 	const int S = d.params.num_images - 1;
 	const float* ref = d.images;
-	const s2* nbs = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
-	for (int k = 1; k < DVP_NEIGHBOUR_NUM; ++k) {
-		const s2 nb = nbs[k];
-		AnchorHead& hd = T->head[k - 1];
-		hd.nb = nb;
-		hd.s_r = hd.s_rr = hd.s_w = 0.0f;
-		if (nb.x == -1 || nb.y == -1) { hd.state = 0; continue; }
-		const int nbc = nb.x + nb.y * W;
-		const int visible = is_set(d.selected_views[nbc], v - 1);
-		hd.state = visible ? 1 : 2;
-		if (!visible) continue;
-		const s2* cand = d.candidate + ((size_t)nbc * S + (v - 1)) * 8;
-		s2 off[9];
+	const s2* cand = d.candidate + ((size_t)nbc * S + (v - 1)) * 8;
+	s2 off[9];
 #pragma unroll
-		for (int t = 0; t < 8; ++t) off[t] = cand[t];
-		off[8] = mks2(0, 0);
-		float av[9], wv[9];
+	for (int t = 0; t < 8; ++t) off[t] = cand[t];
+	off[8] = mks2(0, 0);
+	float av[9];
 #pragma unroll
-		for (int t = 0; t < 9; t++) {
-			int i = off[t].x, j = off[t].y;
-			if (i == 0 && j == 0 && t < 8) {   // default +-5 ring (APD.cu:943-952)
-				const int ri[8] = { -5, -5, -5, 0, 0, 5, 5, 5 };
-				const int rj[8] = { -5, 0, 5, -5, 5, -5, 0, 5 };
-				i = ri[t < 8 ? t : 0];
-				j = rj[t < 8 ? t : 0];
-			}
-			const int rx = nb.x + i, ry = nb.y + j;
-			T->tap[(k - 1) * 9 + t].xy = mks2(rx, ry);
-			av[t] = img_texel(ref, d.org, Pt, W, Hh, rx, ry);
-			wv[t] = bilateral_weight((float)i, (float)j, av[t], cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
+	for (int t = 0; t < 9; t++) {
+		int i = off[t].x, j = off[t].y;
+		if (i == 0 && j == 0 && t < 8) {   // default +-5 ring (APD.cu:943-952)
+			const int ri[8] = { -5, -5, -5, 0, 0, 5, 5, 5 };
+			const int rj[8] = { -5, 0, 5, -5, 5, -5, 0, 5 };
+			i = ri[t < 8 ? t : 0];
+			j = rj[t < 8 ? t : 0];
 		}
-		float s_r = 0.0f, s_rr = 0.0f, s_w = 0.0f;
-#pragma unroll
-		for (int t = 0; t < 9; t++) {
-			const float wa = wv[t] * av[t];
-			T->tap[(k - 1) * 9 + t].w = wv[t];
-			T->tap[(k - 1) * 9 + t].wa = wa;
-			s_r += wa;
-			s_rr += wa * av[t];
-			s_w += wv[t];
-		}
-		hd.s_r = s_r;
-		hd.s_rr = s_rr;
-		hd.s_w = s_w;
+		tp[t].x = nb.x + i;
+		tp[t].y = nb.y + j;
+		av[t] = img_texel(ref, d.org, Pt, W, Hh, tp[t].x, tp[t].y);
+		tp[t].w = (float)i;    // parked until the texels have arrived
+		tp[t].wa = (float)j;
 	}
+	float sr = 0.0f, srr = 0.0f, sw = 0.0f;
+#pragma unroll
+	for (int t = 0; t < 9; t++) {
+		const float w = bilateral_weight(tp[t].w, tp[t].wa, av[t], cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
+		const float wa = w * av[t];
+		tp[t].w = w;
+		tp[t].wa = wa;
+		sr += wa;
+		srr += wa * av[t];
+		sw += w;
+	}
+	*s_r = sr;
+	*s_rr = srr;
+	*s_w = sw;
 }
 
 // ComputeBilateralNCCNew for ALL live planes of a phase and one view, with the planes innermost per
 // anchor tap.  `c` = centre-patch context built with colour-only weights (ComputeBilateralWeight_YZL);
-// neighbours[0] is the pixel itself (APD.cu:3365), anchors 1..11 come from the table.
-// The anchor sub-patches are bandwidth-bound: a 16-byte footprint pulls a 128-byte line nobody else
+// neighbours[0] is the pixel itself (APD.cu:3365), anchors 1..11 = nbs[1..11].
+// The anchor sub-patches are bandwidth-bound: a 16-byte footprint pulls a whole line nobody else
 // reuses before it is evicted.  The planes of a phase project an anchor tap to neighbouring texels,
 // so evaluating a tap for four planes back to back lets them share the line.  Per plane the
 // arithmetic and its order are those of the reference's per-plane loop (taps 0..8 per anchor,
 // anchors 1..11 in order, APD.cu:905-1014).
 //   pass 1: centre patch per live plane (rolled loop, one inlined evaluator)
 //   pass 2: groups of 4 plane slots; per anchor, 3 rounds of (3 taps x 4 planes) = 12 gathers
-template <int SMP>
-DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const AnchorTab& T, int px, int py, int v, const f4* pl /*[8]*/,
-	uint32_t pmask, float* ev /*[8][32], column v-1 written*/) {
+// MVW = row stride of ev[] (capacity in views).
+template <int SMP, int MVW>
+DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const s2* nbs, float cpix, int px, int py, int v, const f4* pl /*[8]*/,
+	uint32_t pmask, float* ev /*[8][MVW], column v-1 written*/) {
 	const ViewConst vc = load_view(d, v);
 	const float fw = uniform_f(vc.fw), fh = uniform_f(vc.fh);
 	const int W = d.width, Hh = d.height, Pt = d.pitch;
@@ -771,7 +761,7 @@ DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const AnchorTab& T, i
 		float H[9];
 		homography(vc, pl[q], H);
 		const f2 pt = apply_homography(H, px, py);
-		if (pt.x >= fw || pt.x < 0.0f || pt.y >= fh || pt.y < 0.0f) { ev[q * 32 + v - 1] = 2.0f; continue; }
+		if (pt.x >= fw || pt.x < 0.0f || pt.y >= fh || pt.y < 0.0f) { ev[q * MVW + v - 1] = 2.0f; continue; }
 		live |= 1u << q;
 		center_cost[q] = c.fast ? ncc_patch_fast<SMP>(d, c, H, src, px, py) : ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
 	}
@@ -787,46 +777,48 @@ DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const AnchorTab& T, i
 			if ((gm >> g) & 1) homography(vc, pl[base + g], H[g]);
 			else { for (int i = 0; i < 9; ++i) H[g][i] = 0.0f; H[g][8] = 1.0f; }   // dead slot: maps everything to (0,0)
 		}
-		for (int k = 0; k < DVP_NEIGHBOUR_NUM - 1; ++k) {
-			const AnchorHead hc = T.head[k];
-			const int st = hc.state;
-			if (st == 0) continue;
+		for (int k = 1; k < DVP_NEIGHBOUR_NUM; ++k) {
+			const s2 nb = nbs[k];
+			if (nb.x == -1 || nb.y == -1) continue;
+			const int nbc = nb.x + nb.y * W;
+			const bool visible = is_set(d.selected_views[nbc], v - 1);
 			uint32_t act = 0;   // slots whose anchor projects inside the source image
 #pragma unroll
 			for (int g = 0; g < 4; ++g) {
 				if (!((gm >> g) & 1)) continue;
-				const f2 nsp = apply_homography(H[g], hc.nb.x, hc.nb.y);
+				const f2 nsp = apply_homography(H[g], nb.x, nb.y);
 				if (nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh) {
-					if (st == 1) { scost[g] += 2.0f; scnt[g] += 1.0f; }
+					if (visible) { scost[g] += 2.0f; scnt[g] += 1.0f; }
 				} else {
 					act |= 1u << g;
 				}
 			}
 			if (!act) continue;
-			if (st != 1) {   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
+			if (!visible) {   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
 #pragma unroll
 				for (int g = 0; g < 4; ++g)
 					if ((act >> g) & 1) { scost[g] += 2.0f; scnt[g] += 1.0f; }
 				continue;
 			}
+			AnchorTap tp[9];
+			float a_sr, a_srr, a_sw;
+			anchor_ref_side(d, nb, nbc, v, cpix, tp, &a_sr, &a_srr, &a_sw);
 			float s_s[4], s_ss[4], s_rs[4];
 #pragma unroll
 			for (int g = 0; g < 4; ++g) { s_s[g] = 0.0f; s_ss[g] = 0.0f; s_rs[g] = 0.0f; }
 #pragma unroll
 			for (int r3 = 0; r3 < 3; ++r3) {
-				AnchorTap tp[3];
 				unsigned off[3][4];
 				TapW<SMP> tw[3][4];
 				float qd[3][4][4];
 #pragma unroll
 				for (int t = 0; t < 3; ++t) {
-					tp[t] = T.tap[k * 9 + r3 * 3 + t];
 #pragma unroll
 					for (int g = 0; g < 4; ++g) {
 						off[t][g] = 0;
 						tw[t][g] = TapW<SMP>();
 						if (!((act >> g) & 1)) continue;   // slot dead or anchor outside for this plane
-						const f2 sp = apply_homography(H[g], tp[t].xy.x, tp[t].xy.y);
+						const f2 sp = apply_homography(H[g], tp[r3 * 3 + t].x, tp[r3 * 3 + t].y);
 						tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t][g], &tw[t][g]);
 					}
 				}
@@ -847,16 +839,16 @@ DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const AnchorTab& T, i
 						float fa, fb;
 						tap_weights(tw[t][g], &fa, &fb);
 						const float b = tex_lerp(fa, fb, qd[t][g][0], qd[t][g][1], qd[t][g][2], qd[t][g][3]);
-						const float wb = tp[t].w * b;
+						const float wb = tp[r3 * 3 + t].w * b;
 						s_s[g] += wb;
 						s_ss[g] = fmaf(wb, b, s_ss[g]);
-						s_rs[g] = fmaf(tp[t].wa, b, s_rs[g]);
+						s_rs[g] = fmaf(tp[r3 * 3 + t].wa, b, s_rs[g]);
 					}
 			}
 #pragma unroll
 			for (int g = 0; g < 4; ++g)
 				if ((act >> g) & 1) {
-					scost[g] += ncc_from_sums(hc.s_r, hc.s_rr, s_s[g], s_ss[g], s_rs[g], hc.s_w);
+					scost[g] += ncc_from_sums(a_sr, a_srr, s_s[g], s_ss[g], s_rs[g], a_sw);
 					scnt[g] += 1.0f;
 				}
 		}
@@ -869,7 +861,7 @@ DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const AnchorTab& T, i
 				sc2 = DVP_MIN(sc2, 2.0f);
 				out = (float)(0.25 * center_cost[base + g] + 0.75 * sc2);
 			}
-			ev[(base + g) * 32 + v - 1] = out;
+			ev[(base + g) * MVW + v - 1] = out;
 		}
 	}
 }
@@ -880,7 +872,8 @@ DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const AnchorTab& T, i
 //   phase 0: the planes of the <= 8 STRONG anchors x all views            -> view selection
 //   phase 1: the current plane and the RANSAC fit plane x selected views  -> adoption, fit test
 //   phase 2: 5 refinement hypotheses x selected views                     -> sequential acceptance
-template <int SMP>
+// MV = capacity (in views) of the per-view private arrays, as in strong_update_px.
+template <int SMP, int MV = 32>
 DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter, unsigned long long* nevals) {
 	const int W = d.width, Hh = d.height;
 	const int center = py * W + px;
@@ -897,14 +890,14 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter,
 		patch_geometry(d, center, &radius, &inc);
 		build_patch_ctx(d, px, py, radius, inc, 1, tab, &c);
 	}
-	float cost_array[8 * 32];
-	for (int i = 0; i < 8 * 32; ++i) cost_array[i] = 0.0f;
+	float cost_array[8 * MV];
+	for (int i = 0; i < 8 * MV; ++i) cost_array[i] = 0.0f;
 	cost_array[0] = 2.0f;
 	uint32_t flag = 0;
 	int positions[8];
 	for (int k = 0; k < 8; ++k) positions[k] = 0;
-	uint8_t vw[32];
-	for (int i = 0; i < 32; ++i) vw[i] = 0;
+	uint8_t vw[MV];
+	for (int i = 0; i < MV; ++i) vw[i] = 0;
 	uint32_t sel_mask = 0;
 	float weight_norm = 0.0f;
 	float final_costs[8];
@@ -914,8 +907,7 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter,
 	bool skip_refine = false;
 
 	f4 pl[8];            // planes evaluated by the current phase
-	float ev[8 * 32];    // their cost vectors [plane][view]
-	AnchorTab T;
+	float ev[8 * MV];    // their cost vectors [plane][view]
 
 	for (int phase = 0; phase < 3; ++phase) {
 		// ---- prologue: the planes of this phase --------------------------------------------------
@@ -934,26 +926,26 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter,
 			vmask = all_views;
 		} else if (phase == 1) {
 			// joint view selection (APD.cu:2781-2850) and the weighted candidate costs (:2852-2874)
-			float priors[32];
-			for (int i = 0; i < 32; ++i) priors[i] = 0.0f;
+			float priors[MV];
+			for (int i = 0; i < MV; ++i) priors[i] = 0.0f;
 			for (int i = 0; i < 8; ++i) {
 				const s2 nb = nbs[i + 1];
 				if (nb.x == -1 || nb.y == -1) continue;
 				const uint32_t sv = d.selected_views[nb.x + nb.y * W];
 				for (int j = 0; j < S; ++j) priors[j] += is_set(sv, j) ? 0.9f : 0.1f;
 			}
-			joint_view_selection(d, center, iter, PH_WEAK, cost_array, priors, vw, &sel_mask, &weight_norm);
+			joint_view_selection<MV>(d, center, iter, PH_WEAK, cost_array, priors, vw, &sel_mask, &weight_norm);
 			uint8_t* gvw = d.view_weight + (size_t)center * 32;
-			for (int i = 0; i < 32; ++i) gvw[i] = vw[i];
+			for (int i = 0; i < 32; ++i) gvw[i] = i < MV ? vw[i < MV ? i : 0] : (uint8_t)0;
 			for (int k = 0; k < 8; ++k) {
 				float fc = 0.0f;
 				for (int j = 0; j < S; ++j) {
 					if (vw[j] > 0) {
 						if (P.geom_consistency) {
-							if ((flag >> k) & 1) fc += vw[j] * (cost_array[k * 32 + j] + P.geom_factor * geom_cost(d, px, py, j + 1, d.planes[positions[k]]));
-							else fc += vw[j] * (cost_array[k * 32 + j] + P.geom_factor * 3.0f);
+							if ((flag >> k) & 1) fc += vw[j] * (cost_array[k * MV + j] + P.geom_factor * geom_cost(d, px, py, j + 1, d.planes[positions[k]]));
+							else fc += vw[j] * (cost_array[k * MV + j] + P.geom_factor * 3.0f);
 						} else {
-							fc += vw[j] * cost_array[k * 32 + j];
+							fc += vw[j] * cost_array[k * MV + j];
 						}
 					}
 				}
@@ -1000,8 +992,7 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter,
 		if (pmask) {
 			for (int v = 0; v < S; ++v) {
 				if (!((vmask >> v) & 1)) continue;
-				build_anchor_tab(d, center, v + 1, cpix, &T);
-				ncc_new_multi<SMP>(d, c, T, px, py, v + 1, pl, pmask, ev);
+				ncc_new_multi<SMP, MV>(d, c, nbs, cpix, px, py, v + 1, pl, pmask, ev);
 				if (nevals) *nevals += (unsigned long long)__builtin_popcount(pmask);
 			}
 		}
@@ -1010,7 +1001,7 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter,
 		if (phase == 0) {
 			for (int k = 0; k < 8; ++k)
 				if ((flag >> k) & 1)
-					for (int v = 0; v < S; ++v) cost_array[k * 32 + v] = ev[k * 32 + v];
+					for (int v = 0; v < S; ++v) cost_array[k * MV + v] = ev[k * MV + v];
 		} else if (phase == 1) {
 			float cn = 0.0f;
 			for (int v = 0; v < S; ++v) {
@@ -1037,8 +1028,8 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter,
 				float tc = 0.0f;
 				for (int j = 0; j < S; ++j) {
 					if (vw[j] > 0) {
-						if (P.geom_consistency) tc += vw[j] * (ev[32 + j] + P.geom_factor * geom_cost(d, px, py, j + 1, pl[1]));
-						else tc += vw[j] * ev[32 + j];
+						if (P.geom_consistency) tc += vw[j] * (ev[MV + j] + P.geom_factor * geom_cost(d, px, py, j + 1, pl[1]));
+						else tc += vw[j] * ev[MV + j];
 					}
 				}
 				tc /= weight_norm;
@@ -1054,8 +1045,8 @@ DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter,
 				float tc = 0.0f;
 				for (int j = 0; j < S; ++j) {
 					if (vw[j] > 0) {
-						if (P.geom_consistency) tc += vw[j] * (ev[i * 32 + j] + P.geom_factor * geom_cost(d, px, py, j + 1, pl[i]));
-						else tc += vw[j] * ev[i * 32 + j];
+						if (P.geom_consistency) tc += vw[j] * (ev[i * MV + j] + P.geom_factor * geom_cost(d, px, py, j + 1, pl[i]));
+						else tc += vw[j] * ev[i * MV + j];
 					}
 				}
 				tc /= weight_norm;
