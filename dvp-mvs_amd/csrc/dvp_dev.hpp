@@ -68,7 +68,11 @@ struct Dev {
 	const float* depths;       // same layout (geom_consistency only)
 	const DvpCamera* cameras;  // [num_images]
 	const ViewConst* views;    // [num_images] (index 0 unused)
-	const uint8_t* sector_lut; // [(2r+1)^2], r = weak_radius: 30-degree sector of offset (i,j) (APD.cu:797-821)
+	// window offsets of GenEdgeInform by 30-degree sector (APD.cu:797-821), r = weak_radius, host-built:
+	// sector s owns sector_taps[sector_start[s] .. sector_start[s+1]) in visit order (i outer, j inner);
+	// an entry is (i + r) | (j + r) << 16
+	const int* sector_taps;
+	const int* sector_start;   // [13]
 	f4* planes;
 	const f4* planes_snap;     // pre-launch copy for the strong update (direction-4 same-colour reads)
 	float* costs;
@@ -439,6 +443,16 @@ DVP_HD float uniform_f(float x) {
 	return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
 #else
 	return x;
+#endif
+}
+
+// element `i` (wave-uniform) of a read-only int table through the constant address space: s_load
+DVP_HD int uniform_load_i32(const int* p, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	typedef const __attribute__((address_space(4))) int* cptr;
+	return *((cptr)p + __builtin_amdgcn_readfirstlane(i));
+#else
+	return p[i];
 #endif
 }
 

@@ -236,7 +236,7 @@ struct dvp_ctx {
 	float* depths = nullptr;
 	uint32_t* edge_bits = nullptr;  // bit-tiled copy of `edge`, rebuilt before the launches that walk lines
 	uint32_t* strong_bits = nullptr; // bit-tiled (weak_info == STRONG), rebuilt before GenNeighbours
-	DvpCamera* cameras = nullptr; ViewConst* views = nullptr; uint8_t* lut = nullptr;
+	DvpCamera* cameras = nullptr; ViewConst* views = nullptr; int* sector_taps = nullptr; int* sector_start = nullptr;
 	f4* planes = nullptr; f4* planes_snap = nullptr; f4* fit_planes = nullptr;
 	int* search_pos = nullptr;   // [16][L]
 	float* costs = nullptr; float* costs_snap = nullptr; float* complex_ = nullptr;
@@ -289,7 +289,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.width = c->W; d.height = c->H; d.num_images = c->NI; d.pitch = c->pitch;
 	d.org = kImgPad * c->pitch + kImgPad;
 	d.plane_stride = (size_t)c->pitch * (c->H + 2 * kImgPad);
-	d.images = c->images; d.depths = c->depths; d.cameras = c->cameras; d.views = c->views; d.sector_lut = c->lut;
+	d.images = c->images; d.depths = c->depths; d.cameras = c->cameras; d.views = c->views; d.sector_taps = c->sector_taps; d.sector_start = c->sector_start;
 	d.search_pos = c->search_pos;
 	d.planes = c->planes; d.planes_snap = c->planes_snap; d.costs = c->costs; d.costs_snap = c->costs_snap;
 	d.selected_views = c->selected_views; d.view_weight = c->view_weight; d.weak_info = c->weak_info;
@@ -590,9 +590,11 @@ int dvp_set_params(dvp_ctx* c, const DvpParams* p) {
 	c->d.params = *p;
 	set_neighbour_consts(&c->d);
 	if (c->lut_radius != p->weak_radius) {
-		const std::vector<uint8_t> lut = make_sector_lut(p->weak_radius);
-		if (dalloc(c, &c->lut, lut.size(), false)) return 1;
-		HIP_TRY(c, hipMemcpyAsync(c->lut, lut.data(), lut.size(), hipMemcpyHostToDevice, c->stream));
+		std::vector<int> taps, start;
+		make_sector_taps(p->weak_radius, &taps, &start);
+		if (dalloc(c, &c->sector_taps, taps.size(), false) || dalloc(c, &c->sector_start, start.size(), false)) return 1;
+		HIP_TRY(c, hipMemcpyAsync(c->sector_taps, taps.data(), taps.size() * 4, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->sector_start, start.data(), start.size() * 4, hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
 		c->lut_radius = p->weak_radius;
 	}
@@ -606,7 +608,7 @@ int dvp_set_profiling(dvp_ctx* c, int on) { c->profiling = on != 0; sync_dev_str
 // ---- launches ---------------------------------------------------------------------------------
 static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 	if (stage < 0 || stage >= DVP_ST_LAUNCHABLE) { c->error = "bad stage id"; return 1; }
-	if (!c->lut) { c->error = "dvp_set_params must be called before running kernels"; return 1; }
+	if (!c->sector_taps) { c->error = "dvp_set_params must be called before running kernels"; return 1; }
 	if (c->d.params.geom_consistency && !c->have_depths) { c->error = "geom_consistency is on but no depth maps were uploaded"; return 1; }
 	const LaunchGeom g = make_geom(c->W, c->H, stage_is_half(stage));
 	LaunchArgs a;
@@ -843,7 +845,7 @@ struct EventPairGuard {
 
 int dvp_eval_cost_vectors(dvp_ctx* c, const int32_t* px, const float* planes, int n, float* out, float* kernel_ms) {
 	if (set_device(c)) return 1;
-	if (!c->lut) { c->error = "dvp_set_params must be called first"; return 1; }
+	if (!c->sector_taps) { c->error = "dvp_set_params must be called first"; return 1; }
 	if (n <= 0) return 0;
 	const size_t S = (size_t)c->NI - 1;
 	DevBuf dpx, dpl, dout;
@@ -867,7 +869,7 @@ int dvp_eval_cost_vectors(dvp_ctx* c, const int32_t* px, const float* planes, in
 
 int dvp_bench_cost_kernel(dvp_ctx* c, int repeat, float* mean_kernel_ms, uint64_t* evals_per_launch) {
 	if (set_device(c)) return 1;
-	if (!c->lut) { c->error = "dvp_set_params must be called first"; return 1; }
+	if (!c->sector_taps) { c->error = "dvp_set_params must be called first"; return 1; }
 	if (repeat < 1) repeat = 1;
 	const LaunchGeom g = make_geom(c->W, c->H, false);
 	LaunchArgs a;

@@ -97,23 +97,29 @@ inline bool stage_is_half(int stage) {
 }
 
 // ---- host-side uniform constants ---------------------------------------------------------------
-// 30-degree sector of offset (i, j) exactly as calculateAngle/getRegion compute it
-// (APD.cu:797-821; the angle passes through a float, APD.cu:3759).  255 = no sector.
-inline std::vector<uint8_t> make_sector_lut(int radius) {
+// The window offsets of GenEdgeInform grouped by 30-degree sector, exactly as calculateAngle/getRegion
+// bin them (APD.cu:797-821; the angle passes through a float, APD.cu:3759), each sector in the
+// reference's visit order (i outer, j inner).  taps[k] = (i + radius) | (j + radius) << 16,
+// start[s]..start[s+1] = sector s.  Offsets that fall in no sector are dropped like getRegion's -1.
+inline void make_sector_taps(int radius, std::vector<int>* taps, std::vector<int>* start) {
 	const double kPI = 3.14159265358979323846;   // APD.h:6
-	const int n = 2 * radius + 1;
-	std::vector<uint8_t> lut((size_t)n * n, 255);
+	std::vector<std::vector<int>> by(12);
 	for (int i = -radius; i <= radius; ++i)
 		for (int j = -radius; j <= radius; ++j) {
+			if (i == 0 && j == 0) continue;
 			double deg = std::atan2((double)j, (double)i) * (180.0 / kPI);
 			if (deg < 0) deg += 360.0;
 			const double a = (double)(float)deg;
-			int r = 255;
 			for (int q = 0; q < 12; ++q)
-				if (a >= 30.0 * q && a < 30.0 * (q + 1)) r = q;
-			lut[(size_t)(i + radius) * n + (j + radius)] = (uint8_t)r;
+				if (a >= 30.0 * q && a < 30.0 * (q + 1)) by[q].push_back((i + radius) | ((j + radius) << 16));
 		}
-	return lut;
+	taps->clear();
+	start->assign(13, 0);
+	for (int q = 0; q < 12; ++q) {
+		(*start)[q] = (int)taps->size();
+		taps->insert(taps->end(), by[q].begin(), by[q].end());
+	}
+	(*start)[12] = (int)taps->size();
 }
 // GenNeighbours' per-launch constants (APD.cu:3375-3380), evaluated in double like the reference
 inline void set_neighbour_consts(Dev* d) {

@@ -48,56 +48,61 @@ DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
 	const int center = px + py * W;
 	const DvpParams& P = d.params;
 	const int S = P.num_images - 1;
-	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
 	const float* ref = d.images;
 	const float cpix = img_texel(ref, d.org, d.pitch, W, H, px, py);
 
-	// visibility-prior tap candidates (APD.cu:3746-3794).  The reference loops views outermost and
-	// recomputes every tap weight per view; the weight does not depend on the view, so taps are
-	// the outer loop here (one selected_views word, one exp per tap) and each set view bit updates
-	// that view's running per-sector arg-max.  Visit order per (view, sector) is unchanged.
+	// visibility-prior tap candidates (APD.cu:3746-3794): per source view, the window offsets whose
+	// pixel sees that view are binned into twelve 30-degree sectors (at most 20 per sector, visit
+	// order), each sector keeps its heaviest offset (first one among equals: the reference's stable
+	// bubble sort), the twelve winners are sorted by weight and the top eight stored.
+	// Sector-major walk: the offsets of sector r in visit order come from a host-built list
+	// (sector_taps / sector_start, wave-uniform -> scalar loads), so a sector's running maximum and the
+	// twelve winners of the view live in registers with static indices.  (Round 1 walked the window once
+	// for all views and kept S x 12 running maxima in a dynamically indexed private array: 3.2 KB of
+	// scratch per lane, 330 GB of write-back per launch at 6208x4128.)  The tap weight is recomputed per
+	// view; that is ~10 % of the old kernel's time.
 	{
-		struct Best { float w; short i, j; };   // one 8-byte private-memory record per (view, sector)
-		Best best[32 * 12];
-		uint32_t has[32];
-		for (int v = 0; v < S; ++v) {
-			has[v] = 0;
-			for (int r = 0; r < 12; ++r) best[v * 12 + r] = Best{ 0.0f, 0, 0 };
-		}
+		struct Best { float w; int i, j; };
 		const int radius = P.weak_radius;
-		for (int i = -radius; i <= radius; i++) {
-			for (int j = -radius; j <= radius; j++) {
-				if (i == 0 && j == 0) continue;
-				const int x = px + i, y = py + j;
-				if (!(x >= 0 && x < W && y >= 0 && y < H)) continue;
-				uint32_t sv = d.selected_views[x + y * W] & all_views;
-				if (!sv) continue;
-				const int r = d.sector_lut[(i + radius) * (2 * radius + 1) + (j + radius)];   // host-built for this radius
-				if (r >= 12) continue;
-				const float a = img_texel(ref, d.org, d.pitch, W, H, x, y);
-				const float w = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
-				for (int v = 0; v < S; ++v) {
-					if (!((sv >> v) & 1)) continue;
-					if (!((has[v] >> r) & 1) || w > best[v * 12 + r].w) {   // first maximum wins (stable bubble sort, APD.cu:823-833)
-						has[v] |= 1u << r;
-						best[v * 12 + r] = Best{ w, (short)i, (short)j };
+		for (int v = 0; v < S; ++v) {
+			Best win[12];
+			bool any = false;
+#pragma unroll
+			for (int r = 0; r < 12; ++r) {
+				Best b = Best{ 0.0f, 0, 0 };
+				bool has = false;
+				int cnt = 0;
+				const int t1 = uniform_load_i32(d.sector_start, r + 1);
+				for (int t = uniform_load_i32(d.sector_start, r); t < t1; ++t) {
+					const int code = uniform_load_i32(d.sector_taps, t);
+					const int i = (code & 0xffff) - radius, j = (code >> 16) - radius;
+					const int x = px + i, y = py + j;
+					if (!(x >= 0 && x < W && y >= 0 && y < H)) continue;
+					if (!((d.selected_views[x + y * W] >> v) & 1)) continue;
+					if (cnt >= 20) continue;   // regionCounts[region] < 20 (APD.cu:3768)
+					cnt++;
+					const float a = img_texel(ref, d.org, d.pitch, W, H, x, y);
+					const float w = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
+					if (!has || w > b.w) { has = true; b = Best{ w, i, j }; }
+				}
+				win[r] = b;
+				any |= has;
+			}
+			if (any) {   // stable descending sort of the 12 sector winners (empty sectors: weight 0, offset (0,0))
+#pragma unroll
+				for (int a = 1; a < 12; ++a) {
+#pragma unroll
+					for (int b = a; b >= 1; --b) {
+						const bool sw = win[b - 1].w < win[b].w;
+						const Best lo = win[b - 1], hi = win[b];
+						win[b - 1] = sw ? hi : lo;
+						win[b] = sw ? lo : hi;
 					}
 				}
 			}
-		}
-		for (int v = 0; v < S; ++v) {
-			// stable descending sort of the 12 sector winners (empty sectors: weight 0, offset (0,0))
-			Best* b_ = best + v * 12;
-			if (has[v]) {
-				for (int a = 1; a < 12; ++a) {
-					const Best t = b_[a];
-					int b = a;
-					for (; b >= 1 && b_[b - 1].w < t.w; --b) b_[b] = b_[b - 1];
-					b_[b] = t;
-				}
-			}
 			s2* cand = d.candidate + ((size_t)center * S + v) * 8;
-			for (int k = 0; k < 8; ++k) cand[k] = mks2(b_[k].i, b_[k].j);
+#pragma unroll
+			for (int k = 0; k < 8; ++k) cand[k] = mks2(win[k].i, win[k].j);
 		}
 	}
 

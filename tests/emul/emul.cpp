@@ -18,7 +18,7 @@ struct Emu {
 	std::vector<float> images, depths;
 	std::vector<DvpCamera> cameras;
 	std::vector<ViewConst> views;
-	std::vector<uint8_t> lut;
+	std::vector<int> sector_taps, sector_start;
 	std::vector<f4> planes, planes_snap, fit_planes;
 	std::vector<int> search_pos;
 	std::vector<float> costs, costs_snap, complex_;
@@ -41,7 +41,8 @@ void refresh(Emu& e) {
 	d.depths = e.depths.data();
 	d.cameras = e.cameras.data();
 	d.views = e.views.data();
-	d.sector_lut = e.lut.data();
+	d.sector_taps = e.sector_taps.data();
+	d.sector_start = e.sector_start.data();
 	d.search_pos = e.search_pos.data();
 	d.planes = e.planes.data(); d.planes_snap = e.planes_snap.data();
 	d.costs = e.costs.data(); d.costs_snap = e.costs_snap.data();
@@ -124,7 +125,7 @@ void* emu_create(int W, int H, int NI) {
 	e->complex_.assign(1, 0.0f);
 	e->radius.assign(L, 5);
 	std::memset(&e->d, 0, sizeof(Dev));
-	e->lut = make_sector_lut(5);
+	make_sector_taps(5, &e->sector_taps, &e->sector_start);
 	refresh(*e);
 	return e;
 }
@@ -160,7 +161,7 @@ void emu_set_params(void* c, const DvpParams* p) {
 	Emu& e = *(Emu*)c;
 	e.d.params = *p;
 	set_neighbour_consts(&e.d);
-	e.lut = make_sector_lut(p->weak_radius);
+	make_sector_taps(p->weak_radius, &e.sector_taps, &e.sector_start);
 	refresh(e);
 }
 void emu_set_seed(void* c, uint64_t s) { ((Emu*)c)->d.seed = s; }
