@@ -40,7 +40,7 @@ PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_r02.json")
 # strong-update instantiation when S <= 8)
 def kernel_name(stage, S):
     return {"strong_update": "dvp_strong_update_v8" if S <= 8 else ("dvp_strong_update_v16" if S <= 16 else "dvp_strong_update"),
-            "weak_update": "dvp_weak_update_list_v16" if S <= 16 else "dvp_weak_update_list", "gen_neighbours": "dvp_gen_neighbours_list",
+            "weak_update": "dvp_weak_update_wave", "gen_neighbours": "dvp_gen_neighbours_list",
             "ransac_fit": "dvp_ransac_fit_plane_list", "find_nearest_strong": "dvp_find_nearest_strong_list",
             "neighbour_update": "dvp_neighbour_update_list"}.get(stage, "dvp_" + stage)
 

@@ -43,18 +43,18 @@ struct ListArgs { int base, count, iter, covered_rows; };
 // their anchor sub-patches gather — behind one L2.  Bijection on [0, nblocks): whole groups of
 // 8 * kListRun blocks are permuted, the ragged tail keeps its order.
 constexpr int kListRun = 16;
-__device__ __forceinline__ int list_block(int b, int nblocks) {
-	const int group = 8 * kListRun;
+__device__ __forceinline__ int list_block(int b, int nblocks, int run) {
+	const int group = 8 * run;
 	if (b >= nblocks / group * group) return b;
 	const int g = b / group, r = b - g * group;
 	const int xcd = r & 7, i = r >> 3;
-	return g * group + xcd * kListRun + i;
+	return g * group + xcd * run + i;
 }
 template <int STAGE, int SMP, int MV = 32>
 __device__ __forceinline__ void stage_body_list(const Dev& d, const ListArgs& a) {
 	__shared__ f2 lds_tab[stage_uses_tab(STAGE) ? kTaps * kTaps * 256 : 1];
 	const PatchTab tab{&lds_tab[stage_uses_tab(STAGE) ? threadIdx.x : 0], 256};
-	const int t = list_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+	const int t = list_block(blockIdx.x, gridDim.x, kListRun) * 256 + threadIdx.x;
 	unsigned long long n = 0;
 	if (t < a.count) {
 		const int center = d.weak_list[a.base + t];
@@ -120,8 +120,27 @@ DVP_KERNEL_LIST(dvp_find_nearest_strong_list, DVP_ST_FIND_NEAREST_STRONG, 1)
 DVP_KERNEL_LIST(dvp_gen_neighbours_list, DVP_ST_GEN_NEIGHBOURS, 1)
 DVP_KERNEL_LIST(dvp_neighbour_update_list, DVP_ST_NEIGHBOUR_UPDATE, 1)
 DVP_KERNEL_LIST(dvp_ransac_fit_plane_list, DVP_ST_RANSAC_FIT, 1)
-DVP_KERNEL_LIST(dvp_weak_update_list, DVP_ST_WEAK_UPDATE, 2)
-DVP_KERNEL_LIST_MV(dvp_weak_update_list_v16, DVP_ST_WEAK_UPDATE, 2, 16)
+
+// Black/RedPixelUpdateWeak (APD.cu:4487-4489): one WAVE per WEAK pixel of the list segment, four
+// pixels per workgroup, per-pixel state in LDS (dvp_weak_wave.hpp)
+template <int SMP>
+__device__ __forceinline__ void weak_wave_body(const Dev& d, const ListArgs& a) {
+	__shared__ WeakShared sh[4];
+	const int wave = threadIdx.x >> 6;
+	const int t = list_block(blockIdx.x, gridDim.x, kListRun * 64) * 4 + wave;
+	if (t >= a.count) return;
+	const int center = d.weak_list[a.base + t];
+	const int py = center / d.width, px = center - py * d.width;
+	if (py >= a.covered_rows) return;   // rows beyond the reference's half grid (APD.cu:4421-4424)
+	unsigned long long n = 0;
+	weak_update_wave<SMP>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, sh[wave]);
+	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
+}
+#ifndef DVP_LB_WEAK
+#define DVP_LB_WEAK 3   // waves per SIMD the wave kernel is compiled for (LDS: 42 KB per workgroup -> 3 workgroups per CU)
+#endif
+extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK) dvp_weak_update_wave(const Dev d, const ListArgs a) { weak_wave_body<0>(d, a); }
+extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK) dvp_weak_update_wave_exact(const Dev d, const ListArgs a) { weak_wave_body<1>(d, a); }
 
 // replicate the image border into the kImgPad-wide frame of a padded plane set
 extern "C" __global__ void dvp_pad_replicate(float* planes, int W, int H, int pitch, size_t plane_stride, int n_planes) {
@@ -669,10 +688,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 			case DVP_ST_GEN_NEIGHBOURS: hipLaunchKernelGGL(ex ? dvp_gen_neighbours_list_exact : dvp_gen_neighbours_list, lg, block, 0, c->stream, c->d, la); break;
 			case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(ex ? dvp_neighbour_update_list_exact : dvp_neighbour_update_list, lg, block, 0, c->stream, c->d, la); break;
 			case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(ex ? dvp_ransac_fit_plane_list_exact : dvp_ransac_fit_plane_list, lg, block, 0, c->stream, c->d, la); break;
-			case DVP_ST_WEAK_UPDATE:
-				if (c->NI - 1 <= 16) hipLaunchKernelGGL(ex ? dvp_weak_update_list_v16_exact : dvp_weak_update_list_v16, lg, block, 0, c->stream, c->d, la);
-				else hipLaunchKernelGGL(ex ? dvp_weak_update_list_exact : dvp_weak_update_list, lg, block, 0, c->stream, c->d, la);
-				break;
+			case DVP_ST_WEAK_UPDATE: hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact : dvp_weak_update_wave, dim3((la.count + 3) / 4), block, 0, c->stream, c->d, la); break;
 			}
 			HIP_TRY(c, hipGetLastError());
 		}

@@ -3,7 +3,7 @@
 #ifndef DVP_STAGES_HPP_
 #define DVP_STAGES_HPP_
 
-#include "dvp_weak.hpp"
+#include "dvp_weak_wave.hpp"
 #include <vector>
 #include <cmath>
 
@@ -78,7 +78,13 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 	else if (STAGE == DVP_ST_RANDOM_INIT) random_init_px<SMP>(d, px, py, tab, nevals);
 	else if (STAGE == DVP_ST_STRONG_UPDATE) { if (d.weak_info[center] != DVP_WEAK) strong_update_px<SMP, MV>(d, px, py, tab, iter, nevals); }
 	else if (STAGE == DVP_ST_RANSAC_FIT) ransac_fit_plane_px(d, px, py, iter);
-	else if (STAGE == DVP_ST_WEAK_UPDATE) { if (d.weak_info[center] == DVP_WEAK) weak_update_px<SMP, MV>(d, px, py, tab, iter, nevals); }
+	else if (STAGE == DVP_ST_WEAK_UPDATE) {
+		// device: own launch shape (one wave per WEAK pixel, dvp_weak_update_wave); this branch is the
+		// host emulation of that wave (tests/emul): DVP_LANES loops over the 64 lanes
+#if !defined(__HIPCC__)
+		if (d.weak_info[center] == DVP_WEAK) { WeakShared sh; weak_update_wave<SMP>(d, px, py, iter, nevals, sh); }
+#endif
+	}
 	else if (STAGE == DVP_ST_GET_DEPTH_NORMAL) get_depth_normal_px(d, px, py);
 	else if (STAGE == DVP_ST_FILTER_STRONG) { if (d.weak_info[center] != DVP_WEAK) filter_strong_px(d, px, py); }
 	else if (STAGE == DVP_ST_DEPTH_TO_WEAK) depth_to_weak_px<SMP>(d, px, py, tab, nevals);
@@ -86,8 +92,7 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 }
 // launch sites whose kernels need the per-lane patch table (LDS on the GPU)
 constexpr bool stage_uses_tab(int stage) {
-	return stage == DVP_ST_RANDOM_INIT || stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_WEAK_UPDATE ||
-	       stage == DVP_ST_DEPTH_TO_WEAK || stage == DVP_ST_LOCAL_REFINE;
+	return stage == DVP_ST_RANDOM_INIT || stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_DEPTH_TO_WEAK || stage == DVP_ST_LOCAL_REFINE;
 }
 constexpr bool stage_is_half_c(int stage) {
 	return stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_WEAK_UPDATE || stage == DVP_ST_FILTER_STRONG;

@@ -19,9 +19,9 @@ DVP_HD void sort_small(float* v, int n) {   // insertion sort, APD.cu:114-123
 
 // GenerateRandomNormal_YZL (APD.cu:501-588): rejection-sample a unit normal that faces the
 // reference viewing ray and the (quirkily transformed) viewing rays of every selected source view.
-DVP_HD f4 random_normal_yzl(const Dev& d, int px, int py, Rng& rng, float depth) {
+// `sel` = the pixel's selected-view mask (selected_views[center] at the time of the call)
+DVP_HD f4 random_normal_yzl_sel(const Dev& d, int px, int py, Rng& rng, float depth, uint32_t sel) {
 	const int W = d.width, H = d.height;
-	const int center = py * W + px;
 	const DvpCamera rc = load_camera(d, 0);
 	f3 vd[20];
 	{
@@ -29,7 +29,6 @@ DVP_HD f4 random_normal_yzl(const Dev& d, int px, int py, Rng& rng, float depth)
 		vd[0] = mk3(v0.x, v0.y, v0.z);
 	}
 	int index = 1;
-	const uint32_t sel = d.selected_views[center];
 	for (int v = 1; v < d.params.num_images; ++v) {
 		if (!is_set(sel, v - 1)) continue;
 		const DvpCamera sc = load_camera(d, v);
@@ -84,6 +83,10 @@ DVP_HD f4 random_normal_yzl(const Dev& d, int px, int py, Rng& rng, float depth)
 	}
 	normalize3(&n);
 	return n;
+}
+
+DVP_HD f4 random_normal_yzl(const Dev& d, int px, int py, Rng& rng, float depth) {
+	return random_normal_yzl_sel(d, px, py, rng, depth, d.selected_views[py * d.width + px]);
 }
 
 // RandomInitialization (APD.cu:1273-1309)

@@ -685,409 +685,5 @@ DVP_HD void ransac_fit_plane_px(const Dev& d, int px, int py, int iter) {
 	}
 }
 
-// ---- ComputeBilateralNCCNew (APD.cu:835-1021) ---------------------------------------------------
-// The deformable NCC of a WEAK pixel = its own 36-tap patch (colour-only weights) + up to 11 anchor
-// sub-patches of 9 visibility-prior taps.  For a given (pixel, view) the anchors, their tap
-// positions, the reference texels, the weights and the three reference sums do not depend on the
-// plane hypothesis; the reference recomputes them (99 exp + 99 texel reads + the candidate
-// offsets) for each of the ~15 hypotheses.  Here that half is computed once per (anchor, group of
-// four planes) and lives in REGISTERS for the duration of the anchor's 9 taps.  (Round 1 kept it in a
-// 1.4 KB per-lane table built once per (pixel, view): the table lived in scratch, was written once
-// and read once per plane group, and that traffic — not the gathers — was most of the kernel's
-// 120 GB of fetches per launch.)
-struct AnchorTap { float w, wa; int x, y; };   // tap weight, weight * ref texel, tap pixel
-
-// reference side of anchor `nb` for view v: 9 taps (8 visibility-prior offsets of the ANCHOR pixel +
-// the anchor itself), weights relative to the centre pixel's grey level, the three reference sums
-// in tap order (APD.cu:905-1000)
-DVP_HD void anchor_ref_side(const Dev& d, s2 nb, int nbc, int v, float cpix, AnchorTap* tp /*[9]*/, float* s_r, float* s_rr, float* s_w) {
-	const int W = d.width, Hh = d.height, Pt = d.pitch;
-	const int S = d.params.num_images - 1;
-	const float* ref = d.images;
-	const s2* cand = d.candidate + ((size_t)nbc * S + (v - 1)) * 8;
-	s2 off[9];
-#pragma unroll
-	for (int t = 0; t < 8; ++t) off[t] = cand[t];
-	off[8] = mks2(0, 0);
-	float av[9];
-#pragma unroll
-	for (int t = 0; t < 9; t++) {
-		int i = off[t].x, j = off[t].y;
-		if (i == 0 && j == 0 && t < 8) {   // default +-5 ring (APD.cu:943-952)
-			const int ri[8] = { -5, -5, -5, 0, 0, 5, 5, 5 };
-			const int rj[8] = { -5, 0, 5, -5, 5, -5, 0, 5 };
-			i = ri[t < 8 ? t : 0];
-			j = rj[t < 8 ? t : 0];
-		}
-		tp[t].x = nb.x + i;
-		tp[t].y = nb.y + j;
-		av[t] = img_texel(ref, d.org, Pt, W, Hh, tp[t].x, tp[t].y);
-		tp[t].w = (float)i;    // parked until the texels have arrived
-		tp[t].wa = (float)j;
-	}
-	float sr = 0.0f, srr = 0.0f, sw = 0.0f;
-#pragma unroll
-	for (int t = 0; t < 9; t++) {
-		const float w = bilateral_weight(tp[t].w, tp[t].wa, av[t], cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
-		const float wa = w * av[t];
-		tp[t].w = w;
-		tp[t].wa = wa;
-		sr += wa;
-		srr += wa * av[t];
-		sw += w;
-	}
-	*s_r = sr;
-	*s_rr = srr;
-	*s_w = sw;
-}
-
-// ComputeBilateralNCCNew for ALL live planes of a phase and one view, with the planes innermost per
-// anchor tap.  `c` = centre-patch context built with colour-only weights (ComputeBilateralWeight_YZL);
-// neighbours[0] is the pixel itself (APD.cu:3365), anchors 1..11 = nbs[1..11].
-// The anchor sub-patches are bandwidth-bound: a 16-byte footprint pulls a whole line nobody else
-// reuses before it is evicted.  The planes of a phase project an anchor tap to neighbouring texels,
-// so evaluating a tap for four planes back to back lets them share the line.  Per plane the
-// arithmetic and its order are those of the reference's per-plane loop (taps 0..8 per anchor,
-// anchors 1..11 in order, APD.cu:905-1014).
-//   pass 1: centre patch per live plane (rolled loop, one inlined evaluator)
-//   pass 2: groups of 4 plane slots; per anchor, 3 rounds of (3 taps x 4 planes) = 12 gathers
-// MVW = row stride of ev[] (capacity in views).
-template <int SMP, int MVW>
-DVP_HD void ncc_new_multi(const Dev& d, const PatchCtx& c, const s2* nbs, float cpix, int px, int py, int v, const f4* pl /*[8]*/,
-	uint32_t pmask, float* ev /*[8][MVW], column v-1 written*/) {
-	const ViewConst vc = load_view(d, v);
-	const float fw = uniform_f(vc.fw), fh = uniform_f(vc.fh);
-	const int W = d.width, Hh = d.height, Pt = d.pitch;
-	const float* src = d.images + (size_t)uniform_i(v) * d.plane_stride * 2;   // wave-uniform base: SGPR base + 32-bit lane offsets
-	float center_cost[8];
-	uint32_t live = 0;   // planes whose centre projects inside the source image
-	for (int q = 0; q < 8; ++q) {
-		if (!((pmask >> q) & 1)) continue;
-		float H[9];
-		homography(vc, pl[q], H);
-		const f2 pt = apply_homography(H, px, py);
-		if (pt.x >= fw || pt.x < 0.0f || pt.y >= fh || pt.y < 0.0f) { ev[q * MVW + v - 1] = 2.0f; continue; }
-		live |= 1u << q;
-		center_cost[q] = c.fast ? ncc_patch_fast<SMP>(d, c, H, src, px, py) : ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
-	}
-	for (int base = 0; base < 8; base += 4) {
-		const uint32_t gm = (live >> base) & 0xFu;
-		if (!gm) continue;
-		float H[4][9];
-		float scost[4], scnt[4];
-#pragma unroll
-		for (int g = 0; g < 4; ++g) {
-			scost[g] = 0.0f;
-			scnt[g] = 0.0f;
-			if ((gm >> g) & 1) homography(vc, pl[base + g], H[g]);
-			else { for (int i = 0; i < 9; ++i) H[g][i] = 0.0f; H[g][8] = 1.0f; }   // dead slot: maps everything to (0,0)
-		}
-		for (int k = 1; k < DVP_NEIGHBOUR_NUM; ++k) {
-			const s2 nb = nbs[k];
-			if (nb.x == -1 || nb.y == -1) continue;
-			const int nbc = nb.x + nb.y * W;
-			const bool visible = is_set(d.selected_views[nbc], v - 1);
-			uint32_t act = 0;   // slots whose anchor projects inside the source image
-#pragma unroll
-			for (int g = 0; g < 4; ++g) {
-				if (!((gm >> g) & 1)) continue;
-				const f2 nsp = apply_homography(H[g], nb.x, nb.y);
-				if (nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh) {
-					if (visible) { scost[g] += 2.0f; scnt[g] += 1.0f; }
-				} else {
-					act |= 1u << g;
-				}
-			}
-			if (!act) continue;
-			if (!visible) {   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
-#pragma unroll
-				for (int g = 0; g < 4; ++g)
-					if ((act >> g) & 1) { scost[g] += 2.0f; scnt[g] += 1.0f; }
-				continue;
-			}
-			AnchorTap tp[9];
-			float a_sr, a_srr, a_sw;
-			anchor_ref_side(d, nb, nbc, v, cpix, tp, &a_sr, &a_srr, &a_sw);
-			float s_s[4], s_ss[4], s_rs[4];
-#pragma unroll
-			for (int g = 0; g < 4; ++g) { s_s[g] = 0.0f; s_ss[g] = 0.0f; s_rs[g] = 0.0f; }
-#pragma unroll
-			for (int r3 = 0; r3 < 3; ++r3) {
-				unsigned off[3][4];
-				TapW<SMP> tw[3][4];
-				float qd[3][4][4];
-#pragma unroll
-				for (int t = 0; t < 3; ++t) {
-#pragma unroll
-					for (int g = 0; g < 4; ++g) {
-						off[t][g] = 0;
-						tw[t][g] = TapW<SMP>();
-						if (!((act >> g) & 1)) continue;   // slot dead or anchor outside for this plane
-						const f2 sp = apply_homography(H[g], tp[r3 * 3 + t].x, tp[r3 * 3 + t].y);
-						tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t][g], &tw[t][g]);
-					}
-				}
-				sched_fence();
-#pragma unroll
-				for (int t = 0; t < 3; ++t)
-#pragma unroll
-					for (int g = 0; g < 4; ++g) {
-						qd[t][g][0] = qd[t][g][1] = qd[t][g][2] = qd[t][g][3] = 0.0f;
-						if ((act >> g) & 1) load_quad(src, off[t][g], &qd[t][g][0], &qd[t][g][1], &qd[t][g][2], &qd[t][g][3]);
-					}
-				sched_fence();
-#pragma unroll
-				for (int t = 0; t < 3; ++t)
-#pragma unroll
-					for (int g = 0; g < 4; ++g) {
-						if (!((act >> g) & 1)) continue;
-						float fa, fb;
-						tap_weights(tw[t][g], &fa, &fb);
-						const float b = tex_lerp(fa, fb, qd[t][g][0], qd[t][g][1], qd[t][g][2], qd[t][g][3]);
-						const float wb = tp[r3 * 3 + t].w * b;
-						s_s[g] += wb;
-						s_ss[g] = fmaf(wb, b, s_ss[g]);
-						s_rs[g] = fmaf(tp[r3 * 3 + t].wa, b, s_rs[g]);
-					}
-			}
-#pragma unroll
-			for (int g = 0; g < 4; ++g)
-				if ((act >> g) & 1) {
-					scost[g] += ncc_from_sums(a_sr, a_srr, s_s[g], s_ss[g], s_rs[g], a_sw);
-					scnt[g] += 1.0f;
-				}
-		}
-#pragma unroll
-		for (int g = 0; g < 4; ++g) {
-			if (!((gm >> g) & 1)) continue;
-			float out = center_cost[base + g];
-			if (scnt[g] > 0.0f) {
-				float sc2 = scost[g] / scnt[g];   // strong_cost /= strong_count (int -> float, exact)
-				sc2 = DVP_MIN(sc2, 2.0f);
-				out = (float)(0.25 * center_cost[base + g] + 0.75 * sc2);
-			}
-			ev[(base + g) * MVW + v - 1] = out;
-		}
-	}
-}
-
-// ---- CheckerboardPropagationWeak + PlaneHypothesisRefinementWeak (APD.cu:2739-3089, 1897-2008) --
-// Three view-major phases through ONE inlined copy of ncc_new_multi, so that the anchor table of a
-// view is built once per phase instead of once per hypothesis:
-//   phase 0: the planes of the <= 8 STRONG anchors x all views            -> view selection
-//   phase 1: the current plane and the RANSAC fit plane x selected views  -> adoption, fit test
-//   phase 2: 5 refinement hypotheses x selected views                     -> sequential acceptance
-// MV = capacity (in views) of the per-view private arrays, as in strong_update_px.
-template <int SMP, int MV = 32>
-DVP_HD void weak_update_px(const Dev& d, int px, int py, PatchTab tab, int iter, unsigned long long* nevals) {
-	const int W = d.width, Hh = d.height;
-	const int center = py * W + px;
-	const DvpParams& P = d.params;
-	const DvpCamera rc = load_camera(d, 0);
-	const int S = P.num_images - 1;
-	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
-	const s2* nbs = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
-	const float cpix = img_texel(d.images, d.org, d.pitch, W, Hh, px, py);
-
-	PatchCtx c;
-	{
-		int radius, inc;
-		patch_geometry(d, center, &radius, &inc);
-		build_patch_ctx(d, px, py, radius, inc, 1, tab, &c);
-	}
-	float cost_array[8 * MV];
-	for (int i = 0; i < 8 * MV; ++i) cost_array[i] = 0.0f;
-	cost_array[0] = 2.0f;
-	uint32_t flag = 0;
-	int positions[8];
-	for (int k = 0; k < 8; ++k) positions[k] = 0;
-	uint8_t vw[MV];
-	for (int i = 0; i < MV; ++i) vw[i] = 0;
-	uint32_t sel_mask = 0;
-	float weight_norm = 0.0f;
-	float final_costs[8];
-	int min_cost_idx = 0;
-	float cost_now = 0.0f, costs_center = 0.0f, depth_now = 0.0f;
-	f4 plane_now = mk4(0, 0, 0, 0);
-	bool skip_refine = false;
-
-	f4 pl[8];            // planes evaluated by the current phase
-	float ev[8 * MV];    // their cost vectors [plane][view]
-
-	for (int phase = 0; phase < 3; ++phase) {
-		// ---- prologue: the planes of this phase --------------------------------------------------
-		uint32_t pmask = 0;    // which pl[] entries are live
-		uint32_t vmask = 0;    // which views are evaluated
-		if (phase == 0) {
-			for (int k = 0; k < 8; ++k) {
-				const s2 nb = nbs[k + 1];
-				if (!(nb.x == -1 || nb.y == -1) && d.weak_info[nb.x + nb.y * W] == DVP_STRONG) {
-					positions[k] = nb.x + nb.y * W;
-					flag |= 1u << k;
-					pl[k] = d.planes[positions[k]];
-				}
-			}
-			pmask = flag;
-			vmask = all_views;
-		} else if (phase == 1) {
-			// joint view selection (APD.cu:2781-2850) and the weighted candidate costs (:2852-2874)
-			float priors[MV];
-			for (int i = 0; i < MV; ++i) priors[i] = 0.0f;
-			for (int i = 0; i < 8; ++i) {
-				const s2 nb = nbs[i + 1];
-				if (nb.x == -1 || nb.y == -1) continue;
-				const uint32_t sv = d.selected_views[nb.x + nb.y * W];
-				for (int j = 0; j < S; ++j) priors[j] += is_set(sv, j) ? 0.9f : 0.1f;
-			}
-			joint_view_selection<MV>(d, center, iter, PH_WEAK, cost_array, priors, vw, &sel_mask, &weight_norm);
-			uint8_t* gvw = d.view_weight + (size_t)center * 32;
-			for (int i = 0; i < 32; ++i) gvw[i] = i < MV ? vw[i < MV ? i : 0] : (uint8_t)0;
-			for (int k = 0; k < 8; ++k) {
-				float fc = 0.0f;
-				for (int j = 0; j < S; ++j) {
-					if (vw[j] > 0) {
-						if (P.geom_consistency) {
-							if ((flag >> k) & 1) fc += vw[j] * (cost_array[k * MV + j] + P.geom_factor * geom_cost(d, px, py, j + 1, d.planes[positions[k]]));
-							else fc += vw[j] * (cost_array[k * MV + j] + P.geom_factor * 3.0f);
-						} else {
-							fc += vw[j] * cost_array[k * MV + j];
-						}
-					}
-				}
-				final_costs[k] = fc / weight_norm;
-			}
-			min_cost_idx = 0;
-			{
-				float mc = final_costs[0];
-				for (int k = 1; k < 8; ++k)
-					if (final_costs[k] <= mc) { mc = final_costs[k]; min_cost_idx = k; }
-			}
-			pl[0] = d.planes[center];
-			pmask = 1u;
-			// the RANSAC fit plane is tried first by the refinement (APD.cu:1920-1949); an all-zero
-			// fit plane makes the reference return from the whole refinement (:1923-1925)
-			const f4 fp = d.fit_planes[center];
-			if (fp.x == 0 && fp.y == 0 && fp.z == 0) skip_refine = true;
-			else { pl[1] = fp; pmask |= 2u; }
-			vmask = sel_mask;
-		} else {
-			if (skip_refine) break;
-			// random refinement hypotheses from the state after the fit-plane test (APD.cu:1952-1979);
-			// hypothesis 4 equals hypothesis 3 and is never accepted after it: not evaluated
-			Rng rd(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_DEPTH_RAND));
-			Rng rn(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_NORMAL));
-			Rng rp(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_DEPTH_PERT));
-			const float depth_rand = rd.uniform() * (P.depth_max - P.depth_min) + P.depth_min;
-			const f4 n_rand = random_normal_yzl(d, px, py, rn, depth_now);
-			const float dmin_p = (1 - 0.02f) * depth_now, dmax_p = (1 + 0.02f) * depth_now;
-			const float depth_pert = rp.uniform() * (dmax_p - dmin_p) + dmin_p;
-			f4 n_pert = plane_now;
-			normalize3(&n_pert);
-			const float rdep[5] = { depth_rand, depth_now, depth_rand, depth_now, depth_pert };
-			const f4 rnrm[5] = { plane_now, n_rand, n_rand, n_pert, plane_now };
-			for (int i = 0; i < 5; ++i) {
-				pl[i] = rnrm[i];
-				pl[i].w = distance_to_origin(rc, px, py, rdep[i], pl[i]);
-			}
-			pmask = 0x1Fu;
-			vmask = sel_mask;
-		}
-
-		// ---- evaluate: view-major, anchor table built once per view ------------------------------
-		if (pmask) {
-			for (int v = 0; v < S; ++v) {
-				if (!((vmask >> v) & 1)) continue;
-				ncc_new_multi<SMP, MV>(d, c, nbs, cpix, px, py, v + 1, pl, pmask, ev);
-				if (nevals) *nevals += (unsigned long long)__builtin_popcount(pmask);
-			}
-		}
-
-		// ---- epilogue ------------------------------------------------------------------------------
-		if (phase == 0) {
-			for (int k = 0; k < 8; ++k)
-				if ((flag >> k) & 1)
-					for (int v = 0; v < S; ++v) cost_array[k * MV + v] = ev[k * MV + v];
-		} else if (phase == 1) {
-			float cn = 0.0f;
-			for (int v = 0; v < S; ++v) {
-				if (vw[v] > 0) {
-					if (P.geom_consistency) cn += vw[v] * (ev[v] + P.geom_factor * geom_cost(d, px, py, v + 1, pl[0]));
-					else cn += vw[v] * ev[v];
-				}
-			}
-			cost_now = cn / weight_norm;
-			costs_center = cost_now;
-			plane_now = pl[0];
-			depth_now = depth_from_plane(rc, plane_now, px, py);
-			if ((flag >> min_cost_idx) & 1) {
-				const f4 cand = d.planes[positions[min_cost_idx]];
-				const float db = depth_from_plane(rc, cand, px, py);
-				if (db >= P.depth_min && db <= P.depth_max && final_costs[min_cost_idx] < cost_now) {
-					depth_now = db;
-					plane_now = cand;
-					cost_now = final_costs[min_cost_idx];
-					d.selected_views[center] = sel_mask;
-				}
-			}
-			if (!skip_refine) {   // fit-plane test
-				float tc = 0.0f;
-				for (int j = 0; j < S; ++j) {
-					if (vw[j] > 0) {
-						if (P.geom_consistency) tc += vw[j] * (ev[MV + j] + P.geom_factor * geom_cost(d, px, py, j + 1, pl[1]));
-						else tc += vw[j] * ev[MV + j];
-					}
-				}
-				tc /= weight_norm;
-				const float db = depth_from_plane(rc, pl[1], px, py);
-				if (db >= P.depth_min && db <= P.depth_max && tc < cost_now) {
-					depth_now = db;
-					plane_now = pl[1];
-					cost_now = tc;
-				}
-			}
-		} else {
-			for (int i = 0; i < 5; ++i) {
-				float tc = 0.0f;
-				for (int j = 0; j < S; ++j) {
-					if (vw[j] > 0) {
-						if (P.geom_consistency) tc += vw[j] * (ev[i * MV + j] + P.geom_factor * geom_cost(d, px, py, j + 1, pl[i]));
-						else tc += vw[j] * ev[i * MV + j];
-					}
-				}
-				tc /= weight_norm;
-				const float db = depth_from_plane(rc, pl[i], px, py);
-				if (db >= P.depth_min && db <= P.depth_max && tc < cost_now) {
-					depth_now = db;
-					plane_now = pl[i];
-					cost_now = tc;
-				}
-			}
-		}
-	}
-
-	f4 final_plane = d.planes[center];
-	if (P.state == DVP_REFINE_INIT) {
-		if (cost_now < costs_center - 0.1) final_plane = plane_now;
-	} else {
-		final_plane = plane_now;
-	}
-	d.planes[center] = final_plane;
-
-	// cost of the final plane with the plain bilateral NCC at the default radius (APD.cu:3072-3088)
-	PatchCtx c2;
-	{
-		int r = P.strong_radius, inc = P.strong_increment;
-		if (P.use_radius) inc = DVP_MAX(2, (int)(2.0 * r / 5.0));
-		build_patch_ctx(d, px, py, r, inc, 0, tab, &c2);
-	}
-	float cn = 0.0f;
-	for (int v = 0; v < S; ++v) {
-		if (vw[v] == 0) continue;
-		cn += vw[v] * ncc_old<SMP>(d, c2, px, py, v + 1, final_plane);
-		if (nevals) *nevals += 1;
-	}
-	d.costs[center] = cn / weight_norm;
-}
-
 }  // namespace dvp
 #endif

@@ -1,0 +1,710 @@
+// dvp_weak_wave.hpp — the weak-pixel update (CheckerboardPropagationWeak +
+// PlaneHypothesisRefinementWeak, APD.cu:2739-3089, 1897-2008) with ONE WAVEFRONT PER WEAK PIXEL.
+//
+// Why not one lane per pixel (round 1): the deformable NCC of a WEAK pixel (ComputeBilateralNCCNew,
+// APD.cu:835-1021) gathers, per (plane, view), 36 centre taps + up to 11 anchors x 9 taps around
+// STRONG points that every pixel draws at random.  With a pixel per lane the 64 gathers of one load
+// instruction land on 64 unrelated cache lines, nothing is reused before it is evicted, and PMC showed
+// the kernel at the HBM roofline moving 64 B per 16-B footprint (6.7 G L2 misses per launch at
+// 6208x4128, L2 hit rate 20 %).  Here the 64 lanes of a wave own the (plane, tap) pairs of one pixel:
+// the <= 8 planes of a phase project a tap to neighbouring texels, so one load instruction touches a
+// few lines instead of 64 and the lines are shared inside the instruction; the per-pixel state
+// (cost vectors, weights, tables) lives in LDS instead of 4 KB of scratch per lane.
+//
+// Code shape.  A wave runs the function below in lock step.  `DVP_LANES(l) { ... }` marks a section in
+// which lane l does its own share (on the device: the calling lane; in the host emulation of
+// tests/emul: a loop over 64 lanes); everything outside such sections is per-pixel ("uniform") code
+// that every lane executes with identical values, writing shared state only from lane 0
+// (`DVP_LANE0`).  wave_sync() orders shared-memory traffic between sections.  All floating-point
+// expressions, their order and their operands are those of the per-pixel formulation (the oracle's),
+// only the assignment of independent work items to lanes is new.
+#ifndef DVP_WEAK_WAVE_HPP_
+#define DVP_WEAK_WAVE_HPP_
+
+#include "dvp_weak.hpp"
+
+namespace dvp {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DVP_LANES(L) for (int L = (int)(threadIdx.x & 63u), once_##L = 1; once_##L; once_##L = 0)
+#define DVP_LANE0 ((threadIdx.x & 63u) == 0u)
+DVP_HD void wave_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#else
+#define DVP_LANES(L) for (int L = 0; L < 64; ++L)
+#define DVP_LANE0 true
+DVP_HD void wave_sync() {}
+#endif
+
+constexpr int kAnchors = DVP_NEIGHBOUR_NUM - 1;   // 11
+constexpr int kAnchorTaps = kAnchors * 9;         // 99
+
+// per-wave shared state (LDS on the device), ~10.5 KB
+struct WeakShared {
+	f2 ctab[kTaps * kTaps];        // centre patch: (w, w*ref) per tap, row-major
+	float caa[kTaps * kTaps];      // w*ref*ref per tap (reference moments only)
+	f4 atap[kAnchorTaps];          // anchor tap: w, w*ref, x, y (ints stored as floats: |x|,|y| < 2^24)
+	f4 ahead[kAnchors];            // anchor: s_r, s_rr, s_w, state (0 absent, 1 visible in this view, 2 not visible)
+	float Hs[8][12];               // plane -> source homographies of the current view (9 used)
+	float bval[8][kAnchorTaps + 1];// bilinear samples per (plane, anchor tap)
+	float rows[8][kTaps][4];       // centre-patch row sums (s_s, s_ss, s_rs) per (plane | view slot, row)
+	float ccost[8];                // centre-patch cost per plane
+	float acost[8][12];            // anchor cost per (plane, anchor)
+	uint32_t acnt[8];              // which anchors count, per plane
+	float cost_array[8][32];
+	float ev[8][32];
+	float gtab[8][32];             // geometric-consistency cost per (plane, view)
+	float probs[32];
+	float priors[32];
+	float fcost[8];
+	int positions[8];
+	uint8_t vw[32];
+	f4 pl[8];
+	uint32_t inside;               // planes whose centre projects inside the current source image
+};
+
+// ComputeGeomConsistencyCost (APD.cu:1218-1256) with both cameras given (lane-varying view index)
+DVP_HD float geom_cost_cams(const Dev& d, const DvpCamera& rc, const DvpCamera& sc, int v, int px, int py, const f4 plane) {
+	const float* dimg = d.depths + (size_t)v * d.plane_stride;
+	const float depth = depth_from_plane(rc, plane, px, py);
+	const f3 fwd = point_on_world((float)px, (float)py, depth, rc);
+	f2 sp;
+	float sd;
+	project_on_camera(fwd, sc, &sp, &sd);
+	const float cx = fminf(fmaxf(sp.x, -1.0f), (float)d.width);
+	const float cy = fminf(fmaxf(sp.y, -1.0f), (float)d.height);
+	const float src_depth = tex_texel(dimg, d.org, d.pitch, d.width, d.height, (int)cx, (int)cy);
+	if (src_depth == 0.0f) return 3.0f;
+	const f3 back = point_on_world(sp.x, sp.y, src_depth, sc);
+	f2 bp;
+	float rd;
+	project_on_camera(back, rc, &bp, &rd);
+	const float dc = px - bp.x, dr = py - bp.y;
+	return fminf(3.0f, sqrtf(dc * dc + dr * dr));
+}
+
+// build_patch_ctx (dvp_ncc.hpp) by the wave: lane t < 36 owns tap t; the reference moments are then
+// summed in the row-then-total order by every lane.
+DVP_HD void wave_patch_ctx(const Dev& d, int px, int py, int radius, int inc, int colour_only, WeakShared& sh, PatchCtx* c) {
+	c->radius = radius;
+	c->inc = inc;
+	c->fast = (inc > 0 && (2 * radius) / inc + 1 == kTaps) ? 1 : 0;
+	c->sum_ref = c->sum_ref_ref = c->wsum = 0.0f;
+	if (!c->fast) return;
+	const int W = d.width, H = d.height, P = d.pitch;
+	const float cpix = img_texel(d.images, d.org, P, W, H, px, py);
+	DVP_LANES(t) {
+		if (t >= kTaps * kTaps) continue;
+		const int ty = t / kTaps, tx = t - ty * kTaps;
+		const int i = -radius + tx * inc, j = -radius + ty * inc;
+		const float a = img_texel(d.images, d.org, P, W, H, px + i, py + j);
+		const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, colour_only);
+		const float wa = w * a;
+		sh.ctab[t] = mk2(w, wa);
+		sh.caa[t] = wa * a;
+	}
+	wave_sync();
+	float sr = 0.0f, srr = 0.0f, ws = 0.0f;
+	for (int ty = 0; ty < kTaps; ++ty) {
+		float sr_row = 0.0f, srr_row = 0.0f, ws_row = 0.0f;
+		for (int tx = 0; tx < kTaps; ++tx) {
+			const f2 t = sh.ctab[ty * kTaps + tx];
+			sr_row += t.y;
+			srr_row += sh.caa[ty * kTaps + tx];
+			ws_row += t.x;
+		}
+		sr += sr_row;
+		srr += srr_row;
+		ws += ws_row;
+	}
+	c->sum_ref = sr;
+	c->sum_ref_ref = srr;
+	c->wsum = ws;
+}
+
+// one row (6 taps) of the 36-tap patch for homography H: the row's three source-side sums
+// (ncc_patch_fast, dvp_ncc.hpp: same products, same shared division per row, same order)
+template <int SMP>
+DVP_HD void patch_row_sums(const Dev& d, const WeakShared& sh, const float* H, const float* src, int px, int py, int radius, int inc, int row, float* out /*[3]*/) {
+	const int W = d.width, Hh = d.height, P = d.pitch;
+	const float fy = (float)(py - radius + row * inc);
+	const float hy1 = H[1] * fy, hy4 = H[4] * fy, hy7 = H[7] * fy;
+	float X[kTaps], Y[kTaps], Z[kTaps], IZ[kTaps];
+#pragma unroll
+	for (int tx = 0; tx < kTaps; ++tx) {
+		const float fx = (float)(px - radius + tx * inc);
+		X[tx] = H[0] * fx + hy1 + H[2];
+		Y[tx] = H[3] * fx + hy4 + H[5];
+		Z[tx] = H[6] * fx + hy7 + H[8];
+	}
+	batch_rcp(Z, kTaps, IZ);
+	unsigned off[kTaps];
+	TapW<SMP> tw[kTaps];
+	float q[kTaps][4];
+#pragma unroll
+	for (int tx = 0; tx < kTaps; ++tx) tex_coord(P, W, Hh, X[tx] * IZ[tx], Y[tx] * IZ[tx], &off[tx], &tw[tx]);
+#pragma unroll
+	for (int tx = 0; tx < kTaps; ++tx) load_quad(src, off[tx], &q[tx][0], &q[tx][1], &q[tx][2], &q[tx][3]);
+	float r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f;
+#pragma unroll
+	for (int tx = 0; tx < kTaps; ++tx) {
+		float fa, fb;
+		tap_weights(tw[tx], &fa, &fb);
+		const float b = tex_lerp(fa, fb, q[tx][0], q[tx][1], q[tx][2], q[tx][3]);
+		const f2 t = sh.ctab[row * kTaps + tx];
+		const float wsb = t.x * b;
+		r_s += wsb;
+		r_ss = fmaf(wsb, b, r_ss);
+		r_rs = fmaf(t.y, b, r_rs);
+	}
+	out[0] = r_s;
+	out[1] = r_ss;
+	out[2] = r_rs;
+}
+
+// ComputeBilateralNCCNew (APD.cu:835-1021) of source view v for the live planes sh.pl[q], q in pmask:
+// sh.ev[q][v-1] = cost.  c = centre-patch context (colour-only weights) built by wave_patch_ctx.
+template <int SMP>
+DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float cpix, int px, int py, int v, uint32_t pmask, WeakShared& sh) {
+	const ViewConst vc = load_view(d, v);
+	const int W = d.width, Hh = d.height, Pt = d.pitch;
+	const int S = d.params.num_images - 1;
+	const float* src = d.images + (size_t)uniform_i(v) * d.plane_stride * 2;
+
+	// ---- homographies + centre test: lane q < 8 ------------------------------------------------------
+	if (DVP_LANE0) sh.inside = 0;
+	wave_sync();
+	DVP_LANES(q) {
+		if (q >= 8 || !((pmask >> q) & 1)) continue;
+		float H[9];
+		homography(vc, sh.pl[q], H);
+		for (int i = 0; i < 9; ++i) sh.Hs[q][i] = H[i];
+		const f2 pt = apply_homography(H, px, py);
+		if (pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f) sh.ev[q][v - 1] = 2.0f;
+		else {
+#if defined(__HIP_DEVICE_COMPILE__)
+			atomicOr(&sh.inside, 1u << q);
+#else
+			sh.inside |= 1u << q;
+#endif
+		}
+	}
+	wave_sync();
+	const uint32_t live = sh.inside;
+	if (!live) return;
+
+	// ---- reference side of the anchors: lane t owns anchor tap t (two rounds) --------------------------
+	for (int t0 = 0; t0 < kAnchorTaps; t0 += 64) {
+		DVP_LANES(l) {
+			const int t = t0 + l;
+			if (t >= kAnchorTaps) continue;
+			const int k = t / 9, tt = t - k * 9;
+			const s2 nb = nbs[k + 1];
+			if (nb.x == -1 || nb.y == -1) { if (tt == 0) sh.ahead[k].w = 0.0f; continue; }
+			const int nbc = nb.x + nb.y * W;
+			const bool visible = is_set(d.selected_views[nbc], v - 1);
+			if (!visible) { if (tt == 0) sh.ahead[k].w = 2.0f; continue; }
+			if (tt == 0) sh.ahead[k].w = 1.0f;
+			int i = 0, j = 0;
+			if (tt < 8) {
+				const s2 o = d.candidate[((size_t)nbc * S + (v - 1)) * 8 + tt];
+				i = o.x;
+				j = o.y;
+				if (i == 0 && j == 0) {   // default +-5 ring (APD.cu:943-952): the 3x3 grid {-5,0,5}^2 without its centre, x-major
+					const int u = tt + (tt >= 4 ? 1 : 0);
+					i = (u / 3 - 1) * 5;
+					j = (u % 3 - 1) * 5;
+				}
+			}
+			const int rx = nb.x + i, ry = nb.y + j;
+			const float a = img_texel(d.images, d.org, Pt, W, Hh, rx, ry);
+			const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
+			sh.atap[t] = mk4(w, w * a, (float)rx, (float)ry);
+			sh.bval[0][t] = a;   // parked: the anchor sums below need the texel (bval is overwritten later)
+		}
+	}
+	wave_sync();
+	DVP_LANES(k) {
+		if (k >= kAnchors || sh.ahead[k].w != 1.0f) continue;
+		float s_r = 0.0f, s_rr = 0.0f, s_w = 0.0f;
+		for (int tt = 0; tt < 9; ++tt) {
+			const f4 tp = sh.atap[k * 9 + tt];
+			s_r += tp.y;
+			s_rr += tp.y * sh.bval[0][k * 9 + tt];
+			s_w += tp.x;
+		}
+		sh.ahead[k].x = s_r;
+		sh.ahead[k].y = s_rr;
+		sh.ahead[k].z = s_w;
+	}
+	wave_sync();
+
+	// ---- centre patch: lane = (plane q, row r) ---------------------------------------------------------
+	if (c.fast) {
+		DVP_LANES(l) {
+			const int q = l >> 3, r = l & 7;
+			if (r >= kTaps || !((live >> q) & 1)) continue;
+			float H[9];
+			for (int i = 0; i < 9; ++i) H[i] = sh.Hs[q][i];
+			float o[3];
+			patch_row_sums<SMP>(d, sh, H, src, px, py, c.radius, c.inc, r, o);
+			sh.rows[q][r][0] = o[0];
+			sh.rows[q][r][1] = o[1];
+			sh.rows[q][r][2] = o[2];
+		}
+		wave_sync();
+		DVP_LANES(q) {
+			if (q >= 8 || !((live >> q) & 1)) continue;
+			float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+			for (int r = 0; r < kTaps; ++r) {
+				s_s += sh.rows[q][r][0];
+				s_ss += sh.rows[q][r][1];
+				s_rs += sh.rows[q][r][2];
+			}
+			sh.ccost[q] = ncc_from_sums(c.sum_ref, c.sum_ref_ref, s_s, s_ss, s_rs, c.wsum);
+		}
+	} else {
+		DVP_LANES(q) {
+			if (q >= 8 || !((live >> q) & 1)) continue;
+			float H[9];
+			for (int i = 0; i < 9; ++i) H[i] = sh.Hs[q][i];
+			sh.ccost[q] = ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
+		}
+	}
+
+	// ---- anchor taps: lane = (tap slot, plane); 8 taps x 8 planes per round ------------------------------
+	DVP_LANES(l) {
+		const int q = l & 7;
+		if (!((live >> q) & 1)) continue;
+		float H[9];
+		for (int i = 0; i < 9; ++i) H[i] = sh.Hs[q][i];
+		constexpr int kUn = 4;   // rounds in flight
+		for (int r0 = 0; r0 < (kAnchorTaps + 7) / 8; r0 += kUn) {
+			unsigned off[kUn];
+			TapW<SMP> tw[kUn];
+			float qd[kUn][4];
+			bool on[kUn];
+#pragma unroll
+			for (int u = 0; u < kUn; ++u) {
+				const int t = (r0 + u) * 8 + (l >> 3);
+				on[u] = false;
+				off[u] = 0;
+				tw[u] = TapW<SMP>();
+				if (t >= kAnchorTaps) continue;
+				const int k = t / 9;
+				if (sh.ahead[k].w != 1.0f) continue;
+				const s2 nb = nbs[k + 1];
+				const f2 nsp = apply_homography(H, nb.x, nb.y);
+				if (nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh) continue;   // anchor outside for this plane
+				const f4 tp = sh.atap[t];
+				const f2 sp = apply_homography(H, (int)tp.z, (int)tp.w);
+				tex_coord(Pt, W, Hh, sp.x, sp.y, &off[u], &tw[u]);
+				on[u] = true;
+			}
+#pragma unroll
+			for (int u = 0; u < kUn; ++u) {
+				qd[u][0] = qd[u][1] = qd[u][2] = qd[u][3] = 0.0f;
+				if (on[u]) load_quad(src, off[u], &qd[u][0], &qd[u][1], &qd[u][2], &qd[u][3]);
+			}
+#pragma unroll
+			for (int u = 0; u < kUn; ++u) {
+				if (!on[u]) continue;
+				float fa, fb;
+				tap_weights(tw[u], &fa, &fb);
+				sh.bval[q][(r0 + u) * 8 + (l >> 3)] = tex_lerp(fa, fb, qd[u][0], qd[u][1], qd[u][2], qd[u][3]);
+			}
+		}
+	}
+	wave_sync();
+
+	// ---- anchor costs: lane = (anchor, plane); then per plane the anchors in order ------------------------
+	DVP_LANES(l) { if (l < 8) sh.acnt[l] = 0; }
+	wave_sync();
+	for (int k0 = 0; k0 < kAnchors; k0 += 8) {
+		DVP_LANES(l) {
+			const int k = k0 + (l >> 3), q = l & 7;
+			if (k >= kAnchors || !((live >> q) & 1)) continue;
+			const float st = sh.ahead[k].w;
+			if (st == 0.0f) continue;
+			float H[9];
+			for (int i = 0; i < 9; ++i) H[i] = sh.Hs[q][i];
+			const s2 nb = nbs[k + 1];
+			const f2 nsp = apply_homography(H, nb.x, nb.y);
+			const bool outside = nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh;
+			float cost;
+			if (outside) {
+				if (st != 1.0f) continue;       // outside and not visible: not counted
+				cost = 2.0f;
+			} else if (st != 1.0f) {
+				cost = 2.0f;                    // anchor not visible in this view: the reference's 0/0 path yields exactly 2
+			} else {
+				float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+				for (int tt = 0; tt < 9; ++tt) {
+					const f4 tp = sh.atap[k * 9 + tt];
+					const float b = sh.bval[q][k * 9 + tt];
+					const float wb = tp.x * b;
+					s_s += wb;
+					s_ss = fmaf(wb, b, s_ss);
+					s_rs = fmaf(tp.y, b, s_rs);
+				}
+				const f4 hd = sh.ahead[k];
+				cost = ncc_from_sums(hd.x, hd.y, s_s, s_ss, s_rs, hd.z);
+			}
+			sh.acost[q][k] = cost;
+#if defined(__HIP_DEVICE_COMPILE__)
+			atomicOr(&sh.acnt[q], 1u << k);
+#else
+			sh.acnt[q] |= 1u << k;
+#endif
+		}
+	}
+	wave_sync();
+	DVP_LANES(q) {
+		if (q >= 8 || !((live >> q) & 1)) continue;
+		float scost = 0.0f, scnt = 0.0f;
+		const uint32_t m = sh.acnt[q];
+		for (int k = 0; k < kAnchors; ++k)
+			if ((m >> k) & 1) { scost += sh.acost[q][k]; scnt += 1.0f; }
+		float out = sh.ccost[q];
+		if (scnt > 0.0f) {
+			float sc2 = scost / scnt;
+			sc2 = DVP_MIN(sc2, 2.0f);
+			out = (float)(0.25 * sh.ccost[q] + 0.75 * sc2);
+		}
+		sh.ev[q][v - 1] = out;
+	}
+	wave_sync();
+}
+
+// gtab[q][j] = ComputeGeomConsistencyCost(pixel, view j+1, sh.pl[q]) for q in pmask, views with weight > 0
+DVP_HD void wave_geom_table(const Dev& d, const DvpCamera& rc, int px, int py, uint32_t pmask, WeakShared& sh) {
+	const int S = d.params.num_images - 1;
+	for (int j0 = 0; j0 < S; j0 += 8) {
+		DVP_LANES(l) {
+			const int q = l >> 3, j = j0 + (l & 7);
+			if (j >= S || !((pmask >> q) & 1) || sh.vw[j] == 0) continue;
+			sh.gtab[q][j] = geom_cost_cams(d, rc, d.cameras[j + 1], j + 1, px, py, sh.pl[q]);
+		}
+	}
+	wave_sync();
+}
+
+template <int SMP>
+DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned long long* nevals, WeakShared& sh) {
+	const int W = d.width, Hh = d.height;
+	const int center = py * W + px;
+	const DvpParams& P = d.params;
+	const DvpCamera rc = load_camera(d, 0);
+	const int S = P.num_images - 1;
+	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
+	const s2* nbs = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
+	const float cpix = img_texel(d.images, d.org, d.pitch, W, Hh, px, py);
+	unsigned long long evals = 0;
+
+	PatchCtx c;
+	c.tab = PatchTab{nullptr, 0};
+	{
+		int radius, inc;
+		patch_geometry(d, center, &radius, &inc);
+		wave_patch_ctx(d, px, py, radius, inc, 1, sh, &c);
+	}
+	DVP_LANES(l) {
+		for (int i = l; i < 8 * 32; i += 64) (&sh.cost_array[0][0])[i] = 0.0f;
+		if (l < 32) sh.vw[l] = 0;
+		if (l < 8) sh.positions[l] = 0;
+	}
+	wave_sync();
+	if (DVP_LANE0) sh.cost_array[0][0] = 2.0f;   // `= { 2.0f }` sets one element (APD.cu:2769)
+	uint32_t flag = 0;
+	uint32_t sel_mask = 0;
+	uint32_t sel_now = d.selected_views[center];   // what random_normal_yzl reads (updated on adoption)
+	float weight_norm = 0.0f;
+	int min_cost_idx = 0;
+	float cost_now = 0.0f, costs_center = 0.0f, depth_now = 0.0f;
+	f4 plane_now = mk4(0, 0, 0, 0);
+	bool skip_refine = false;
+	f4 pl1 = mk4(0, 0, 0, 0);
+
+	for (int phase = 0; phase < 3; ++phase) {
+		uint32_t pmask = 0, vmask = 0;
+		if (phase == 0) {
+			for (int k = 0; k < 8; ++k) {
+				const s2 nb = nbs[k + 1];
+				if (!(nb.x == -1 || nb.y == -1) && d.weak_info[nb.x + nb.y * W] == DVP_STRONG) {
+					flag |= 1u << k;
+					if (DVP_LANE0) {
+						sh.positions[k] = nb.x + nb.y * W;
+						sh.pl[k] = d.planes[nb.x + nb.y * W];
+					}
+				}
+			}
+			pmask = flag;
+			vmask = all_views;
+		} else if (phase == 1) {
+			// joint view selection (APD.cu:2781-2850): lane j owns view j for the per-view parts
+			const float thr = (float)(0.8 * dvp_expf((iter) * (iter) / (-90.0f)));
+			DVP_LANES(j) {
+				if (j >= S) continue;
+				float pr = 0.0f;
+				for (int i = 0; i < 8; ++i) {
+					const s2 nb = nbs[i + 1];
+					if (nb.x == -1 || nb.y == -1) continue;
+					pr += is_set(d.selected_views[nb.x + nb.y * W], j) ? 0.9f : 0.1f;
+				}
+				float count = 0;
+				int count_false = 0;
+				float tmpw = 0;
+				for (int k = 0; k < 8; k++) {
+					const float cst = sh.cost_array[k][j];
+					if (cst < thr) { tmpw += dvp_expf(cst * cst / (-0.18f)); count++; }
+					if (cst > 1.2f) count_false++;
+				}
+				float p = 0.0f;
+				if (count > 2 && count_false < 3) p = tmpw / count;
+				else if (count_false < 3) p = dvp_expf(thr * thr / (-0.32f));
+				sh.probs[j] = p * pr;
+			}
+			wave_sync();
+			float psum = 0.0f;
+			for (int i = 0; i < S; ++i) psum += sh.probs[i];
+			const float inv = 1.0f / psum;
+			float cum = 0.0f;
+			wave_sync();
+			for (int i = 0; i < S; ++i) {
+				cum += sh.probs[i] * inv;
+				if (DVP_LANE0) sh.priors[i] = cum;   // the CDF (priors[] is free from here on)
+			}
+			wave_sync();
+			Rng rv(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_VIEW));
+			for (int s = 0; s < 15; ++s) {
+				const float rp = rv.uniform() - FLT_EPSILON;
+				for (int v = 0; v < S; ++v)
+					if (sh.priors[v] > rp) { if (DVP_LANE0) sh.vw[v] += 1; break; }
+			}
+			wave_sync();
+			sel_mask = 0;
+			weight_norm = 0;
+			for (int i = 0; i < S; ++i)
+				if (sh.vw[i] > 0) { set_bit(&sel_mask, i); weight_norm += sh.vw[i]; }
+			DVP_LANES(i) { if (i < 32) d.view_weight[(size_t)center * 32 + i] = sh.vw[i]; }
+			// weighted candidate costs (APD.cu:2852-2874); sh.pl[k] still holds the anchors' planes
+			if (P.geom_consistency) wave_geom_table(d, rc, px, py, flag, sh);
+			DVP_LANES(k) {
+				if (k >= 8) continue;
+				float fc = 0.0f;
+				for (int j = 0; j < S; ++j) {
+					const int w = sh.vw[j];
+					if (w > 0) {
+						if (P.geom_consistency) {
+							if ((flag >> k) & 1) fc += w * (sh.cost_array[k][j] + P.geom_factor * sh.gtab[k][j]);
+							else fc += w * (sh.cost_array[k][j] + P.geom_factor * 3.0f);
+						} else {
+							fc += w * sh.cost_array[k][j];
+						}
+					}
+				}
+				sh.fcost[k] = fc / weight_norm;
+			}
+			wave_sync();
+			min_cost_idx = 0;
+			{
+				float mc = sh.fcost[0];
+				for (int k = 1; k < 8; ++k)
+					if (sh.fcost[k] <= mc) { mc = sh.fcost[k]; min_cost_idx = k; }
+			}
+			const f4 fp = d.fit_planes[center];
+			pl1 = fp;
+			pmask = 1u;
+			if (fp.x == 0 && fp.y == 0 && fp.z == 0) skip_refine = true;
+			else pmask |= 2u;
+			wave_sync();
+			if (DVP_LANE0) {
+				sh.pl[0] = d.planes[center];
+				if (!skip_refine) sh.pl[1] = fp;
+			}
+			vmask = sel_mask;
+		} else {
+			if (skip_refine) break;
+			Rng rd(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_DEPTH_RAND));
+			Rng rn(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_NORMAL));
+			Rng rp(d.seed, (uint32_t)center, rng_site(PH_WEAK, iter, SUB_DEPTH_PERT));
+			const float depth_rand = rd.uniform() * (P.depth_max - P.depth_min) + P.depth_min;
+			const f4 n_rand = random_normal_yzl_sel(d, px, py, rn, depth_now, sel_now);
+			const float dmin_p = (1 - 0.02f) * depth_now, dmax_p = (1 + 0.02f) * depth_now;
+			const float depth_pert = rp.uniform() * (dmax_p - dmin_p) + dmin_p;
+			f4 n_pert = plane_now;
+			normalize3(&n_pert);
+			const float rdep[5] = { depth_rand, depth_now, depth_rand, depth_now, depth_pert };
+			const f4 rnrm[5] = { plane_now, n_rand, n_rand, n_pert, plane_now };
+			wave_sync();
+#pragma unroll
+			for (int i = 0; i < 5; ++i) {
+				f4 h = rnrm[i];
+				h.w = distance_to_origin(rc, px, py, rdep[i], h);
+				if (DVP_LANE0) sh.pl[i] = h;
+			}
+			pmask = 0x1Fu;
+			vmask = sel_mask;
+		}
+		wave_sync();
+
+		// ---- evaluate: view by view ----------------------------------------------------------------------
+		if (pmask) {
+			for (int v = 0; v < S; ++v) {
+				if (!((vmask >> v) & 1)) continue;
+				wave_ncc_new<SMP>(d, c, nbs, cpix, px, py, v + 1, pmask, sh);
+				evals += (unsigned long long)__builtin_popcount(pmask);
+			}
+		}
+
+		// ---- epilogue ----------------------------------------------------------------------------------------
+		if (phase == 0) {
+			DVP_LANES(l) {
+				for (int i = l; i < 8 * 32; i += 64) {
+					const int k = i >> 5, v = i & 31;
+					if (((flag >> k) & 1) && v < S) sh.cost_array[k][v] = sh.ev[k][v];
+				}
+			}
+			wave_sync();
+		} else if (phase == 1) {
+			if (P.geom_consistency) wave_geom_table(d, rc, px, py, pmask, sh);
+			float cn = 0.0f;
+			for (int v = 0; v < S; ++v) {
+				const int w = sh.vw[v];
+				if (w > 0) {
+					if (P.geom_consistency) cn += w * (sh.ev[0][v] + P.geom_factor * sh.gtab[0][v]);
+					else cn += w * sh.ev[0][v];
+				}
+			}
+			cost_now = cn / weight_norm;
+			costs_center = cost_now;
+			plane_now = sh.pl[0];
+			depth_now = depth_from_plane(rc, plane_now, px, py);
+			if ((flag >> min_cost_idx) & 1) {
+				const f4 cand = d.planes[sh.positions[min_cost_idx]];
+				const float db = depth_from_plane(rc, cand, px, py);
+				if (db >= P.depth_min && db <= P.depth_max && sh.fcost[min_cost_idx] < cost_now) {
+					depth_now = db;
+					plane_now = cand;
+					cost_now = sh.fcost[min_cost_idx];
+					sel_now = sel_mask;
+					if (DVP_LANE0) d.selected_views[center] = sel_mask;
+				}
+			}
+			if (!skip_refine) {   // fit-plane test
+				float tc = 0.0f;
+				for (int j = 0; j < S; ++j) {
+					const int w = sh.vw[j];
+					if (w > 0) {
+						if (P.geom_consistency) tc += w * (sh.ev[1][j] + P.geom_factor * sh.gtab[1][j]);
+						else tc += w * sh.ev[1][j];
+					}
+				}
+				tc /= weight_norm;
+				const float db = depth_from_plane(rc, pl1, px, py);
+				if (db >= P.depth_min && db <= P.depth_max && tc < cost_now) {
+					depth_now = db;
+					plane_now = pl1;
+					cost_now = tc;
+				}
+			}
+		} else {
+			if (P.geom_consistency) wave_geom_table(d, rc, px, py, pmask, sh);
+			for (int i = 0; i < 5; ++i) {
+				float tc = 0.0f;
+				for (int j = 0; j < S; ++j) {
+					const int w = sh.vw[j];
+					if (w > 0) {
+						if (P.geom_consistency) tc += w * (sh.ev[i][j] + P.geom_factor * sh.gtab[i][j]);
+						else tc += w * sh.ev[i][j];
+					}
+				}
+				tc /= weight_norm;
+				const f4 h = sh.pl[i];
+				const float db = depth_from_plane(rc, h, px, py);
+				if (db >= P.depth_min && db <= P.depth_max && tc < cost_now) {
+					depth_now = db;
+					plane_now = h;
+					cost_now = tc;
+				}
+			}
+		}
+	}
+
+	f4 final_plane = d.planes[center];
+	if (P.state == DVP_REFINE_INIT) {
+		if (cost_now < costs_center - 0.1) final_plane = plane_now;
+	} else {
+		final_plane = plane_now;
+	}
+	wave_sync();
+	if (DVP_LANE0) d.planes[center] = final_plane;
+
+	// cost of the final plane with the plain bilateral NCC at the default radius (APD.cu:3072-3088):
+	// lane = (view slot, patch row), eight views per round
+	PatchCtx c2;
+	c2.tab = PatchTab{nullptr, 0};
+	{
+		int r = P.strong_radius, inc = P.strong_increment;
+		if (P.use_radius) inc = DVP_MAX(2, (int)(2.0 * r / 5.0));
+		wave_patch_ctx(d, px, py, r, inc, 0, sh, &c2);
+	}
+	for (int v0 = 0; v0 < S; v0 += 8) {
+		DVP_LANES(l) {
+			const int vs = l >> 3, r = l & 7, v = v0 + vs;
+			if (v >= S || sh.vw[v] == 0) continue;
+			if (c2.fast ? r >= kTaps : r != 0) continue;
+			const ViewConst vc = d.views[v + 1];
+			float H[9];
+			homography(vc, final_plane, H);
+			const f2 pt = apply_homography(H, px, py);
+			const bool in = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f);
+			const float* src = d.images + (size_t)(v + 1) * d.plane_stride * 2;
+			if (!c2.fast) {
+				sh.ev[0][v] = in ? ncc_patch_generic(d, H, src, px, py, c2.radius, c2.inc, 0) : 2.0f;
+			} else if (in) {
+				float o[3];
+				patch_row_sums<SMP>(d, sh, H, src, px, py, c2.radius, c2.inc, r, o);
+				sh.rows[vs][r][0] = o[0];
+				sh.rows[vs][r][1] = o[1];
+				sh.rows[vs][r][2] = o[2];
+			} else if (r == 0) {
+				sh.ev[0][v] = 2.0f;
+				sh.rows[vs][0][3] = -1.0f;   // marks "outside" for the totalling lane
+			}
+			if (c2.fast && in && r == 0) sh.rows[vs][0][3] = 1.0f;
+		}
+		wave_sync();
+		if (c2.fast) {
+			DVP_LANES(l) {
+				const int v = v0 + l;
+				if (l >= 8 || v >= S || sh.vw[v] == 0 || sh.rows[l][0][3] < 0.0f) continue;
+				float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+				for (int r = 0; r < kTaps; ++r) {
+					s_s += sh.rows[l][r][0];
+					s_ss += sh.rows[l][r][1];
+					s_rs += sh.rows[l][r][2];
+				}
+				sh.ev[0][v] = ncc_from_sums(c2.sum_ref, c2.sum_ref_ref, s_s, s_ss, s_rs, c2.wsum);
+			}
+			wave_sync();
+		}
+	}
+	float cn = 0.0f;
+	for (int v = 0; v < S; ++v) {
+		if (sh.vw[v] == 0) continue;
+		cn += sh.vw[v] * sh.ev[0][v];
+		evals += 1;
+	}
+	if (DVP_LANE0) {
+		d.costs[center] = cn / weight_norm;
+		if (nevals) *nevals += evals;
+	}
+	wave_sync();
+}
+
+}  // namespace dvp
+#endif
