@@ -132,6 +132,7 @@ __device__ __forceinline__ void weak_wave_body(const Dev& d, const ListArgs& a) 
 	const int center = d.weak_list[a.base + t];
 	const int py = center / d.width, px = center - py * d.width;
 	if (py >= a.covered_rows) return;   // rows beyond the reference's half grid (APD.cu:4421-4424)
+	if (d.weak_info[center] != DVP_WEAK) return;   // NeigbourUpdate turned it UNKNOWN since the list was built (APD.cu:3119-3123)
 	unsigned long long n = 0;
 	weak_update_wave<SMP>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, sh[wave]);
 	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);

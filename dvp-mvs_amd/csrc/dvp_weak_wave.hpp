@@ -42,18 +42,13 @@ DVP_HD void wave_sync() {}
 constexpr int kAnchors = DVP_NEIGHBOUR_NUM - 1;   // 11
 constexpr int kAnchorTaps = kAnchors * 9;         // 99
 
-// per-wave shared state (LDS on the device), ~10.5 KB
+// per-wave shared state (LDS on the device), ~6.7 KB
 struct WeakShared {
 	f2 ctab[kTaps * kTaps];        // centre patch: (w, w*ref) per tap, row-major
 	float caa[kTaps * kTaps];      // w*ref*ref per tap (reference moments only)
-	f4 atap[kAnchorTaps];          // anchor tap: w, w*ref, x, y (ints stored as floats: |x|,|y| < 2^24)
-	f4 ahead[kAnchors];            // anchor: s_r, s_rr, s_w, state (0 absent, 1 visible in this view, 2 not visible)
-	float Hs[8][12];               // plane -> source homographies of the current view (9 used)
-	float bval[8][kAnchorTaps + 1];// bilinear samples per (plane, anchor tap)
-	float rows[8][kTaps][4];       // centre-patch row sums (s_s, s_ss, s_rs) per (plane | view slot, row)
-	float ccost[8];                // centre-patch cost per plane
-	float acost[8][12];            // anchor cost per (plane, anchor)
-	uint32_t acnt[8];              // which anchors count, per plane
+	float rows[2][8][kTaps][4];    // centre-patch row sums (s_s, s_ss, s_rs) per (plane | view slot, row), double-buffered
+	float acost[2][8][12];         // anchor cost per (plane, anchor), < 0: does not count
+	int inq[2][8];                 // plane's centre projects inside the source image
 	float cost_array[8][32];
 	float ev[8][32];
 	float gtab[8][32];             // geometric-consistency cost per (plane, view)
@@ -63,7 +58,6 @@ struct WeakShared {
 	int positions[8];
 	uint8_t vw[32];
 	f4 pl[8];
-	uint32_t inside;               // planes whose centre projects inside the current source image
 };
 
 // ComputeGeomConsistencyCost (APD.cu:1218-1256) with both cameras given (lane-varying view index)
@@ -167,216 +161,153 @@ DVP_HD void patch_row_sums(const Dev& d, const WeakShared& sh, const float* H, c
 
 // ComputeBilateralNCCNew (APD.cu:835-1021) of source view v for the live planes sh.pl[q], q in pmask:
 // sh.ev[q][v-1] = cost.  c = centre-patch context (colour-only weights) built by wave_patch_ctx.
+// One shared-memory hand-over per view:
+//   section 1  lane (plane q, anchor k): the whole anchor sub-patch of that pair in registers — the
+//              anchor's 9 reference taps (offsets, texels, weights, sums: identical in the 8 plane lanes
+//              of an anchor, which costs nothing in lock step) and the 9 gathers in the source image;
+//              the 8 planes of one tap sit in adjacent lanes of ONE load instruction and share lines.
+//              Then lane (plane q, row r): one row of the 36-tap centre patch.
+//   section 2  lane q: rows and anchors summed in the reference's order -> ev.
+// `buf` alternates between calls so that section 2 of one view and section 1 of the next need no
+// barrier between them.
 template <int SMP>
-DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float cpix, int px, int py, int v, uint32_t pmask, WeakShared& sh) {
+DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float cpix, int px, int py, int v, uint32_t pmask, int buf, WeakShared& sh) {
 	const ViewConst vc = load_view(d, v);
 	const int W = d.width, Hh = d.height, Pt = d.pitch;
 	const int S = d.params.num_images - 1;
 	const float* src = d.images + (size_t)uniform_i(v) * d.plane_stride * 2;
 
-	// ---- homographies + centre test: lane q < 8 ------------------------------------------------------
-	if (DVP_LANE0) sh.inside = 0;
+	DVP_LANES(l) {
+		// ---- anchors: 8 planes x 8 anchors per round ---------------------------------------------------
+		for (int k0 = 0; k0 < kAnchors; k0 += 8) {
+			const int k = k0 + (l >> 3), q = l & 7;
+			if (k >= kAnchors || !((pmask >> q) & 1)) continue;
+			float H[9];
+			homography(vc, sh.pl[q], H);
+			const f2 pt = apply_homography(H, px, py);
+			const bool inside = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f);
+			if (k == 0) sh.inq[buf][q] = inside ? 1 : 0;
+			if (!inside) continue;
+			float cost = -1.0f;   // < 0: this anchor does not count
+			const s2 nb = nbs[k + 1];
+			if (!(nb.x == -1 || nb.y == -1)) {
+				const int nbc = nb.x + nb.y * W;
+				const bool visible = is_set(d.selected_views[nbc], v - 1);
+				const f2 nsp = apply_homography(H, nb.x, nb.y);
+				const bool outside = nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh;
+				if (outside) {
+					if (visible) cost = 2.0f;
+				} else if (!visible) {
+					cost = 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
+				} else {
+					// reference side (APD.cu:905-1000): 8 visibility-prior offsets of the anchor + the anchor itself
+					const s2* cand = d.candidate + ((size_t)nbc * S + (v - 1)) * 8;
+					int tx[9], ty[9];
+					float ti[9], tj[9];
+#pragma unroll
+					for (int t = 0; t < 9; ++t) {
+						int i = 0, j = 0;
+						if (t < 8) {
+							const s2 o = cand[t];
+							i = o.x;
+							j = o.y;
+							if (i == 0 && j == 0) {   // default +-5 ring (APD.cu:943-952): {-5,0,5}^2 without its centre, x-major
+								const int u = t + (t >= 4 ? 1 : 0);
+								i = (u / 3 - 1) * 5;
+								j = (u % 3 - 1) * 5;
+							}
+						}
+						tx[t] = nb.x + i;
+						ty[t] = nb.y + j;
+						ti[t] = (float)i;
+						tj[t] = (float)j;
+					}
+					// source side first (addresses need only the offsets): 9 gathers in flight
+					unsigned off[9];
+					TapW<SMP> tw[9];
+					float qd[9][4];
+#pragma unroll
+					for (int t = 0; t < 9; ++t) {
+						const f2 sp = apply_homography(H, tx[t], ty[t]);
+						tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t], &tw[t]);
+					}
+#pragma unroll
+					for (int t = 0; t < 9; ++t) load_quad(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
+					float av[9];
+#pragma unroll
+					for (int t = 0; t < 9; ++t) av[t] = img_texel(d.images, d.org, Pt, W, Hh, tx[t], ty[t]);
+					float a_sr = 0.0f, a_srr = 0.0f, a_sw = 0.0f;
+					float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+#pragma unroll
+					for (int t = 0; t < 9; ++t) {
+						const float w = bilateral_weight(ti[t], tj[t], av[t], cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
+						const float wa = w * av[t];
+						a_sr += wa;
+						a_srr += wa * av[t];
+						a_sw += w;
+						float fa, fb;
+						tap_weights(tw[t], &fa, &fb);
+						const float b = tex_lerp(fa, fb, qd[t][0], qd[t][1], qd[t][2], qd[t][3]);
+						const float wb = w * b;
+						s_s += wb;
+						s_ss = fmaf(wb, b, s_ss);
+						s_rs = fmaf(wa, b, s_rs);
+					}
+					cost = ncc_from_sums(a_sr, a_srr, s_s, s_ss, s_rs, a_sw);
+				}
+			}
+			sh.acost[buf][q][k] = cost;
+		}
+		// ---- centre patch: lane = (plane q, row r) -------------------------------------------------------
+		{
+			const int q = l >> 3, r = l & 7;
+			if (((pmask >> q) & 1) && (c.fast ? r < kTaps : r == 0)) {
+				float H[9];
+				homography(vc, sh.pl[q], H);
+				const f2 pt = apply_homography(H, px, py);
+				if (!(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f)) {
+					if (c.fast) {
+						float o[3];
+						patch_row_sums<SMP>(d, sh, H, src, px, py, c.radius, c.inc, r, o);
+						sh.rows[buf][q][r][0] = o[0];
+						sh.rows[buf][q][r][1] = o[1];
+						sh.rows[buf][q][r][2] = o[2];
+					} else {
+						sh.rows[buf][q][0][0] = ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
+					}
+				}
+			}
+		}
+	}
 	wave_sync();
 	DVP_LANES(q) {
 		if (q >= 8 || !((pmask >> q) & 1)) continue;
-		float H[9];
-		homography(vc, sh.pl[q], H);
-		for (int i = 0; i < 9; ++i) sh.Hs[q][i] = H[i];
-		const f2 pt = apply_homography(H, px, py);
-		if (pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f) sh.ev[q][v - 1] = 2.0f;
-		else {
-#if defined(__HIP_DEVICE_COMPILE__)
-			atomicOr(&sh.inside, 1u << q);
-#else
-			sh.inside |= 1u << q;
-#endif
-		}
-	}
-	wave_sync();
-	const uint32_t live = sh.inside;
-	if (!live) return;
-
-	// ---- reference side of the anchors: lane t owns anchor tap t (two rounds) --------------------------
-	for (int t0 = 0; t0 < kAnchorTaps; t0 += 64) {
-		DVP_LANES(l) {
-			const int t = t0 + l;
-			if (t >= kAnchorTaps) continue;
-			const int k = t / 9, tt = t - k * 9;
-			const s2 nb = nbs[k + 1];
-			if (nb.x == -1 || nb.y == -1) { if (tt == 0) sh.ahead[k].w = 0.0f; continue; }
-			const int nbc = nb.x + nb.y * W;
-			const bool visible = is_set(d.selected_views[nbc], v - 1);
-			if (!visible) { if (tt == 0) sh.ahead[k].w = 2.0f; continue; }
-			if (tt == 0) sh.ahead[k].w = 1.0f;
-			int i = 0, j = 0;
-			if (tt < 8) {
-				const s2 o = d.candidate[((size_t)nbc * S + (v - 1)) * 8 + tt];
-				i = o.x;
-				j = o.y;
-				if (i == 0 && j == 0) {   // default +-5 ring (APD.cu:943-952): the 3x3 grid {-5,0,5}^2 without its centre, x-major
-					const int u = tt + (tt >= 4 ? 1 : 0);
-					i = (u / 3 - 1) * 5;
-					j = (u % 3 - 1) * 5;
-				}
-			}
-			const int rx = nb.x + i, ry = nb.y + j;
-			const float a = img_texel(d.images, d.org, Pt, W, Hh, rx, ry);
-			const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
-			sh.atap[t] = mk4(w, w * a, (float)rx, (float)ry);
-			sh.bval[0][t] = a;   // parked: the anchor sums below need the texel (bval is overwritten later)
-		}
-	}
-	wave_sync();
-	DVP_LANES(k) {
-		if (k >= kAnchors || sh.ahead[k].w != 1.0f) continue;
-		float s_r = 0.0f, s_rr = 0.0f, s_w = 0.0f;
-		for (int tt = 0; tt < 9; ++tt) {
-			const f4 tp = sh.atap[k * 9 + tt];
-			s_r += tp.y;
-			s_rr += tp.y * sh.bval[0][k * 9 + tt];
-			s_w += tp.x;
-		}
-		sh.ahead[k].x = s_r;
-		sh.ahead[k].y = s_rr;
-		sh.ahead[k].z = s_w;
-	}
-	wave_sync();
-
-	// ---- centre patch: lane = (plane q, row r) ---------------------------------------------------------
-	if (c.fast) {
-		DVP_LANES(l) {
-			const int q = l >> 3, r = l & 7;
-			if (r >= kTaps || !((live >> q) & 1)) continue;
-			float H[9];
-			for (int i = 0; i < 9; ++i) H[i] = sh.Hs[q][i];
-			float o[3];
-			patch_row_sums<SMP>(d, sh, H, src, px, py, c.radius, c.inc, r, o);
-			sh.rows[q][r][0] = o[0];
-			sh.rows[q][r][1] = o[1];
-			sh.rows[q][r][2] = o[2];
-		}
-		wave_sync();
-		DVP_LANES(q) {
-			if (q >= 8 || !((live >> q) & 1)) continue;
+		if (!sh.inq[buf][q]) { sh.ev[q][v - 1] = 2.0f; continue; }
+		float cc;
+		if (c.fast) {
 			float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
 			for (int r = 0; r < kTaps; ++r) {
-				s_s += sh.rows[q][r][0];
-				s_ss += sh.rows[q][r][1];
-				s_rs += sh.rows[q][r][2];
+				s_s += sh.rows[buf][q][r][0];
+				s_ss += sh.rows[buf][q][r][1];
+				s_rs += sh.rows[buf][q][r][2];
 			}
-			sh.ccost[q] = ncc_from_sums(c.sum_ref, c.sum_ref_ref, s_s, s_ss, s_rs, c.wsum);
+			cc = ncc_from_sums(c.sum_ref, c.sum_ref_ref, s_s, s_ss, s_rs, c.wsum);
+		} else {
+			cc = sh.rows[buf][q][0][0];
 		}
-	} else {
-		DVP_LANES(q) {
-			if (q >= 8 || !((live >> q) & 1)) continue;
-			float H[9];
-			for (int i = 0; i < 9; ++i) H[i] = sh.Hs[q][i];
-			sh.ccost[q] = ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
-		}
-	}
-
-	// ---- anchor taps: lane = (tap slot, plane); 8 taps x 8 planes per round ------------------------------
-	DVP_LANES(l) {
-		const int q = l & 7;
-		if (!((live >> q) & 1)) continue;
-		float H[9];
-		for (int i = 0; i < 9; ++i) H[i] = sh.Hs[q][i];
-		constexpr int kUn = 4;   // rounds in flight
-		for (int r0 = 0; r0 < (kAnchorTaps + 7) / 8; r0 += kUn) {
-			unsigned off[kUn];
-			TapW<SMP> tw[kUn];
-			float qd[kUn][4];
-			bool on[kUn];
-#pragma unroll
-			for (int u = 0; u < kUn; ++u) {
-				const int t = (r0 + u) * 8 + (l >> 3);
-				on[u] = false;
-				off[u] = 0;
-				tw[u] = TapW<SMP>();
-				if (t >= kAnchorTaps) continue;
-				const int k = t / 9;
-				if (sh.ahead[k].w != 1.0f) continue;
-				const s2 nb = nbs[k + 1];
-				const f2 nsp = apply_homography(H, nb.x, nb.y);
-				if (nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh) continue;   // anchor outside for this plane
-				const f4 tp = sh.atap[t];
-				const f2 sp = apply_homography(H, (int)tp.z, (int)tp.w);
-				tex_coord(Pt, W, Hh, sp.x, sp.y, &off[u], &tw[u]);
-				on[u] = true;
-			}
-#pragma unroll
-			for (int u = 0; u < kUn; ++u) {
-				qd[u][0] = qd[u][1] = qd[u][2] = qd[u][3] = 0.0f;
-				if (on[u]) load_quad(src, off[u], &qd[u][0], &qd[u][1], &qd[u][2], &qd[u][3]);
-			}
-#pragma unroll
-			for (int u = 0; u < kUn; ++u) {
-				if (!on[u]) continue;
-				float fa, fb;
-				tap_weights(tw[u], &fa, &fb);
-				sh.bval[q][(r0 + u) * 8 + (l >> 3)] = tex_lerp(fa, fb, qd[u][0], qd[u][1], qd[u][2], qd[u][3]);
-			}
-		}
-	}
-	wave_sync();
-
-	// ---- anchor costs: lane = (anchor, plane); then per plane the anchors in order ------------------------
-	DVP_LANES(l) { if (l < 8) sh.acnt[l] = 0; }
-	wave_sync();
-	for (int k0 = 0; k0 < kAnchors; k0 += 8) {
-		DVP_LANES(l) {
-			const int k = k0 + (l >> 3), q = l & 7;
-			if (k >= kAnchors || !((live >> q) & 1)) continue;
-			const float st = sh.ahead[k].w;
-			if (st == 0.0f) continue;
-			float H[9];
-			for (int i = 0; i < 9; ++i) H[i] = sh.Hs[q][i];
-			const s2 nb = nbs[k + 1];
-			const f2 nsp = apply_homography(H, nb.x, nb.y);
-			const bool outside = nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh;
-			float cost;
-			if (outside) {
-				if (st != 1.0f) continue;       // outside and not visible: not counted
-				cost = 2.0f;
-			} else if (st != 1.0f) {
-				cost = 2.0f;                    // anchor not visible in this view: the reference's 0/0 path yields exactly 2
-			} else {
-				float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
-				for (int tt = 0; tt < 9; ++tt) {
-					const f4 tp = sh.atap[k * 9 + tt];
-					const float b = sh.bval[q][k * 9 + tt];
-					const float wb = tp.x * b;
-					s_s += wb;
-					s_ss = fmaf(wb, b, s_ss);
-					s_rs = fmaf(tp.y, b, s_rs);
-				}
-				const f4 hd = sh.ahead[k];
-				cost = ncc_from_sums(hd.x, hd.y, s_s, s_ss, s_rs, hd.z);
-			}
-			sh.acost[q][k] = cost;
-#if defined(__HIP_DEVICE_COMPILE__)
-			atomicOr(&sh.acnt[q], 1u << k);
-#else
-			sh.acnt[q] |= 1u << k;
-#endif
-		}
-	}
-	wave_sync();
-	DVP_LANES(q) {
-		if (q >= 8 || !((live >> q) & 1)) continue;
 		float scost = 0.0f, scnt = 0.0f;
-		const uint32_t m = sh.acnt[q];
-		for (int k = 0; k < kAnchors; ++k)
-			if ((m >> k) & 1) { scost += sh.acost[q][k]; scnt += 1.0f; }
-		float out = sh.ccost[q];
+		for (int k = 0; k < kAnchors; ++k) {
+			const float ac = sh.acost[buf][q][k];
+			if (ac >= 0.0f) { scost += ac; scnt += 1.0f; }
+		}
+		float out = cc;
 		if (scnt > 0.0f) {
-			float sc2 = scost / scnt;
+			float sc2 = scost / scnt;   // strong_cost /= strong_count (int -> float, exact)
 			sc2 = DVP_MIN(sc2, 2.0f);
-			out = (float)(0.25 * sh.ccost[q] + 0.75 * sc2);
+			out = (float)(0.25 * cc + 0.75 * sc2);
 		}
 		sh.ev[q][v - 1] = out;
 	}
-	wave_sync();
 }
 
 // gtab[q][j] = ComputeGeomConsistencyCost(pixel, view j+1, sh.pl[q]) for q in pmask, views with weight > 0
@@ -427,6 +358,7 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 	f4 plane_now = mk4(0, 0, 0, 0);
 	bool skip_refine = false;
 	f4 pl1 = mk4(0, 0, 0, 0);
+	int nbuf = 0;
 
 	for (int phase = 0; phase < 3; ++phase) {
 		uint32_t pmask = 0, vmask = 0;
@@ -555,9 +487,11 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 		if (pmask) {
 			for (int v = 0; v < S; ++v) {
 				if (!((vmask >> v) & 1)) continue;
-				wave_ncc_new<SMP>(d, c, nbs, cpix, px, py, v + 1, pmask, sh);
+				wave_ncc_new<SMP>(d, c, nbs, cpix, px, py, v + 1, pmask, nbuf, sh);
+				nbuf ^= 1;
 				evals += (unsigned long long)__builtin_popcount(pmask);
 			}
+			wave_sync();
 		}
 
 		// ---- epilogue ----------------------------------------------------------------------------------------
@@ -668,25 +602,25 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 			} else if (in) {
 				float o[3];
 				patch_row_sums<SMP>(d, sh, H, src, px, py, c2.radius, c2.inc, r, o);
-				sh.rows[vs][r][0] = o[0];
-				sh.rows[vs][r][1] = o[1];
-				sh.rows[vs][r][2] = o[2];
+				sh.rows[0][vs][r][0] = o[0];
+				sh.rows[0][vs][r][1] = o[1];
+				sh.rows[0][vs][r][2] = o[2];
 			} else if (r == 0) {
 				sh.ev[0][v] = 2.0f;
-				sh.rows[vs][0][3] = -1.0f;   // marks "outside" for the totalling lane
+				sh.rows[0][vs][0][3] = -1.0f;   // marks "outside" for the totalling lane
 			}
-			if (c2.fast && in && r == 0) sh.rows[vs][0][3] = 1.0f;
+			if (c2.fast && in && r == 0) sh.rows[0][vs][0][3] = 1.0f;
 		}
 		wave_sync();
 		if (c2.fast) {
 			DVP_LANES(l) {
 				const int v = v0 + l;
-				if (l >= 8 || v >= S || sh.vw[v] == 0 || sh.rows[l][0][3] < 0.0f) continue;
+				if (l >= 8 || v >= S || sh.vw[v] == 0 || sh.rows[0][l][0][3] < 0.0f) continue;
 				float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
 				for (int r = 0; r < kTaps; ++r) {
-					s_s += sh.rows[l][r][0];
-					s_ss += sh.rows[l][r][1];
-					s_rs += sh.rows[l][r][2];
+					s_s += sh.rows[0][l][r][0];
+					s_ss += sh.rows[0][l][r][1];
+					s_rs += sh.rows[0][l][r][2];
 				}
 				sh.ev[0][v] = ncc_from_sums(c2.sum_ref, c2.sum_ref_ref, s_s, s_ss, s_rs, c2.wsum);
 			}
