@@ -8,6 +8,8 @@
 
 namespace dvp {
 
+#include "dvp_sector5.inc"
+
 // ---- GenEdgeInform (APD.cu:3731-3890) ----------------------------------------------------------
 // The reference bins the 120 offsets of the 11x11 window into 30-degree sectors with fp64 atan2
 // per offset, bubble-sorts each sector and then the 12 winners (24-byte structs in scratch).
@@ -61,8 +63,63 @@ DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
 	// for all views and kept S x 12 running maxima in a dynamically indexed private array: 3.2 KB of
 	// scratch per lane, 330 GB of write-back per launch at 6208x4128.)  The tap weight is recomputed per
 	// view; that is ~10 % of the old kernel's time.
-	{
-		struct Best { float w; int i, j; };
+	struct Best { float w; int i, j; };
+	if (P.weak_radius == 5) {
+		// The default window (weak_radius = 5, main.h:104; the reference never changes it): the sector lists
+		// are compile-time constants (dvp_sector5.inc), both loops are fully unrolled, and the 120 tap
+		// weights — which do not depend on the view — are computed ONCE and stay in registers; a view then
+		// costs one selected_views word and a compare/select per tap.
+		float wt[12][kSector5Max];
+		uint32_t inb[12];
+#pragma unroll
+		for (int r = 0; r < 12; ++r) {
+			inb[r] = 0;
+#pragma unroll
+			for (int t = 0; t < kSector5Max; ++t) {
+				wt[r][t] = 0.0f;
+				if (t >= kSector5Count[r]) continue;
+				const int i = kSector5[r][t][0], j = kSector5[r][t][1];
+				const int x = px + i, y = py + j;
+				if (x >= 0 && x < W && y >= 0 && y < H) inb[r] |= 1u << t;
+				const float a = img_texel(ref, d.org, d.pitch, W, H, x, y);
+				wt[r][t] = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
+			}
+		}
+		for (int v = 0; v < S; ++v) {
+			Best win[12];
+			bool any = false;
+#pragma unroll
+			for (int r = 0; r < 12; ++r) {
+				Best b = Best{ 0.0f, 0, 0 };
+				bool has = false;
+#pragma unroll
+				for (int t = 0; t < kSector5Max; ++t) {
+					if (t >= kSector5Count[r]) continue;
+					const int i = kSector5[r][t][0], j = kSector5[r][t][1];
+					if (!((inb[r] >> t) & 1)) continue;
+					if (!((d.selected_views[center + i + j * W] >> v) & 1)) continue;
+					if (!has || wt[r][t] > b.w) { has = true; b = Best{ wt[r][t], i, j }; }
+				}
+				win[r] = b;
+				any |= has;
+			}
+			if (any) {   // stable descending sort of the 12 sector winners (empty sectors: weight 0, offset (0,0))
+#pragma unroll
+				for (int a = 1; a < 12; ++a) {
+#pragma unroll
+					for (int b = a; b >= 1; --b) {
+						const bool sw = win[b - 1].w < win[b].w;
+						const Best lo = win[b - 1], hi = win[b];
+						win[b - 1] = sw ? hi : lo;
+						win[b] = sw ? lo : hi;
+					}
+				}
+			}
+			s2* cand = d.candidate + ((size_t)center * S + v) * 8;
+#pragma unroll
+			for (int k = 0; k < 8; ++k) cand[k] = mks2(win[k].i, win[k].j);
+		}
+	} else {
 		const int radius = P.weak_radius;
 		for (int v = 0; v < S; ++v) {
 			Best win[12];
