@@ -85,7 +85,7 @@ struct Dev {
 	const int* neighbours_map;
 	s2* neighbours;            // 12 per WEAK pixel
 	f4* fit_planes;
-	s2* candidate;             // [pixel][view][8]
+	s2* candidate;             // [view][pixel][8]: cand_ptr(); 64 x-adjacent pixels write/read 2 KB contiguous per view
 	const uint8_t* edge;
 	int* search_pos;           // [16][L]: sample positions of the strong update's 16 propagation slots (strong_search_px)
 	uint32_t* edge_bits;       // the edge map as 32x32-pixel bit tiles (128 B each), see edge_bit()
@@ -159,6 +159,10 @@ struct Rng {
 // an unclamped coordinate in [-kImgPad, W-1+kImgPad] IS clamp-to-edge addressing, so the bilinear
 // footprint needs no integer clamps.
 constexpr int kImgPad = 2;
+
+// the 8 visibility-prior offsets of (pixel, source view v = 0..S-1).  Host-visible layout of
+// DVP_BUF_CANDIDATE stays [pixel][view][8] (dvp_download_buffer transposes).
+DVP_HD size_t cand_index(const Dev& d, int pixel, int v) { return ((size_t)v * ((size_t)d.width * d.height) + (size_t)pixel) * 8; }
 
 DVP_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 

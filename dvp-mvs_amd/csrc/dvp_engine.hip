@@ -808,10 +808,27 @@ static void* buffer_ptr(dvp_ctx* c, int id, size_t* bytes) {
 	return nullptr;
 }
 long long dvp_buffer_bytes(dvp_ctx* c, int id) { size_t b; buffer_ptr(c, id, &b); return (long long)b; }
+// DVP_BUF_CANDIDATE is [view][pixel][8] on the device and [pixel][view][8] (the reference's order,
+// main.h:41 with the view stride fixed) at the boundary
+static void candidate_transpose(const dvp_ctx* c, const s2* src, s2* dst, bool to_device) {
+	const size_t L = c->L, S = (size_t)c->NI - 1;
+	for (size_t v = 0; v < S; ++v)
+		for (size_t p = 0; p < L; ++p) {
+			const size_t dev = (v * L + p) * 8, host = (p * S + v) * 8;
+			std::memcpy(to_device ? dst + dev : dst + host, to_device ? src + host : src + dev, 8 * sizeof(s2));
+		}
+}
 int dvp_download_buffer(dvp_ctx* c, int id, void* dst) {
 	if (set_device(c)) return 1;
 	size_t b; void* p = buffer_ptr(c, id, &b);
 	if (!p) { c->error = "bad or unallocated buffer id"; return 1; }
+	if (id == DVP_BUF_CANDIDATE) {
+		std::vector<s2> tmp(b / sizeof(s2));
+		HIP_TRY(c, hipMemcpyAsync(tmp.data(), p, b, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		candidate_transpose(c, tmp.data(), (s2*)dst, false);
+		return 0;
+	}
 	HIP_TRY(c, hipMemcpyAsync(dst, p, b, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	return 0;
@@ -820,6 +837,12 @@ int dvp_upload_buffer(dvp_ctx* c, int id, const void* src) {
 	if (set_device(c)) return 1;
 	size_t b; void* p = buffer_ptr(c, id, &b);
 	if (!p) { c->error = "bad or unallocated buffer id"; return 1; }
+	std::vector<s2> tmp;
+	if (id == DVP_BUF_CANDIDATE) {
+		tmp.resize(b / sizeof(s2));
+		candidate_transpose(c, (const s2*)src, tmp.data(), true);
+		src = tmp.data();
+	}
 	HIP_TRY(c, hipMemcpyAsync(p, src, b, hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	return 0;

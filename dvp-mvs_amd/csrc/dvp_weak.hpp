@@ -64,7 +64,12 @@ DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
 	// scratch per lane, 330 GB of write-back per launch at 6208x4128.)  The tap weight is recomputed per
 	// view; that is ~10 % of the old kernel's time.
 	struct Best { float w; int i, j; };
+	struct alignas(16) Cand8 { s2 o[8]; };
+#ifndef DVP_GEI_GENERIC
 	if (P.weak_radius == 5) {
+#else
+	if (false) {
+#endif
 		// The default window (weak_radius = 5, main.h:104; the reference never changes it): the sector lists
 		// are compile-time constants (dvp_sector5.inc), both loops are fully unrolled, and the 120 tap
 		// weights — which do not depend on the view — are computed ONCE and stay in registers; a view then
@@ -115,9 +120,10 @@ DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
 					}
 				}
 			}
-			s2* cand = d.candidate + ((size_t)center * S + v) * 8;
+			Cand8 rec;
 #pragma unroll
-			for (int k = 0; k < 8; ++k) cand[k] = mks2(win[k].i, win[k].j);
+			for (int k = 0; k < 8; ++k) rec.o[k] = mks2(win[k].i, win[k].j);
+			*reinterpret_cast<Cand8*>(d.candidate + cand_index(d, center, v)) = rec;   // two 16-byte stores
 		}
 	} else {
 		const int radius = P.weak_radius;
@@ -157,9 +163,10 @@ DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
 					}
 				}
 			}
-			s2* cand = d.candidate + ((size_t)center * S + v) * 8;
+			Cand8 rec;
 #pragma unroll
-			for (int k = 0; k < 8; ++k) cand[k] = mks2(win[k].i, win[k].j);
+			for (int k = 0; k < 8; ++k) rec.o[k] = mks2(win[k].i, win[k].j);
+			*reinterpret_cast<Cand8*>(d.candidate + cand_index(d, center, v)) = rec;   // two 16-byte stores
 		}
 	}
 

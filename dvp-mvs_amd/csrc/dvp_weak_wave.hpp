@@ -201,7 +201,7 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 					cost = 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
 				} else {
 					// reference side (APD.cu:905-1000): 8 visibility-prior offsets of the anchor + the anchor itself
-					const s2* cand = d.candidate + ((size_t)nbc * S + (v - 1)) * 8;
+					const s2* cand = d.candidate + cand_index(d, nbc, v - 1);
 					int tx[9], ty[9];
 					float ti[9], tj[9];
 #pragma unroll

@@ -217,8 +217,23 @@ static void* buf_ptr(Emu& e, int id, size_t* bytes) {
 	return nullptr;
 }
 long long emu_buffer_bytes(void* c, int id) { size_t b; buf_ptr(*(Emu*)c, id, &b); return (long long)b; }
-int emu_get_buffer(void* c, int id, void* dst) { size_t b; void* p = buf_ptr(*(Emu*)c, id, &b); if (!p) return -1; std::memcpy(dst, p, b); return 0; }
-int emu_set_buffer(void* c, int id, const void* src) { size_t b; void* p = buf_ptr(*(Emu*)c, id, &b); if (!p) return -1; std::memcpy(p, src, b); return 0; }
+// the candidate buffer is [view][pixel][8] inside the kernels, [pixel][view][8] at the boundary
+static void cand_transpose(Emu& e, const s2* src, s2* dst, bool to_dev) {
+	const size_t L = (size_t)e.W * e.H, S = (size_t)e.NI - 1;
+	for (size_t v = 0; v < S; ++v)
+		for (size_t p = 0; p < L; ++p)
+			std::memcpy(to_dev ? dst + (v * L + p) * 8 : dst + (p * S + v) * 8, to_dev ? src + (p * S + v) * 8 : src + (v * L + p) * 8, 8 * sizeof(s2));
+}
+int emu_get_buffer(void* c, int id, void* dst) {
+	size_t b; void* p = buf_ptr(*(Emu*)c, id, &b); if (!p) return -1;
+	if (id == DVP_BUF_CANDIDATE) cand_transpose(*(Emu*)c, (const s2*)p, (s2*)dst, false); else std::memcpy(dst, p, b);
+	return 0;
+}
+int emu_set_buffer(void* c, int id, const void* src) {
+	size_t b; void* p = buf_ptr(*(Emu*)c, id, &b); if (!p) return -1;
+	if (id == DVP_BUF_CANDIDATE) cand_transpose(*(Emu*)c, (const s2*)src, (s2*)p, true); else std::memcpy(p, src, b);
+	return 0;
+}
 int emu_weak_count(void* c) { return ((Emu*)c)->d.weak_count; }
 
 // Launch-geometry property: the block -> tile -> pixel map of a launch visits every pixel it is meant
