@@ -186,6 +186,13 @@ extern "C" __global__ void dvp_pack_edge_bits(const uint8_t* __restrict__ edge, 
 	if (w < words) bits[w] = pack_edge_word(edge, W, H, tiles_x, w, equals);
 }
 
+// visibility-prior candidates of GenEdgeInform: pixels x source views (blockIdx.y = view, wave-uniform)
+extern "C" __global__ void __launch_bounds__(256) dvp_gen_candidates(const Dev d, const LaunchArgs a) {
+	int px, py;
+	if (block_to_pixel(blockIdx.x, threadIdx.x & 63, threadIdx.x >> 6, a.tiles_x, a.tiles, a.rows, 0, 0, d.width, d.height, &px, &py))
+		gen_candidates_px(d, px, py, (int)blockIdx.y);
+}
+
 // sample search of the strong update (same red/black launch geometry, no LDS, small register footprint)
 extern "C" __global__ void __launch_bounds__(256) dvp_strong_search(const Dev d, const LaunchArgs a) {
 	int px, py;
@@ -699,7 +706,10 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 		HIP_TRY(c, hipGetLastError());
 	}
 	switch (stage) {
-	case DVP_ST_GEN_EDGE_INFORM: hipLaunchKernelGGL(c->d.sampler ? dvp_gen_edge_inform_exact : dvp_gen_edge_inform, grid, block, 0, c->stream, c->d, a); break;
+	case DVP_ST_GEN_EDGE_INFORM:
+		hipLaunchKernelGGL(dvp_gen_candidates, dim3(g.grid(), (unsigned)(c->NI - 1)), block, 0, c->stream, c->d, a);
+		hipLaunchKernelGGL(c->d.sampler ? dvp_gen_edge_inform_exact : dvp_gen_edge_inform, grid, block, 0, c->stream, c->d, a);
+		break;
 	case DVP_ST_RANDOM_INIT: hipLaunchKernelGGL(c->d.sampler ? dvp_random_init_exact : dvp_random_init, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_STRONG_UPDATE:
 		if (c->NI - 1 <= kNarrowViews) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v8_exact : dvp_strong_update_v8, grid, block, 0, c->stream, c->d, a);

@@ -71,7 +71,12 @@ constexpr int kNarrowViews = 8;   // view capacity of the narrow strong-update i
 template <int STAGE, int SMP, int MV = 32>
 DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long* nevals, PatchTab tab) {
 	const int center = px + py * d.width;
-	if (STAGE == DVP_ST_GEN_EDGE_INFORM) gen_edge_inform_px(d, px, py);
+	if (STAGE == DVP_ST_GEN_EDGE_INFORM) {
+		gen_edge_inform_px(d, px, py);
+#if !defined(__HIP_DEVICE_COMPILE__)   // device: own launch shape, pixels x views (dvp_gen_candidates)
+		for (int v = 0; v < d.params.num_images - 1; ++v) gen_candidates_px(d, px, py, v);
+#endif
+	}
 	else if (STAGE == DVP_ST_FIND_NEAREST_STRONG) find_nearest_strong_px(d, px, py);
 	else if (STAGE == DVP_ST_GEN_NEIGHBOURS) gen_neighbours_px(d, px, py);
 	else if (STAGE == DVP_ST_NEIGHBOUR_UPDATE) neighbour_update_px(d, px, py);

@@ -45,131 +45,97 @@ DVP_HD void edge_ray_line(const Dev& d, int k, int line) {
 	}
 }
 
-DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
+// Visibility-prior tap candidates of (pixel, source view v) (APD.cu:3746-3794): the window offsets whose
+// pixel sees view v are binned into twelve 30-degree sectors (at most 20 per sector, visit order), each
+// sector keeps its heaviest offset (first one among equals: the reference's stable bubble sort), the
+// twelve winners are sorted by weight and the top eight stored.
+// Launch shape: pixels x views (the view is wave-uniform), one pass over the window per lane, the twelve
+// winners in registers.  (Round 1 walked the window once per pixel for all views and kept S x 12 running
+// maxima in a dynamically indexed private array: 3.2 KB of scratch per lane, 330 GB of write-back per
+// launch at 6208x4128.)  For the default window (weak_radius = 5, main.h:104; the reference never
+// changes it) the sector lists are compile-time constants (dvp_sector5.inc): every load has a static
+// offset and no branch in front of it, so the compiler batches them.
+DVP_HD void gen_candidates_px(const Dev& d, int px, int py, int v) {
 	const int W = d.width, H = d.height;
 	const int center = px + py * W;
 	const DvpParams& P = d.params;
-	const int S = P.num_images - 1;
 	const float* ref = d.images;
 	const float cpix = img_texel(ref, d.org, d.pitch, W, H, px, py);
-
-	// visibility-prior tap candidates (APD.cu:3746-3794): per source view, the window offsets whose
-	// pixel sees that view are binned into twelve 30-degree sectors (at most 20 per sector, visit
-	// order), each sector keeps its heaviest offset (first one among equals: the reference's stable
-	// bubble sort), the twelve winners are sorted by weight and the top eight stored.
-	// Sector-major walk: the offsets of sector r in visit order come from a host-built list
-	// (sector_taps / sector_start, wave-uniform -> scalar loads), so a sector's running maximum and the
-	// twelve winners of the view live in registers with static indices.  (Round 1 walked the window once
-	// for all views and kept S x 12 running maxima in a dynamically indexed private array: 3.2 KB of
-	// scratch per lane, 330 GB of write-back per launch at 6208x4128.)  The tap weight is recomputed per
-	// view; that is ~10 % of the old kernel's time.
 	struct Best { float w; int i, j; };
 	struct alignas(16) Cand8 { s2 o[8]; };
+	Best win[12];
+	bool any = false;
 #ifndef DVP_GEI_GENERIC
 	if (P.weak_radius == 5) {
 #else
 	if (false) {
 #endif
-		// The default window (weak_radius = 5, main.h:104; the reference never changes it): the sector lists
-		// are compile-time constants (dvp_sector5.inc), both loops are fully unrolled, and the 120 tap
-		// weights — which do not depend on the view — are computed ONCE and stay in registers; a view then
-		// costs one selected_views word and a compare/select per tap.
-		float wt[12][kSector5Max];
-		uint32_t inb[12];
 #pragma unroll
 		for (int r = 0; r < 12; ++r) {
-			inb[r] = 0;
+			Best b = Best{ 0.0f, 0, 0 };
+			bool has = false;
 #pragma unroll
 			for (int t = 0; t < kSector5Max; ++t) {
-				wt[r][t] = 0.0f;
 				if (t >= kSector5Count[r]) continue;
 				const int i = kSector5[r][t][0], j = kSector5[r][t][1];
 				const int x = px + i, y = py + j;
-				if (x >= 0 && x < W && y >= 0 && y < H) inb[r] |= 1u << t;
+				const bool in = x >= 0 && x < W && y >= 0 && y < H;
+				// clamped address: the load is unconditional (in-bounds), its value is used only when `in`
+				const uint32_t sv = d.selected_views[clampi(y, 0, H - 1) * W + clampi(x, 0, W - 1)];
 				const float a = img_texel(ref, d.org, d.pitch, W, H, x, y);
-				wt[r][t] = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
+				const float w = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
+				if (in && ((sv >> v) & 1) && (!has || w > b.w)) { has = true; b = Best{ w, i, j }; }
 			}
-		}
-		for (int v = 0; v < S; ++v) {
-			Best win[12];
-			bool any = false;
-#pragma unroll
-			for (int r = 0; r < 12; ++r) {
-				Best b = Best{ 0.0f, 0, 0 };
-				bool has = false;
-#pragma unroll
-				for (int t = 0; t < kSector5Max; ++t) {
-					if (t >= kSector5Count[r]) continue;
-					const int i = kSector5[r][t][0], j = kSector5[r][t][1];
-					if (!((inb[r] >> t) & 1)) continue;
-					if (!((d.selected_views[center + i + j * W] >> v) & 1)) continue;
-					if (!has || wt[r][t] > b.w) { has = true; b = Best{ wt[r][t], i, j }; }
-				}
-				win[r] = b;
-				any |= has;
-			}
-			if (any) {   // stable descending sort of the 12 sector winners (empty sectors: weight 0, offset (0,0))
-#pragma unroll
-				for (int a = 1; a < 12; ++a) {
-#pragma unroll
-					for (int b = a; b >= 1; --b) {
-						const bool sw = win[b - 1].w < win[b].w;
-						const Best lo = win[b - 1], hi = win[b];
-						win[b - 1] = sw ? hi : lo;
-						win[b] = sw ? lo : hi;
-					}
-				}
-			}
-			Cand8 rec;
-#pragma unroll
-			for (int k = 0; k < 8; ++k) rec.o[k] = mks2(win[k].i, win[k].j);
-			*reinterpret_cast<Cand8*>(d.candidate + cand_index(d, center, v)) = rec;   // two 16-byte stores
+			win[r] = b;
+			any |= has;
 		}
 	} else {
 		const int radius = P.weak_radius;
-		for (int v = 0; v < S; ++v) {
-			Best win[12];
-			bool any = false;
 #pragma unroll
-			for (int r = 0; r < 12; ++r) {
-				Best b = Best{ 0.0f, 0, 0 };
-				bool has = false;
-				int cnt = 0;
-				const int t1 = uniform_load_i32(d.sector_start, r + 1);
-				for (int t = uniform_load_i32(d.sector_start, r); t < t1; ++t) {
-					const int code = uniform_load_i32(d.sector_taps, t);
-					const int i = (code & 0xffff) - radius, j = (code >> 16) - radius;
-					const int x = px + i, y = py + j;
-					if (!(x >= 0 && x < W && y >= 0 && y < H)) continue;
-					if (!((d.selected_views[x + y * W] >> v) & 1)) continue;
-					if (cnt >= 20) continue;   // regionCounts[region] < 20 (APD.cu:3768)
-					cnt++;
-					const float a = img_texel(ref, d.org, d.pitch, W, H, x, y);
-					const float w = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
-					if (!has || w > b.w) { has = true; b = Best{ w, i, j }; }
-				}
-				win[r] = b;
-				any |= has;
+		for (int r = 0; r < 12; ++r) {
+			Best b = Best{ 0.0f, 0, 0 };
+			bool has = false;
+			int cnt = 0;
+			const int t1 = uniform_load_i32(d.sector_start, r + 1);
+			for (int t = uniform_load_i32(d.sector_start, r); t < t1; ++t) {
+				const int code = uniform_load_i32(d.sector_taps, t);
+				const int i = (code & 0xffff) - radius, j = (code >> 16) - radius;
+				const int x = px + i, y = py + j;
+				if (!(x >= 0 && x < W && y >= 0 && y < H)) continue;
+				if (!((d.selected_views[x + y * W] >> v) & 1)) continue;
+				if (cnt >= 20) continue;   // regionCounts[region] < 20 (APD.cu:3768)
+				cnt++;
+				const float a = img_texel(ref, d.org, d.pitch, W, H, x, y);
+				const float w = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
+				if (!has || w > b.w) { has = true; b = Best{ w, i, j }; }
 			}
-			if (any) {   // stable descending sort of the 12 sector winners (empty sectors: weight 0, offset (0,0))
-#pragma unroll
-				for (int a = 1; a < 12; ++a) {
-#pragma unroll
-					for (int b = a; b >= 1; --b) {
-						const bool sw = win[b - 1].w < win[b].w;
-						const Best lo = win[b - 1], hi = win[b];
-						win[b - 1] = sw ? hi : lo;
-						win[b] = sw ? lo : hi;
-					}
-				}
-			}
-			Cand8 rec;
-#pragma unroll
-			for (int k = 0; k < 8; ++k) rec.o[k] = mks2(win[k].i, win[k].j);
-			*reinterpret_cast<Cand8*>(d.candidate + cand_index(d, center, v)) = rec;   // two 16-byte stores
+			win[r] = b;
+			any |= has;
 		}
 	}
+	if (any) {   // stable descending sort of the 12 sector winners (empty sectors: weight 0, offset (0,0))
+#pragma unroll
+		for (int a = 1; a < 12; ++a) {
+#pragma unroll
+			for (int b = a; b >= 1; --b) {
+				const bool sw = win[b - 1].w < win[b].w;
+				const Best lo = win[b - 1], hi = win[b];
+				win[b - 1] = sw ? hi : lo;
+				win[b] = sw ? lo : hi;
+			}
+		}
+	}
+	Cand8 rec;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) rec.o[k] = mks2(win[k].i, win[k].j);
+	*reinterpret_cast<Cand8*>(d.candidate + cand_index(d, center, v)) = rec;   // two 16-byte stores
+}
 
+// the per-pixel rest of GenEdgeInform (APD.cu:3796-3890); candidates: gen_candidates_px, edge_neigh: edge_ray_line
+DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
+	const int W = d.width, H = d.height;
+	const int center = px + py * W;
+	const DvpParams& P = d.params;
 	const int dxs[8] = { 0, 0, -1, 1, -1, 1, -1, 1 };
 	const int dys[8] = { -1, 1, 0, 0, -1, 1, 1, -1 };
 	if (P.use_edge) {
