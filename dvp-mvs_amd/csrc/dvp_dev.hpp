@@ -94,6 +94,7 @@ struct Dev {
 	s2* edge_neigh;            // 8 per pixel
 	const int* label;
 	s2* label_boundary;        // 8 per WEAK pixel
+	s2* label_stop;            // 8 per pixel: nearest pixel with label -1 per direction (valid during GenEdgeInform when use_label)
 	float* complex_;           // per WEAK pixel
 	int* radius;
 	// WEAK pixels compacted: pixel indices in raster order, black ((x+y) even) first, then red;

@@ -201,8 +201,8 @@ extern "C" __global__ void __launch_bounds__(256) dvp_strong_search(const Dev d,
 }
 
 // line-scan pre-pass of GenEdgeInform: nearest edge pixel in 8 directions (blockIdx.y = direction)
-extern "C" __global__ void __launch_bounds__(256) dvp_edge_rays(const Dev d) {
-	edge_ray_line(d, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+extern "C" __global__ void __launch_bounds__(256) dvp_edge_rays(const Dev d, int what) {
+	edge_ray_line(d, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, what);
 }
 
 extern "C" __global__ void dvp_prepare_views(const DvpCamera* cams, ViewConst* views, int n) {
@@ -269,7 +269,7 @@ struct dvp_ctx {
 	float* costs = nullptr; float* costs_snap = nullptr; float* complex_ = nullptr;
 	uint32_t* selected_views = nullptr;
 	uint8_t* view_weight = nullptr; uint8_t* weak_info = nullptr; uint8_t* weak_reliable = nullptr; uint8_t* edge = nullptr;
-	s2* weak_nearest_strong = nullptr; s2* neighbours = nullptr; s2* candidate = nullptr; s2* edge_neigh = nullptr; s2* label_boundary = nullptr;
+	s2* label_stop = nullptr; s2* weak_nearest_strong = nullptr; s2* neighbours = nullptr; s2* candidate = nullptr; s2* edge_neigh = nullptr; s2* label_boundary = nullptr;
 	int* neighbours_map = nullptr; int* label = nullptr; int* radius = nullptr;
 	unsigned long long* eval_counter = nullptr;
 	float* scratch_out = nullptr;
@@ -323,7 +323,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.weak_reliable = c->weak_reliable; d.weak_nearest_strong = c->weak_nearest_strong;
 	d.neighbours_map = c->neighbours_map; d.neighbours = c->neighbours; d.fit_planes = c->fit_planes;
 	d.candidate = c->candidate; d.edge = c->edge; d.edge_bits = c->edge_bits; d.strong_bits = c->strong_bits; d.edge_tiles_x = edge_tiles_x(c->W); d.edge_neigh = c->edge_neigh; d.label = c->label;
-	d.label_boundary = c->label_boundary; d.complex_ = c->complex_; d.radius = c->radius;
+	d.label_boundary = c->label_boundary; d.label_stop = c->label_stop; d.complex_ = c->complex_; d.radius = c->radius;
 	d.weak_list = c->weak_list;
 	d.eval_counter = c->profiling ? c->eval_counter : nullptr;
 }
@@ -702,7 +702,15 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 		}
 	} else {
 	if (stage == DVP_ST_GEN_EDGE_INFORM && c->d.params.use_edge) {
-		hipLaunchKernelGGL(dvp_edge_rays, dim3((c->W + c->H + 255) / 256, 8), dim3(256), 0, c->stream, c->d);
+		hipLaunchKernelGGL(dvp_edge_rays, dim3((c->W + c->H + 255) / 256, 8), dim3(256), 0, c->stream, c->d, 0);
+		HIP_TRY(c, hipGetLastError());
+	}
+	if (stage == DVP_ST_GEN_EDGE_INFORM && c->d.params.use_label && c->d.weak_count > 0) {   // label boundaries are searched for WEAK pixels only
+		if (!c->label_stop) {
+			if (dalloc(c, &c->label_stop, c->L * 8, false)) return 1;
+			sync_dev_struct(c);
+		}
+		hipLaunchKernelGGL(dvp_edge_rays, dim3((c->W + c->H + 255) / 256, 8), dim3(256), 0, c->stream, c->d, 1);
 		HIP_TRY(c, hipGetLastError());
 	}
 	switch (stage) {

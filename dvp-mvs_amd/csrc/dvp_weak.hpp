@@ -20,7 +20,9 @@ namespace dvp {
 // one image line of one direction and walks it once AGAINST the direction, carrying the last edge
 // pixel seen: O(L) reads per direction, same result.
 DVP_HD int edge_ray_lines(int W, int H, int k) { return k < 2 ? W : (k < 4 ? H : W + H - 1); }
-DVP_HD void edge_ray_line(const Dev& d, int k, int line) {
+// what = 0: nearest edge pixel -> edge_neigh;  what = 1: nearest pixel with label -1 -> label_stop
+// (the walks of the label-boundary search stop there, APD.cu:3861-3873)
+DVP_HD void edge_ray_line(const Dev& d, int k, int line, int what = 0) {
 	const int W = d.width, H = d.height;
 	const int dxs[8] = { 0, 0, -1, 1, -1, 1, -1, 1 };
 	const int dys[8] = { -1, 1, 0, 0, -1, 1, 1, -1 };
@@ -38,8 +40,13 @@ DVP_HD void edge_ray_line(const Dev& d, int k, int line) {
 	s2 last = mks2(-1, -1);
 	while (x >= 0 && x < W && y >= 0 && y < H) {
 		const int c = x + y * W;
-		d.edge_neigh[(size_t)c * 8 + k] = last;
-		if (d.edge[c]) last = mks2(x, y);
+		if (what == 0) {
+			d.edge_neigh[(size_t)c * 8 + k] = last;
+			if (d.edge[c]) last = mks2(x, y);
+		} else {
+			d.label_stop[(size_t)c * 8 + k] = last;
+			if (d.label[c] == -1) last = mks2(x, y);
+		}
 		x -= dx;
 		y -= dy;
 	}
@@ -162,14 +169,26 @@ DVP_HD void gen_edge_inform_px(const Dev& d, int px, int py) {
 		const int cl = d.label[center];
 		if (cl > 0) {
 			for (int k = 0; k < 8; k++) {
-				int nx = px + dxs[k], ny = py + dys[k];
+				// The reference walks from the pixel to the first label -1 (or the border) and keeps the LAST
+				// pixel of its own label it passed (APD.cu:3861-3873): thousands of dependent loads per ray
+				// on a large region.  Same answer from the other end: the line-scan pre-pass (edge_ray_line,
+				// what = 1) gives the stop pixel, and the farthest pixel of the own label is the first one
+				// met walking BACK from there — on a region bounded by edges that is the first probe.
+				const s2 stop = d.label_stop[(size_t)center * 8 + k];
+				int nx, ny;   // last pixel before the stop (or the last pixel inside the image)
+				if (stop.x != -1) { nx = stop.x - dxs[k]; ny = stop.y - dys[k]; }
+				else {
+					int steps = 1 << 30;   // pixels from (px,py) to the border along k
+					if (dxs[k] > 0) steps = DVP_MIN(steps, W - 1 - px); else if (dxs[k] < 0) steps = DVP_MIN(steps, px);
+					if (dys[k] > 0) steps = DVP_MIN(steps, H - 1 - py); else if (dys[k] < 0) steps = DVP_MIN(steps, py);
+					nx = px + steps * dxs[k];
+					ny = py + steps * dys[k];
+				}
 				int lx = -1, ly = -1;
-				while (!(nx < 0 || nx >= W || ny < 0 || ny >= H)) {
-					const int nl = d.label[nx + ny * W];
-					if (nl == cl) { lx = nx; ly = ny; }
-					else if (nl == -1) break;
-					nx += dxs[k];
-					ny += dys[k];
+				while (nx != px || ny != py) {
+					if (d.label[nx + ny * W] == cl) { lx = nx; ly = ny; break; }
+					nx -= dxs[k];
+					ny -= dys[k];
 				}
 				lb[k] = mks2(lx, ly);
 			}

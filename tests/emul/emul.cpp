@@ -25,7 +25,7 @@ struct Emu {
 	std::vector<uint32_t> selected_views;
 	std::vector<uint8_t> view_weight, weak_info, weak_reliable, edge;
 	std::vector<uint32_t> edge_bits, strong_bits;
-	std::vector<s2> weak_nearest_strong, neighbours, candidate, edge_neigh, label_boundary;
+	std::vector<s2> weak_nearest_strong, neighbours, candidate, edge_neigh, label_boundary, label_stop;
 	std::vector<int> neighbours_map, label, radius;
 	unsigned long long evals = 0;
 	bool count = false;
@@ -62,6 +62,7 @@ void refresh(Emu& e) {
 	d.edge_neigh = e.edge_neigh.data();
 	d.label = e.label.data();
 	d.label_boundary = e.label_boundary.data();
+	d.label_stop = e.label_stop.data();
 	d.complex_ = e.complex_.data();
 	d.radius = e.radius.data();
 	d.eval_counter = nullptr;
@@ -120,6 +121,7 @@ void* emu_create(int W, int H, int NI) {
 	e->edge_bits.assign(edge_bits_words(W, H), 0u);
 	e->strong_bits.assign(edge_bits_words(W, H), 0u);
 	e->edge_neigh.assign(L * 8, mks2(-1, -1));
+	e->label_stop.assign(L * 8, mks2(-1, -1));
 	e->label.assign(L, 0);
 	e->label_boundary.assign(8, mks2(-1, -1));
 	e->complex_.assign(1, 0.0f);
@@ -272,6 +274,11 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 #pragma omp parallel for schedule(dynamic, 16) collapse(2)
 			for (int k = 0; k < 8; ++k)
 				for (int line = 0; line < e.W + e.H; ++line) edge_ray_line(e.d, k, line);
+		}
+		if (e.d.params.use_label && e.d.weak_count > 0) {
+#pragma omp parallel for schedule(dynamic, 16) collapse(2)
+			for (int k = 0; k < 8; ++k)
+				for (int line = 0; line < e.W + e.H; ++line) edge_ray_line(e.d, k, line, 1);
 		}
 		launch<DVP_ST_GEN_EDGE_INFORM>(e, iter, colour);
 		break;
