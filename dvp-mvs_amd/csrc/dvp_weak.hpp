@@ -481,10 +481,16 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 		float min_cost = FLT_MAX;
 		int max_count = 3;
 		bool has_strong_plane = false;
-		// three alternating phases (see ransac_fit_plane_px): (A) draws until one survives the cheap
-		// rejections — distinct indices, pixel inside the triangle, normal length, non-degenerate plane
-		// (all pure tests: their order does not matter) —, (B) the three line walks, back to (A) on an
-		// edge hit, (C) inlier count and bookkeeping for all lanes that hold a survivor
+		// The reference caches the line tests in edge_test[160][160], filled symmetrically by whichever
+		// orientation of a pair is tested first (APD.cu:3574, 3588-3604); BresenhamLine walks from its second
+		// argument under a step limit, so the cached answer is that orientation's.  Here: 2 bits per
+		// unordered pair (0 untested, 1 edge hit, 2 clear).  Every draw that passes the index and triangle
+		// tests fills its three pairs, in the reference's order, before any further test.
+		uint32_t memo[(max_pt_num * (max_pt_num - 1) / 2 + 15) / 16];
+		for (int i = 0; i < (valid_count * (valid_count - 1) / 2 + 15) / 16; ++i) memo[i] = 0u;
+		// two alternating phases: (A) each lane advances through its own draws until one passes the
+		// index and triangle tests, (B) the lanes that hold one run the (cached) line tests together, then
+		// the remaining rejections, the inlier count and the bookkeeping.  Same draws and tests per lane.
 		for (;;) {
 			bool ok = false;
 			int ai = 0, bi = 0, ci = 0;
@@ -499,27 +505,38 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 					ci = (int)(r_ransac.next() % (uint32_t)valid_count);
 					if (ai == bi || bi == ci || ai == ci) continue;
 					if (!point_in_triangle(spv[ai], spv[bi], spv[ci], px, py)) continue;
-					AN = spn[ai];   // the reference uses a_index for all three normals (APD.cu:3605-3607)
-					const float nn = AN.x * AN.x + AN.y * AN.y + AN.z * AN.z;
-					if (nn < 0.9f) continue;
-					A = sp3[ai];
-					const f3 B = sp3[bi], C = sp3[ci];
-					const f3 AC = mk3(A.x - C.x, A.y - C.y, A.z - C.z);
-					const f3 BC = mk3(B.x - C.x, B.y - C.y, B.z - C.z);
-					cv.x = AC.y * BC.z - BC.y * AC.z;
-					cv.y = -(AC.x * BC.z - BC.x * AC.z);
-					cv.z = AC.x * BC.y - BC.x * AC.y;
-					cv.w = 0.0f;
-					if ((cv.x == 0 && cv.y == 0 && cv.z == 0) || cv.x != cv.x || cv.y != cv.y || cv.z != cv.z) continue;
 					cand = true;
 					break;
 				}
 				if (!cand) break;
-				// the reference memoises these tests in a 25 KB per-thread table (APD.cu:3574); the test
-				// is a pure function of its end points, so it is re-evaluated instead
-				if (edge_limit && (bresenham_hits_edge(d, spv[ai].x, spv[ai].y, spv[bi].x, spv[bi].y) ||
-				                   bresenham_hits_edge(d, spv[bi].x, spv[bi].y, spv[ci].x, spv[ci].y) ||
-				                   bresenham_hits_edge(d, spv[ci].x, spv[ci].y, spv[ai].x, spv[ai].y))) continue;
+				if (edge_limit) {
+					const int pa[3] = { ai, bi, ci }, pb[3] = { bi, ci, ai };
+					bool hit = false;
+#pragma unroll
+					for (int e = 0; e < 3; ++e) {
+						const int hi = pa[e] > pb[e] ? pa[e] : pb[e], lo = pa[e] > pb[e] ? pb[e] : pa[e];
+						const int idx = hi * (hi - 1) / 2 + lo;
+						uint32_t st = (memo[idx >> 4] >> ((idx & 15) * 2)) & 3u;
+						if (st == 0u) {
+							st = bresenham_hits_edge(d, spv[pa[e]].x, spv[pa[e]].y, spv[pb[e]].x, spv[pb[e]].y) ? 1u : 2u;
+							memo[idx >> 4] |= st << ((idx & 15) * 2);
+						}
+						hit |= st == 1u;
+					}
+					if (hit) continue;
+				}
+				AN = spn[ai];   // the reference uses a_index for all three normals (APD.cu:3605-3607)
+				const float nn = AN.x * AN.x + AN.y * AN.y + AN.z * AN.z;
+				if (nn < 0.9f) continue;
+				A = sp3[ai];
+				const f3 B = sp3[bi], C = sp3[ci];
+				const f3 AC = mk3(A.x - C.x, A.y - C.y, A.z - C.z);
+				const f3 BC = mk3(B.x - C.x, B.y - C.y, B.z - C.z);
+				cv.x = AC.y * BC.z - BC.y * AC.z;
+				cv.y = -(AC.x * BC.z - BC.x * AC.z);
+				cv.z = AC.x * BC.y - BC.x * AC.y;
+				cv.w = 0.0f;
+				if ((cv.x == 0 && cv.y == 0 && cv.z == 0) || cv.x != cv.x || cv.y != cv.y || cv.z != cv.z) continue;
 				ok = true;
 				break;
 			}
@@ -631,6 +648,7 @@ DVP_HD void ransac_fit_plane_px(const Dev& d, int px, int py, int iter) {
 	// same tests per lane — only the interleaving across lanes changes (a draw that fails a cheap
 	// test no longer makes 63 other lanes wait through the walks of the one lane that passed).
 	int it = 0;
+	uint64_t memo_lo = 0, memo_hi = 0;
 	for (;;) {
 		bool cand = false;
 		int ai = 0, bi = 0, ci = 0;
@@ -649,9 +667,23 @@ DVP_HD void ransac_fit_plane_px(const Dev& d, int px, int py, int iter) {
 		}
 		if (!cand) break;
 		if (edge_limit) {
-			if (bresenham_hits_edge(d, sp[ai].x, sp[ai].y, sp[bi].x, sp[bi].y) ||
-				bresenham_hits_edge(d, sp[bi].x, sp[bi].y, sp[ci].x, sp[ci].y) ||
-				bresenham_hits_edge(d, sp[ci].x, sp[ci].y, sp[ai].x, sp[ai].y)) continue;
+			// edge_test[11][11] of the reference (APD.cu:4260, 4283-4299): symmetric, first evaluation wins;
+			// 55 unordered pairs x 2 bits in two registers
+			const int pa[3] = { ai, bi, ci }, pb[3] = { bi, ci, ai };
+			bool hit = false;
+#pragma unroll
+			for (int e = 0; e < 3; ++e) {
+				const int hi = pa[e] > pb[e] ? pa[e] : pb[e], lo = pa[e] > pb[e] ? pb[e] : pa[e];
+				const int idx = hi * (hi - 1) / 2 + lo;   // < 55
+				const int sh = (idx & 31) * 2;
+				uint32_t st = (uint32_t)(((idx < 32) ? memo_lo : memo_hi) >> sh) & 3u;
+				if (st == 0u) {
+					st = bresenham_hits_edge(d, sp[pa[e]].x, sp[pa[e]].y, sp[pb[e]].x, sp[pb[e]].y) ? 1u : 2u;
+					if (idx < 32) memo_lo |= (uint64_t)st << sh; else memo_hi |= (uint64_t)st << sh;
+				}
+				hit |= st == 1u;
+			}
+			if (hit) continue;
 		}
 		const f3 A = sp3[ai], B = sp3[bi], C = sp3[ci];
 		const f3 AC = mk3(A.x - C.x, A.y - C.y, A.z - C.z);

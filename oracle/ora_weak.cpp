@@ -339,8 +339,11 @@ void GenNeighbours_px(Ctx& h, const int2 point) {
 		float min_cost = FLT_MAX;
 		int max_count = 3;
 		bool has_strong_plane = false;
-		// the reference caches Bresenham results in edge_test[160][160] (:3574); the test is a
-		// pure function of the two end points, so it is simply re-evaluated here.
+		// symmetric first-evaluation-wins cache of the line tests (APD.cu:3574, 3588-3604): BresenhamLine
+		// walks from its second argument with a step limit, so the answer for an unordered pair is the
+		// one of the orientation in which the pair was first tested
+		std::vector<unsigned char> edge_test((size_t)max_pt_num * max_pt_num, 0);
+		auto tested = [&](int a, int b) -> unsigned char& { return edge_test[(size_t)a * max_pt_num + b]; };
 		while (iteration > 0 && max_iter > 0) {
 			max_iter--;
 			int a_index = (int)(r_ransac.next() % (uint32_t)valid_count);
@@ -349,9 +352,13 @@ void GenNeighbours_px(Ctx& h, const int2 point) {
 			if (a_index == b_index || b_index == c_index || a_index == c_index) continue;
 			if (!PointinTriangle(strong_points_valid[a_index], strong_points_valid[b_index], strong_points_valid[c_index], point)) continue;
 			if (edge_limit) {
-				if (BresenhamLine(strong_points_valid[a_index], strong_points_valid[b_index], h) ||
-					BresenhamLine(strong_points_valid[b_index], strong_points_valid[c_index], h) ||
-					BresenhamLine(strong_points_valid[c_index], strong_points_valid[a_index], h)) continue;
+				if (tested(a_index, b_index) == 0)
+					tested(a_index, b_index) = tested(b_index, a_index) = BresenhamLine(strong_points_valid[a_index], strong_points_valid[b_index], h) ? 1 : 2;
+				if (tested(b_index, c_index) == 0)
+					tested(b_index, c_index) = tested(c_index, b_index) = BresenhamLine(strong_points_valid[b_index], strong_points_valid[c_index], h) ? 1 : 2;
+				if (tested(c_index, a_index) == 0)
+					tested(c_index, a_index) = tested(a_index, c_index) = BresenhamLine(strong_points_valid[c_index], strong_points_valid[a_index], h) ? 1 : 2;
+				if (tested(a_index, b_index) == 1 || tested(b_index, c_index) == 1 || tested(c_index, a_index) == 1) continue;
 			}
 			const float3& AN = strong_points_valid_normals[a_index];
 			const float3& BN = strong_points_valid_normals[a_index];   // a_index three times (:3605-3607): kept
@@ -479,6 +486,7 @@ void RANSACToGetFitPlane_px(Ctx& h, const int2 point, int iter) {
 	float min_cost = FLT_MAX;
 	float4 best_plane = make_float4(0, 0, 0, 0);
 	bool has_best_plane = false;
+	unsigned char edge_test[NEIGHBOUR_NUM - 1][NEIGHBOUR_NUM - 1] = {};   // APD.cu:4260: symmetric, first evaluation wins
 	while (iteration--) {
 		int a_index = (int)(r_ransac.next() % (uint32_t)strong_count);
 		int b_index = (int)(r_ransac.next() % (uint32_t)strong_count);
@@ -490,9 +498,13 @@ void RANSACToGetFitPlane_px(Ctx& h, const int2 point, int iter) {
 		if (Vec3DotVec3(AN, BN) < 0.9f || Vec3DotVec3(AN, CN) < 0.9f || Vec3DotVec3(BN, CN) < 0.9f) continue;
 		if (!PointinTriangle(strong_points[a_index], strong_points[b_index], strong_points[c_index], point)) continue;
 		if (edge_limit) {
-			if (BresenhamLine(strong_points[a_index], strong_points[b_index], h) ||
-				BresenhamLine(strong_points[b_index], strong_points[c_index], h) ||
-				BresenhamLine(strong_points[c_index], strong_points[a_index], h)) continue;
+			if (edge_test[a_index][b_index] == 0)
+				edge_test[a_index][b_index] = edge_test[b_index][a_index] = BresenhamLine(strong_points[a_index], strong_points[b_index], h) ? 1 : 2;
+			if (edge_test[b_index][c_index] == 0)
+				edge_test[b_index][c_index] = edge_test[c_index][b_index] = BresenhamLine(strong_points[b_index], strong_points[c_index], h) ? 1 : 2;
+			if (edge_test[c_index][a_index] == 0)
+				edge_test[c_index][a_index] = edge_test[a_index][c_index] = BresenhamLine(strong_points[c_index], strong_points[a_index], h) ? 1 : 2;
+			if (edge_test[a_index][b_index] == 1 || edge_test[b_index][c_index] == 1 || edge_test[c_index][a_index] == 1) continue;
 		}
 		const float3& A = strong_points_3d[a_index];
 		const float3& B = strong_points_3d[b_index];
