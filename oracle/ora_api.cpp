@@ -91,7 +91,7 @@ void ora_set_params(void* c, const PatchMatchParams* p) { Ctx& h = *(Ctx*)c; h.p
 void ora_set_seed(void* c, uint64_t seed) { ((Ctx*)c)->seed = seed; }
 void ora_set_sampler(void* c, int sampler) { ((Ctx*)c)->sampler = sampler; }
 // 0 = numerics contract (default), 1 = literal per-operator evaluation of the NCC expressions (KAT cross-check)
-void ora_set_numerics(void* c, int numerics) { ((Ctx*)c)->numerics = numerics; }
+void ora_set_numerics(void* c, int numerics) { ((Ctx*)c)->numerics = numerics; literal_mode() = numerics; }
 void ora_count_evals(void* c, int on) { Ctx& h = *(Ctx*)c; h.count_evals = on != 0; h.ncc_evals = 0; }
 long long ora_get_evals(void* c) { return ((Ctx*)c)->ncc_evals; }
 
@@ -221,7 +221,7 @@ int ora_run_patchmatch(void* c, double* iter_seconds) {
 }
 
 // function-level entry points for known-answer tests
-float ora_expf(float x) { return dvp_expf(x); }
+float ora_expf(float x) { return dvp_expf_contract(x); }
 uint32_t ora_rand_u32(uint64_t seed, uint32_t pixel, uint32_t site, uint32_t k) { return dvp_rand_u32(seed, pixel, site, k); }
 float ora_tex_linear(const float* img, int W, int H, float x, float y, int sampler) { return tex_linear(img, W, H, x, y, sampler); }
 void ora_homography(const Camera* ref, const Camera* src, const float* plane, float* H) {

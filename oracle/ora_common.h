@@ -52,6 +52,13 @@
 
 namespace ora {
 
+// numerics == 1 ("literal", Oracle.set_numerics): every site the numerics contract restates is evaluated
+// as the reference's SOURCE TEXT says instead — true divisions in ComputeHomography /
+// ComputeCorrespondingPoint, column-major single-chain moment sums, tex2D(x + 0.5f), libm expf, the
+// `complex` sigmoid in double.  Process-wide switch (the free functions below take no context); used by
+// tests only, to measure how far the contract is from a literal reading (tests/test_literal_mode.py).
+inline int& literal_mode() { static int v = 0; return v; }
+
 struct float4 { float x, y, z, w; };
 struct float3 { float x, y, z; };
 struct float2 { float x, y; };
@@ -122,7 +129,7 @@ static_assert(sizeof(PatchMatchParams) == 76, "PatchMatchParams layout");
 // exp: Cephes-style expf.  n = rint(x*log2e); r = x - n*ln2 (two-term); degree-6 polynomial;
 // scale by 2^n through the exponent field (two-step so that results down to the denormal range
 // stay correct).  Only fmaf/mul/add/rint: bit-identical on any IEEE-754 machine.
-inline float dvp_expf(float x) {
+inline float dvp_expf_contract(float x) {
 	if (!(x > -103.0f)) return (x != x) ? x : 0.0f;   // underflow (NaN propagates)
 	if (x > 88.72f) return INFINITY;
 	const float n = rintf(x * 1.44269504088896341f);
@@ -145,6 +152,8 @@ inline float dvp_expf(float x) {
 	std::memcpy(&s2, &b2, 4);
 	return (y * s1) * s2;
 }
+// exp() at the reference's call sites: the contract polynomial, or libm's expf in literal mode
+inline float dvp_expf(float x) { return literal_mode() ? expf(x) : dvp_expf_contract(x); }
 
 // ---------------------------------------------------------------------------------------------
 // Counter-based RNG (replaces curandState, APD.cu:1258-1271).  splitmix64 finaliser over a

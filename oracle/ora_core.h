@@ -334,19 +334,32 @@ inline void ComputeHomography(const Camera& ref_camera, const Camera& src_camera
 	// reciprocal of the divisor, one reciprocal per distinct divisor.  That is how the reference is
 	// actually compiled: nvcc --use_fast_math (CMakeLists.txt:21) implies -prec-div=false, i.e.
 	// a/b -> a * rcp(b) (div.approx.f32).  See the numerics contract in ora_common.h.
-	const float inv_w = 1.0f / pl.w;
-	const float inv_k0 = 1.0f / ref_camera.K[0];
-	const float inv_k4 = 1.0f / ref_camera.K[4];
-	for (int i = 0; i < 3; ++i) {
-		H[3 * i + 0] = R_relative[3 * i + 0] - t_relative[i] * pl.x * inv_w;
-		H[3 * i + 1] = R_relative[3 * i + 1] - t_relative[i] * pl.y * inv_w;
-		H[3 * i + 2] = R_relative[3 * i + 2] - t_relative[i] * pl.z * inv_w;
-	}
 	float tmp[9];
-	for (int i = 0; i < 3; ++i) {
-		tmp[3 * i + 0] = H[3 * i + 0] * inv_k0;
-		tmp[3 * i + 1] = H[3 * i + 1] * inv_k4;
-		tmp[3 * i + 2] = -H[3 * i + 0] * ref_camera.K[2] * inv_k0 - H[3 * i + 1] * ref_camera.K[5] * inv_k4 + H[3 * i + 2];
+	if (literal_mode()) {   // APD.cu:709-730 as written: a * b / c left to right, true divisions
+		for (int i = 0; i < 3; ++i) {
+			H[3 * i + 0] = R_relative[3 * i + 0] - t_relative[i] * pl.x / pl.w;
+			H[3 * i + 1] = R_relative[3 * i + 1] - t_relative[i] * pl.y / pl.w;
+			H[3 * i + 2] = R_relative[3 * i + 2] - t_relative[i] * pl.z / pl.w;
+		}
+		for (int i = 0; i < 3; ++i) {
+			tmp[3 * i + 0] = H[3 * i + 0] / ref_camera.K[0];
+			tmp[3 * i + 1] = H[3 * i + 1] / ref_camera.K[4];
+			tmp[3 * i + 2] = -H[3 * i + 0] * ref_camera.K[2] / ref_camera.K[0] - H[3 * i + 1] * ref_camera.K[5] / ref_camera.K[4] + H[3 * i + 2];
+		}
+	} else {
+		const float inv_w = 1.0f / pl.w;
+		const float inv_k0 = 1.0f / ref_camera.K[0];
+		const float inv_k4 = 1.0f / ref_camera.K[4];
+		for (int i = 0; i < 3; ++i) {
+			H[3 * i + 0] = R_relative[3 * i + 0] - t_relative[i] * pl.x * inv_w;
+			H[3 * i + 1] = R_relative[3 * i + 1] - t_relative[i] * pl.y * inv_w;
+			H[3 * i + 2] = R_relative[3 * i + 2] - t_relative[i] * pl.z * inv_w;
+		}
+		for (int i = 0; i < 3; ++i) {
+			tmp[3 * i + 0] = H[3 * i + 0] * inv_k0;
+			tmp[3 * i + 1] = H[3 * i + 1] * inv_k4;
+			tmp[3 * i + 2] = -H[3 * i + 0] * ref_camera.K[2] * inv_k0 - H[3 * i + 1] * ref_camera.K[5] * inv_k4 + H[3 * i + 2];
+		}
 	}
 	H[0] = src_camera.K[0] * tmp[0] + src_camera.K[2] * tmp[6];
 	H[1] = src_camera.K[0] * tmp[1] + src_camera.K[2] * tmp[7];
@@ -363,6 +376,7 @@ inline float2 ComputeCorrespondingPoint(const float* H, const int2 p) {   // APD
 	pt.x = H[0] * p.x + H[1] * p.y + H[2];
 	pt.y = H[3] * p.x + H[4] * p.y + H[5];
 	pt.z = H[6] * p.x + H[7] * p.y + H[8];
+	if (literal_mode()) return make_float2(pt.x / pt.z, pt.y / pt.z);
 	const float inv_z = 1.0f / pt.z;   // x/z, y/z as x*rcp(z), y*rcp(z): see ComputeHomography
 	return make_float2(pt.x * inv_z, pt.y * inv_z);
 }

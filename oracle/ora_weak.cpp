@@ -98,7 +98,8 @@ void GenEdgeInform_px(Ctx& h, const int2 point) {
 			float density = 1.0f * edge_pix / tot_pix;
 			// reference: 1.0f / (1.0f + exp(-25.0 * (density - 0.35))) in double (:3844); restated in
 			// binary32 with dvp_expf (documented deviation, ~1e-7 relative on a probability).
-			h.complex_[h.neighbours_map[center]] = 1.0f / (1.0f + dvp_expf(-25.0f * (density - 0.35f)));
+			if (literal_mode()) h.complex_[h.neighbours_map[center]] = (float)(1.0f / (1.0f + exp(-25.0 * (density - 0.35))));   // APD.cu:3844 in double
+			else h.complex_[h.neighbours_map[center]] = 1.0f / (1.0f + dvp_expf(-25.0f * (density - 0.35f)));
 		}
 		if (h.params.state == REFINE_INIT && h.params.use_detail && edge[center]) {
 			if (h.weak_info[center] != STRONG) h.weak_info[center] = UNKNOWN;
