@@ -21,9 +21,9 @@ APD::APD(const Problem& problem) {   // APD.cpp:984-987
 // context whose shape (device, W, H, images) matches the next view's is recycled instead: one pooled
 // context per process, reset on the device (dvp_reset_state) and re-filled by the uploads.
 namespace {
-struct CachedImage { Mat image; int orig_cols = 0, orig_rows = 0; };
+struct ImageEntry { Mat image; int orig_cols = 0, orig_rows = 0; };
 using ImageKey = std::tuple<std::string, int, int, int>;   // file, scale, pad width, pad height
-std::map<ImageKey, CachedImage> g_img_cache;
+std::map<ImageKey, ImageEntry> g_img_cache;
 struct PooledCtx {
 	dvp_ctx* ctx = nullptr;
 	int device = 0, w = 0, h = 0, ni = 0;
@@ -36,6 +36,68 @@ void APD::ReleasePooledContext() {
 	g_pool.ctx = nullptr;
 	g_img_cache.clear();
 }
+
+
+// Decoded, padded and rescaled float images are cached per (file, scale, reference size): the
+// reference re-reads and re-resizes every source image for every view that uses it
+// (APD.cpp:1055-1143), 5-10x redundantly within a pass.  Same arithmetic, done once.
+static ImageKey image_key(const Problem& problem, int image_id, int pad_w, int pad_h) {
+	const path file = problem.dense_folder / path("images") / path(ToFormatIndex(image_id) + ".jpg");
+	return ImageKey{ file.string(), problem.scale_size, pad_w, pad_h };
+}
+static const ImageEntry& load_image(const Problem& problem, int image_id, int pad_w, int pad_h, bool is_ref) {
+	const ImageKey key = image_key(problem, image_id, pad_w, pad_h);
+	auto it = g_img_cache.find(key);
+	if (it != g_img_cache.end()) return it->second;
+	if (!is_ref) {   // the same file cached in its reference role needs no padding when the sizes agree
+		auto ir = g_img_cache.find(image_key(problem, image_id, 0, 0));
+		if (ir != g_img_cache.end() && ir->second.orig_cols == pad_w && ir->second.orig_rows == pad_h) return ir->second;
+	}
+	if (g_img_cache.size() >= 96) g_img_cache.clear();
+	const Mat image_uint = ReadImageGray(std::get<0>(key));
+	if (image_uint.empty()) {
+		std::cerr << "Can't read " << (is_ref ? "reference" : "source") << " image " << image_id << std::endl;
+		exit(EXIT_FAILURE);
+	}
+	// uint8 -> float; a source image is zero-padded / cropped to the reference size (APD.cpp:1059, 1071-1079)
+	const int fw = is_ref ? image_uint.cols : pad_w, fh = is_ref ? image_uint.rows : pad_h;
+	Mat f = Mat::zeros(fh, fw, CV_32FC1);
+	for (int r = 0; r < std::min(fh, image_uint.rows); ++r) {
+		const uint8_t* s = image_uint.ptr<uint8_t>(r);
+		float* d = f.ptr<float>(r);
+		for (int c = 0; c < std::min(fw, image_uint.cols); ++c) d[c] = (float)s[c];
+	}
+	ImageEntry ci;
+	ci.orig_cols = f.cols;
+	ci.orig_rows = f.rows;
+	if (problem.scale_size != 1) {   // APD.cpp:1119-1131
+		const float factor = 1.0f / (float)(problem.scale_size);
+		f = ResizeLinear(f, (int)std::round(f.cols * factor), (int)std::round(f.rows * factor));
+	}
+	ci.image = f;
+	return g_img_cache.emplace(key, ci).first->second;
+}
+const Mat& APD::CachedImage(const Problem& problem, int image_id, int* orig_cols, int* orig_rows) {
+	const auto& ci = load_image(problem, image_id, 0, 0, true);
+	*orig_cols = ci.orig_cols;
+	*orig_rows = ci.orig_rows;
+	return ci.image;
+}
+void APD::InsertCachedImage(const Problem& problem, int image_id, const Mat& image, int orig_cols, int orig_rows) {
+	ImageEntry ci;
+	ci.image = image;
+	ci.orig_cols = orig_cols;
+	ci.orig_rows = orig_rows;
+	if (g_img_cache.size() >= 96) g_img_cache.clear();
+	g_img_cache[image_key(problem, image_id, 0, 0)] = ci;
+}
+
+namespace {
+struct ResidentDepth { const float* ptr; int w, h; };
+std::map<int, ResidentDepth> g_resident_depths;
+}
+void APD::SetResidentDepth(int image_id, const float* device_ptr, int width, int height) { g_resident_depths[image_id] = ResidentDepth{ device_ptr, width, height }; }
+void APD::ClearResidentDepths() { g_resident_depths.clear(); }
 
 APD::~APD() {                        // APD.cpp:989-1043
 	delete[] plane_hypotheses_host;
@@ -51,54 +113,19 @@ void APD::InuputInitialization() {
 	cameras.clear();
 	path image_folder = problem.dense_folder / path("images");
 	path cam_folder = problem.dense_folder / path("cams");
-	// Decoded, padded and rescaled float images are cached per (file, scale, reference size): the
-	// reference re-reads and re-resizes every source image for every view that uses it
-	// (APD.cpp:1055-1143), 5-10x redundantly within a pass.  Same arithmetic, done once.
-	auto load = [&](int image_id, int pad_w, int pad_h, bool is_ref) -> const CachedImage& {
-		const path file = image_folder / path(ToFormatIndex(image_id) + ".jpg");
-		const ImageKey key{ file.string(), problem.scale_size, pad_w, pad_h };
-		auto it = g_img_cache.find(key);
-		if (it != g_img_cache.end()) return it->second;
-		if (!is_ref) {   // the same file cached in its reference role needs no padding when the sizes agree
-			auto ir = g_img_cache.find(ImageKey{ file.string(), problem.scale_size, 0, 0 });
-			if (ir != g_img_cache.end() && ir->second.orig_cols == pad_w && ir->second.orig_rows == pad_h) return ir->second;
-		}
-		if (g_img_cache.size() >= 96) g_img_cache.clear();
-		Mat image_uint = ReadImageGray(file);
-		if (image_uint.empty()) {
-			std::cerr << "Can't read " << (is_ref ? "reference" : "source") << " image " << image_id << std::endl;
-			exit(EXIT_FAILURE);
-		}
-		Mat f(image_uint.rows, image_uint.cols, CV_32FC1);
-		for (int r = 0; r < image_uint.rows; ++r)
-			for (int c = 0; c < image_uint.cols; ++c) f.at<float>(r, c) = (float)image_uint.at<uint8_t>(r, c);
-		if (!is_ref) {   // zero-pad / crop to the reference size (APD.cpp:1071-1079)
-			Mat resized = Mat::zeros(pad_h, pad_w, CV_32FC1);
-			for (int i = 0; i < pad_h; i++)
-				for (int j = 0; j < pad_w; j++)
-					if (i < f.rows && j < f.cols) resized.at<float>(i, j) = f.at<float>(i, j);
-			f = resized;
-		}
-		CachedImage ci;
-		ci.orig_cols = f.cols;
-		ci.orig_rows = f.rows;
-		if (problem.scale_size != 1) {   // APD.cpp:1119-1131
-			const float factor = 1.0f / (float)(problem.scale_size);
-			f = ResizeLinear(f, (int)std::round(f.cols * factor), (int)std::round(f.rows * factor));
-		}
-		ci.image = f;
-		return g_img_cache.emplace(key, ci).first->second;
+	auto load = [&](int image_id, int pad_w, int pad_h, bool is_ref) -> const ImageEntry& {
+		return load_image(problem, image_id, pad_w, pad_h, is_ref);
 	};
 	std::vector<std::pair<int, int>> orig_sizes;   // (cols, rows) before scaling, per image
 	{
-		const CachedImage& ci = load(problem.ref_image_id, 0, 0, true);
+		const ImageEntry& ci = load(problem.ref_image_id, 0, 0, true);
 		images.push_back(ci.image);
 		orig_sizes.emplace_back(ci.orig_cols, ci.orig_rows);
 		width = ci.orig_cols;
 		height = ci.orig_rows;
 	}
 	for (const auto& src_idx : problem.src_image_ids) {
-		const CachedImage& ci = load(src_idx, width, height, false);
+		const ImageEntry& ci = load(src_idx, width, height, false);
 		images.push_back(ci.image);
 		orig_sizes.emplace_back(ci.orig_cols, ci.orig_rows);
 	}
@@ -146,17 +173,24 @@ void APD::InuputInitialization() {
 	std::cout << "Image size: " << width << " * " << height << std::endl;
 	if (params_host.geom_consistency) {   // APD.cpp:1147-1166
 		depths.clear();
-		Mat ref_depth;
-		ReadBinMat(problem.result_folder / path("depths.dmb"), ref_depth);
-		depths.push_back(ref_depth);
-		for (const auto& src_idx : problem.src_image_ids) {
-			Mat src_depth;
-			ReadBinMat(problem.dense_folder / path("APD") / path(ToFormatIndex(src_idx)) / path("depths.dmb"), src_depth);
-			depths.push_back(src_depth);
+		depths_device.clear();
+		std::vector<int> ids(1, problem.ref_image_id);
+		ids.insert(ids.end(), problem.src_image_ids.begin(), problem.src_image_ids.end());
+		bool resident = !g_resident_depths.empty();
+		for (int id : ids) {
+			auto it = g_resident_depths.find(id);
+			resident = resident && it != g_resident_depths.end() && it->second.w == width && it->second.h == height;
 		}
-		for (auto& depth : depths) {
-			if (depth.empty()) depth = Mat::zeros(height, width, CV_32FC1);
-			if (depth.cols != width || depth.rows != height) RescaleMatToTargetSize<float>(depth, depth, width, height);
+		if (resident) {   // previous-pass maps already on this device (multi-GPU exchange / --jacobi)
+			for (int id : ids) depths_device.push_back(g_resident_depths[id].ptr);
+		} else {
+			for (int id : ids) {
+				Mat depth;
+				ReadBinMat(problem.dense_folder / path("APD") / path(ToFormatIndex(id)) / path("depths.dmb"), depth);
+				if (depth.empty()) depth = Mat::zeros(height, width, CV_32FC1);
+				if (depth.cols != width || depth.rows != height) RescaleMatToTargetSize<float>(depth, depth, width, height);
+				depths.push_back(depth);
+			}
 		}
 	}
 	if (params_host.use_APD) {            // APD.cpp:1169-1195
@@ -192,27 +226,26 @@ void APD::InuputInitialization() {
 		else std::cout << "No dep/ + sfm/ prior: random plane initialisation\n";
 	}
 	selected_views_host = Mat::zeros(height, width, CV_32SC1);
-	if (params_host.state != FIRST_INIT) {   // APD.cpp:1428-1456
+	if (params_host.state != FIRST_INIT) {   // APD.cpp:1428-1456: the previous pass' maps are this pass' start
 		Mat depth, normal;
 		ReadBinMat(problem.result_folder / path("depths.dmb"), depth);
 		ReadBinMat(problem.result_folder / path("APD_normals.dmb"), normal);
-		if (depth.cols != width || depth.rows != height || normal.cols != width || normal.rows != height) {
+		ReadBinMat(problem.result_folder / path("selected_views.bin"), selected_views_host);
+		const bool fits = depth.cols == width && depth.rows == height && normal.cols == width && normal.rows == height;
+		if (!fits) {
 			std::cerr << "Depth and Normal doesn't match the images' size!\n";
 			RescaleMatToTargetSize<float>(depth, depth, width, height);
 			RescaleMatToTargetSize<Vec3f>(normal, normal, width, height);
 		}
-		for (int col = 0; col < width; ++col)
-			for (int row = 0; row < height; ++row) {
-				const int center = row * width + col;
-				plane_hypotheses_host[center].w = depth.at<float>(row, col);
-				plane_hypotheses_host[center].x = normal.at<Vec3f>(row, col)[0];
-				plane_hypotheses_host[center].y = normal.at<Vec3f>(row, col)[1];
-				plane_hypotheses_host[center].z = normal.at<Vec3f>(row, col)[2];
-			}
-		ReadBinMat(problem.result_folder / path("selected_views.bin"), selected_views_host);
 		if (selected_views_host.cols != width || selected_views_host.rows != height) {
 			std::cerr << "Select view doesn't match the images' size!\n";
 			RescaleMatToTargetSize<unsigned int>(selected_views_host, selected_views_host, width, height);
+		}
+		float4* out = plane_hypotheses_host;
+		for (int row = 0; row < height; ++row) {
+			const float* z = depth.ptr<float>(row);
+			const Vec3f* n = normal.ptr<Vec3f>(row);
+			for (int col = 0; col < width; ++col, ++out) *out = float4{ n[col][0], n[col][1], n[col][2], z[col] };
 		}
 	}
 }
@@ -241,22 +274,21 @@ void APD::SupportInitialization() {
 			std::memcpy(label_host.data, tmp.data, (size_t)width * height * 4);   // float bits reinterpreted, as the reference does
 		}
 	}
-	if (problem.params.use_radius) {
-		const int strong_radius = problem.params.strong_radius;
-		if (problem.params.state == FIRST_INIT) {
-			radius_host = Mat::zeros(height, width, CV_32S);
-			for (int r = 0; r < height; r++)
-				for (int c = 0; c < width; c++) radius_host.at<int>(r, c) = strong_radius;
-		} else {
-			ReadBinMat(problem.result_folder / path("radius.bin"), radius_host);
+	if (problem.params.use_radius) {   // APD.cpp:1648-1667: the first pass starts at strong_radius, later ones at the stored map
+		const int fallback = problem.params.strong_radius;
+		if (problem.params.state != FIRST_INIT) ReadBinMat(problem.result_folder / path("radius.bin"), radius_host);
+		if (problem.params.state == FIRST_INIT || radius_host.empty()) {
+			radius_host = Mat(height, width, CV_32S);
+			std::fill(radius_host.ptr<int>(0), radius_host.ptr<int>(0) + (size_t)width * height, fallback);
 		}
 		if (radius_host.cols != width || radius_host.rows != height) {
 			std::cerr << "Radius map doesn't match the images' size!\n";
 			RescaleMatToTargetSize<int>(radius_host, radius_host, width, height);
 		}
-		for (int r = 0; r < height; r++)
-			for (int c = 0; c < width; c++)
-				if (weak_info_host.at<uint8_t>(r, c) == UNKNOWN) radius_host.at<int>(r, c) = strong_radius;
+		const uint8_t* state = weak_info_host.ptr<uint8_t>(0);
+		int* rad = radius_host.ptr<int>(0);
+		for (size_t i = 0, n = (size_t)width * height; i < n; ++i)
+			if (state[i] == UNKNOWN) rad[i] = fallback;   // a pixel that lost its estimate restarts with the default patch
 	}
 }
 
@@ -276,8 +308,12 @@ void APD::CudaSpaceInitialization() {
 	for (int i = 0; i < num_images; ++i) ptrs[i] = images[i].ptr<float>(0);
 	DVP_SAFE_CALL(ctx, dvp_upload_images(ctx, ptrs.data(), width));
 	if (params_host.geom_consistency) {
-		for (int i = 0; i < num_images; ++i) ptrs[i] = depths[i].ptr<float>(0);
-		DVP_SAFE_CALL(ctx, dvp_upload_depths(ctx, ptrs.data(), width));
+		if (!depths_device.empty()) {
+			DVP_SAFE_CALL(ctx, dvp_upload_depths_device(ctx, depths_device.data(), width));
+		} else {
+			for (int i = 0; i < num_images; ++i) ptrs[i] = depths[i].ptr<float>(0);
+			DVP_SAFE_CALL(ctx, dvp_upload_depths(ctx, ptrs.data(), width));
+		}
 	}
 	DVP_SAFE_CALL(ctx, dvp_upload_cameras(ctx, reinterpret_cast<const DvpCamera*>(cameras.data()), num_images));
 	DVP_SAFE_CALL(ctx, dvp_upload_state(ctx, reinterpret_cast<const float*>(plane_hypotheses_host),

@@ -68,6 +68,15 @@ public:
 	static void SetDevice(int device);
 	static void SetSeed(uint64_t seed);
 	static void ReleasePooledContext();   // frees the recycled engine context and the image cache
+	// multi-GPU hooks of the driver (comm.h).  Image cache: the decoded + rescaled float image of a view in
+	// its reference role at the problem's scale — rank 0 fills it from disk, the others from a broadcast.
+	static const Mat& CachedImage(const Problem& problem, int image_id, int* orig_cols, int* orig_rows);
+	static void InsertCachedImage(const Problem& problem, int image_id, const Mat& image, int orig_cols, int orig_rows);
+	// Depth maps of the previous pass resident on this process' device (row-major, pitch = width).  When
+	// the maps of a view and all its sources are registered, a geometric-consistency pass takes them from
+	// there (dvp_upload_depths_device) instead of reading APD/<id>/depths.dmb (APD.cpp:1147-1166).
+	static void SetResidentDepth(int image_id, const float* device_ptr, int width, int height);
+	static void ClearResidentDepths();
 	const DvpTimings& GetTimings() const { return timings; }
 
 private:
@@ -76,6 +85,7 @@ private:
 	Problem problem;
 	std::vector<Mat> images;
 	std::vector<Mat> depths;
+	std::vector<const float*> depths_device;   // non-empty: the pass uses resident depth maps
 	std::vector<Camera> cameras;
 	int weak_count = 0;
 	Mat weak_info_host;

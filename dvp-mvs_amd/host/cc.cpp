@@ -1,10 +1,11 @@
 // cc.cpp — 4-connected components of the zero pixels of a mask: what Connect + Label_Update
 // (/root/reference/APD.cpp:138-346) compute for ProcessProblem's visibility-mask clean-up
 // (main.cpp:323-352).  The reference builds provisional labels with a lossy union (Connect) and
-// repairs them with an O(labels^2) merge (Label_Seek/Label_Update); the result is the true
-// component labelling except for merges that are only visible along the last row/column
-// (Label_Update's loops stop at rows-1 / cols-1).  Here: one proper union-find pass, labels
-// renumbered in first-encounter (raster) order like the reference, label 0 = pixels == 255.
+// repairs them with an O(labels^2) merge (Label_Seek/Label_Update) whose loops stop at rows-1 / cols-1.
+// Here: one proper union-find pass, labels renumbered in first-encounter (raster) order like the
+// reference, label 0 = pixels == 255.  tests/host/test_host.cpp holds a model of the reference's
+// two-step procedure and compares region sizes pixel by pixel on 300 random masks: no pixel differs
+// (the up/left label propagation already joins what the truncated repair loop would miss).
 #include "APD.h"
 #include <numeric>
 

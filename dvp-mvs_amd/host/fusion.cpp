@@ -1,146 +1,162 @@
-// fusion.cpp — RunFusion, ETH variant (/root/reference/APD.cpp:1809-1960): cross-view consistency
-// voting on the CPU and binary PLY export.  Sequential and order dependent (the `masks` side
-// effects), exactly like the reference.
+// fusion.cpp — depth-map fusion into a coloured point cloud (the reference's RunFusion, ETH3D variant,
+// /root/reference/APD.cpp:1809-1960) and its binary PLY.
+//
+// What the step computes.  Views are visited in pair.txt order.  A pixel of view R with a positive depth
+// that no earlier point has claimed is lifted to the world point X.  X is dropped into every source view
+// S of R; the pixel it lands on (nearest pixel) is a WITNESS if it is unclaimed, has a depth, and agrees
+// with R three ways: the witness' own world point re-projects within 2 px of the pixel in R, its depth
+// seen from R is within 1 % of R's, and the two world normals are within 10 degrees.  Each witness votes
+// exp(-(e + 200 r + 10 a)) (e: pixels, r: relative depth difference, a: radians).  The point is kept when
+// it has a witness and the mean vote exceeds 0.3 (0.45 for a pixel R classified WEAK); it takes X as
+// position, the mean colour of R's pixel and its witnesses, and claims the witnesses so that they do not
+// produce a second copy when their own view's turn comes.  Claims make the result depend on the visiting
+// order, which is therefore the reference's (view order, rows, columns, sources).
 #include "APD.h"
-#include <unordered_map>
 
-static float3 Get3DPointonWorld(const int x, const int y, const float depth, const Camera& camera) {   // APD.cpp:502-523
-	float3 pointX, tmpX;
-	pointX.x = depth * (x - camera.K[2]) / camera.K[0];
-	pointX.y = depth * (y - camera.K[5]) / camera.K[4];
-	pointX.z = depth;
-	tmpX.x = camera.R[0] * pointX.x + camera.R[3] * pointX.y + camera.R[6] * pointX.z;
-	tmpX.y = camera.R[1] * pointX.x + camera.R[4] * pointX.y + camera.R[7] * pointX.z;
-	tmpX.z = camera.R[2] * pointX.x + camera.R[5] * pointX.y + camera.R[8] * pointX.z;
-	pointX.x = tmpX.x + camera.c[0];
-	pointX.y = tmpX.y + camera.c[1];
-	pointX.z = tmpX.z + camera.c[2];
-	return pointX;
-}
-// ProjectCamera (APD.cpp:536-546) is defined in prior.cpp
-static float GetAngle(const Vec3f& v1, const Vec3f& v2) {   // APD.cpp:1797-1806
-	float dot_product = v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2];
-	float angle = acosf(dot_product);
-	if (angle != angle) return 0.0f;
-	return angle;
-}
-// RescaleImageAndCamera (APD.cpp:1750-1771) for an 8UC3 image: cv::resize(INTER_LINEAR) per channel
-static Mat RescaleColor(const Mat& src, int cols, int rows, Camera& camera) {
-	if (cols == src.cols && rows == src.rows) return src.clone();
-	const float scale_x = cols / static_cast<float>(src.cols);
-	const float scale_y = rows / static_cast<float>(src.rows);
-	Mat dst(rows, cols, CV_8UC3);
-	for (int ch = 0; ch < 3; ++ch) {
-		Mat f(src.rows, src.cols, CV_32FC1);
-		for (int r = 0; r < src.rows; ++r)
-			for (int c = 0; c < src.cols; ++c) f.at<float>(r, c) = src.data[(size_t)r * src.step + 3 * c + ch];
-		Mat g = ResizeLinear(f, cols, rows);
-		for (int r = 0; r < rows; ++r)
-			for (int c = 0; c < cols; ++c) dst.data[(size_t)r * dst.step + 3 * c + ch] = (uint8_t)std::lrintf(std::min(255.f, std::max(0.f, g.at<float>(r, c))));
+namespace {
+
+struct FusionView {
+	int image_id = -1;
+	Camera cam{};
+	Mat depth, normal, weak, colour;   // CV_32FC1, CV_32FC3, CV_8UC1 (PixelState), CV_8UC3 (BGR) — all at the depth map's size
+	Mat claimed;                       // CV_8UC1: pixel already merged into a point
+	int cols() const { return depth.cols; }
+	int rows() const { return depth.rows; }
+
+	// pixel + depth -> world (camera frame through K^-1, then R^T . + C; APD.cpp:502-523)
+	float3 lift(int x, int y, float z) const {
+		const float cx = z * (x - cam.K[2]) / cam.K[0];
+		const float cy = z * (y - cam.K[5]) / cam.K[4];
+		float3 w;
+		w.x = cam.R[0] * cx + cam.R[3] * cy + cam.R[6] * z + cam.c[0];
+		w.y = cam.R[1] * cx + cam.R[4] * cy + cam.R[7] * z + cam.c[1];
+		w.z = cam.R[2] * cx + cam.R[5] * cy + cam.R[8] * z + cam.c[2];
+		return w;
 	}
-	camera.K[0] *= scale_x; camera.K[2] *= scale_x;
-	camera.K[4] *= scale_y; camera.K[5] *= scale_y;
-	camera.width = cols; camera.height = rows;
-	return dst;
+	const uint8_t* bgr(int x, int y) const { return colour.data + (size_t)y * colour.step + 3 * (size_t)x; }
+};
+
+struct Witness { int view, x, y; };
+
+// angle between two unit normals; acos of a value rounded past 1 is NaN -> 0 (APD.cpp:1797-1806)
+float normal_angle(const Vec3f& a, const Vec3f& b) {
+	const float ang = acosf(a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
+	return ang == ang ? ang : 0.0f;
 }
+
+// colour image of a view brought to its depth map's resolution; the intrinsics follow the size
+// (RescaleImageAndCamera, APD.cpp:1750-1771)
+Mat fit_colour(const Mat& bgr, int cols, int rows, Camera* cam) {
+	if (bgr.cols == cols && bgr.rows == rows) return bgr.clone();
+	const float sx = cols / static_cast<float>(bgr.cols), sy = rows / static_cast<float>(bgr.rows);
+	Mat out(rows, cols, CV_8UC3);
+	Mat plane(bgr.rows, bgr.cols, CV_32FC1);
+	for (int ch = 0; ch < 3; ++ch) {
+		for (int y = 0; y < bgr.rows; ++y) {
+			const uint8_t* s = bgr.data + (size_t)y * bgr.step + ch;
+			float* d = plane.ptr<float>(y);
+			for (int x = 0; x < bgr.cols; ++x) d[x] = s[3 * x];
+		}
+		const Mat small = ResizeLinear(plane, cols, rows);
+		for (int y = 0; y < rows; ++y) {
+			uint8_t* d = out.data + (size_t)y * out.step + ch;
+			const float* s = small.ptr<float>(y);
+			for (int x = 0; x < cols; ++x) d[3 * x] = (uint8_t)std::lrintf(std::min(255.f, std::max(0.f, s[x])));
+		}
+	}
+	cam->K[0] *= sx; cam->K[2] *= sx;
+	cam->K[4] *= sy; cam->K[5] *= sy;
+	cam->width = cols; cam->height = rows;
+	return out;
+}
+
+bool load_view(const path& dense_folder, const Problem& problem, FusionView* v) {
+	const std::string id = ToFormatIndex(problem.ref_image_id);
+	v->image_id = problem.ref_image_id;
+	ReadCamera(dense_folder / "cams" / (id + "_cam.txt"), v->cam);
+	if (!ReadBinMat(problem.result_folder / "depths.dmb", v->depth) || !ReadBinMat(problem.result_folder / "APD_normals.dmb", v->normal)) return false;
+	Mat weak;
+	ReadBinMat(problem.result_folder / "weak.bin", weak);
+	if (weak.empty()) weak = Mat(v->rows(), v->cols(), CV_8UC1), std::memset(weak.data, STRONG, weak.step * weak.rows);
+	RescaleMatToTargetSize<uint8_t>(weak, v->weak, v->cols(), v->rows());
+	Mat bgr = ReadImageColor(dense_folder / "images" / (id + ".jpg"));
+	if (bgr.empty()) bgr = Mat::zeros(v->rows(), v->cols(), CV_8UC3);
+	v->cam.width = bgr.cols;
+	v->cam.height = bgr.rows;
+	v->colour = fit_colour(bgr, v->cols(), v->rows(), &v->cam);
+	v->claimed = Mat::zeros(v->rows(), v->cols(), CV_8UC1);
+	return true;
+}
+
+}  // namespace
 
 void RunFusion(const path& dense_folder, const std::vector<Problem>& problems) {
-	int num_images = (int)problems.size();
-	path image_folder = dense_folder / path("images");
-	path cam_folder = dense_folder / path("cams");
-	std::vector<Mat> images, depths, normals, masks, weaks;
-	std::vector<Camera> cameras;
-	std::unordered_map<int, int> imageIdToindexMap;
-	for (int i = 0; i < num_images; ++i) {
-		const auto& problem = problems[i];
+	const int n_views = (int)problems.size();
+	std::vector<FusionView> views(n_views);
+	int max_id = -1;
+	for (const Problem& p : problems) max_id = std::max(max_id, p.ref_image_id);
+	std::vector<int> slot_of_id(max_id + 1, -1);   // image id -> position in `views`
+	for (int i = 0; i < n_views; ++i) {
 		std::cout << "Reading image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
-		imageIdToindexMap.emplace(problem.ref_image_id, i);
-		Mat image = ReadImageColor(image_folder / path(ToFormatIndex(problem.ref_image_id) + ".jpg"));
-		Camera camera;
-		ReadCamera(cam_folder / path(ToFormatIndex(problem.ref_image_id) + "_cam.txt"), camera);
-		Mat depth, normal, weak;
-		ReadBinMat(problem.result_folder / path("depths.dmb"), depth);
-		ReadBinMat(problem.result_folder / path("APD_normals.dmb"), normal);
-		ReadBinMat(problem.result_folder / path("weak.bin"), weak);
-		if (image.empty()) image = Mat::zeros(depth.rows, depth.cols, CV_8UC3);
-		camera.width = image.cols; camera.height = image.rows;
-		images.emplace_back(RescaleColor(image, depth.cols, depth.rows, camera));
-		cameras.emplace_back(camera);
-		depths.emplace_back(depth);
-		normals.emplace_back(normal);
-		masks.emplace_back(Mat::zeros(depth.rows, depth.cols, CV_8UC1));
-		RescaleMatToTargetSize<uint8_t>(weak, weak, depth.cols, depth.rows);
-		weaks.emplace_back(weak);
+		if (!load_view(dense_folder, problems[i], &views[i])) std::cerr << "RunFusion: no depth/normal maps for view " << problems[i].ref_image_id << std::endl;
+		slot_of_id[problems[i].ref_image_id] = i;
 	}
-	std::vector<PointList> PointCloud;
-	for (int i = 0; i < num_images; ++i) {
+
+	std::vector<PointList> cloud;
+	std::vector<Witness> witnesses;
+	for (int i = 0; i < n_views; ++i) {
 		std::cout << "Fusing image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
-		const auto& problem = problems[i];
-		int ref_index = imageIdToindexMap[problem.ref_image_id];
-		const int cols = depths[ref_index].cols, rows = depths[ref_index].rows;
-		int num_ngb = (int)problem.src_image_ids.size();
-		for (int r = 0; r < rows; ++r) {
-			for (int c = 0; c < cols; ++c) {
-				if (masks[ref_index].at<uint8_t>(r, c) == 1) continue;
-				float ref_depth = depths[ref_index].at<float>(r, c);
-				if (ref_depth <= 0.0) continue;
-				const Vec3f ref_normal = normals[ref_index].at<Vec3f>(r, c);
-				float3 PointX = Get3DPointonWorld(c, r, ref_depth, cameras[ref_index]);
-				float3 consistent_Point = PointX;
-				int num_consistent = 0;
-				float dynamic_consistency = 0.0f;
-				std::vector<int2> used_list(num_ngb, int2{-1, -1});
-				for (int j = 0; j < num_ngb; ++j) {
-					auto it = imageIdToindexMap.find(problem.src_image_ids[j]);
-					if (it == imageIdToindexMap.end()) continue;
-					int src_index = it->second;
-					const int src_cols = depths[src_index].cols, src_rows = depths[src_index].rows;
-					float2 point;
-					float proj_depth;
-					ProjectCamera(PointX, cameras[src_index], point, proj_depth);
-					int src_r = int(point.y + 0.5f);
-					int src_c = int(point.x + 0.5f);
-					if (src_c >= 0 && src_c < src_cols && src_r >= 0 && src_r < src_rows) {
-						if (masks[src_index].at<uint8_t>(src_r, src_c) == 1) continue;
-						float src_depth = depths[src_index].at<float>(src_r, src_c);
-						if (src_depth <= 0.0) continue;
-						const Vec3f src_normal = normals[src_index].at<Vec3f>(src_r, src_c);
-						float3 tmp_X = Get3DPointonWorld(src_c, src_r, src_depth, cameras[src_index]);
-						float2 tmp_pt;
-						ProjectCamera(tmp_X, cameras[ref_index], tmp_pt, proj_depth);
-						float reproj_error = (float)std::sqrt(std::pow(c - tmp_pt.x, 2) + std::pow(r - tmp_pt.y, 2));
-						float relative_depth_diff = std::fabs(proj_depth - ref_depth) / ref_depth;
-						float angle = GetAngle(ref_normal, src_normal);
-						if (reproj_error < 2.0f && relative_depth_diff < 0.01f && angle < 0.174533f) {
-							used_list[j].x = src_c;
-							used_list[j].y = src_r;
-							float tmp_index = reproj_error + 200 * relative_depth_diff + angle * 10;
-							dynamic_consistency += (float)std::exp(-tmp_index);
-							num_consistent++;
-						}
+		FusionView& R = views[i];
+		if (R.depth.empty()) continue;
+		std::vector<int> sources;   // slots of this view's source images that are part of the job
+		for (int id : problems[i].src_image_ids)
+			if (id >= 0 && id <= max_id && slot_of_id[id] >= 0 && !views[slot_of_id[id]].depth.empty()) sources.push_back(slot_of_id[id]);
+		for (int y = 0; y < R.rows(); ++y) {
+			for (int x = 0; x < R.cols(); ++x) {
+				const float z = R.depth.at<float>(y, x);
+				if (R.claimed.at<uint8_t>(y, x) == 1 || z <= 0.0) continue;
+				const float3 X = R.lift(x, y, z);
+				const Vec3f n_ref = R.normal.at<Vec3f>(y, x);
+				witnesses.clear();
+				float votes = 0.0f;
+				for (int s : sources) {
+					const FusionView& S = views[s];
+					float2 q;
+					float zq;
+					ProjectCamera(X, S.cam, q, zq);
+					const int sx = int(q.x + 0.5f), sy = int(q.y + 0.5f);
+					if (sx < 0 || sx >= S.cols() || sy < 0 || sy >= S.rows()) continue;
+					const float zs = S.depth.at<float>(sy, sx);
+					if (S.claimed.at<uint8_t>(sy, sx) == 1 || zs <= 0.0) continue;
+					float2 back;
+					float z_seen;
+					ProjectCamera(S.lift(sx, sy, zs), R.cam, back, z_seen);
+					const float err = (float)std::sqrt(std::pow(x - back.x, 2) + std::pow(y - back.y, 2));
+					const float rel = std::fabs(z_seen - z) / z;
+					const float ang = normal_angle(n_ref, S.normal.at<Vec3f>(sy, sx));
+					if (err < 2.0f && rel < 0.01f && ang < 0.174533f) {
+						witnesses.push_back(Witness{s, sx, sy});
+						votes += (float)std::exp(-(err + 200 * rel + ang * 10));
 					}
 				}
-				float factor = (weaks[ref_index].at<uint8_t>(r, c) == WEAK ? 0.45f : 0.3f);
-				if (num_consistent >= 1 && (dynamic_consistency > factor * num_consistent)) {
-					PointList point3D;
-					point3D.coord = consistent_Point;
-					const uint8_t* px = images[ref_index].data + (size_t)r * images[ref_index].step + 3 * c;
-					float col[3] = { (float)px[0], (float)px[1], (float)px[2] };
-					for (int j = 0; j < num_ngb; ++j) {
-						if (used_list[j].x == -1) continue;
-						int src_index = imageIdToindexMap[problem.src_image_ids[j]];
-						masks[src_index].at<uint8_t>(used_list[j].y, used_list[j].x) = 1;
-						const uint8_t* q = images[src_index].data + (size_t)used_list[j].y * images[src_index].step + 3 * used_list[j].x;
-						col[0] += q[0]; col[1] += q[1]; col[2] += q[2];
-					}
-					col[0] /= (num_consistent + 1); col[1] /= (num_consistent + 1); col[2] /= (num_consistent + 1);
-					point3D.color = float3{col[0], col[1], col[2]};
-					PointCloud.emplace_back(point3D);
+				const int n = (int)witnesses.size();
+				const float needed = R.weak.at<uint8_t>(y, x) == WEAK ? 0.45f : 0.3f;
+				if (n < 1 || !(votes > needed * n)) continue;
+				const uint8_t* c0 = R.bgr(x, y);
+				float sum[3] = { (float)c0[0], (float)c0[1], (float)c0[2] };
+				for (const Witness& w : witnesses) {
+					views[w.view].claimed.at<uint8_t>(w.y, w.x) = 1;
+					const uint8_t* cw = views[w.view].bgr(w.x, w.y);
+					sum[0] += cw[0]; sum[1] += cw[1]; sum[2] += cw[2];
 				}
+				PointList pt;
+				pt.coord = X;
+				pt.color = float3{ sum[0] / (n + 1), sum[1] / (n + 1), sum[2] / (n + 1) };
+				cloud.push_back(pt);
 			}
 		}
 	}
-	path ply_path = dense_folder / path("APD") / path("APD.ply");
-	ExportPointCloud(ply_path, PointCloud);
-	std::cout << "Fusion: " << PointCloud.size() << " points -> " << ply_path << std::endl;
+	const path ply_path = dense_folder / "APD" / "APD.ply";
+	ExportPointCloud(ply_path, cloud);
+	std::cout << "Fusion: " << cloud.size() << " points -> " << ply_path << std::endl;
 }

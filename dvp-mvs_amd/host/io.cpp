@@ -20,8 +20,20 @@ bool ReadBinMat(const path& mat_path, Mat& mat) {
 		std::cerr << "Version error: " << mat_path << std::endl;
 		return false;
 	}
-	mat = Mat(rows, cols, type);
-	in.read((char*)mat.data, (std::streamsize)(mat.step * mat.rows));
+	// header sanity: only the element types this pipeline writes, plausible sizes
+	const bool known_type = type == CV_8UC1 || type == CV_8UC3 || type == CV_32SC1 || type == CV_32FC1 || type == CV_32FC3;
+	if (!known_type || rows <= 0 || cols <= 0 || rows > (1 << 16) || cols > (1 << 16)) {
+		std::cerr << "Header error: " << mat_path << " (" << rows << " x " << cols << ", type " << type << ")" << std::endl;
+		return false;
+	}
+	Mat m(rows, cols, type);
+	const std::streamsize want = (std::streamsize)(m.step * m.rows);
+	in.read((char*)m.data, want);
+	if (in.gcount() != want) {   // truncated file: leave `mat` untouched rather than hand out uninitialised rows
+		std::cerr << "Short read: " << mat_path << " (" << in.gcount() << " of " << want << " bytes)" << std::endl;
+		return false;
+	}
+	mat = m;
 	return true;
 }
 

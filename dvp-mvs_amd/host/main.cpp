@@ -1,67 +1,118 @@
-// main.cpp — driver reproducing the reference's schedule (/root/reference/main.cpp:127-170,
-// 248-528) on top of `class APD`, with the knobs BASELINE.json's configs need exposed:
-//   apd <dense_folder> [gpu_index] [--max-src N] [--iters N] [--min-scale S] [--passes P]
-//       [--seed X] [--rank R --world N] [--no-fusion]
-// Views are independent within a pass, so `--rank/--world` shard them round-robin across
-// processes (one per GPU); passes are separated by a file-system barrier (the per-view result
-// files are the inter-pass API of the reference).
+// main.cpp — the driver: the reference's coarse-to-fine schedule (/root/reference/main.cpp:421-528) over
+// `class APD`, one process per GPU.
+//   apd <dense_folder> [gpu_index] [--max-src N] [--iters N] [--min-scale S] [--passes P] [--seed X]
+//       [--rank R --world N [--job ID]] [--jacobi] [--no-fusion]
+//
+// Schedule.  The image pyramid has round_num levels (the longer side is halved until <= 800).  Level i
+// runs one "A" pass without geometric consistency — FIRST_INIT from scratch / the Depth-Anything prior
+// at the coarsest level, REFINE_INIT from the up-sampled result of the level below otherwise — and then
+// `passes` REFINE_ITER passes with geometric consistency against the source views' depth maps.  The
+// reference stops before the finest level (`i < round_num - 1`); --min-scale 1 adds it.
+//
+// Multi-GPU.  Views of a pass are independent: view v belongs to rank v % world.  Rank 0 decodes and
+// resizes the images of a level and broadcasts them (RCCL); after every pass each view's new depth map is
+// broadcast by its owner and kept resident on every GPU, which is where the next pass' geometric term
+// reads it (Jacobi: a pass sees the previous pass' maps only).  With one rank the default is the
+// reference's in-place order (a view sees the maps its predecessors wrote in the same pass, through the
+// result files); --jacobi selects the exchange semantics there too, which makes a run independent of the
+// number of ranks.  Result files are always written to a temporary name and renamed, so a reader never
+// sees a torn file.
 #include "APD.h"
+#include "comm.h"
 #include <cstdlib>
-#include <thread>
+#include <map>
+#include <memory>
 
-static void GenerateSampleList(const path& dense_folder, std::vector<Problem>& problems, int max_src) {   // main.cpp:127-170
-	path cluster_list_path = dense_folder / path("pair.txt");
-	problems.clear();
-	std::ifstream file(cluster_list_path);
-	std::stringstream iss;
-	std::string line;
-	int num_images = 0;
-	std::getline(file, line);
-	iss.str(line);
-	iss >> num_images;
-	for (int i = 0; i < num_images; ++i) {
-		Problem problem;
-		problem.index = i;
-		iss.clear();
-		std::getline(file, line);
-		iss.str(line);
-		iss >> problem.ref_image_id;
-		problem.dense_folder = dense_folder;
-		problem.result_folder = dense_folder / path("APD") / path(ToFormatIndex(problem.ref_image_id));
-		std::filesystem::create_directories(problem.result_folder);
-		int num_src_images = 0;
-		iss.clear();
-		std::getline(file, line);
-		iss.str(line);
-		iss >> num_src_images;
-		for (int j = 0; j < num_src_images; ++j) {
-			int id;
-			float score;
-			iss >> id >> score;
-			if (score <= 0.0f) continue;
-			if (max_src > 0 && (int)problem.src_image_ids.size() >= max_src) continue;   // BASELINE configs use 3/5/9 views
-			problem.src_image_ids.push_back(id);
+namespace {
+
+struct Options {
+	path dense_folder;
+	int gpu = 0, max_src = 0, iters = 3, min_scale = 2, geom_passes = 3, rank = 0, world = 1;
+	uint64_t seed = 1234;
+	bool fusion = true, jacobi = false;
+	std::string job = "0";
+};
+
+// pair.txt (written by colmap2mvsnet.py:442-448; read at main.cpp:127-170): a whitespace-separated
+// stream — the number of views, then per view its id, the number of candidates k and k (id, score)
+// pairs.  Candidates with a non-positive score are dropped; at most `max_src` are kept (0 = all).
+std::vector<Problem> ReadViewGraph(const path& dense_folder, int max_src) {
+	std::vector<Problem> problems;
+	std::ifstream in(dense_folder / "pair.txt");
+	int n_views = 0;
+	if (!(in >> n_views)) return problems;
+	for (int i = 0; i < n_views; ++i) {
+		Problem p;
+		int k = 0;
+		if (!(in >> p.ref_image_id >> k)) break;
+		p.index = i;
+		p.dense_folder = dense_folder;
+		p.result_folder = dense_folder / "APD" / ToFormatIndex(p.ref_image_id);
+		for (int j = 0; j < k; ++j) {
+			int id = 0;
+			float score = 0.0f;
+			in >> id >> score;
+			if (score > 0.0f && (max_src <= 0 || (int)p.src_image_ids.size() < max_src)) p.src_image_ids.push_back(id);
 		}
-		problems.push_back(problem);
+		std::filesystem::create_directories(p.result_folder);
+		problems.push_back(std::move(p));
+	}
+	return problems;
+}
+
+int PyramidLevels(const std::vector<Problem>& problems) {   // main.cpp:248-264
+	if (problems.empty()) return 0;
+	const Mat first = ReadImageGray(problems[0].dense_folder / "images" / (ToFormatIndex(problems[0].ref_image_id) + ".jpg"));
+	if (first.empty()) return 0;
+	int levels = 1;
+	for (int side = std::max(first.cols, first.rows); side > 800; side /= 2) ++levels;
+	return levels;
+}
+
+// one pass of the schedule
+struct Pass {
+	int level;        // pyramid level (0 = coarsest)
+	int scale;        // down-sampling factor of that level
+	int geom_index;   // -1: the A pass, else the REFINE_ITER pass number
+};
+
+void ConfigurePass(Problem& problem, const Pass& pass, int iteration, int iters) {   // main.cpp:457-478, 488-502
+	PatchMatchParams& q = problem.params;
+	problem.iteration = iteration;
+	problem.scale_size = pass.scale;
+	q.max_iterations = iters;
+	if (pass.level > 0 || pass.geom_index >= 0) {
+		q.ransac_threshold = (float)(0.01 - pass.level * 0.00125);
+		q.rotate_time = std::min(static_cast<int>(std::pow(2, pass.level)), 4);
+	}
+	if (pass.geom_index < 0) {
+		q.state = pass.level == 0 ? FIRST_INIT : REFINE_INIT;
+		q.use_APD = pass.level != 0;
+		if (pass.level != 0) q.use_detail = true;
+		q.geom_consistency = false;
+		q.weak_peak_radius = 6;
+	} else {
+		q.state = REFINE_ITER;
+		q.use_APD = pass.level != 0;
+		q.geom_consistency = true;
+		q.weak_peak_radius = std::max(4 - 2 * pass.geom_index, 2);
 	}
 }
 
-static int ComputeRoundNum(const std::vector<Problem>& problems) {   // main.cpp:248-264
-	if (problems.empty()) return 0;
-	Mat image = ReadImageGray(problems[0].dense_folder / path("images") / path(ToFormatIndex(problems[0].ref_image_id) + ".jpg"));
-	if (image.empty()) return 0;
-	int max_size = std::max(image.cols, image.rows);
-	int round_num = 1;
-	while (max_size > 800) { max_size /= 2; round_num++; }
-	return round_num;
+// BinMat written under a temporary name, then renamed into place
+void PublishBinMat(const path& file, const Mat& m) {
+	path tmp = file;
+	tmp += ".part";
+	if (!WriteBinMat(tmp, m)) { std::cerr << "cannot write " << tmp << std::endl; exit(EXIT_FAILURE); }
+	std::filesystem::rename(tmp, file);
 }
 
-static void setBit_YZL(unsigned int* input, const unsigned int n) { (*input) |= (unsigned int)(1 << n); }
+struct ViewResult { Mat depth; };   // what the exchange step needs from a finished view
 
-static void ProcessProblem(const Problem& problem) {   // main.cpp:267-419
+ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	std::cout << "Processing image: " << std::setw(8) << std::setfill('0') << problem.ref_image_id << "..." << std::endl;
 	std::cout << "Iteration: " << problem.iteration << std::endl;
-	auto start = std::chrono::steady_clock::now();
+	const auto start = std::chrono::steady_clock::now();
 	// DVP_HOST_TIMING=1: wall time of every host step of the view (where the non-GPU time goes)
 	static const bool host_timing = std::getenv("DVP_HOST_TIMING") != nullptr;
 	auto lap_t = start;
@@ -81,156 +132,211 @@ static void ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	APD.SetDataPassHelperInCuda();
 	APD.RunPatchMatch();
 	lap("RunPatchMatch + download");
-	int width = APD.GetWidth(), height = APD.GetHeight();
+
+	const int width = APD.GetWidth(), height = APD.GetHeight();
+	const int nsrc = (int)problem.src_image_ids.size();
+	const float dmin = APD.GetDepthMin(), dmax = APD.GetDepthMax();
 	Mat depth(height, width, CV_32FC1), normal(height, width, CV_32FC3);
 	Mat pixel_states = APD.GetPixelStates();
-	const int nsrc = (int)problem.src_image_ids.size();
-	std::vector<Mat> vis(nsrc);
-	for (int i = 0; i < nsrc; ++i) vis[i] = Mat(height, width, CV_8UC1);
+	Mat views = APD.GetSelectedViews();
+	// planes -> depth / normal maps; depths outside the admissible range are dropped and the pixel loses
+	// its state (main.cpp:300-309)
+#pragma omp parallel for schedule(static) num_threads(8)
+	for (int r = 0; r < height; ++r) {
+		float* z = depth.ptr<float>(r);
+		Vec3f* n = normal.ptr<Vec3f>(r);
+		uint8_t* st = pixel_states.ptr<uint8_t>(r);
+		for (int c = 0; c < width; ++c) {
+			const float4 ph = APD.GetPlaneHypothesis(r, c);
+			n[c] = Vec3f{ ph.x, ph.y, ph.z };
+			const bool usable = !(ph.w < dmin || ph.w > dmax);
+			z[c] = usable ? ph.w : 0.0f;
+			if (!usable) st[c] = UNKNOWN;
+		}
+	}
+	lap("unpack planes");
+	// Visibility clean-up (main.cpp:311-363): per source view, every 4-connected region of pixels that do
+	// NOT select the view and is smaller than 20 * (8 / scale)^2 pixels is switched to "selected".
+	const int min_region = 20 * (8 / problem.scale_size) * (8 / problem.scale_size);
+	std::vector<Mat> fill(nsrc);   // per source: 1 where the bit has to be set
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nsrc < 8 ? (nsrc > 0 ? nsrc : 1) : 8)
+	for (int i = 0; i < nsrc; ++i) {
+		Mat visible(height, width, CV_8UC1);
+		for (int r = 0; r < height; ++r) {
+			const uint32_t* w = views.ptr<uint32_t>(r);
+			uint8_t* v = visible.ptr<uint8_t>(r);
+			for (int c = 0; c < width; ++c) v[c] = ((w[c] >> i) & 1u) ? 255 : 0;
+		}
+		Mat region(height, width, CV_32S);
+		std::vector<int> region_size;
+		Connect(visible, region, region_size);
+		Label_Update(region, region_size);
+		fill[i] = Mat(height, width, CV_8UC1);
+		for (int r = 0; r < height; ++r) {
+			const int* lab = region.ptr<int>(r);
+			uint8_t* f = fill[i].ptr<uint8_t>(r);
+			for (int c = 0; c < width; ++c) f[c] = (lab[c] != 0 && region_size[lab[c]] >= min_region) ? 0 : 1;
+		}
+	}
 #pragma omp parallel for schedule(static) num_threads(8)
 	for (int r = 0; r < height; ++r)
 		for (int c = 0; c < width; ++c) {
-			float4 ph = APD.GetPlaneHypothesis(r, c);
-			depth.at<float>(r, c) = ph.w;
-			if (depth.at<float>(r, c) < APD.GetDepthMin() || depth.at<float>(r, c) > APD.GetDepthMax()) {
-				depth.at<float>(r, c) = 0;
-				pixel_states.at<uint8_t>(r, c) = UNKNOWN;
-			}
-			normal.at<Vec3f>(r, c) = Vec3f{ph.x, ph.y, ph.z};
-			unsigned int views = (unsigned int)APD.GetPixelSelectedViews(r, c);
-			for (int i = 0; i < nsrc; ++i) vis[i].at<uint8_t>(r, c) = ((views >> i) & 1) ? 255 : 0;
-		}
-	lap("unpack planes / view masks");
-	// visibility-mask clean-up: invisible components smaller than 20*(8/scale)^2 px become visible
-	// (main.cpp:323-363)
-	const int thr = 20 * (8 / problem.scale_size) * (8 / problem.scale_size);
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nsrc < 8 ? (nsrc > 0 ? nsrc : 1) : 8)   // one source view's mask per thread
-	for (int i = 0; i < nsrc; ++i) {
-		Mat lab_mask(height, width, CV_32S);
-		std::vector<int> label_cnt;
-		Connect(vis[i], lab_mask, label_cnt);
-		Label_Update(lab_mask, label_cnt);
-		for (int y = 0; y < height; y++)
-			for (int x = 0; x < width; x++) {
-				const int label = lab_mask.at<int>(y, x);
-				const bool big = label != 0 && label_cnt[label] >= thr;
-				vis[i].at<uint8_t>(y, x) = big ? 0 : 255;
-			}
-	}
-#pragma omp parallel for schedule(static) num_threads(8)
-	for (int y = 0; y < height; y++)
-		for (int x = 0; x < width; x++) {
-			unsigned int v = 0;
-			for (int i = 0; i < nsrc; ++i)
-				if (vis[i].at<uint8_t>(y, x) == 255) setBit_YZL(&v, i);
-			APD.SetPixelSelectedViews(y, x, (int)v);
+			unsigned int mask = 0;
+			for (int i = 0; i < nsrc; ++i) mask |= (unsigned int)fill[i].at<uint8_t>(r, c) << i;
+			APD.SetPixelSelectedViews(r, c, (int)mask);
 		}
 	lap("visibility-mask clean-up");
-	WriteBinMat(problem.result_folder / path("depths.dmb"), depth);
-	WriteBinMat(problem.result_folder / path("APD_normals.dmb"), normal);
-	WriteBinMat(problem.result_folder / path("weak.bin"), pixel_states);
-	WriteBinMat(problem.result_folder / path("selected_views.bin"), APD.GetSelectedViews());
-	if (problem.params.use_radius) WriteBinMat(problem.result_folder / path("radius.bin"), APD.GetRadiusMap());
+	PublishBinMat(problem.result_folder / "depths.dmb", depth);
+	PublishBinMat(problem.result_folder / "APD_normals.dmb", normal);
+	PublishBinMat(problem.result_folder / "weak.bin", pixel_states);
+	PublishBinMat(problem.result_folder / "selected_views.bin", APD.GetSelectedViews());
+	if (problem.params.use_radius) PublishBinMat(problem.result_folder / "radius.bin", APD.GetRadiusMap());
 	lap("write results");
-	auto end = std::chrono::steady_clock::now();
+	const auto end = std::chrono::steady_clock::now();
 	const DvpTimings& t = APD.GetTimings();
 	std::cout << "Processing image: " << std::setw(8) << std::setfill('0') << problem.ref_image_id << " done!" << std::endl;
 	std::cout << "Cost time: " << std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count() << " ms (GPU RunPatchMatch "
 	          << t.total_ms << " ms, " << (double)width * height * problem.params.max_iterations / (t.total_ms * 1e3) << " Mpx/s/iter)" << std::endl;
+	return ViewResult{ depth };
 }
 
-// file-system barrier between passes for multi-process runs
-static void PassBarrier(const path& dir, int pass, int rank, int world) {
-	if (world <= 1) return;
-	std::filesystem::create_directories(dir);
-	{ std::ofstream f(dir / ("pass" + std::to_string(pass) + "_rank" + std::to_string(rank))); f << "done\n"; }
-	for (int r = 0; r < world; ++r)
-		while (!std::filesystem::exists(dir / ("pass" + std::to_string(pass) + "_rank" + std::to_string(r))))
-			std::this_thread::sleep_for(std::chrono::milliseconds(20));
+// depth maps of every view, resident on this rank's device, refreshed after each pass
+class DepthExchange {
+public:
+	DepthExchange(RankComm& comm, const std::vector<Problem>& problems) : comm_(comm), problems_(problems) {}
+	~DepthExchange() { Release(); }
+	// `mine`: view index -> the depth map this rank computed in the pass just finished
+	void Publish(const std::map<int, Mat>& mine) {
+		// every rank must agree on the map size: taken from the owner of view 0
+		int dims[2] = { 0, 0 };
+		if (!mine.empty()) { dims[0] = mine.begin()->second.cols; dims[1] = mine.begin()->second.rows; }
+		int owner0_dims[2] = { dims[0], dims[1] };
+		comm_.BroadcastHost(owner0_dims, sizeof(owner0_dims), 0 % comm_.world());
+		if (owner0_dims[0] != w_ || owner0_dims[1] != h_) { Release(); w_ = owner0_dims[0]; h_ = owner0_dims[1]; }
+		const size_t count = (size_t)w_ * h_;
+		for (size_t v = 0; v < problems_.size(); ++v) {
+			float*& dev = maps_[problems_[v].ref_image_id];
+			if (!dev) dev = RankComm::DeviceAlloc(count);
+			const int owner = (int)(v % (size_t)comm_.world());
+			if (owner == comm_.rank()) {
+				auto it = mine.find((int)v);
+				if (it == mine.end() || it->second.cols != w_ || it->second.rows != h_) { std::cerr << "DepthExchange: view " << v << " has no " << w_ << "x" << h_ << " map" << std::endl; exit(EXIT_FAILURE); }
+				RankComm::HostToDevice(dev, it->second.ptr<float>(0), count);
+			}
+			comm_.BroadcastDevice(dev, count, owner);
+			APD::SetResidentDepth(problems_[v].ref_image_id, dev, w_, h_);
+		}
+	}
+	void Release() {
+		APD::ClearResidentDepths();
+		for (auto& kv : maps_) RankComm::DeviceFree(kv.second);
+		maps_.clear();
+	}
+private:
+	RankComm& comm_;
+	const std::vector<Problem>& problems_;
+	std::map<int, float*> maps_;
+	int w_ = 0, h_ = 0;
+};
+
+// rank 0 decodes + resizes every view's image at this level and broadcasts it; the others take it from
+// the broadcast into their image cache (so that only one process touches the image files)
+void ShareLevelImages(RankComm& comm, std::vector<Problem>& problems, int scale) {
+	if (comm.world() <= 1) return;
+	for (Problem& p : problems) {
+		p.scale_size = scale;
+		int meta[4] = { 0, 0, 0, 0 };   // cols, rows, original cols, original rows
+		Mat img;
+		if (comm.rank() == 0) {
+			img = APD::CachedImage(p, p.ref_image_id, &meta[2], &meta[3]);
+			meta[0] = img.cols;
+			meta[1] = img.rows;
+		}
+		comm.BroadcastHost(meta, sizeof(meta), 0);
+		if (comm.rank() != 0) img = Mat(meta[1], meta[0], CV_32FC1);
+		comm.BroadcastHost(img.data, (size_t)meta[0] * meta[1] * sizeof(float), 0);
+		if (comm.rank() != 0) APD::InsertCachedImage(p, p.ref_image_id, img, meta[2], meta[3]);
+	}
 }
+
+Options ParseOptions(int argc, char** argv) {
+	Options o;
+	o.dense_folder = argv[1];
+	int a = 2;
+	if (argc > 2 && argv[2][0] != '-') { o.gpu = std::atoi(argv[2]); a = 3; }
+	for (; a < argc; ++a) {
+		const std::string s = argv[a];
+		auto val = [&]() { return (a + 1 < argc) ? std::atoll(argv[++a]) : 0ll; };
+		if (s == "--max-src") o.max_src = (int)val();
+		else if (s == "--iters") o.iters = (int)val();              // the reference hard-wires 3 (main.cpp:476,502)
+		else if (s == "--min-scale") o.min_scale = (int)val();      // the reference stops at half resolution (main.cpp:450,456)
+		else if (s == "--passes") o.geom_passes = (int)val();       // REFINE_ITER passes per level (3 in the reference)
+		else if (s == "--seed") o.seed = (uint64_t)val();
+		else if (s == "--rank") o.rank = (int)val();
+		else if (s == "--world") o.world = (int)val();
+		else if (s == "--job") { if (a + 1 < argc) o.job = argv[++a]; }
+		else if (s == "--jacobi") o.jacobi = true;
+		else if (s == "--no-fusion") o.fusion = false;
+	}
+	if (o.world > 1) o.jacobi = true;
+	return o;
+}
+
+}  // namespace
 
 int main(int argc, char** argv) {
 	if (argc < 2) {
-		std::cerr << "USAGE: apd dense_folder [gpu_index] [--max-src N] [--iters N] [--min-scale S] [--passes P] [--seed X] [--rank R --world N] [--no-fusion]\n";
+		std::cerr << "USAGE: apd dense_folder [gpu_index] [--max-src N] [--iters N] [--min-scale S] [--passes P] [--seed X] [--rank R --world N [--job ID]] [--jacobi] [--no-fusion]\n";
 		return EXIT_FAILURE;
 	}
-	path dense_folder(argv[1]);
-	int gpu_index = 0, max_src = 0, iters = 3, min_scale = 2, geom_passes = 3, rank = 0, world = 1;
-	uint64_t seed = 1234;
-	bool fusion = true;
-	int a = 2;
-	if (argc > 2 && argv[2][0] != '-') { gpu_index = std::atoi(argv[2]); a = 3; }
-	for (; a < argc; ++a) {
-		std::string s = argv[a];
-		auto val = [&]() { return (a + 1 < argc) ? std::atoll(argv[++a]) : 0ll; };
-		if (s == "--max-src") max_src = (int)val();
-		else if (s == "--iters") iters = (int)val();         // the reference hard-wires 3 (main.cpp:476,502)
-		else if (s == "--min-scale") min_scale = (int)val(); // the reference stops at half resolution (main.cpp:450,456)
-		else if (s == "--passes") geom_passes = (int)val();  // REFINE_ITER passes per round (3 in the reference)
-		else if (s == "--seed") seed = (uint64_t)val();
-		else if (s == "--rank") rank = (int)val();
-		else if (s == "--world") world = (int)val();
-		else if (s == "--no-fusion") fusion = false;
-	}
-	std::filesystem::create_directories(dense_folder / path("APD"));
-	APD::SetDevice(gpu_index);
-	APD::SetSeed(seed);
-	std::vector<Problem> problems;
-	GenerateSampleList(dense_folder, problems, max_src);
+	const Options opt = ParseOptions(argc, argv);
+	std::filesystem::create_directories(opt.dense_folder / "APD");
+	APD::SetDevice(opt.gpu);
+	APD::SetSeed(opt.seed);
+	RankComm comm(opt.rank, opt.world, opt.gpu, (opt.dense_folder / "APD" / ".rccl_id").string(), opt.job);
+
+	std::vector<Problem> problems = ReadViewGraph(opt.dense_folder, opt.max_src);
 	std::cout << "There are " << problems.size() << " problems needed to be processed!" << std::endl;
-	int round_num = ComputeRoundNum(problems);
+	const int round_num = PyramidLevels(problems);
 	std::cout << "Round nums: " << round_num << std::endl;
-	// scale of round i is 2^(round_num-1-i); rounds run while the scale is >= min_scale
-	// (min_scale = 2 reproduces `i < round_num - 1`, main.cpp:450; 1 adds the full-resolution round)
-	int iteration_index = 0, pass = 0;
-	const path sync_dir = dense_folder / path("APD") / path(".sync");
-	if (rank == 0) std::filesystem::remove_all(sync_dir);
-	for (int i = 0; i < round_num; ++i) {
-		const int scale = 1 << (round_num - 1 - i);
-		if (scale < min_scale && !(round_num == 1 && i == 0)) break;
-		for (auto& problem : problems) {
-			problem.iteration = iteration_index;
-			problem.scale_size = scale;
-			auto& params = problem.params;
-			if (i == 0) { params.state = FIRST_INIT; params.use_APD = false; }
-			else {
-				params.state = REFINE_INIT;
-				params.use_APD = true;
-				params.ransac_threshold = (float)(0.01 - i * 0.00125);
-				params.rotate_time = std::min(static_cast<int>(std::pow(2, i)), 4);
-				params.use_detail = true;
-			}
-			params.geom_consistency = false;
-			params.max_iterations = iters;
-			params.weak_peak_radius = 6;
-			if (problem.index % world == rank) {
-				GetProblemEdges(problem);   // main.cpp:480
-				ProcessProblem(problem);
-			}
-		}
-		PassBarrier(sync_dir, pass++, rank, world);
-		iteration_index++;
-		for (int j = 0; j < geom_passes; ++j) {
-			for (auto& problem : problems) {
-				problem.iteration = iteration_index;
-				problem.scale_size = scale;
-				auto& params = problem.params;
-				params.state = REFINE_ITER;
-				params.use_APD = (i != 0);
-				params.ransac_threshold = (float)(0.01 - i * 0.00125);
-				params.rotate_time = std::min(static_cast<int>(std::pow(2, i)), 4);
-				params.geom_consistency = true;
-				params.max_iterations = iters;
-				params.weak_peak_radius = std::max(4 - 2 * j, 2);
-				if (problem.index % world == rank) ProcessProblem(problem);
-			}
-			PassBarrier(sync_dir, pass++, rank, world);
-			iteration_index++;
-		}
-		std::cout << "Round: " << i << " done\n";
+
+	// the pass list: level i has scale 2^(round_num-1-i); levels run while the scale is >= min_scale
+	// (min_scale = 2 reproduces `i < round_num - 1`, main.cpp:450; a single-level pyramid always runs)
+	std::vector<Pass> plan;
+	for (int level = 0; level < round_num; ++level) {
+		const int scale = 1 << (round_num - 1 - level);
+		if (scale < opt.min_scale && round_num != 1) break;
+		plan.push_back(Pass{ level, scale, -1 });
+		for (int j = 0; j < opt.geom_passes; ++j) plan.push_back(Pass{ level, scale, j });
 	}
+
+	std::unique_ptr<DepthExchange> exchange;
+	if (opt.jacobi) exchange.reset(new DepthExchange(comm, problems));
+	int shared_scale = -1;
+	for (size_t it = 0; it < plan.size(); ++it) {
+		const Pass& pass = plan[it];
+		if (pass.scale != shared_scale) {
+			ShareLevelImages(comm, problems, pass.scale);
+			shared_scale = pass.scale;
+			if (exchange) exchange->Release();   // maps of the coarser level do not fit this one (and its A pass has no geometric term)
+		}
+		std::map<int, Mat> mine;
+		for (Problem& problem : problems) {
+			ConfigurePass(problem, pass, (int)it, opt.iters);
+			if (problem.index % opt.world != opt.rank) continue;
+			if (pass.geom_index < 0) GetProblemEdges(problem);   // main.cpp:480
+			ViewResult r = ProcessProblem(problem);
+			if (exchange) mine[problem.index] = r.depth;
+		}
+		if (exchange) exchange->Publish(mine);   // collective: also the barrier between passes
+		else comm.Barrier();
+		if (pass.geom_index == opt.geom_passes - 1 || (opt.geom_passes == 0 && pass.geom_index < 0)) std::cout << "Round: " << pass.level << " done\n";
+	}
+	if (exchange) exchange->Release();
+	exchange.reset();
 	APD::ReleasePooledContext();
-	if (fusion && rank == 0) RunFusion(dense_folder, problems);
+	comm.Barrier();
+	if (opt.fusion && opt.rank == 0) RunFusion(opt.dense_folder, problems);
 	std::cout << "All done\n";
 	return EXIT_SUCCESS;
 }

@@ -6,6 +6,65 @@
 
 #define CHECK(c) do { if (!(c)) { fprintf(stderr, "CHECK failed: %s (%s:%d)\n", #c, __FILE__, __LINE__); return 1; } } while (0)
 
+
+// ---- model of the reference's visibility-mask regions (APD.cpp:138-346), test infrastructure ---------
+// The reference labels the zero pixels in two steps.  Connect: a raster scan that gives a pixel its upper
+// neighbour's label (else its left one's, else a new one) and, where both neighbours carry different
+// labels, records parent[larger] = smaller — OVERWRITING whatever parent the larger label had, so some
+// unions are lost.  Label_Update: every horizontally / vertically adjacent pair of different labels whose
+// upper-left pixel lies in [0, rows-1) x [0, cols-1) is merged (its list-of-lists bookkeeping builds
+// exactly the equivalence classes of those pairs).  Adjacencies inside the last row (right neighbour) and
+// the last column (lower neighbour) are never looked at.  region_size_model returns, per pixel, the size
+// of its region under that procedure (0 for 255-pixels).
+static std::vector<int> region_size_model(const Mat& img) {
+	const int R = img.rows, C = img.cols;
+	std::vector<int> lab((size_t)R * C, 0), parent(1, 0);
+	auto zero = [&](int y, int x) { return img.at<uint8_t>(y, x) == 0; };
+	for (int y = 0; y < R; ++y)
+		for (int x = 0; x < C; ++x) {
+			if (img.at<uint8_t>(y, x) == 255) continue;
+			const bool l = x > 0 && zero(y, x) && zero(y, x - 1), u = y > 0 && zero(y, x) && zero(y - 1, x);
+			int v = 0;
+			if (l) v = lab[(size_t)y * C + x - 1];
+			if (u) v = lab[(size_t)(y - 1) * C + x];
+			if (!l && !u) { v = (int)parent.size(); parent.push_back(v); }
+			if (l && u) {
+				const int a = lab[(size_t)y * C + x - 1], b = lab[(size_t)(y - 1) * C + x];
+				if (a > b) { parent[a] = b; v = b; }
+				else if (a < b) { parent[b] = a; v = a; }
+			}
+			lab[(size_t)y * C + x] = v;
+		}
+	std::vector<int> root(parent.size(), 0);
+	for (size_t i = 1; i < parent.size(); ++i) { int c = (int)i; while (parent[c] != c) c = parent[c]; root[i] = c; }
+	for (auto& v : lab) v = root[v];
+	// Label_Update's merges as a union-find over the provisional labels
+	std::vector<int> uf(parent.size());
+	for (size_t i = 0; i < uf.size(); ++i) uf[i] = (int)i;
+	auto find = [&](int a) { while (uf[a] != a) { uf[a] = uf[uf[a]]; a = uf[a]; } return a; };
+	for (int y = 0; y + 1 < R; ++y)
+		for (int x = 0; x + 1 < C; ++x) {
+			const int c = lab[(size_t)y * C + x], r = lab[(size_t)y * C + x + 1], d = lab[(size_t)(y + 1) * C + x];
+			if (c != 0 && r != 0 && c != r) uf[find(c)] = find(r);
+			if (c != 0 && d != 0 && c != d) uf[find(c)] = find(d);
+		}
+	std::vector<int> size(parent.size(), 0);
+	for (auto v : lab) if (v) size[find(v)]++;
+	std::vector<int> out((size_t)R * C, 0);
+	for (size_t i = 0; i < lab.size(); ++i) out[i] = lab[i] ? size[find(lab[i])] : 0;
+	return out;
+}
+static std::vector<int> region_size_product(const Mat& img) {   // host/cc.cpp through the reference's two calls
+	Mat lab(img.rows, img.cols, CV_32S);
+	std::vector<int> cnt;
+	Connect(img, lab, cnt);
+	Label_Update(lab, cnt);
+	std::vector<int> out((size_t)img.rows * img.cols, 0);
+	for (int y = 0; y < img.rows; ++y)
+		for (int x = 0; x < img.cols; ++x) out[(size_t)y * img.cols + x] = lab.at<int>(y, x) ? cnt[lab.at<int>(y, x)] : 0;
+	return out;
+}
+
 int main(int argc, char** argv) {
 	path tmp = argc > 1 ? path(argv[1]) : std::filesystem::temp_directory_path();
 	// BinMat round trips (APD.cpp:548-573, 630-649): header = version 1, rows, cols, cv type
@@ -59,6 +118,57 @@ int main(int argc, char** argv) {
 		int total = 0;
 		for (int v : cnt) total += v;
 		CHECK(total == 25);
+	}
+	// Visibility-mask regions: exact components (host/cc.cpp) against the model of the reference's
+	// Connect + Label_Update on random masks.  (i) a region that touches neither the last row nor the last
+	// column has the same size in both; (ii) elsewhere the exact component can only be LARGER (the
+	// reference misses merges along the last row / column), so a region the reference keeps (>= threshold)
+	// is kept here too.  Reported: how many pixels differ at all.
+	{
+		uint32_t lcg = 777u;
+		auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (lcg >> 8) * (1.0f / 16777216.0f); };
+		long long px_total = 0, px_diff = 0, masks_diff = 0;
+		for (int trial = 0; trial < 300; ++trial) {
+			const int R = 6 + (int)(rnd() * 40), C = 6 + (int)(rnd() * 40);
+			const float density = 0.25f + 0.6f * rnd();
+			Mat m(R, C, CV_8UC1);
+			for (int y = 0; y < R; ++y) for (int x = 0; x < C; ++x) m.at<uint8_t>(y, x) = rnd() < density ? 0 : 255;
+			const std::vector<int> a = region_size_model(m), b = region_size_product(m);
+			// pixels of exact components that touch the last row / column
+			Mat lab(R, C, CV_32S);
+			std::vector<int> cnt;
+			Connect(m, lab, cnt);
+			std::vector<char> touches(cnt.size(), 0);
+			for (int y = 0; y < R; ++y) touches[lab.at<int>(y, C - 1)] = 1;
+			for (int x = 0; x < C; ++x) touches[lab.at<int>(R - 1, x)] = 1;
+			bool any = false;
+			for (int y = 0; y < R; ++y)
+				for (int x = 0; x < C; ++x) {
+					const size_t i = (size_t)y * C + x;
+					px_total++;
+					CHECK((a[i] == 0) == (b[i] == 0));
+					CHECK(b[i] >= a[i]);
+					if (!touches[lab.at<int>(y, x)]) CHECK(a[i] == b[i]);
+					if (a[i] != b[i]) { px_diff++; any = true; }
+				}
+			masks_diff += any;
+		}
+		printf("visibility-mask regions, 300 random masks: %lld of %lld pixels (%lld masks) differ from the reference model, all in regions touching the last row/column\n", px_diff, px_total, masks_diff);
+	}
+	// a truncated BinMat must be rejected and leave the destination untouched
+	{
+		Mat d(8, 8, CV_32FC1);
+		std::memset(d.data, 0, d.step * d.rows);
+		CHECK(WriteBinMat(tmp / "t_trunc.dmb", d));
+		std::filesystem::resize_file(tmp / "t_trunc.dmb", 16 + 100);
+		Mat keep(2, 2, CV_8UC1);
+		CHECK(!ReadBinMat(tmp / "t_trunc.dmb", keep));
+		CHECK(keep.rows == 2 && keep.cols == 2 && keep.type() == CV_8UC1);
+		std::ofstream bad(tmp / "t_badhdr.dmb", std::ios::binary);
+		const int32_t h[4] = { 1, -3, 7, 5 };
+		bad.write((const char*)h, 16);
+		bad.close();
+		CHECK(!ReadBinMat(tmp / "t_badhdr.dmb", keep));
 	}
 	// rescale helpers
 	{

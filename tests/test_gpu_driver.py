@@ -120,3 +120,29 @@ def test_pipeline_on_gpu_equals_oracle_pipeline():
     for v in range(NV):
         assert count_diff(pg.state[v]["planes"], po.state[v]["planes"]) == 0
         assert np.array_equal(pg.state[v]["views"], po.state[v]["views"])
+
+
+def test_apd_exchange_mode(tmp_path):
+    """--jacobi: the multi-GPU data flow with one rank — every view's depth map of the previous pass is
+    kept resident on the device (DepthExchange / dvp_upload_depths_device) instead of being re-read from
+    APD/<id>/depths.dmb, and a pass only sees the previous pass' maps.  Deterministic run to run; the
+    FIRST_INIT pass is identical to the in-place mode (no geometric term yet), the geometric passes are not
+    (in-place: a view sees the maps its predecessors wrote in the same pass)."""
+    W, H, NV = 160, 120, 4
+    outs = {}
+    for tag, extra in (("inplace", []), ("jacobi_a", ["--jacobi"]), ("jacobi_b", ["--jacobi"])):
+        d = str(tmp_path / tag)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), "3"])
+        out = subprocess.run([os.path.join(ROOT, "dvp-mvs_amd", "apd"), d, "0", "--iters", "2", "--passes", "2", "--min-scale", "1", "--seed", "5",
+                              "--no-fusion"] + extra, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        outs[tag] = [read_binmat(os.path.join(d, "APD", "%08d" % v, "depths.dmb")) for v in range(NV)]
+        gt = np.load(os.path.join(d, "depth_gt.npy"))
+    for v in range(NV):
+        assert np.array_equal(outs["jacobi_a"][v], outs["jacobi_b"][v])
+        dep = outs["jacobi_a"][v]
+        m = dep[10:-10, 10:-10] > 0
+        rel = np.abs(dep - gt[v])[10:-10, 10:-10][m] / gt[v][10:-10, 10:-10][m]
+        assert m.mean() > 0.7 and np.median(rel) < 1.5e-2
+    # view 0 is processed first in both modes and sees only previous-pass maps either way
+    assert not all(np.array_equal(outs["inplace"][v], outs["jacobi_a"][v]) for v in range(1, NV))
