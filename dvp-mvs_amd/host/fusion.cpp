@@ -78,7 +78,8 @@ bool load_view(const path& dense_folder, const Problem& problem, FusionView* v) 
 	Mat weak;
 	ReadBinMat(problem.result_folder / "weak.bin", weak);
 	if (weak.empty()) weak = Mat(v->rows(), v->cols(), CV_8UC1), std::memset(weak.data, STRONG, weak.step * weak.rows);
-	RescaleMatToTargetSize<uint8_t>(weak, v->weak, v->cols(), v->rows());
+	v->weak = weak;
+	RescaleMatToTargetSize<uint8_t>(weak, v->weak, v->cols(), v->rows());   // no-op when the sizes agree
 	Mat bgr = ReadImageColor(dense_folder / "images" / (id + ".jpg"));
 	if (bgr.empty()) bgr = Mat::zeros(v->rows(), v->cols(), CV_8UC3);
 	v->cam.width = bgr.cols;

@@ -65,7 +65,29 @@ static std::vector<int> region_size_product(const Mat& img) {   // host/cc.cpp t
 	return out;
 }
 
+// `test_host --fuse <dense_folder>`: RunFusion on a folder whose APD/<id>/ maps were written by the caller
+// (tests/test_boundary.py::test_fusion_cpu); prints the number of fused points
+static int fuse_folder(const path& folder) {
+	std::ifstream in(folder / "pair.txt");
+	int n = 0;
+	in >> n;
+	std::vector<Problem> problems;
+	for (int i = 0; i < n; ++i) {
+		Problem p;
+		int k = 0;
+		in >> p.ref_image_id >> k;
+		p.index = i;
+		p.dense_folder = folder;
+		p.result_folder = folder / "APD" / ToFormatIndex(p.ref_image_id);
+		for (int j = 0; j < k; ++j) { int id; float sc; in >> id >> sc; if (sc > 0) p.src_image_ids.push_back(id); }
+		problems.push_back(p);
+	}
+	RunFusion(folder, problems);
+	return 0;
+}
+
 int main(int argc, char** argv) {
+	if (argc > 2 && std::string(argv[1]) == "--fuse") return fuse_folder(argv[2]);
 	path tmp = argc > 1 ? path(argv[1]) : std::filesystem::temp_directory_path();
 	// BinMat round trips (APD.cpp:548-573, 630-649): header = version 1, rows, cols, cv type
 	{

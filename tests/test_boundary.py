@@ -63,3 +63,43 @@ def test_host_layer_cpp():
         out = subprocess.run([os.path.join(ROOT, "tests", "host", "test_host"), d], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "host tests ok" in out.stdout
+
+
+def test_fusion_cpu(tmp_path):
+    """RunFusion (host/fusion.cpp) without a GPU: three views of the synthetic scene with their TRUE depth /
+    normal maps as APD/<id>/ results.  Every interior pixel of view 0 has consistent witnesses, is fused
+    once, and claims its witnesses, so the cloud has roughly one point per pixel of the union of the
+    views' footprints — far fewer than 3 x W x H — and the points lie on the scene's surfaces."""
+    import subprocess
+    import sys
+    W, H, NV = 96, 64, 3
+    d = str(tmp_path / "scene")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), "2"], stdout=subprocess.DEVNULL)
+    gt = np.load(os.path.join(d, "depth_gt.npy"))
+
+    def write_binmat(path, a, typ):
+        with open(path, "wb") as f:
+            f.write(np.array([1, a.shape[0], a.shape[1], typ], np.int32).tobytes())
+            f.write(np.ascontiguousarray(a).tobytes())
+    n = np.array([0.25, 0.1, -1.0])
+    n /= np.linalg.norm(n)
+    for v in range(NV):
+        r = os.path.join(d, "APD", "%08d" % v)
+        os.makedirs(r, exist_ok=True)
+        write_binmat(os.path.join(r, "depths.dmb"), gt[v].astype(np.float32), 5)
+        write_binmat(os.path.join(r, "APD_normals.dmb"), np.tile(n.astype(np.float32), (H, W, 1)), 21)
+        write_binmat(os.path.join(r, "weak.bin"), np.ones((H, W), np.uint8), 0)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "host")])
+    out = subprocess.run([os.path.join(ROOT, "tests", "host", "test_host"), "--fuse", d], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-500:] + out.stderr[-500:]
+    raw = open(os.path.join(d, "APD", "APD.ply"), "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    npts = int(head.decode().split("element vertex ")[1].split("\n")[0])
+    assert 0.6 * W * H < npts < 1.6 * W * H, npts
+    pts = np.frombuffer(body, np.dtype([("xyz", "<f4", 3), ("nrm", "<f4", 3), ("bgr", "u1", 3)]) if len(body) == npts * 27 else
+                        np.dtype([("xyz", "<f4", 3), ("bgr", "u1", 3)]))
+    X = pts["xyz"].astype(np.float64)
+    # the scene: Z = 4 + 0.25 X + 0.1 Y (first plane), the same + 0.45 behind the step, and the wall between them
+    res = X[:, 2] - (4.0 + 0.25 * X[:, 0] + 0.1 * X[:, 1])
+    on_surface = (np.abs(res) < 2e-2) | (np.abs(res - 0.45) < 2e-2) | (np.abs(X[:, 0] - 0.35) < 2e-2)
+    assert on_surface.mean() > 0.97, on_surface.mean()
