@@ -11,6 +11,8 @@ static int g_device = 0;
 static uint64_t g_seed = 0x5eed5eedULL;
 void APD::SetDevice(int device) { g_device = device; }   // cudaSetDevice(argv[2]), main.cpp:430-434
 void APD::SetSeed(uint64_t seed) { g_seed = seed; }      // the reference seeds with clock64() (APD.cu:1270)
+static bool g_use_label_files = false;
+void APD::SetUseLabelFiles(bool on) { g_use_label_files = on; }
 
 APD::APD(const Problem& problem) {   // APD.cpp:984-987
 	params_host = problem.params;
@@ -272,6 +274,12 @@ void APD::SupportInitialization() {
 			Mat tmp;
 			RescaleMatToTargetSize<float>(ref_dep, tmp, width, height);
 			std::memcpy(label_host.data, tmp.data, (size_t)width * height * 4);   // float bits reinterpreted, as the reference does
+		} else if (g_use_label_files) {   // the commented-out load of APD.cpp:1630-1633
+			Mat lab;
+			if (ReadBinMat(problem.result_folder / path("labels_" + std::to_string(scale) + ".dmb"), lab) && lab.type() == CV_32SC1) {
+				if (lab.cols != width || lab.rows != height) RescaleMatToTargetSize<int>(lab, lab, width, height);
+				label_host = lab;
+			}
 		}
 	}
 	if (problem.params.use_radius) {   // APD.cpp:1648-1667: the first pass starts at strong_radius, later ones at the stored map

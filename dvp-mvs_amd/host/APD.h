@@ -34,8 +34,10 @@ void ProjectCamera(const float3 PointX, const Camera camera, float2& point, floa
 bool MetricDepthFromPrior(Mat& dep, const std::vector<float2>& xy, const std::vector<float3>& xyz, const Camera& cam);   // APD.cpp:1221-1356
 void PlanesFromDepth(const Mat& dep, const Camera& cam, float4* planes);                              // APD.cpp:1365-1422
 bool BuildPlanePrior(const Problem& problem, const Camera& scaled_ref_camera, int width, int height, float4* planes);
-// image I/O without OpenCV: images/<id>.pgm|.ppm (binary P5/P6) next to / instead of <id>.jpg
-// (tools/jpg2pnm.py converts); returns an empty Mat if nothing readable is found.
+// image I/O without OpenCV: images/<id>.jpg through the built-in baseline decoder (host/jpeg.cpp), else
+// <id>.pgm|.ppm (binary P5/P6); returns an empty Mat if nothing readable is found.
+Mat DecodeJpeg(const path& file, int channels);     // 1: luma plane (libjpeg JCS_GRAYSCALE), 3: BGR
+Mat LabelSegment(const int scale, const Mat& src_image);   // EdgeSegment mode 1 (APD.cpp:348-401, 437-499), host/labels.cpp
 Mat ReadImageGray(const path& image_path_jpg);      // stands in for cv::imread(IMREAD_GRAYSCALE), APD.cpp:1057
 Mat ReadImageColor(const path& image_path_jpg);     // cv::imread(IMREAD_COLOR) (BGR), APD.cpp:1842
 Mat ResizeLinear(const Mat& src_f32, int new_cols, int new_rows);   // cv::resize(INTER_LINEAR), APD.cpp:1129
@@ -68,6 +70,10 @@ public:
 	static void SetDevice(int device);
 	static void SetSeed(uint64_t seed);
 	static void ReleasePooledContext();   // frees the recycled engine context and the image cache
+	// The shipped reference writes labels_<s>.dmb but never loads it (the load is commented out,
+	// APD.cpp:1630-1633): its label map stays zero unless MVS4/<id>.dmb needs rescaling.  true: load
+	// labels_<s>.dmb in SupportInitialization (what the commented-out lines do).  Default false.
+	static void SetUseLabelFiles(bool on);
 	// multi-GPU hooks of the driver (comm.h).  Image cache: the decoded + rescaled float image of a view in
 	// its reference role at the problem's scale — rank 0 fills it from disk, the others from a broadcast.
 	static const Mat& CachedImage(const Problem& problem, int image_id, int* orig_cols, int* orig_rows);

@@ -5,8 +5,7 @@
 // documented algorithm for 8-bit input, aperture 3, L2gradient = true — Sobel 3x3 with replicated
 // border, squared thresholds on dx^2+dy^2, non-maximum suppression with the tan(22.5 deg)
 // fixed-point sector test, hysteresis over 8-connected candidates.  PARITY UNPINNED (no OpenCV to
-// compare with).  The label path (mode 1: Roberts + HoughLinesP) is not restated: the shipped
-// reference never loads labels_<s>.dmb (APD.cpp:1630-1633).
+// compare with).  The label path (mode 1: Roberts + HoughLinesP) lives in labels.cpp.
 #include "APD.h"
 #include <vector>
 
@@ -77,9 +76,9 @@ static Mat CannyL2(const Mat& src, double low_thresh, double high_thresh) {
 
 // EdgeSegment(scale, src_image, mode = 0, use_canny = true) — APD.cpp:348-466
 Mat EdgeSegment(const int scale, const Mat& src_image, int mode, bool use_canny) {
-	(void)scale;
+	if (mode == 1 && !use_canny) return LabelSegment(scale, src_image);
 	if (mode != 0 || !use_canny) {
-		std::cerr << "EdgeSegment: only mode 0 with use_canny is available in this build\n";
+		std::cerr << "EdgeSegment: mode " << mode << " (debug image / Roberts edge map) is not available in this build\n";
 		return Mat::zeros(src_image.rows, src_image.cols, CV_8UC1);
 	}
 	const int rows = src_image.rows, cols = src_image.cols;
@@ -119,11 +118,15 @@ Mat EdgeSegment(const int scale, const Mat& src_image, int mode, bool use_canny)
 void GetProblemEdges(const Problem& problem) {
 	int scale = 0;
 	while ((1 << scale) < problem.scale_size) scale++;
-	if (!problem.params.use_edge) return;
-	path edge_path = problem.result_folder / path("edges_" + std::to_string(scale) + ".dmb");
-	if (std::filesystem::exists(edge_path)) return;
+	const path edge_path = problem.result_folder / path("edges_" + std::to_string(scale) + ".dmb");
+	const path label_path = problem.result_folder / path("labels_" + std::to_string(scale) + ".dmb");
+	const bool need_edge = problem.params.use_edge && !std::filesystem::exists(edge_path);
+	const bool need_label = problem.params.use_label && !std::filesystem::exists(label_path);
+	if (!need_edge && !need_label) return;
 	Mat image_uint = ReadImageGray(problem.dense_folder / path("images") / path(ToFormatIndex(problem.ref_image_id) + ".jpg"));
 	if (image_uint.empty()) return;
+	if (need_label) WriteBinMat(label_path, EdgeSegment(scale, image_uint, 1));   // from the full-size image (main.cpp:236)
+	if (!need_edge) return;
 	Mat f(image_uint.rows, image_uint.cols, CV_32FC1);
 	for (int r = 0; r < f.rows; ++r)
 		for (int c = 0; c < f.cols; ++c) f.at<float>(r, c) = image_uint.at<uint8_t>(r, c);

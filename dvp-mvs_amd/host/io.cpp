@@ -176,15 +176,20 @@ static bool read_pnm(const path& p, int want_channels, Mat& out) {
 	}
 	return true;
 }
+// images/<id>.jpg as the reference's converter writes it (baseline JPEG: host/jpeg.cpp); a .pgm / .ppm of
+// the same stem is used when there is no .jpg (synthetic datasets are written loss-free)
 static Mat read_image(const path& jpg, int channels) {
+	const std::string ext = jpg.extension().string();
+	if ((ext == ".jpg" || ext == ".jpeg" || ext == ".JPG" || ext == ".JPEG") && std::filesystem::exists(jpg)) {
+		Mat m = DecodeJpeg(jpg, channels);
+		if (!m.empty()) return m;
+	}
 	Mat m;
 	path p = jpg;
 	for (const char* ext : { ".pgm", ".ppm" }) {
 		p.replace_extension(ext);
 		if (std::filesystem::exists(p) && read_pnm(p, channels, m)) return m;
 	}
-	if (std::filesystem::exists(jpg))
-		std::cerr << "No JPEG decoder in this build (no OpenCV/libjpeg): convert " << jpg << " with tools/jpg2pnm.py\n";
 	return Mat();
 }
 Mat ReadImageGray(const path& p) { return read_image(p, 1); }

@@ -1,7 +1,7 @@
 // main.cpp — the driver: the reference's coarse-to-fine schedule (/root/reference/main.cpp:421-528) over
 // `class APD`, one process per GPU.
 //   apd <dense_folder> [gpu_index] [--max-src N] [--iters N] [--min-scale S] [--passes P] [--seed X]
-//       [--rank R --world N [--job ID]] [--jacobi] [--no-fusion]
+//       [--rank R --world N [--job ID]] [--jacobi] [--labels] [--no-fusion]
 //
 // Schedule.  The image pyramid has round_num levels (the longer side is halved until <= 800).  Level i
 // runs one "A" pass without geometric consistency — FIRST_INIT from scratch / the Depth-Anything prior
@@ -29,7 +29,7 @@ struct Options {
 	path dense_folder;
 	int gpu = 0, max_src = 0, iters = 3, min_scale = 2, geom_passes = 3, rank = 0, world = 1;
 	uint64_t seed = 1234;
-	bool fusion = true, jacobi = false;
+	bool fusion = true, jacobi = false, label_files = false;
 	std::string job = "0";
 };
 
@@ -276,6 +276,7 @@ Options ParseOptions(int argc, char** argv) {
 		else if (s == "--world") o.world = (int)val();
 		else if (s == "--job") { if (a + 1 < argc) o.job = argv[++a]; }
 		else if (s == "--jacobi") o.jacobi = true;
+		else if (s == "--labels") o.label_files = true;          // load labels_<s>.dmb (APD::SetUseLabelFiles)
 		else if (s == "--no-fusion") o.fusion = false;
 	}
 	if (o.world > 1) o.jacobi = true;
@@ -293,6 +294,7 @@ int main(int argc, char** argv) {
 	std::filesystem::create_directories(opt.dense_folder / "APD");
 	APD::SetDevice(opt.gpu);
 	APD::SetSeed(opt.seed);
+	APD::SetUseLabelFiles(opt.label_files);
 	RankComm comm(opt.rank, opt.world, opt.gpu, (opt.dense_folder / "APD" / ".rccl_id").string(), opt.job);
 
 	std::vector<Problem> problems = ReadViewGraph(opt.dense_folder, opt.max_src);

@@ -86,8 +86,27 @@ static int fuse_folder(const path& folder) {
 	return 0;
 }
 
+// `test_host --jpeg in.jpg out.bin channels`: DecodeJpeg -> raw bytes preceded by int32 rows, cols, channels
+static int dump_jpeg(const path& in, const path& out, int channels) {
+	const Mat m = DecodeJpeg(in, channels);
+	if (m.empty()) return 2;
+	std::ofstream f(out, std::ios::binary);
+	const int32_t hdr[3] = { m.rows, m.cols, channels };
+	f.write((const char*)hdr, 12);
+	f.write((const char*)m.data, (std::streamsize)(m.step * m.rows));
+	return 0;
+}
+// `test_host --labels image.pgm scale out.dmb`: LabelSegment -> BinMat (CV_32SC1)
+static int dump_labels(const path& in, int scale, const path& out) {
+	const Mat img = ReadImageGray(in);
+	if (img.empty()) return 2;
+	return WriteBinMat(out, EdgeSegment(scale, img, 1)) ? 0 : 3;
+}
+
 int main(int argc, char** argv) {
 	if (argc > 2 && std::string(argv[1]) == "--fuse") return fuse_folder(argv[2]);
+	if (argc > 4 && std::string(argv[1]) == "--jpeg") return dump_jpeg(argv[2], argv[3], std::atoi(argv[4]));
+	if (argc > 4 && std::string(argv[1]) == "--labels") return dump_labels(argv[2], std::atoi(argv[3]), argv[4]);
 	path tmp = argc > 1 ? path(argv[1]) : std::filesystem::temp_directory_path();
 	// BinMat round trips (APD.cpp:548-573, 630-649): header = version 1, rows, cols, cv type
 	{

@@ -103,3 +103,77 @@ def test_fusion_cpu(tmp_path):
     res = X[:, 2] - (4.0 + 0.25 * X[:, 0] + 0.1 * X[:, 1])
     on_surface = (np.abs(res) < 2e-2) | (np.abs(res - 0.45) < 2e-2) | (np.abs(X[:, 0] - 0.35) < 2e-2)
     assert on_surface.mean() > 0.97, on_surface.mean()
+
+
+def _host_tool(*args):
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "host")])
+    return subprocess.run([os.path.join(ROOT, "tests", "host", "test_host")] + [str(a) for a in args], capture_output=True, text=True)
+
+
+def test_jpeg_decoder_equals_libjpeg(tmp_path):
+    """host/jpeg.cpp against this image's libjpeg (through PIL): the grey output — what
+    cv::imread(IMREAD_GRAYSCALE) hands the reference (APD.cpp:1057) — must be bit-identical to libjpeg's
+    JCS_GRAYSCALE decode for 4:4:4, 4:2:2, 4:2:0, single-component files and restart markers."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    cases = [(64, 48, 0, 90, False, 0), (123, 77, 2, 75, False, 0), (200, 150, 1, 95, False, 0), (90, 61, 0, 85, True, 0), (333, 222, 2, 50, False, 3)]
+    for i, (w, h, sub, q, gray, rst) in enumerate(cases):
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = 127 + 60 * np.sin(xx / 7.0) * np.cos(yy / 5.0) + rng.normal(0, 12, (h, w))
+        f = str(tmp_path / ("t%d.jpg" % i))
+        if gray:
+            Image.fromarray(np.clip(base, 0, 255).astype(np.uint8), "L").save(f, quality=q)
+        else:
+            rgb = np.stack([base, base * 0.8 + 30 * np.sin(yy / 3.0), 255 - base], 2)
+            kw = dict(quality=q, subsampling=sub)
+            if rst:
+                kw["restart_marker_blocks"] = rst
+            Image.fromarray(np.clip(rgb, 0, 255).astype(np.uint8), "RGB").save(f, **kw)
+        ref = Image.open(f)
+        ref.draft("L", ref.size)      # libjpeg decodes straight to JCS_GRAYSCALE
+        assert ref.mode == "L"
+        ref = np.asarray(ref)
+        out = str(tmp_path / "o.bin")
+        r = _host_tool("--jpeg", f, out, 1)
+        assert r.returncode == 0, r.stderr
+        a = np.fromfile(out, np.uint8)
+        rows, cols, ch = np.frombuffer(a[:12].tobytes(), np.int32)
+        got = a[12:].reshape(rows, cols)
+        assert got.shape == ref.shape and np.array_equal(got, ref), (i, int((got != ref).sum()))
+        r = _host_tool("--jpeg", f, out, 3)   # colour: JFIF equations, replicated chroma (documented deviation at chroma edges)
+        a = np.fromfile(out, np.uint8)
+        bgr = a[12:].reshape(rows, cols, 3)
+        rgb_ref = np.asarray(Image.open(f).convert("RGB")).astype(int)
+        assert np.abs(bgr[:, :, ::-1].astype(int) - rgb_ref).mean() < (0.1 if (gray or sub == 0) else 5.0)
+    # progressive files are rejected, not mis-decoded
+    f = str(tmp_path / "prog.jpg")
+    Image.fromarray(np.zeros((32, 32, 3), np.uint8)).save(f, progressive=True)
+    assert _host_tool("--jpeg", f, str(tmp_path / "o.bin"), 1).returncode == 2
+
+
+def test_label_segmentation(tmp_path):
+    """EdgeSegment mode 1 (host/labels.cpp; APD.cpp:348-401, 437-499): two flat regions separated by a
+    textured band get two different positive labels, texture is 0, and the map has the size of the
+    requested pyramid level."""
+    rng = np.random.default_rng(1)
+    H, W = 300, 400
+    img = np.full((H, W), 100, np.uint8)
+    img[:, 200:] = 160
+    img[:, 190:210] = rng.integers(0, 255, (H, 20))
+    img[100:140, 60:100] = rng.integers(0, 255, (40, 40))
+    pgm = str(tmp_path / "i.pgm")
+    with open(pgm, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (W, H))
+        f.write(img.tobytes())
+    for scale in (0, 1):
+        out = str(tmp_path / "l.dmb")
+        r = _host_tool("--labels", pgm, scale, out)
+        assert r.returncode == 0, r.stderr
+        a = np.fromfile(out, np.int32)
+        ver, rows, cols, typ = a[:4]
+        assert (ver, rows, cols, typ) == (1, H >> scale, W >> scale, 4)
+        lab = a[4:].reshape(rows, cols)
+        left, right, band, island = lab[rows // 2, cols // 8], lab[rows // 2, cols * 7 // 8], lab[rows // 2, cols // 2], lab[rows * 2 // 5, cols // 5]
+        assert left > 0 and right > 0 and left != right and band == 0 and island == 0
+        assert (lab == left).mean() > 0.3 and (lab == right).mean() > 0.3
