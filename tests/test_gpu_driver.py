@@ -146,3 +146,26 @@ def test_apd_exchange_mode(tmp_path):
         assert m.mean() > 0.7 and np.median(rel) < 1.5e-2
     # view 0 is processed first in both modes and sees only previous-pass maps either way
     assert not all(np.array_equal(outs["inplace"][v], outs["jacobi_a"][v]) for v in range(1, NV))
+
+
+def test_apd_jpeg_folder_with_label_files(tmp_path):
+    """A folder in the converter's own format (images/%08d.jpg, 4:2:0 colour JPEG) runs unmodified through
+    the built-in decoder; --labels makes SupportInitialization load the labels_<s>.dmb that GetProblemEdges
+    writes (Roberts + components + Hough, host/labels.cpp)."""
+    W, H, NV = 192, 144, 4
+    d = str(tmp_path / "scene")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), "3", "--jpg"])
+    assert not [f for f in os.listdir(os.path.join(d, "images")) if not f.endswith(".jpg")]
+    out = subprocess.run([os.path.join(ROOT, "dvp-mvs_amd", "apd"), d, "0", "--iters", "3", "--passes", "1", "--min-scale", "1", "--seed", "3", "--labels"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    gt = np.load(os.path.join(d, "depth_gt.npy"))
+    for v in range(NV):
+        r = os.path.join(d, "APD", "%08d" % v)
+        lab = read_binmat(os.path.join(r, "labels_0.dmb"))
+        assert lab.shape == (H, W) and lab.dtype == np.int32 and lab.min() >= -1
+        dep = read_binmat(os.path.join(r, "depths.dmb"))
+        m = dep[10:-10, 10:-10] > 0
+        rel = np.abs(dep - gt[v])[10:-10, 10:-10][m] / gt[v][10:-10, 10:-10][m]
+        assert m.mean() > 0.7 and np.median(rel) < 2e-2, (v, m.mean(), np.median(rel))
+    assert os.path.exists(os.path.join(d, "APD", "APD.ply"))

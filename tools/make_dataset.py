@@ -4,7 +4,7 @@
 pair.txt.  With --prior also the inputs of the FIRST_INIT plane prior (APD.cpp:1210-1424):
 dep/%08d.dmb = 255 - s(x,y) * true depth (a stand-in for a Depth-Anything map: right up to a slowly
 varying unknown scale) and sfm/%08d.txt = sparse points "x2d y2d X Y Z r g b".
-usage: make_dataset.py OUT W H NUM_VIEWS [SRC_PER_VIEW] [--prior]"""
+usage: make_dataset.py OUT W H NUM_VIEWS [SRC_PER_VIEW] [--prior] [--jpg]"""
 import importlib
 import os
 import sys
@@ -58,6 +58,9 @@ def main():
     prior = "--prior" in sys.argv
     if prior:
         sys.argv.remove("--prior")
+    jpg = "--jpg" in sys.argv     # images/%08d.jpg (colour, like colmap2mvsnet.py:424-430 writes) instead of .pgm
+    if jpg:
+        sys.argv.remove("--jpg")
     out, W, H, NV = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     nsrc = int(sys.argv[5]) if len(sys.argv) > 5 else min(NV - 1, 4)
     synth = importlib.import_module("dvp-mvs_amd.synth")
@@ -66,9 +69,13 @@ def main():
     os.makedirs(os.path.join(out, "cams"), exist_ok=True)
     for i in range(NV):
         img = sc["images"][i].astype(np.uint8)
-        with open(os.path.join(out, "images", "%08d.pgm" % i), "wb") as f:
-            f.write(b"P5\n%d %d\n255\n" % (W, H))
-            f.write(img.tobytes())
+        if jpg:
+            from PIL import Image
+            Image.fromarray(np.stack([img, img, img], 2), "RGB").save(os.path.join(out, "images", "%08d.jpg" % i), quality=98, subsampling=2)
+        else:
+            with open(os.path.join(out, "images", "%08d.pgm" % i), "wb") as f:
+                f.write(b"P5\n%d %d\n255\n" % (W, H))
+                f.write(img.tobytes())
         write_cam(os.path.join(out, "cams", "%08d_cam.txt" % i), sc["cameras"][i])
         if prior:
             write_prior(out, i, sc["cameras"][i], sc["depth_gt"][i], np.random.default_rng(100 + i))
