@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 
 NCC_BYTES = 724            # algorithmic bytes of one bilateral-NCC evaluation
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
-VALU_PEAK_GINST = 1228.8   # wave64 VALU instructions/s: 256 CU x 4 SIMD x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md "Wave scheduling")
+SIMD_PEAK_GCYC = 2457.6    # SIMD cycles/s: 256 CU x 4 SIMD x 2.4 GHz (MI355X_MICROARCH.md: 256 CUs, 4 SIMDs per CU, 2400 MHz max clock)
 PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_r02.json")
 
 # launch site -> kernel name in a rocprofv3 trace (list launches for the weak path; the narrow
@@ -130,11 +130,16 @@ def pmc_lookup(kernel, W, H, S):
 
 def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
     """Roofline entry of one launch site.  `bound` = the limiter with the larger fraction of its peak:
-    VALU issue (wave64 VALU instructions / s against 256 CU x 4 SIMD x 2.4 GHz / 2) or physical HBM
-    traffic (PMC FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction) — both <= 1 by construction; they need
-    the PMC table entry of this (kernel, size).  The cache-oblivious algorithmic rate (724 B per NCC
-    evaluation) is reported beside it; it exceeds the HBM peak whenever the caches serve
-    the re-reads, i.e. it is a work rate, not a bound."""
+      valu: cycles the SIMDs' vector ALUs were busy (PMC SQ_ACTIVE_INST_VALU, quad-cycles -> x4) over the
+            cycles available (1024 SIMDs x 2.4 GHz x launch time).  On this part a non-packed wave64 VALU
+            instruction occupies its SIMD for 4 cycles (measured: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.0
+            quad-cycle; the 157 TFLOP/s fp32 figure assumes packed fp32), i.e. 614 G wave-instructions/s;
+      hbm:  physical traffic (PMC FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md)
+            over 8 TB/s.
+    Both are <= 1 by construction and need the PMC entry of this (kernel, size) in profiles/pmc_r02.json;
+    the launch time is measured live.  The cache-oblivious algorithmic rate (724 B per NCC evaluation,
+    SURVEY 8d) is reported beside them; it exceeds the HBM peak whenever L1/L2/Infinity Cache serve the
+    re-reads — a work rate, not a bound."""
     k = kernel_name(stage, S)
     sec = avg_ms * 1e-3
     alg = evals_per_launch * NCC_BYTES / sec / 1e9 if (sec > 0 and evals_per_launch) else None
@@ -143,20 +148,23 @@ def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
          "algorithmic_gbs": round(alg, 1) if alg else None, "algorithmic_frac_of_hbm_peak": round(alg / HBM_PEAK_GBS, 4) if alg else None}
     if pmc and sec > 0:
         traffic = pmc.get("hbm_bytes_per_launch")
-        valu = pmc.get("SQ_INSTS_VALU")
+        busy_quads = pmc.get("SQ_ACTIVE_INST_VALU")
+        insts = pmc.get("SQ_INSTS_VALU")
         hbm_gbs = traffic / sec / 1e9 if traffic else None
-        valu_g = valu / sec / 1e9 if valu else None
+        busy_gcyc = busy_quads * 4.0 / sec / 1e9 if busy_quads else None
         fh = hbm_gbs / HBM_PEAK_GBS if hbm_gbs else 0.0
-        fv = valu_g / VALU_PEAK_GINST if valu_g else 0.0
+        fv = busy_gcyc / SIMD_PEAK_GCYC if busy_gcyc else 0.0
         if fv >= fh:
-            r.update(bound="valu", achieved=round(valu_g, 1), peak=VALU_PEAK_GINST, unit="Ginstr/s", frac=round(fv, 4))
+            r.update(bound="valu", achieved=round(busy_gcyc, 1), peak=SIMD_PEAK_GCYC, unit="G VALU-busy SIMD cycles/s", frac=round(fv, 4))
         else:
             r.update(bound="hbm", achieved=round(hbm_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fh, 4))
         r.update(traffic=traffic, physical_hbm_gbs=round(hbm_gbs, 1) if hbm_gbs else None, physical_hbm_frac=round(fh, 4),
-                 valu_ginstr_s=round(valu_g, 1) if valu_g else None, valu_issue_frac=round(fv, 4),
-                 valu_instr_per_wave_eval=round(valu * 64.0 / evals_per_launch, 1) if (valu and evals_per_launch) else None,
+                 valu_busy_frac=round(fv, 4),
+                 valu_ginstr_s=round(insts / sec / 1e9, 1) if insts else None,
+                 valu_cycles_per_instr=round(4.0 * busy_quads / insts, 2) if (busy_quads and insts) else None,
+                 valu_instr_per_wave_eval=round(insts * 64.0 / evals_per_launch, 1) if (insts and evals_per_launch) else None,
                  pmc_source="profiles/pmc_r02.json[%s|%dx%d|S%d]" % (k, W, H, S))
-        for c in ("l2_hit_rate", "wait_any_frac", "valu_busy_frac", "scratch_bytes_per_lane"):
+        for c in ("l2_hit_rate", "wait_any_frac"):
             if c in pmc:
                 r[c] = pmc[c]
     else:
