@@ -42,13 +42,11 @@ DVP_HD void wave_sync() {}
 constexpr int kAnchors = DVP_NEIGHBOUR_NUM - 1;   // 11
 constexpr int kAnchorTaps = kAnchors * 9;         // 99
 
-// per-wave shared state (LDS on the device), ~10 KB
+// per-wave shared state (LDS on the device), ~6.7 KB
 struct WeakShared {
 	f2 ctab[kTaps * kTaps];        // centre patch: (w, w*ref) per tap, row-major
 	float caa[kTaps * kTaps];      // w*ref*ref per tap (reference moments only)
 	float rows[2][8][kTaps][4];    // centre-patch row sums (s_s, s_ss, s_rs) per (plane | view slot, row), double-buffered
-	f4 atap[2][kAnchorTaps];       // reference side of an anchor tap: w, w*ref, w*ref*ref, position (packed 16|16)
-	int astate[2][kAnchors];       // 0 absent, 1 visible in the current view, 2 not visible
 	float acost[2][8][12];         // anchor cost per (plane, anchor), < 0: does not count
 	int inq[2][8];                 // plane's centre projects inside the source image
 	float cost_array[8][32];
@@ -179,60 +177,22 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 	const int S = d.params.num_images - 1;
 	const float* src = d.images + (size_t)uniform_i(v) * d.plane_stride * 2;
 
-	// ---- reference side of the anchors (APD.cu:905-1000), once per view: lane t owns anchor tap t ----------
-	// 8 visibility-prior offsets of the ANCHOR pixel + the anchor itself; weights relative to the centre
-	// pixel's grey level.  (w, w*ref, w*ref*ref, tap position) go to shared memory; the 8 plane lanes of an
-	// anchor read them back instead of each recomputing 9 exponentials.
-	for (int t0 = 0; t0 < kAnchorTaps; t0 += 64) {
-		DVP_LANES(l) {
-			const int t = t0 + l;
-			if (t >= kAnchorTaps) continue;
-			const int k = t / 9, tt = t - k * 9;
-			const s2 nb = nbs[k + 1];
-			if (nb.x == -1 || nb.y == -1) { if (tt == 0) sh.astate[buf][k] = 0; continue; }
-			const int nbc = nb.x + nb.y * W;
-			if (!is_set(d.selected_views[nbc], v - 1)) { if (tt == 0) sh.astate[buf][k] = 2; continue; }
-			if (tt == 0) sh.astate[buf][k] = 1;
-			int i = 0, j = 0;
-			if (tt < 8) {
-				const s2 o = d.candidate[cand_index(d, nbc, v - 1) + tt];
-				i = o.x;
-				j = o.y;
-				if (i == 0 && j == 0) {   // default +-5 ring (APD.cu:943-952): {-5,0,5}^2 without its centre, x-major
-					const int u = tt + (tt >= 4 ? 1 : 0);
-					i = (u / 3 - 1) * 5;
-					j = (u % 3 - 1) * 5;
-				}
-			}
-			const int rx = nb.x + i, ry = nb.y + j;
-			const float a = img_texel(d.images, d.org, Pt, W, Hh, rx, ry);
-			const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
-			const float wa = w * a;
-			union { int i; float f; } xy;
-			xy.i = ((rx + 64) & 0xffff) | ((ry + 64) << 16);   // rx, ry >= -20: both fields non-negative
-			sh.atap[buf][t] = mk4(w, wa, wa * a, xy.f);
-		}
-	}
-	wave_sync();
 	DVP_LANES(l) {
 		// ---- anchors: 8 planes x 8 anchors per round ---------------------------------------------------
-		const int q = l & 7;
-		float H[9];
-		bool inside = false;
-		if ((pmask >> q) & 1) {
+		for (int k0 = 0; k0 < kAnchors; k0 += 8) {
+			const int k = k0 + (l >> 3), q = l & 7;
+			if (k >= kAnchors || !((pmask >> q) & 1)) continue;
+			float H[9];
 			homography(vc, sh.pl[q], H);
 			const f2 pt = apply_homography(H, px, py);
-			inside = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f);
-			if ((l >> 3) == 0) sh.inq[buf][q] = inside ? 1 : 0;
-		}
-		for (int k0 = 0; k0 < kAnchors; k0 += 8) {
-			const int k = k0 + (l >> 3);
-			if (k >= kAnchors || !inside) continue;
+			const bool inside = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f);
+			if (k == 0) sh.inq[buf][q] = inside ? 1 : 0;
+			if (!inside) continue;
 			float cost = -1.0f;   // < 0: this anchor does not count
-			const int st = sh.astate[buf][k];
-			if (st != 0) {
-				const s2 nb = nbs[k + 1];
-				const bool visible = st == 1;
+			const s2 nb = nbs[k + 1];
+			if (!(nb.x == -1 || nb.y == -1)) {
+				const int nbc = nb.x + nb.y * W;
+				const bool visible = is_set(d.selected_views[nbc], v - 1);
 				const f2 nsp = apply_homography(H, nb.x, nb.y);
 				const bool outside = nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh;
 				if (outside) {
@@ -240,35 +200,58 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 				} else if (!visible) {
 					cost = 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
 				} else {
-					f4 tp[9];
+					// reference side (APD.cu:905-1000): 8 visibility-prior offsets of the anchor + the anchor itself
+					const s2* cand = d.candidate + cand_index(d, nbc, v - 1);
+					int tx[9], ty[9];
+					float ti[9], tj[9];
 #pragma unroll
-					for (int t = 0; t < 9; ++t) tp[t] = sh.atap[buf][k * 9 + t];
+					for (int t = 0; t < 9; ++t) {
+						int i = 0, j = 0;
+						if (t < 8) {
+							const s2 o = cand[t];
+							i = o.x;
+							j = o.y;
+							if (i == 0 && j == 0) {   // default +-5 ring (APD.cu:943-952): {-5,0,5}^2 without its centre, x-major
+								const int u = t + (t >= 4 ? 1 : 0);
+								i = (u / 3 - 1) * 5;
+								j = (u % 3 - 1) * 5;
+							}
+						}
+						tx[t] = nb.x + i;
+						ty[t] = nb.y + j;
+						ti[t] = (float)i;
+						tj[t] = (float)j;
+					}
+					// source side first (addresses need only the offsets): 9 gathers in flight
 					unsigned off[9];
 					TapW<SMP> tw[9];
 					float qd[9][4];
 #pragma unroll
 					for (int t = 0; t < 9; ++t) {
-						union { float f; int i; } xy;
-						xy.f = tp[t].w;
-						const f2 sp = apply_homography(H, (xy.i & 0xffff) - 64, (int)((unsigned)xy.i >> 16) - 64);
+						const f2 sp = apply_homography(H, tx[t], ty[t]);
 						tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t], &tw[t]);
 					}
 #pragma unroll
 					for (int t = 0; t < 9; ++t) load_quad(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
+					float av[9];
+#pragma unroll
+					for (int t = 0; t < 9; ++t) av[t] = img_texel(d.images, d.org, Pt, W, Hh, tx[t], ty[t]);
 					float a_sr = 0.0f, a_srr = 0.0f, a_sw = 0.0f;
 					float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
 #pragma unroll
 					for (int t = 0; t < 9; ++t) {
-						a_sr += tp[t].y;
-						a_srr += tp[t].z;
-						a_sw += tp[t].x;
+						const float w = bilateral_weight(ti[t], tj[t], av[t], cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
+						const float wa = w * av[t];
+						a_sr += wa;
+						a_srr += wa * av[t];
+						a_sw += w;
 						float fa, fb;
 						tap_weights(tw[t], &fa, &fb);
 						const float b = tex_lerp(fa, fb, qd[t][0], qd[t][1], qd[t][2], qd[t][3]);
-						const float wb = tp[t].x * b;
+						const float wb = w * b;
 						s_s += wb;
 						s_ss = fmaf(wb, b, s_ss);
-						s_rs = fmaf(tp[t].y, b, s_rs);
+						s_rs = fmaf(wa, b, s_rs);
 					}
 					cost = ncc_from_sums(a_sr, a_srr, s_s, s_ss, s_rs, a_sw);
 				}
@@ -277,20 +260,20 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 		}
 		// ---- centre patch: lane = (plane q, row r) -------------------------------------------------------
 		{
-			const int cq = l >> 3, r = l & 7;
-			if (((pmask >> cq) & 1) && (c.fast ? r < kTaps : r == 0)) {
-				float Hc[9];
-				homography(vc, sh.pl[cq], Hc);
-				const f2 pt = apply_homography(Hc, px, py);
+			const int q = l >> 3, r = l & 7;
+			if (((pmask >> q) & 1) && (c.fast ? r < kTaps : r == 0)) {
+				float H[9];
+				homography(vc, sh.pl[q], H);
+				const f2 pt = apply_homography(H, px, py);
 				if (!(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f)) {
 					if (c.fast) {
 						float o[3];
-						patch_row_sums<SMP>(d, sh, Hc, src, px, py, c.radius, c.inc, r, o);
-						sh.rows[buf][cq][r][0] = o[0];
-						sh.rows[buf][cq][r][1] = o[1];
-						sh.rows[buf][cq][r][2] = o[2];
+						patch_row_sums<SMP>(d, sh, H, src, px, py, c.radius, c.inc, r, o);
+						sh.rows[buf][q][r][0] = o[0];
+						sh.rows[buf][q][r][1] = o[1];
+						sh.rows[buf][q][r][2] = o[2];
 					} else {
-						sh.rows[buf][cq][0][0] = ncc_patch_generic(d, Hc, src, px, py, c.radius, c.inc, 1);
+						sh.rows[buf][q][0][0] = ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
 					}
 				}
 			}
