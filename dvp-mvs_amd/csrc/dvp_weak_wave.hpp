@@ -42,13 +42,13 @@ DVP_HD void wave_sync() {}
 constexpr int kAnchors = DVP_NEIGHBOUR_NUM - 1;   // 11
 constexpr int kAnchorTaps = kAnchors * 9;         // 99
 
-// per-wave shared state (LDS on the device), ~6.7 KB
+// per-wave shared state (LDS on the device), ~11.5 KB
 struct WeakShared {
 	f2 ctab[kTaps * kTaps];        // centre patch: (w, w*ref) per tap, row-major
 	float caa[kTaps * kTaps];      // w*ref*ref per tap (reference moments only)
-	float rows[2][8][kTaps][4];    // centre-patch row sums (s_s, s_ss, s_rs) per (plane | view slot, row), double-buffered
-	float acost[2][8][12];         // anchor cost per (plane, anchor), < 0: does not count
-	int inq[2][8];                 // plane's centre projects inside the source image
+	float rows[8][8][kTaps][3];    // centre-patch row sums (s_s, s_ss, s_rs) per (view slot, plane, row)
+	float acost[8][8][kAnchors];   // anchor cost per (view slot, plane, anchor), < 0: does not count
+	int inq[8][8];                 // (view slot, plane): the centre projects inside the source image
 	float cost_array[8][32];
 	float ev[8][32];
 	float gtab[8][32];             // geometric-consistency cost per (plane, view)
@@ -159,154 +159,184 @@ DVP_HD void patch_row_sums(const Dev& d, const WeakShared& sh, const float* H, c
 	out[2] = r_rs;
 }
 
-// ComputeBilateralNCCNew (APD.cu:835-1021) of source view v for the live planes sh.pl[q], q in pmask:
-// sh.ev[q][v-1] = cost.  c = centre-patch context (colour-only weights) built by wave_patch_ctx.
-// One shared-memory hand-over per view:
-//   section 1  lane (plane q, anchor k): the whole anchor sub-patch of that pair in registers — the
+// ComputeBilateralNCCNew (APD.cu:835-1021) for the live planes sh.pl[q] (q in pmask) and the source views
+// in vmask: sh.ev[q][view] = cost.  c = centre-patch context (colour-only weights) built by wave_patch_ctx.
+// Views are taken eight at a time with ONE shared-memory hand-over per batch:
+//   section 1  per view of the batch, back to back:
+//              lane (plane q, anchor k): the whole anchor sub-patch of that pair in registers — the
 //              anchor's 9 reference taps (offsets, texels, weights, sums: identical in the 8 plane lanes
 //              of an anchor, which costs nothing in lock step) and the 9 gathers in the source image;
 //              the 8 planes of one tap sit in adjacent lanes of ONE load instruction and share lines.
+//              The anchor pixel and its view mask do not depend on the view and are fetched once.
 //              Then lane (plane q, row r): one row of the 36-tap centre patch.
-//   section 2  lane q: rows and anchors summed in the reference's order -> ev.
-// `buf` alternates between calls so that section 2 of one view and section 1 of the next need no
-// barrier between them.
+//   section 2  lane (view slot, plane q): rows and anchors summed in the reference's order -> ev.
 template <int SMP>
-DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float cpix, int px, int py, int v, uint32_t pmask, int buf, WeakShared& sh) {
-	const ViewConst vc = load_view(d, v);
+DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float cpix, int px, int py, uint32_t vmask, uint32_t pmask, WeakShared& sh) {
 	const int W = d.width, Hh = d.height, Pt = d.pitch;
-	const int S = d.params.num_images - 1;
-	const float* src = d.images + (size_t)uniform_i(v) * d.plane_stride * 2;
-
-	DVP_LANES(l) {
-		// ---- anchors: 8 planes x 8 anchors per round ---------------------------------------------------
-		for (int k0 = 0; k0 < kAnchors; k0 += 8) {
-			const int k = k0 + (l >> 3), q = l & 7;
-			if (k >= kAnchors || !((pmask >> q) & 1)) continue;
-			float H[9];
-			homography(vc, sh.pl[q], H);
-			const f2 pt = apply_homography(H, px, py);
-			const bool inside = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f);
-			if (k == 0) sh.inq[buf][q] = inside ? 1 : 0;
-			if (!inside) continue;
-			float cost = -1.0f;   // < 0: this anchor does not count
-			const s2 nb = nbs[k + 1];
-			if (!(nb.x == -1 || nb.y == -1)) {
-				const int nbc = nb.x + nb.y * W;
-				const bool visible = is_set(d.selected_views[nbc], v - 1);
-				const f2 nsp = apply_homography(H, nb.x, nb.y);
-				const bool outside = nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh;
-				if (outside) {
-					if (visible) cost = 2.0f;
-				} else if (!visible) {
-					cost = 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
-				} else {
-					// reference side (APD.cu:905-1000): 8 visibility-prior offsets of the anchor + the anchor itself
-					const s2* cand = d.candidate + cand_index(d, nbc, v - 1);
-					int tx[9], ty[9];
-					float ti[9], tj[9];
+	uint32_t rest = vmask;
+	while (rest) {
+		uint32_t batch = 0;
+		for (int n = 0; n < 8 && rest; ++n) { const uint32_t low = rest & (0u - rest); batch |= low; rest ^= low; }
+		DVP_LANES(l) {
+			const int q = l & 7, kk = l >> 3;
+			const bool plane_on = (pmask >> q) & 1;
+			// the anchors this lane serves (one per round), fetched once for all views
+			s2 nb[2];
+			uint32_t sv[2];
+			int nbc[2];
 #pragma unroll
-					for (int t = 0; t < 9; ++t) {
-						int i = 0, j = 0;
-						if (t < 8) {
-							const s2 o = cand[t];
-							i = o.x;
-							j = o.y;
-							if (i == 0 && j == 0) {   // default +-5 ring (APD.cu:943-952): {-5,0,5}^2 without its centre, x-major
-								const int u = t + (t >= 4 ? 1 : 0);
-								i = (u / 3 - 1) * 5;
-								j = (u % 3 - 1) * 5;
+			for (int rd = 0; rd < 2; ++rd) {
+				const int k = rd * 8 + kk;
+				nb[rd] = mks2(-1, -1);
+				sv[rd] = 0;
+				nbc[rd] = 0;
+				if (k < kAnchors && plane_on) {
+					nb[rd] = nbs[k + 1];
+					if (!(nb[rd].x == -1 || nb[rd].y == -1)) { nbc[rd] = nb[rd].x + nb[rd].y * W; sv[rd] = d.selected_views[nbc[rd]]; }
+				}
+			}
+			int slot = 0;
+			for (uint32_t todo = batch; todo; todo &= todo - 1, ++slot) {
+				const int v = __builtin_ctz(todo) + 1;   // 1-based image index of the source view
+				const ViewConst vc = load_view(d, v);
+				const float* src = d.images + (size_t)uniform_i(v) * d.plane_stride * 2;
+				float H[9];
+				bool inside = false;
+				if (plane_on) {
+					homography(vc, sh.pl[q], H);
+					const f2 pt = apply_homography(H, px, py);
+					inside = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f);
+					if (kk == 0) sh.inq[slot][q] = inside ? 1 : 0;
+				}
+				// ---- anchors: 8 planes x 8 anchors per round ------------------------------------------------
+#pragma unroll
+				for (int rd = 0; rd < 2; ++rd) {
+					const int k = rd * 8 + kk;
+					if (k >= kAnchors || !inside) continue;
+					float cost = -1.0f;   // < 0: this anchor does not count
+					if (!(nb[rd].x == -1 || nb[rd].y == -1)) {
+						const bool visible = is_set(sv[rd], v - 1);
+						const f2 nsp = apply_homography(H, nb[rd].x, nb[rd].y);
+						const bool outside = nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh;
+						if (outside) {
+							if (visible) cost = 2.0f;
+						} else if (!visible) {
+							cost = 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
+						} else {
+							// reference side (APD.cu:905-1000): 8 visibility-prior offsets of the anchor + the anchor itself
+							const s2* cand = d.candidate + cand_index(d, nbc[rd], v - 1);
+							int tx[9], ty[9];
+							float ti[9], tj[9];
+#pragma unroll
+							for (int t = 0; t < 9; ++t) {
+								int i = 0, j = 0;
+								if (t < 8) {
+									const s2 o = cand[t];
+									i = o.x;
+									j = o.y;
+									if (i == 0 && j == 0) {   // default +-5 ring (APD.cu:943-952): {-5,0,5}^2 without its centre, x-major
+										const int u = t + (t >= 4 ? 1 : 0);
+										i = (u / 3 - 1) * 5;
+										j = (u % 3 - 1) * 5;
+									}
+								}
+								tx[t] = nb[rd].x + i;
+								ty[t] = nb[rd].y + j;
+								ti[t] = (float)i;
+								tj[t] = (float)j;
+							}
+							// source side first (addresses need only the offsets): 9 gathers in flight
+							unsigned off[9];
+							TapW<SMP> tw[9];
+							float qd[9][4];
+#pragma unroll
+							for (int t = 0; t < 9; ++t) {
+								const f2 sp = apply_homography(H, tx[t], ty[t]);
+								tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t], &tw[t]);
+							}
+#pragma unroll
+							for (int t = 0; t < 9; ++t) load_quad(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
+							float av[9];
+#pragma unroll
+							for (int t = 0; t < 9; ++t) av[t] = img_texel(d.images, d.org, Pt, W, Hh, tx[t], ty[t]);
+							float a_sr = 0.0f, a_srr = 0.0f, a_sw = 0.0f;
+							float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+#pragma unroll
+							for (int t = 0; t < 9; ++t) {
+								const float w = bilateral_weight(ti[t], tj[t], av[t], cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
+								const float wa = w * av[t];
+								a_sr += wa;
+								a_srr += wa * av[t];
+								a_sw += w;
+								float fa, fb;
+								tap_weights(tw[t], &fa, &fb);
+								const float b = tex_lerp(fa, fb, qd[t][0], qd[t][1], qd[t][2], qd[t][3]);
+								const float wb = w * b;
+								s_s += wb;
+								s_ss = fmaf(wb, b, s_ss);
+								s_rs = fmaf(wa, b, s_rs);
+							}
+							cost = ncc_from_sums(a_sr, a_srr, s_s, s_ss, s_rs, a_sw);
+						}
+					}
+					sh.acost[slot][q][k] = cost;
+				}
+				// ---- centre patch: lane = (plane, row) -----------------------------------------------------------
+				{
+					const int cq = l >> 3, r = l & 7;
+					if (((pmask >> cq) & 1) && (c.fast ? r < kTaps : r == 0)) {
+						float Hc[9];
+						homography(vc, sh.pl[cq], Hc);
+						const f2 pt = apply_homography(Hc, px, py);
+						if (!(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f)) {
+							if (c.fast) {
+								float o[3];
+								patch_row_sums<SMP>(d, sh, Hc, src, px, py, c.radius, c.inc, r, o);
+								sh.rows[slot][cq][r][0] = o[0];
+								sh.rows[slot][cq][r][1] = o[1];
+								sh.rows[slot][cq][r][2] = o[2];
+							} else {
+								sh.rows[slot][cq][0][0] = ncc_patch_generic(d, Hc, src, px, py, c.radius, c.inc, 1);
 							}
 						}
-						tx[t] = nb.x + i;
-						ty[t] = nb.y + j;
-						ti[t] = (float)i;
-						tj[t] = (float)j;
-					}
-					// source side first (addresses need only the offsets): 9 gathers in flight
-					unsigned off[9];
-					TapW<SMP> tw[9];
-					float qd[9][4];
-#pragma unroll
-					for (int t = 0; t < 9; ++t) {
-						const f2 sp = apply_homography(H, tx[t], ty[t]);
-						tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t], &tw[t]);
-					}
-#pragma unroll
-					for (int t = 0; t < 9; ++t) load_quad(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
-					float av[9];
-#pragma unroll
-					for (int t = 0; t < 9; ++t) av[t] = img_texel(d.images, d.org, Pt, W, Hh, tx[t], ty[t]);
-					float a_sr = 0.0f, a_srr = 0.0f, a_sw = 0.0f;
-					float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
-#pragma unroll
-					for (int t = 0; t < 9; ++t) {
-						const float w = bilateral_weight(ti[t], tj[t], av[t], cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
-						const float wa = w * av[t];
-						a_sr += wa;
-						a_srr += wa * av[t];
-						a_sw += w;
-						float fa, fb;
-						tap_weights(tw[t], &fa, &fb);
-						const float b = tex_lerp(fa, fb, qd[t][0], qd[t][1], qd[t][2], qd[t][3]);
-						const float wb = w * b;
-						s_s += wb;
-						s_ss = fmaf(wb, b, s_ss);
-						s_rs = fmaf(wa, b, s_rs);
-					}
-					cost = ncc_from_sums(a_sr, a_srr, s_s, s_ss, s_rs, a_sw);
-				}
-			}
-			sh.acost[buf][q][k] = cost;
-		}
-		// ---- centre patch: lane = (plane q, row r) -------------------------------------------------------
-		{
-			const int q = l >> 3, r = l & 7;
-			if (((pmask >> q) & 1) && (c.fast ? r < kTaps : r == 0)) {
-				float H[9];
-				homography(vc, sh.pl[q], H);
-				const f2 pt = apply_homography(H, px, py);
-				if (!(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f)) {
-					if (c.fast) {
-						float o[3];
-						patch_row_sums<SMP>(d, sh, H, src, px, py, c.radius, c.inc, r, o);
-						sh.rows[buf][q][r][0] = o[0];
-						sh.rows[buf][q][r][1] = o[1];
-						sh.rows[buf][q][r][2] = o[2];
-					} else {
-						sh.rows[buf][q][0][0] = ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 1);
 					}
 				}
 			}
 		}
-	}
-	wave_sync();
-	DVP_LANES(q) {
-		if (q >= 8 || !((pmask >> q) & 1)) continue;
-		if (!sh.inq[buf][q]) { sh.ev[q][v - 1] = 2.0f; continue; }
-		float cc;
-		if (c.fast) {
-			float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
-			for (int r = 0; r < kTaps; ++r) {
-				s_s += sh.rows[buf][q][r][0];
-				s_ss += sh.rows[buf][q][r][1];
-				s_rs += sh.rows[buf][q][r][2];
+		wave_sync();
+		DVP_LANES(l) {
+			const int slot = l >> 3, q = l & 7;
+			uint32_t todo = batch;
+			for (int n = 0; n < slot && todo; ++n) todo &= todo - 1;
+			if (!todo || !((pmask >> q) & 1)) continue;
+			const int v = __builtin_ctz(todo);   // 0-based view index
+			if (!sh.inq[slot][q]) { sh.ev[q][v] = 2.0f; continue; }
+			float cc;
+			if (c.fast) {
+				float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+				for (int r = 0; r < kTaps; ++r) {
+					s_s += sh.rows[slot][q][r][0];
+					s_ss += sh.rows[slot][q][r][1];
+					s_rs += sh.rows[slot][q][r][2];
+				}
+				cc = ncc_from_sums(c.sum_ref, c.sum_ref_ref, s_s, s_ss, s_rs, c.wsum);
+			} else {
+				cc = sh.rows[slot][q][0][0];
 			}
-			cc = ncc_from_sums(c.sum_ref, c.sum_ref_ref, s_s, s_ss, s_rs, c.wsum);
-		} else {
-			cc = sh.rows[buf][q][0][0];
+			float scost = 0.0f, scnt = 0.0f;
+			for (int k = 0; k < kAnchors; ++k) {
+				const float ac = sh.acost[slot][q][k];
+				if (ac >= 0.0f) { scost += ac; scnt += 1.0f; }
+			}
+			float out = cc;
+			if (scnt > 0.0f) {
+				float sc2 = scost / scnt;   // strong_cost /= strong_count (int -> float, exact)
+				sc2 = DVP_MIN(sc2, 2.0f);
+				out = (float)(0.25 * cc + 0.75 * sc2);
+			}
+			sh.ev[q][v] = out;
 		}
-		float scost = 0.0f, scnt = 0.0f;
-		for (int k = 0; k < kAnchors; ++k) {
-			const float ac = sh.acost[buf][q][k];
-			if (ac >= 0.0f) { scost += ac; scnt += 1.0f; }
-		}
-		float out = cc;
-		if (scnt > 0.0f) {
-			float sc2 = scost / scnt;   // strong_cost /= strong_count (int -> float, exact)
-			sc2 = DVP_MIN(sc2, 2.0f);
-			out = (float)(0.25 * cc + 0.75 * sc2);
-		}
-		sh.ev[q][v - 1] = out;
+		wave_sync();
 	}
 }
 
@@ -358,7 +388,6 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 	f4 plane_now = mk4(0, 0, 0, 0);
 	bool skip_refine = false;
 	f4 pl1 = mk4(0, 0, 0, 0);
-	int nbuf = 0;
 
 	for (int phase = 0; phase < 3; ++phase) {
 		uint32_t pmask = 0, vmask = 0;
@@ -484,14 +513,9 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 		wave_sync();
 
 		// ---- evaluate: view by view ----------------------------------------------------------------------
-		if (pmask) {
-			for (int v = 0; v < S; ++v) {
-				if (!((vmask >> v) & 1)) continue;
-				wave_ncc_new<SMP>(d, c, nbs, cpix, px, py, v + 1, pmask, nbuf, sh);
-				nbuf ^= 1;
-				evals += (unsigned long long)__builtin_popcount(pmask);
-			}
-			wave_sync();
+		if (pmask && vmask) {
+			wave_ncc_new<SMP>(d, c, nbs, cpix, px, py, vmask, pmask, sh);
+			evals += (unsigned long long)__builtin_popcount(pmask) * (unsigned long long)__builtin_popcount(vmask);
 		}
 
 		// ---- epilogue ----------------------------------------------------------------------------------------
@@ -607,15 +631,15 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 				sh.rows[0][vs][r][2] = o[2];
 			} else if (r == 0) {
 				sh.ev[0][v] = 2.0f;
-				sh.rows[0][vs][0][3] = -1.0f;   // marks "outside" for the totalling lane
+				sh.inq[0][vs] = 0;   // "outside" for the totalling lane
 			}
-			if (c2.fast && in && r == 0) sh.rows[0][vs][0][3] = 1.0f;
+			if (c2.fast && in && r == 0) sh.inq[0][vs] = 1;
 		}
 		wave_sync();
 		if (c2.fast) {
 			DVP_LANES(l) {
 				const int v = v0 + l;
-				if (l >= 8 || v >= S || sh.vw[v] == 0 || sh.rows[0][l][0][3] < 0.0f) continue;
+				if (l >= 8 || v >= S || sh.vw[v] == 0 || !sh.inq[0][l]) continue;
 				float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
 				for (int r = 0; r < kTaps; ++r) {
 					s_s += sh.rows[0][l][r][0];
