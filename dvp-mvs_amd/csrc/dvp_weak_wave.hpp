@@ -190,7 +190,7 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 				nb[rd] = mks2(-1, -1);
 				sv[rd] = 0;
 				nbc[rd] = 0;
-				if (k < kAnchors) {
+				if (k < kAnchors && plane_on) {
 					nb[rd] = nbs[k + 1];
 					if (!(nb[rd].x == -1 || nb[rd].y == -1)) { nbc[rd] = nb[rd].x + nb[rd].y * W; sv[rd] = d.selected_views[nbc[rd]]; }
 				}
@@ -212,104 +212,72 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 #pragma unroll
 				for (int rd = 0; rd < 2; ++rd) {
 					const int k = rd * 8 + kk;
-					if (k >= kAnchors || nb[rd].x == -1 || nb[rd].y == -1) {
-						if (k < kAnchors && inside) sh.acost[slot][q][k] = -1.0f;   // absent anchor: does not count
-						continue;
-					}
-					const bool visible = is_set(sv[rd], v - 1);
-					// reference side (APD.cu:905-1000): the anchor's 8 visibility-prior offsets + the anchor itself,
-					// weights relative to the centre pixel's grey level.  It is the same for the eight plane lanes
-					// of the anchor (all of them are here: the branch above depends on the anchor only), so lane q
-					// evaluates tap q, every lane tap 8, and the group trades (w, w*ref, w*ref*ref) by lane
-					// permutes instead of each lane computing nine exponentials.
-					int tx[9], ty[9];
-					float tw_[9], twa[9], twaa[9];
-					if (visible) {
-						const s2* cand = d.candidate + cand_index(d, nbc[rd], v - 1);
-						float ti[9], tj[9];
-#pragma unroll
-						for (int t = 0; t < 9; ++t) {
-							int i = 0, j = 0;
-							if (t < 8) {
-								const s2 o = cand[t];
-								i = o.x;
-								j = o.y;
-								if (i == 0 && j == 0) {   // default +-5 ring (APD.cu:943-952): {-5,0,5}^2 without its centre, x-major
-									const int u = t + (t >= 4 ? 1 : 0);
-									i = (u / 3 - 1) * 5;
-									j = (u % 3 - 1) * 5;
-								}
-							}
-							tx[t] = nb[rd].x + i;
-							ty[t] = nb[rd].y + j;
-							ti[t] = (float)i;
-							tj[t] = (float)j;
-						}
-#if defined(__HIP_DEVICE_COMPILE__)
-						int ox = tx[0], oy = ty[0];
-						float oi = ti[0], oj = tj[0];
-#pragma unroll
-						for (int t = 1; t < 8; ++t)
-							if (q == t) { ox = tx[t]; oy = ty[t]; oi = ti[t]; oj = tj[t]; }
-						const float a_own = img_texel(d.images, d.org, Pt, W, Hh, ox, oy);
-						const float a_8 = img_texel(d.images, d.org, Pt, W, Hh, tx[8], ty[8]);
-						const float w_own = bilateral_weight(oi, oj, a_own, cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
-						const float wa_own = w_own * a_own, waa_own = wa_own * a_own;
-						tw_[8] = bilateral_weight(ti[8], tj[8], a_8, cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
-						twa[8] = tw_[8] * a_8;
-						twaa[8] = twa[8] * a_8;
-#pragma unroll
-						for (int t = 0; t < 8; ++t) {
-							const int from = (l & 56) | t;
-							tw_[t] = __shfl(w_own, from);
-							twa[t] = __shfl(wa_own, from);
-							twaa[t] = __shfl(waa_own, from);
-						}
-#else
-#pragma unroll
-						for (int t = 0; t < 9; ++t) {
-							const float a = img_texel(d.images, d.org, Pt, W, Hh, tx[t], ty[t]);
-							tw_[t] = bilateral_weight(ti[t], tj[t], a, cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
-							twa[t] = tw_[t] * a;
-							twaa[t] = twa[t] * a;
-						}
-#endif
-					}
-					if (!inside) continue;
+					if (k >= kAnchors || !inside) continue;
 					float cost = -1.0f;   // < 0: this anchor does not count
-					const f2 nsp = apply_homography(H, nb[rd].x, nb[rd].y);
-					const bool outside = nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh;
-					if (outside) {
-						if (visible) cost = 2.0f;
-					} else if (!visible) {
-						cost = 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
-					} else {
-						unsigned off[9];
-						TapW<SMP> tw[9];
-						float qd[9][4];
+					if (!(nb[rd].x == -1 || nb[rd].y == -1)) {
+						const bool visible = is_set(sv[rd], v - 1);
+						const f2 nsp = apply_homography(H, nb[rd].x, nb[rd].y);
+						const bool outside = nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh;
+						if (outside) {
+							if (visible) cost = 2.0f;
+						} else if (!visible) {
+							cost = 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
+						} else {
+							// reference side (APD.cu:905-1000): 8 visibility-prior offsets of the anchor + the anchor itself
+							const s2* cand = d.candidate + cand_index(d, nbc[rd], v - 1);
+							int tx[9], ty[9];
+							float ti[9], tj[9];
 #pragma unroll
-						for (int t = 0; t < 9; ++t) {
-							const f2 sp = apply_homography(H, tx[t], ty[t]);
-							tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t], &tw[t]);
+							for (int t = 0; t < 9; ++t) {
+								int i = 0, j = 0;
+								if (t < 8) {
+									const s2 o = cand[t];
+									i = o.x;
+									j = o.y;
+									if (i == 0 && j == 0) {   // default +-5 ring (APD.cu:943-952): {-5,0,5}^2 without its centre, x-major
+										const int u = t + (t >= 4 ? 1 : 0);
+										i = (u / 3 - 1) * 5;
+										j = (u % 3 - 1) * 5;
+									}
+								}
+								tx[t] = nb[rd].x + i;
+								ty[t] = nb[rd].y + j;
+								ti[t] = (float)i;
+								tj[t] = (float)j;
+							}
+							// source side first (addresses need only the offsets): 9 gathers in flight
+							unsigned off[9];
+							TapW<SMP> tw[9];
+							float qd[9][4];
+#pragma unroll
+							for (int t = 0; t < 9; ++t) {
+								const f2 sp = apply_homography(H, tx[t], ty[t]);
+								tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t], &tw[t]);
+							}
+#pragma unroll
+							for (int t = 0; t < 9; ++t) load_quad(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
+							float av[9];
+#pragma unroll
+							for (int t = 0; t < 9; ++t) av[t] = img_texel(d.images, d.org, Pt, W, Hh, tx[t], ty[t]);
+							float a_sr = 0.0f, a_srr = 0.0f, a_sw = 0.0f;
+							float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+#pragma unroll
+							for (int t = 0; t < 9; ++t) {
+								const float w = bilateral_weight(ti[t], tj[t], av[t], cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
+								const float wa = w * av[t];
+								a_sr += wa;
+								a_srr += wa * av[t];
+								a_sw += w;
+								float fa, fb;
+								tap_weights(tw[t], &fa, &fb);
+								const float b = tex_lerp(fa, fb, qd[t][0], qd[t][1], qd[t][2], qd[t][3]);
+								const float wb = w * b;
+								s_s += wb;
+								s_ss = fmaf(wb, b, s_ss);
+								s_rs = fmaf(wa, b, s_rs);
+							}
+							cost = ncc_from_sums(a_sr, a_srr, s_s, s_ss, s_rs, a_sw);
 						}
-#pragma unroll
-						for (int t = 0; t < 9; ++t) load_quad(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
-						float a_sr = 0.0f, a_srr = 0.0f, a_sw = 0.0f;
-						float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
-#pragma unroll
-						for (int t = 0; t < 9; ++t) {
-							a_sr += twa[t];
-							a_srr += twaa[t];
-							a_sw += tw_[t];
-							float fa, fb;
-							tap_weights(tw[t], &fa, &fb);
-							const float b = tex_lerp(fa, fb, qd[t][0], qd[t][1], qd[t][2], qd[t][3]);
-							const float wb = tw_[t] * b;
-							s_s += wb;
-							s_ss = fmaf(wb, b, s_ss);
-							s_rs = fmaf(twa[t], b, s_rs);
-						}
-						cost = ncc_from_sums(a_sr, a_srr, s_s, s_ss, s_rs, a_sw);
 					}
 					sh.acost[slot][q][k] = cost;
 				}
