@@ -33,7 +33,13 @@ if ROOT not in sys.path:
 
 NCC_BYTES = 724            # algorithmic bytes of one bilateral-NCC evaluation
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
-SIMD_PEAK_GCYC = 2457.6    # SIMD cycles/s: 256 CU x 4 SIMD x 2.4 GHz (MI355X_MICROARCH.md: 256 CUs, 4 SIMDs per CU, 2400 MHz max clock)
+# non-packed fp32 VALU issue rate of MI355X, MEASURED with tools/valu_peak.hip (independent v_fma_f32 chains,
+# profiles/r02_valu_peak.txt): G wave64 instructions/s by waves per SIMD.  The ceiling needs >= 8 waves per SIMD
+# (974.6 = one instruction per ~2.5 cycles per SIMD at the nominal 2.4 GHz; MI355X_MICROARCH.md gives 2 cycles);
+# the NCC kernels hold 2 waves per SIMD (256 VGPRs + a 72 KB patch table per workgroup), whose ceiling is 756.2.
+VALU_PEAK_GINST = 974.6
+VALU_CEILING_BY_WAVES = {1: 502.9, 2: 756.2, 4: 893.4, 8: 974.6}
+WAVES_PER_SIMD = {"strong_update": 2, "depth_to_weak": 2, "local_refine": 2, "random_init": 2, "weak_update": 3}
 PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_r02.json")
 
 # launch site -> kernel name in a rocprofv3 trace (list launches for the weak path; the narrow
@@ -130,10 +136,10 @@ def pmc_lookup(kernel, W, H, S):
 
 def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
     """Roofline entry of one launch site.  `bound` = the limiter with the larger fraction of its peak:
-      valu: cycles the SIMDs' vector ALUs were busy (PMC SQ_ACTIVE_INST_VALU, quad-cycles -> x4) over the
-            cycles available (1024 SIMDs x 2.4 GHz x launch time).  On this part a non-packed wave64 VALU
-            instruction occupies its SIMD for 4 cycles (measured: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.0
-            quad-cycle; the 157 TFLOP/s fp32 figure assumes packed fp32), i.e. 614 G wave-instructions/s;
+      valu: wave64 VALU instructions per second (PMC SQ_INSTS_VALU of this kernel at this size / live launch
+            time) over the MEASURED issue peak of the part (tools/valu_peak.hip: 974.6 G/s with 8 waves per
+            SIMD).  `valu_frac_of_occupancy_ceiling` relates the same rate to the measured ceiling at the
+            kernel's own occupancy (2 waves per SIMD: 756.2 G/s) — what is left without freeing registers/LDS;
       hbm:  physical traffic (PMC FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md)
             over 8 TB/s.
     Both are <= 1 by construction and need the PMC entry of this (kernel, size) in profiles/pmc_r02.json;
@@ -148,20 +154,20 @@ def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
          "algorithmic_gbs": round(alg, 1) if alg else None, "algorithmic_frac_of_hbm_peak": round(alg / HBM_PEAK_GBS, 4) if alg else None}
     if pmc and sec > 0:
         traffic = pmc.get("hbm_bytes_per_launch")
-        busy_quads = pmc.get("SQ_ACTIVE_INST_VALU")
         insts = pmc.get("SQ_INSTS_VALU")
         hbm_gbs = traffic / sec / 1e9 if traffic else None
-        busy_gcyc = busy_quads * 4.0 / sec / 1e9 if busy_quads else None
+        ginst = insts / sec / 1e9 if insts else None
         fh = hbm_gbs / HBM_PEAK_GBS if hbm_gbs else 0.0
-        fv = busy_gcyc / SIMD_PEAK_GCYC if busy_gcyc else 0.0
+        fv = ginst / VALU_PEAK_GINST if ginst else 0.0
         if fv >= fh:
-            r.update(bound="valu", achieved=round(busy_gcyc, 1), peak=SIMD_PEAK_GCYC, unit="G VALU-busy SIMD cycles/s", frac=round(fv, 4))
+            r.update(bound="valu", achieved=round(ginst, 1), peak=VALU_PEAK_GINST, unit="G wave64 VALU instr/s", frac=round(fv, 4))
         else:
             r.update(bound="hbm", achieved=round(hbm_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fh, 4))
+        wps = WAVES_PER_SIMD.get(stage)
         r.update(traffic=traffic, physical_hbm_gbs=round(hbm_gbs, 1) if hbm_gbs else None, physical_hbm_frac=round(fh, 4),
-                 valu_busy_frac=round(fv, 4),
-                 valu_ginstr_s=round(insts / sec / 1e9, 1) if insts else None,
-                 valu_cycles_per_instr=round(4.0 * busy_quads / insts, 2) if (busy_quads and insts) else None,
+                 valu_ginstr_s=round(ginst, 1) if ginst else None, valu_issue_frac=round(fv, 4),
+                 waves_per_simd=wps,
+                 valu_frac_of_occupancy_ceiling=round(ginst / VALU_CEILING_BY_WAVES.get(wps, VALU_PEAK_GINST), 4) if (ginst and wps in VALU_CEILING_BY_WAVES) else None,
                  valu_instr_per_wave_eval=round(insts * 64.0 / evals_per_launch, 1) if (insts and evals_per_launch) else None,
                  pmc_source="profiles/pmc_r02.json[%s|%dx%d|S%d]" % (k, W, H, S))
         for c in ("l2_hit_rate", "wait_any_frac"):
