@@ -177,20 +177,27 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 	while (rest) {
 		uint32_t batch = 0;
 		for (int n = 0; n < 8 && rest; ++n) { const uint32_t low = rest & (0u - rest); batch |= low; rest ^= low; }
+		// lane -> (anchor k, plane q): item = round * 64 + lane, k = item / np, q = item % np with np = the
+		// number of plane slots in use (8 candidates in phase 0, 2 and 5 in the refinement phases): the 55 or
+		// 22 (anchor, plane) pairs of a refinement phase fit ONE round instead of two
+		int np = 32 - __builtin_clz(pmask | 1u);
+		if (kAnchors * np > 64) np = 8;   // two rounds: 8 planes per anchor keep a lane on ONE plane in both
+		const int rounds = (kAnchors * np + 63) / 64;
 		DVP_LANES(l) {
-			const int q = l & 7, kk = l >> 3;
-			const bool plane_on = (pmask >> q) & 1;
 			// the anchors this lane serves (one per round), fetched once for all views
 			s2 nb[2];
 			uint32_t sv[2];
-			int nbc[2];
+			int nbc[2], ak[2];
+			const int q = l % np;   // np == 8: the same plane in both rounds; np < 8: a single round
+			const bool plane_on = (pmask >> q) & 1;
 #pragma unroll
 			for (int rd = 0; rd < 2; ++rd) {
-				const int k = rd * 8 + kk;
+				const int k = (rd * 64 + l) / np;
+				ak[rd] = (rd < rounds && k < kAnchors) ? k : kAnchors;
 				nb[rd] = mks2(-1, -1);
 				sv[rd] = 0;
 				nbc[rd] = 0;
-				if (k < kAnchors && plane_on) {
+				if (ak[rd] < kAnchors && plane_on) {
 					nb[rd] = nbs[k + 1];
 					if (!(nb[rd].x == -1 || nb[rd].y == -1)) { nbc[rd] = nb[rd].x + nb[rd].y * W; sv[rd] = d.selected_views[nbc[rd]]; }
 				}
@@ -206,12 +213,12 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 					homography(vc, sh.pl[q], H);
 					const f2 pt = apply_homography(H, px, py);
 					inside = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f);
-					if (kk == 0) sh.inq[slot][q] = inside ? 1 : 0;
+					if (l < np) sh.inq[slot][q] = inside ? 1 : 0;
 				}
 				// ---- anchors: 8 planes x 8 anchors per round ------------------------------------------------
 #pragma unroll
 				for (int rd = 0; rd < 2; ++rd) {
-					const int k = rd * 8 + kk;
+					const int k = ak[rd];
 					if (k >= kAnchors || !inside) continue;
 					float cost = -1.0f;   // < 0: this anchor does not count
 					if (!(nb[rd].x == -1 || nb[rd].y == -1)) {
