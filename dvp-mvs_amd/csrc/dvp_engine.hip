@@ -137,6 +137,18 @@ __device__ __forceinline__ void weak_wave_body(const Dev& d, const ListArgs& a) 
 	weak_update_wave<SMP>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, sh[wave]);
 	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
 }
+// second half of GenNeighbours (RANSAC plane + ranking): one wave per WEAK pixel, point tables in LDS
+extern "C" __global__ void __launch_bounds__(256) dvp_gen_neighbours_fit(const Dev d, const ListArgs a) {
+	__shared__ FitShared sh[4];
+	const int wave = threadIdx.x >> 6;
+	const int t = list_block(blockIdx.x, gridDim.x, kListRun * 64) * 4 + wave;
+	if (t >= a.count) return;
+	const int center = d.weak_list[a.base + t];
+	if (d.weak_info[center] != DVP_WEAK) return;
+	const int py = center / d.width, px = center - py * d.width;
+	gen_neighbours_fit_wave(d, px, py, sh[wave]);
+}
+
 #ifndef DVP_LB_WEAK
 #define DVP_LB_WEAK 3   // waves per SIMD the wave kernel is compiled for (LDS: 42 KB per workgroup -> 3 workgroups per CU)
 #endif
@@ -269,7 +281,7 @@ struct dvp_ctx {
 	float* costs = nullptr; float* costs_snap = nullptr; float* complex_ = nullptr;
 	uint32_t* selected_views = nullptr;
 	uint8_t* view_weight = nullptr; uint8_t* weak_info = nullptr; uint8_t* weak_reliable = nullptr; uint8_t* edge = nullptr;
-	s2* label_stop = nullptr; s2* weak_nearest_strong = nullptr; s2* neighbours = nullptr; s2* candidate = nullptr; s2* edge_neigh = nullptr; s2* label_boundary = nullptr;
+	s2* label_stop = nullptr; s2* weak_nearest_strong = nullptr; s2* neighbours = nullptr; s2* gn_points = nullptr; int* gn_count = nullptr; s2* candidate = nullptr; s2* edge_neigh = nullptr; s2* label_boundary = nullptr;
 	int* neighbours_map = nullptr; int* label = nullptr; int* radius = nullptr;
 	unsigned long long* eval_counter = nullptr;
 	float* scratch_out = nullptr;
@@ -321,7 +333,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.planes = c->planes; d.planes_snap = c->planes_snap; d.costs = c->costs; d.costs_snap = c->costs_snap;
 	d.selected_views = c->selected_views; d.view_weight = c->view_weight; d.weak_info = c->weak_info;
 	d.weak_reliable = c->weak_reliable; d.weak_nearest_strong = c->weak_nearest_strong;
-	d.neighbours_map = c->neighbours_map; d.neighbours = c->neighbours; d.fit_planes = c->fit_planes;
+	d.neighbours_map = c->neighbours_map; d.neighbours = c->neighbours; d.gn_points = c->gn_points; d.gn_count = c->gn_count; d.fit_planes = c->fit_planes;
 	d.candidate = c->candidate; d.edge = c->edge; d.edge_bits = c->edge_bits; d.strong_bits = c->strong_bits; d.edge_tiles_x = edge_tiles_x(c->W); d.edge_neigh = c->edge_neigh; d.label = c->label;
 	d.label_boundary = c->label_boundary; d.label_stop = c->label_stop; d.complex_ = c->complex_; d.radius = c->radius;
 	d.weak_list = c->weak_list;
@@ -480,6 +492,7 @@ static int ensure_weak_buffers(dvp_ctx* c, size_t weak_count) {
 	if (need > c->weak_alloc) {
 		// grow (old blocks stay owned by the context until destroy; growth is rare)
 		if (dalloc(c, &c->neighbours, need * DVP_NEIGHBOUR_NUM, false)) return 1;
+		if (dalloc(c, &c->gn_points, need * kGnMaxPoints, false) || dalloc(c, &c->gn_count, need)) return 1;
 		if (dalloc(c, &c->complex_, need)) return 1;
 		if (dalloc(c, &c->label_boundary, need * 8, false)) return 1;
 		c->weak_alloc = need;
@@ -693,7 +706,10 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 			const bool ex = c->d.sampler != 0;
 			switch (stage) {
 			case DVP_ST_FIND_NEAREST_STRONG: hipLaunchKernelGGL(ex ? dvp_find_nearest_strong_list_exact : dvp_find_nearest_strong_list, lg, block, 0, c->stream, c->d, la); break;
-			case DVP_ST_GEN_NEIGHBOURS: hipLaunchKernelGGL(ex ? dvp_gen_neighbours_list_exact : dvp_gen_neighbours_list, lg, block, 0, c->stream, c->d, la); break;
+			case DVP_ST_GEN_NEIGHBOURS:
+				hipLaunchKernelGGL(ex ? dvp_gen_neighbours_list_exact : dvp_gen_neighbours_list, lg, block, 0, c->stream, c->d, la);
+				hipLaunchKernelGGL(dvp_gen_neighbours_fit, dim3((la.count + 3) / 4), block, 0, c->stream, c->d, la);
+				break;
 			case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(ex ? dvp_neighbour_update_list_exact : dvp_neighbour_update_list, lg, block, 0, c->stream, c->d, la); break;
 			case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(ex ? dvp_ransac_fit_plane_list_exact : dvp_ransac_fit_plane_list, lg, block, 0, c->stream, c->d, la); break;
 			case DVP_ST_WEAK_UPDATE: hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact : dvp_weak_update_wave, dim3((la.count + 3) / 4), block, 0, c->stream, c->d, la); break;

@@ -78,7 +78,12 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 #endif
 	}
 	else if (STAGE == DVP_ST_FIND_NEAREST_STRONG) find_nearest_strong_px(d, px, py);
-	else if (STAGE == DVP_ST_GEN_NEIGHBOURS) gen_neighbours_px(d, px, py);
+	else if (STAGE == DVP_ST_GEN_NEIGHBOURS) {
+		gen_neighbours_px(d, px, py);
+#if !defined(__HIPCC__)   // device: second half in its own launch shape, one wave per WEAK pixel (dvp_gen_neighbours_fit)
+		if (d.weak_info[center] == DVP_WEAK) { FitShared sh; gen_neighbours_fit_wave(d, px, py, sh); }
+#endif
+	}
 	else if (STAGE == DVP_ST_NEIGHBOUR_UPDATE) neighbour_update_px(d, px, py);
 	else if (STAGE == DVP_ST_RANDOM_INIT) random_init_px<SMP>(d, px, py, tab, nevals);
 	else if (STAGE == DVP_ST_STRONG_UPDATE) { if (d.weak_info[center] != DVP_WEAK) strong_update_px<SMP, MV>(d, px, py, tab, iter, nevals); }

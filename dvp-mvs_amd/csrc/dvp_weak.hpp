@@ -297,19 +297,22 @@ DVP_HD bool bresenham_hits_edge(const Dev& d, int Ax, int Ay, int Bx, int By) {
 }
 
 // ---- GenNeighbours (APD.cu:3330-3711) -----------------------------------------------------------
+// First half, one lane per WEAK pixel: the anchor candidates (directional search APD.cu:3382-3452, label
+// extension :3455-3560).  The search of a direction depends on the points found for the directions
+// before it and on how many random tries those consumed, so a pixel is sequential here.  The second half
+// (RANSAC plane + ranking, :3562-3711) is gen_neighbours_fit_wave.
+constexpr int kGnMaxPoints = 160;   // max_pt_num (APD.cu:3338)
 DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 	const int W = d.width, H = d.height;
 	const int center = px + py * W;
 	if (d.weak_info[center] != DVP_WEAK) return;
 	const DvpParams& P = d.params;
 	const DvpCamera cam = load_camera(d, 0);
-	const int max_pt_num = 160;
+	const int max_pt_num = kGnMaxPoints;
 	const int min_margin = 6;
-	const float depth_diff = P.depth_max - P.depth_min;
 	s2* neighbours = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
 	Rng r_limit(d.seed, (uint32_t)center, rng_site(PH_NEIGHBOURS, 0, SUB_LIMIT));
 	Rng r_search(d.seed, (uint32_t)center, rng_site(PH_NEIGHBOURS, 0, SUB_SEARCH));
-	Rng r_ransac(d.seed, (uint32_t)center, rng_site(PH_NEIGHBOURS, 0, SUB_RANSAC));
 
 	for (int i = 0; i < DVP_NEIGHBOUR_NUM; ++i) neighbours[i] = mks2(-1, -1);
 	neighbours[0] = mks2(px, py);
@@ -451,147 +454,13 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 		}
 	}
 
-	if (strong_point_size <= 3) { d.weak_reliable[center] = 0; return; }
-
-	s2 spv[max_pt_num];
-	f3 sp3[max_pt_num];
-	f3 spn[max_pt_num];
-	int valid_count = 0;
-	float X[3];
-	get_3d_point(cam, px, py, d.planes[center].w, X);
-	const float center_z = X[2];
-	for (int i = 0; i <= extend_index; ++i) {
-		const s2 sp = strong_points[i];
-		if (sp.x == -1) continue;
-		const int spc = sp.x + sp.y * W;
-		const f4 pl = d.planes[spc];
-		spv[valid_count] = sp;
-		get_3d_point(cam, sp.x, sp.y, pl.w, X);
-		sp3[valid_count] = mk3(X[0], X[1], X[2]);
-		const f4 n4 = normal_world_to_cam(cam, pl);
-		spn[valid_count] = mk3(n4.x, n4.y, n4.z);
-		valid_count++;
-	}
-	for (int i = valid_count; i < DVP_NEIGHBOUR_NUM - 1; ++i) spv[i] = mks2(-1, -1);   // only spv[0..10] are read beyond valid_count (neighbours[1..11])
-
-	f4 best_plane = mk4(0, 0, 0, 0);
-	bool has_valid_plane = false;
-	{
-		int iteration = 300, max_iter = 200;
-		float min_cost = FLT_MAX;
-		int max_count = 3;
-		bool has_strong_plane = false;
-		// The reference caches the line tests in edge_test[160][160], filled symmetrically by whichever
-		// orientation of a pair is tested first (APD.cu:3574, 3588-3604); BresenhamLine walks from its second
-		// argument under a step limit, so the cached answer is that orientation's.  Here: 2 bits per
-		// unordered pair (0 untested, 1 edge hit, 2 clear).  Every draw that passes the index and triangle
-		// tests fills its three pairs, in the reference's order, before any further test.
-		uint32_t memo[(max_pt_num * (max_pt_num - 1) / 2 + 15) / 16];
-		for (int i = 0; i < (valid_count * (valid_count - 1) / 2 + 15) / 16; ++i) memo[i] = 0u;
-		// two alternating phases: (A) each lane advances through its own draws until one passes the
-		// index and triangle tests, (B) the lanes that hold one run the (cached) line tests together, then
-		// the remaining rejections, the inlier count and the bookkeeping.  Same draws and tests per lane.
-		for (;;) {
-			bool ok = false;
-			int ai = 0, bi = 0, ci = 0;
-			f3 AN = mk3(0, 0, 0), A = mk3(0, 0, 0);
-			f4 cv = mk4(0, 0, 0, 0);
-			for (;;) {
-				bool cand = false;
-				while (iteration > 0 && max_iter > 0) {
-					max_iter--;
-					ai = (int)(r_ransac.next() % (uint32_t)valid_count);
-					bi = (int)(r_ransac.next() % (uint32_t)valid_count);
-					ci = (int)(r_ransac.next() % (uint32_t)valid_count);
-					if (ai == bi || bi == ci || ai == ci) continue;
-					if (!point_in_triangle(spv[ai], spv[bi], spv[ci], px, py)) continue;
-					cand = true;
-					break;
-				}
-				if (!cand) break;
-				if (edge_limit) {
-					const int pa[3] = { ai, bi, ci }, pb[3] = { bi, ci, ai };
-					bool hit = false;
-#pragma unroll
-					for (int e = 0; e < 3; ++e) {
-						const int hi = pa[e] > pb[e] ? pa[e] : pb[e], lo = pa[e] > pb[e] ? pb[e] : pa[e];
-						const int idx = hi * (hi - 1) / 2 + lo;
-						uint32_t st = (memo[idx >> 4] >> ((idx & 15) * 2)) & 3u;
-						if (st == 0u) {
-							st = bresenham_hits_edge(d, spv[pa[e]].x, spv[pa[e]].y, spv[pb[e]].x, spv[pb[e]].y) ? 1u : 2u;
-							memo[idx >> 4] |= st << ((idx & 15) * 2);
-						}
-						hit |= st == 1u;
-					}
-					if (hit) continue;
-				}
-				AN = spn[ai];   // the reference uses a_index for all three normals (APD.cu:3605-3607)
-				const float nn = AN.x * AN.x + AN.y * AN.y + AN.z * AN.z;
-				if (nn < 0.9f) continue;
-				A = sp3[ai];
-				const f3 B = sp3[bi], C = sp3[ci];
-				const f3 AC = mk3(A.x - C.x, A.y - C.y, A.z - C.z);
-				const f3 BC = mk3(B.x - C.x, B.y - C.y, B.z - C.z);
-				cv.x = AC.y * BC.z - BC.y * AC.z;
-				cv.y = -(AC.x * BC.z - BC.x * AC.z);
-				cv.z = AC.x * BC.y - BC.x * AC.y;
-				cv.w = 0.0f;
-				if ((cv.x == 0 && cv.y == 0 && cv.z == 0) || cv.x != cv.x || cv.y != cv.y || cv.z != cv.z) continue;
-				ok = true;
-				break;
-			}
-			if (!ok) break;
-			iteration--;
-			normalize3(&cv);
-			cv.w = -(cv.x * A.x + cv.y * A.y + cv.z * A.z);
-			bool is_strong_plane = true;
-			if (P.use_label && d.label[center] > 0 && fabsf(AN.x * cv.x + AN.y * cv.y + AN.z * cv.z) < 0.9f) is_strong_plane = false;
-			if (has_strong_plane && !is_strong_plane) continue;
-			int temp_count = 0;
-			for (int si = 0; si < valid_count; ++si) {
-				const float fx = (spv[si].x - cam.K[2]) / cam.K[0];
-				const float fy = (spv[si].y - cam.K[5]) / cam.K[4];
-				const float fit_depth = -cv.w / (cv.x * fx + cv.y * fy + cv.z);
-				const float dist = fabsf(fit_depth - sp3[si].z);
-				if (dist / depth_diff < P.ransac_threshold) temp_count++;
-			}
-			if (temp_count < 6) continue;
-			const float fx = (px - cam.K[2]) / cam.K[0];
-			const float fy = (py - cam.K[5]) / cam.K[4];
-			const float fit_depth = -cv.w / (cv.x * fx + cv.y * fy + cv.z);
-			const float center_distance = fabsf(fit_depth - center_z);
-			if (temp_count > max_count || (!has_strong_plane && is_strong_plane)) {
-				if (!has_strong_plane && is_strong_plane) has_strong_plane = true;
-				best_plane = cv;
-				max_count = temp_count;
-				min_cost = center_distance;
-				has_valid_plane = true;
-			} else if (temp_count == max_count) {
-				if (center_distance < min_cost) { best_plane = cv; max_count = temp_count; min_cost = center_distance; }
-			}
-		}
-	}
-	if (!has_valid_plane) { d.weak_reliable[center] = 0; return; }
-
-	float weight[max_pt_num];
-	for (int i = 0; i < valid_count; ++i) {
-		const float fx = (spv[i].x - cam.K[2]) / cam.K[0];
-		const float fy = (spv[i].y - cam.K[5]) / cam.K[4];
-		const float fit_depth = -best_plane.w / (best_plane.x * fx + best_plane.y * fy + best_plane.z);
-		const float dist = fabsf(fit_depth - sp3[i].z);
-		if (dist / depth_diff >= P.ransac_threshold) { spv[i] = mks2(-1, -1); weight[i] = FLT_MAX; }
-		else weight[i] = dist;
-	}
-	for (int i = 1; i < valid_count; i++) {   // sort_small_weighted (APD.cu:125-138)
-		const s2 tp = spv[i];
-		const float tw = weight[i];
-		int j = i;
-		for (; j >= 1 && tw < weight[j - 1]; j--) { spv[j] = spv[j - 1]; weight[j] = weight[j - 1]; }
-		spv[j] = tp;
-		weight[j] = tw;
-	}
-	for (int i = 1; i < DVP_NEIGHBOUR_NUM; ++i) neighbours[i] = spv[i - 1];
-	d.weak_reliable[center] = 1;
+	// hand-over to the plane-fit half (gen_neighbours_fit_wave, dvp_weak_wave.hpp): the candidate list as it
+	// stands — the 32 directional slots with their holes, then the label-extension points
+	const int wi = d.neighbours_map[center];
+	if (strong_point_size <= 3) { d.weak_reliable[center] = 0; d.gn_count[wi] = 0; return; }
+	s2* out = d.gn_points + (size_t)wi * kGnMaxPoints;
+	for (int i = 0; i <= extend_index; ++i) out[i] = strong_points[i];
+	d.gn_count[wi] = extend_index + 1;
 }
 
 // NeigbourUpdate (APD.cu:3713-3729)

@@ -671,5 +671,254 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 	wave_sync();
 }
 
+// ---- GenNeighbours, second half (APD.cu:3562-3711): RANSAC plane through the candidate anchors, then the
+// anchors ranked by their distance to that plane — ONE WAVE per WEAK pixel.
+//
+// A pixel per lane keeps its 160-entry point tables in scratch and reads them at random indices for 200
+// draws: 64 lanes x divergent indices = one cache sector per access, 600 GB of fetches per launch at
+// 6208x4128 with the vector ALUs 28 % busy.  Here the tables of one pixel live in LDS and the wave splits
+// the work that is independent:
+//   1. the 200 draws (index triples + the cheap rejections) — the RNG is counter-based and every draw
+//      consumes exactly three numbers, so draw t owns counters 3t..3t+2;
+//   2. in draw order (cheap, every lane in step): which unordered pairs need a line test and in which
+//      orientation they are asked FIRST — the reference caches the test per pair, symmetric, first asker
+//      wins (APD.cu:3574, 3588-3604);
+//   3. the line walks, one per lane;
+//   4. per draw: plane, label test, inlier count, distance of the pixel's own depth to the plane;
+//   5. in draw order (every lane in step): the reference's running best (APD.cu:3646-3668);
+//   6. residuals of all points, their stable rank by residual (== the reference's insertion sort,
+//      APD.cu:125-138), neighbours[1..11].
+constexpr int kGnDraws = 200;
+constexpr int kGnPairWords = (kGnMaxPoints * (kGnMaxPoints - 1) / 2 + 31) / 32;
+struct FitShared {
+	s2 raw[kGnMaxPoints];          // the candidate list as handed over (holes = (-1,-1))
+	uint8_t slot_of[kGnMaxPoints]; // valid point j -> index in raw
+	s2 spv[kGnMaxPoints];
+	f3 sp3[kGnMaxPoints];          // camera-frame 3-D point
+	f3 spn[kGnMaxPoints];          // camera-frame normal
+	f2 fxy[kGnMaxPoints];          // ((x - cx) / fx, (y - cy) / fy)
+	float weight[kGnMaxPoints];
+	uint32_t trip[kGnDraws];       // a | b << 8 | c << 16 | passed << 24
+	uint32_t seen[kGnPairWords];   // unordered pair already queued for its line test
+	uint32_t hit[kGnPairWords];    // ... and the test found an edge pixel
+	uint16_t walk[3 * kGnDraws];   // queued tests: from | to << 8 (orientation of the first asker)
+	f4 cand_plane[kGnDraws];
+	float cand_dist[kGnDraws];
+	int cand_info[kGnDraws];       // bit 0 valid, bit 1 "strong plane", bits 8..: inlier count
+};
+
+DVP_HD int gn_pair_index(int a, int b) { const int hi = a > b ? a : b, lo = a > b ? b : a; return hi * (hi - 1) / 2 + lo; }
+
+DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh) {
+	const int W = d.width;
+	const int center = px + py * W;
+	const DvpParams& P = d.params;
+	const int wi = d.neighbours_map[center];
+	const int listed = d.gn_count[wi];
+	if (listed <= 0) return;   // fewer than four candidates: the first half already marked the pixel unreliable
+	const DvpCamera cam = load_camera(d, 0);
+	const float depth_diff = P.depth_max - P.depth_min;
+	s2* neighbours = d.neighbours + (size_t)wi * DVP_NEIGHBOUR_NUM;
+	const uint32_t site = rng_site(PH_NEIGHBOURS, 0, SUB_RANSAC);
+	bool edge_limit = false;   // same draw as in the first half (APD.cu:3366-3374)
+	if (P.use_limit) {
+		edge_limit = true;
+		if (P.use_edge) {
+			Rng r_limit(d.seed, (uint32_t)center, rng_site(PH_NEIGHBOURS, 0, SUB_LIMIT));
+			if (r_limit.uniform() - FLT_EPSILON < d.complex_[wi]) edge_limit = false;
+		}
+	}
+
+	// ---- the point tables -------------------------------------------------------------------------------
+	for (int i0 = 0; i0 < listed; i0 += 64) {
+		DVP_LANES(l) { if (i0 + l < listed) sh.raw[i0 + l] = d.gn_points[(size_t)wi * kGnMaxPoints + i0 + l]; }
+	}
+	wave_sync();
+	int valid_count = 0;
+	for (int i = 0; i < listed; ++i)
+		if (sh.raw[i].x != -1) { if (DVP_LANE0) sh.slot_of[valid_count] = (uint8_t)i; ++valid_count; }
+	wave_sync();
+	for (int j0 = 0; j0 < valid_count; j0 += 64) {
+		DVP_LANES(l) {
+			const int j = j0 + l;
+			if (j >= valid_count) continue;
+			const s2 sp = sh.raw[sh.slot_of[j]];
+			const f4 pl = d.planes[sp.x + sp.y * W];
+			float X[3];
+			get_3d_point(cam, sp.x, sp.y, pl.w, X);
+			const f4 n4 = normal_world_to_cam(cam, pl);
+			sh.spv[j] = sp;
+			sh.sp3[j] = mk3(X[0], X[1], X[2]);
+			sh.spn[j] = mk3(n4.x, n4.y, n4.z);
+			sh.fxy[j] = mk2((sp.x - cam.K[2]) / cam.K[0], (sp.y - cam.K[5]) / cam.K[4]);
+		}
+	}
+	float Xc[3];
+	get_3d_point(cam, px, py, d.planes[center].w, Xc);
+	const float center_z = Xc[2];
+	DVP_LANES(l) { for (int i = l; i < kGnPairWords; i += 64) { sh.seen[i] = 0u; sh.hit[i] = 0u; } }
+	wave_sync();
+
+	// ---- 1. the draws -------------------------------------------------------------------------------------
+	for (int t0 = 0; t0 < kGnDraws; t0 += 64) {
+		DVP_LANES(l) {
+			const int t = t0 + l;
+			if (t >= kGnDraws) continue;
+			const int ai = (int)(rand_u32(d.seed, (uint32_t)center, site, 3u * t) % (uint32_t)valid_count);
+			const int bi = (int)(rand_u32(d.seed, (uint32_t)center, site, 3u * t + 1u) % (uint32_t)valid_count);
+			const int ci = (int)(rand_u32(d.seed, (uint32_t)center, site, 3u * t + 2u) % (uint32_t)valid_count);
+			const bool pass = !(ai == bi || bi == ci || ai == ci) && point_in_triangle(sh.spv[ai], sh.spv[bi], sh.spv[ci], px, py);
+			sh.trip[t] = (uint32_t)ai | ((uint32_t)bi << 8) | ((uint32_t)ci << 16) | (pass ? 1u << 24 : 0u);
+		}
+	}
+	wave_sync();
+	// ---- 2. + 3. line tests: who asks first, then the walks -----------------------------------------------------
+	if (edge_limit) {
+		int n_walk = 0;
+		for (int t = 0; t < kGnDraws; ++t) {
+			const uint32_t tr = sh.trip[t];
+			if (!(tr >> 24)) continue;
+			const int p[4] = { (int)(tr & 255u), (int)((tr >> 8) & 255u), (int)((tr >> 16) & 255u), (int)(tr & 255u) };
+#pragma unroll
+			for (int e = 0; e < 3; ++e) {   // (a,b), (b,c), (c,a) — the reference's order
+				const int idx = gn_pair_index(p[e], p[e + 1]);
+				if ((sh.seen[idx >> 5] >> (idx & 31)) & 1u) continue;
+				if (DVP_LANE0) { sh.seen[idx >> 5] |= 1u << (idx & 31); sh.walk[n_walk] = (uint16_t)(p[e] | (p[e + 1] << 8)); }
+				wave_sync();   // the next pair may be the same one
+				++n_walk;
+			}
+		}
+		wave_sync();
+		for (int j0 = 0; j0 < n_walk; j0 += 64) {
+			DVP_LANES(l) {
+				const int j = j0 + l;
+				if (j >= n_walk) continue;
+				const int a = sh.walk[j] & 255, b = sh.walk[j] >> 8;
+				if (bresenham_hits_edge(d, sh.spv[a].x, sh.spv[a].y, sh.spv[b].x, sh.spv[b].y)) {
+					const int idx = gn_pair_index(a, b);
+#if defined(__HIP_DEVICE_COMPILE__)
+					atomicOr(&sh.hit[idx >> 5], 1u << (idx & 31));
+#else
+					sh.hit[idx >> 5] |= 1u << (idx & 31);
+#endif
+				}
+			}
+		}
+		wave_sync();
+	}
+	// ---- 4. candidates ---------------------------------------------------------------------------------------
+	const bool label_test = P.use_label && d.label[center] > 0;
+	const float fxc = (px - cam.K[2]) / cam.K[0], fyc = (py - cam.K[5]) / cam.K[4];
+	for (int t0 = 0; t0 < kGnDraws; t0 += 64) {
+		DVP_LANES(l) {
+			const int t = t0 + l;
+			if (t >= kGnDraws) continue;
+			sh.cand_info[t] = 0;
+			const uint32_t tr = sh.trip[t];
+			if (!(tr >> 24)) continue;
+			const int ai = (int)(tr & 255u), bi = (int)((tr >> 8) & 255u), ci = (int)((tr >> 16) & 255u);
+			if (edge_limit) {
+				const int i0 = gn_pair_index(ai, bi), i1 = gn_pair_index(bi, ci), i2 = gn_pair_index(ci, ai);
+				if (((sh.hit[i0 >> 5] >> (i0 & 31)) | (sh.hit[i1 >> 5] >> (i1 & 31)) | (sh.hit[i2 >> 5] >> (i2 & 31))) & 1u) continue;
+			}
+			const f3 AN = sh.spn[ai];   // the reference uses a_index for all three normals (APD.cu:3605-3607)
+			if (AN.x * AN.x + AN.y * AN.y + AN.z * AN.z < 0.9f) continue;
+			const f3 A = sh.sp3[ai], B = sh.sp3[bi], C = sh.sp3[ci];
+			const f3 AC = mk3(A.x - C.x, A.y - C.y, A.z - C.z);
+			const f3 BC = mk3(B.x - C.x, B.y - C.y, B.z - C.z);
+			f4 cv;
+			cv.x = AC.y * BC.z - BC.y * AC.z;
+			cv.y = -(AC.x * BC.z - BC.x * AC.z);
+			cv.z = AC.x * BC.y - BC.x * AC.y;
+			cv.w = 0.0f;
+			if ((cv.x == 0 && cv.y == 0 && cv.z == 0) || cv.x != cv.x || cv.y != cv.y || cv.z != cv.z) continue;
+			normalize3(&cv);
+			cv.w = -(cv.x * A.x + cv.y * A.y + cv.z * A.z);
+			const bool strong = !(label_test && fabsf(AN.x * cv.x + AN.y * cv.y + AN.z * cv.z) < 0.9f);
+			int count = 0;
+			for (int si = 0; si < valid_count; ++si) {
+				const f2 f = sh.fxy[si];
+				const float fit_depth = -cv.w / (cv.x * f.x + cv.y * f.y + cv.z);
+				if (fabsf(fit_depth - sh.sp3[si].z) / depth_diff < P.ransac_threshold) count++;
+			}
+			const float fit_depth = -cv.w / (cv.x * fxc + cv.y * fyc + cv.z);
+			sh.cand_plane[t] = cv;
+			sh.cand_dist[t] = fabsf(fit_depth - center_z);
+			sh.cand_info[t] = 1 | (strong ? 2 : 0) | (count << 8);
+		}
+	}
+	wave_sync();
+	// ---- 5. the running best, in draw order -------------------------------------------------------------------
+	f4 best_plane = mk4(0, 0, 0, 0);
+	bool has_valid_plane = false, has_strong_plane = false;
+	float min_cost = FLT_MAX;
+	int max_count = 3;
+	for (int t = 0; t < kGnDraws; ++t) {
+		const int info = sh.cand_info[t];
+		if (!(info & 1)) continue;
+		const bool strong = (info & 2) != 0;
+		if (has_strong_plane && !strong) continue;
+		const int count = info >> 8;
+		if (count < 6) continue;
+		const float center_distance = sh.cand_dist[t];
+		if (count > max_count || (!has_strong_plane && strong)) {
+			if (!has_strong_plane && strong) has_strong_plane = true;
+			best_plane = sh.cand_plane[t];
+			max_count = count;
+			min_cost = center_distance;
+			has_valid_plane = true;
+		} else if (count == max_count) {
+			if (center_distance < min_cost) { best_plane = sh.cand_plane[t]; max_count = count; min_cost = center_distance; }
+		}
+	}
+	if (!has_valid_plane) { if (DVP_LANE0) d.weak_reliable[center] = 0; return; }
+	// ---- 6. residuals, stable rank, neighbours ---------------------------------------------------------------------
+	for (int j0 = 0; j0 < valid_count; j0 += 64) {
+		DVP_LANES(l) {
+			const int j = j0 + l;
+			if (j >= valid_count) continue;
+			const f2 f = sh.fxy[j];
+			const float fit_depth = -best_plane.w / (best_plane.x * f.x + best_plane.y * f.y + best_plane.z);
+			const float dist = fabsf(fit_depth - sh.sp3[j].z);
+			sh.weight[j] = (dist / depth_diff >= P.ransac_threshold) ? FLT_MAX : dist;
+		}
+	}
+	wave_sync();
+	bool any_nan = false;   // a NaN residual (0/0 in the plane equation) has no rank: take the reference's insertion sort literally
+	for (int i = 0; i < valid_count; ++i) any_nan = any_nan || sh.weight[i] != sh.weight[i];
+	if (any_nan) {
+		DVP_LANES(l) {
+			if (l != 0) continue;
+			for (int i = 0; i < valid_count; ++i)
+				if (sh.weight[i] == FLT_MAX) sh.spv[i] = mks2(-1, -1);
+			for (int i = 1; i < valid_count; i++) {   // sort_small_weighted (APD.cu:125-138)
+				const s2 tp = sh.spv[i];
+				const float tw = sh.weight[i];
+				int j = i;
+				for (; j >= 1 && tw < sh.weight[j - 1]; j--) { sh.spv[j] = sh.spv[j - 1]; sh.weight[j] = sh.weight[j - 1]; }
+				sh.spv[j] = tp;
+				sh.weight[j] = tw;
+			}
+			for (int i = 1; i < DVP_NEIGHBOUR_NUM; ++i) neighbours[i] = (i - 1 < valid_count) ? sh.spv[i - 1] : mks2(-1, -1);
+			d.weak_reliable[center] = 1;
+		}
+		return;
+	}
+	for (int j0 = 0; j0 < valid_count; j0 += 64) {
+		DVP_LANES(l) {
+			const int j = j0 + l;
+			if (j >= valid_count) continue;
+			const float w = sh.weight[j];
+			int rank = 0;
+			for (int i = 0; i < valid_count; ++i) {
+				const float wi_ = sh.weight[i];
+				rank += (wi_ < w || (wi_ == w && i < j)) ? 1 : 0;
+			}
+			if (rank < DVP_NEIGHBOUR_NUM - 1) neighbours[1 + rank] = (w == FLT_MAX) ? mks2(-1, -1) : sh.spv[j];
+		}
+	}
+	if (DVP_LANE0) d.weak_reliable[center] = 1;
+}
+
 }  // namespace dvp
 #endif

@@ -25,7 +25,8 @@ struct Emu {
 	std::vector<uint32_t> selected_views;
 	std::vector<uint8_t> view_weight, weak_info, weak_reliable, edge;
 	std::vector<uint32_t> edge_bits, strong_bits;
-	std::vector<s2> weak_nearest_strong, neighbours, candidate, edge_neigh, label_boundary, label_stop;
+	std::vector<s2> weak_nearest_strong, neighbours, candidate, edge_neigh, label_boundary, label_stop, gn_points;
+	std::vector<int> gn_count;
 	std::vector<int> neighbours_map, label, radius;
 	unsigned long long evals = 0;
 	bool count = false;
@@ -53,6 +54,8 @@ void refresh(Emu& e) {
 	d.weak_nearest_strong = e.weak_nearest_strong.data();
 	d.neighbours_map = e.neighbours_map.data();
 	d.neighbours = e.neighbours.data();
+	d.gn_points = e.gn_points.data();
+	d.gn_count = e.gn_count.data();
 	d.fit_planes = e.fit_planes.data();
 	d.candidate = e.candidate.data();
 	d.edge = e.edge.data();
@@ -116,6 +119,8 @@ void* emu_create(int W, int H, int NI) {
 	e->weak_nearest_strong.assign(L, mks2(-1, -1));
 	e->neighbours_map.assign(L, 0);
 	e->neighbours.assign(DVP_NEIGHBOUR_NUM, mks2(-1, -1));
+	e->gn_points.assign(kGnMaxPoints, mks2(-1, -1));
+	e->gn_count.assign(1, 0);
 	e->candidate.assign(L * (size_t)(S > 0 ? S : 1) * 8, mks2(0, 0));
 	e->edge.assign(L, 0);
 	e->edge_bits.assign(edge_bits_words(W, H), 0u);
@@ -189,6 +194,8 @@ void emu_upload_state(void* c, const f4* planes, const uint32_t* views, const ui
 	e.d.weak_count = wc;
 	const size_t n = (size_t)(wc > 0 ? wc : 1);
 	e.neighbours.assign(n * DVP_NEIGHBOUR_NUM, mks2(-1, -1));
+	e.gn_points.assign(n * kGnMaxPoints, mks2(-1, -1));
+	e.gn_count.assign(n, 0);
 	e.complex_.assign(n, 0.0f);
 	e.label_boundary.assign(n * 8, mks2(-1, -1));
 	refresh(e);
