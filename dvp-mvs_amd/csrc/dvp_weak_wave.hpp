@@ -705,7 +705,29 @@ struct FitShared {
 	f4 cand_plane[kGnDraws];
 	float cand_dist[kGnDraws];
 	int cand_info[kGnDraws];       // bit 0 valid, bit 1 "strong plane", bits 8..: inlier count
+	uint8_t plist[kGnDraws];       // draws that passed the index and triangle tests (any order)
+	int req_idx[64], mark[64];     // one batch of line-test requests: pair index / pair to mark
+	uint8_t req_from[64], req_to[64];
+	int part_t[64];                // per-lane winner of the running best
+	uint8_t part_nan[64];
+	int n_pass, n_walk;
 };
+
+// shared-memory counters / bit sets touched by several lanes of the wave in one section
+DVP_HD int wave_counter_add(int* counter) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return atomicAdd(counter, 1);
+#else
+	return (*counter)++;
+#endif
+}
+DVP_HD void wave_bits_or(uint32_t* word, uint32_t bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	atomicOr(word, bits);
+#else
+	*word |= bits;
+#endif
+}
 
 DVP_HD int gn_pair_index(int a, int b) { const int hi = a > b ? a : b, lo = a > b ? b : a; return hi * (hi - 1) / 2 + lo; }
 
@@ -756,10 +778,12 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 	float Xc[3];
 	get_3d_point(cam, px, py, d.planes[center].w, Xc);
 	const float center_z = Xc[2];
-	DVP_LANES(l) { for (int i = l; i < kGnPairWords; i += 64) { sh.seen[i] = 0u; sh.hit[i] = 0u; } }
+	DVP_LANES(l) { for (int i = l; i < kGnPairWords; i += 64) { sh.seen[i] = 0u; sh.hit[i] = 0u; } sh.mark[l] = -1; }
 	wave_sync();
 
-	// ---- 1. the draws -------------------------------------------------------------------------------------
+	// ---- 1. the draws; the ones that pass the index and triangle tests are queued ----------------------------
+	if (DVP_LANE0) { sh.n_pass = 0; sh.n_walk = 0; }
+	wave_sync();
 	for (int t0 = 0; t0 < kGnDraws; t0 += 64) {
 		DVP_LANES(l) {
 			const int t = t0 + l;
@@ -769,26 +793,48 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 			const int ci = (int)(rand_u32(d.seed, (uint32_t)center, site, 3u * t + 2u) % (uint32_t)valid_count);
 			const bool pass = !(ai == bi || bi == ci || ai == ci) && point_in_triangle(sh.spv[ai], sh.spv[bi], sh.spv[ci], px, py);
 			sh.trip[t] = (uint32_t)ai | ((uint32_t)bi << 8) | ((uint32_t)ci << 16) | (pass ? 1u << 24 : 0u);
+			sh.cand_info[t] = 0;
+			if (pass) sh.plist[wave_counter_add(&sh.n_pass)] = (uint8_t)t;
 		}
 	}
 	wave_sync();
+	const int n_pass = sh.n_pass;
 	// ---- 2. + 3. line tests: who asks first, then the walks -----------------------------------------------------
+	// Requests in the reference's order: draw t asks (a,b), (b,c), (c,a).  64 requests at a time: a request is
+	// a first asker when its pair is neither marked from an earlier batch nor asked by a lower lane of this
+	// batch; first askers mark the pair and queue the walk in THEIR orientation.
 	if (edge_limit) {
-		int n_walk = 0;
-		for (int t = 0; t < kGnDraws; ++t) {
-			const uint32_t tr = sh.trip[t];
-			if (!(tr >> 24)) continue;
-			const int p[4] = { (int)(tr & 255u), (int)((tr >> 8) & 255u), (int)((tr >> 16) & 255u), (int)(tr & 255u) };
-#pragma unroll
-			for (int e = 0; e < 3; ++e) {   // (a,b), (b,c), (c,a) — the reference's order
-				const int idx = gn_pair_index(p[e], p[e + 1]);
-				if ((sh.seen[idx >> 5] >> (idx & 31)) & 1u) continue;
-				if (DVP_LANE0) { sh.seen[idx >> 5] |= 1u << (idx & 31); sh.walk[n_walk] = (uint16_t)(p[e] | (p[e + 1] << 8)); }
-				wave_sync();   // the next pair may be the same one
-				++n_walk;
+		for (int r0 = 0; r0 < 3 * kGnDraws; r0 += 64) {
+			DVP_LANES(l) {
+				const int r = r0 + l, t = r / 3, e = r - 3 * t;
+				int idx = -1;
+				if (r < 3 * kGnDraws && (sh.trip[t] >> 24)) {
+					const uint32_t tr = sh.trip[t];
+					const int p[4] = { (int)(tr & 255u), (int)((tr >> 8) & 255u), (int)((tr >> 16) & 255u), (int)(tr & 255u) };
+					idx = gn_pair_index(p[e], p[e + 1]);
+					sh.req_from[l] = (uint8_t)p[e];
+					sh.req_to[l] = (uint8_t)p[e + 1];
+				}
+				sh.req_idx[l] = idx;
 			}
+			wave_sync();
+			DVP_LANES(l) {
+				const int idx = sh.req_idx[l];
+				if (idx < 0 || ((sh.seen[idx >> 5] >> (idx & 31)) & 1u)) continue;
+				bool dup = false;
+				for (int m = 0; m < l; ++m) dup = dup || sh.req_idx[m] == idx;
+				if (dup) continue;
+				sh.walk[wave_counter_add(&sh.n_walk)] = (uint16_t)(sh.req_from[l] | (sh.req_to[l] << 8));
+				sh.mark[l] = idx;
+			}
+			wave_sync();
+			DVP_LANES(l) {   // marks after every lane of the batch has looked at the old state
+				const int idx = sh.mark[l];
+				if (idx >= 0) { wave_bits_or(&sh.seen[idx >> 5], 1u << (idx & 31)); sh.mark[l] = -1; }
+			}
+			wave_sync();
 		}
-		wave_sync();
+		const int n_walk = sh.n_walk;
 		for (int j0 = 0; j0 < n_walk; j0 += 64) {
 			DVP_LANES(l) {
 				const int j = j0 + l;
@@ -796,26 +842,20 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 				const int a = sh.walk[j] & 255, b = sh.walk[j] >> 8;
 				if (bresenham_hits_edge(d, sh.spv[a].x, sh.spv[a].y, sh.spv[b].x, sh.spv[b].y)) {
 					const int idx = gn_pair_index(a, b);
-#if defined(__HIP_DEVICE_COMPILE__)
-					atomicOr(&sh.hit[idx >> 5], 1u << (idx & 31));
-#else
-					sh.hit[idx >> 5] |= 1u << (idx & 31);
-#endif
+					wave_bits_or(&sh.hit[idx >> 5], 1u << (idx & 31));
 				}
 			}
 		}
 		wave_sync();
 	}
-	// ---- 4. candidates ---------------------------------------------------------------------------------------
+	// ---- 4. candidates: one queued draw per lane ------------------------------------------------------------------
 	const bool label_test = P.use_label && d.label[center] > 0;
 	const float fxc = (px - cam.K[2]) / cam.K[0], fyc = (py - cam.K[5]) / cam.K[4];
-	for (int t0 = 0; t0 < kGnDraws; t0 += 64) {
+	for (int j0 = 0; j0 < n_pass; j0 += 64) {
 		DVP_LANES(l) {
-			const int t = t0 + l;
-			if (t >= kGnDraws) continue;
-			sh.cand_info[t] = 0;
+			if (j0 + l >= n_pass) continue;
+			const int t = sh.plist[j0 + l];
 			const uint32_t tr = sh.trip[t];
-			if (!(tr >> 24)) continue;
 			const int ai = (int)(tr & 255u), bi = (int)((tr >> 8) & 255u), ci = (int)((tr >> 16) & 255u);
 			if (edge_limit) {
 				const int i0 = gn_pair_index(ai, bi), i1 = gn_pair_index(bi, ci), i2 = gn_pair_index(ci, ai);
@@ -848,27 +888,69 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 		}
 	}
 	wave_sync();
-	// ---- 5. the running best, in draw order -------------------------------------------------------------------
+	// ---- 5. the running best, in draw order (APD.cu:3646-3668) ------------------------------------------------------
+	// The reference's update rule — a candidate with at least 6 inliers replaces the best one when it has
+	// more inliers, or as many and a strictly smaller distance, and the FIRST "strong" candidate replaces
+	// whatever came before, after which only strong ones are looked at — selects, among the strong
+	// candidates if there is one (else among all), the one with (most inliers, then smallest distance, then
+	// earliest draw).  Every lane folds the draws t = l, l + 64, ... that way, then the 64 partial winners are
+	// folded.  A NaN distance does not obey that order: then the scan is done literally.
 	f4 best_plane = mk4(0, 0, 0, 0);
-	bool has_valid_plane = false, has_strong_plane = false;
-	float min_cost = FLT_MAX;
-	int max_count = 3;
-	for (int t = 0; t < kGnDraws; ++t) {
-		const int info = sh.cand_info[t];
-		if (!(info & 1)) continue;
-		const bool strong = (info & 2) != 0;
-		if (has_strong_plane && !strong) continue;
-		const int count = info >> 8;
-		if (count < 6) continue;
-		const float center_distance = sh.cand_dist[t];
-		if (count > max_count || (!has_strong_plane && strong)) {
-			if (!has_strong_plane && strong) has_strong_plane = true;
-			best_plane = sh.cand_plane[t];
-			max_count = count;
-			min_cost = center_distance;
-			has_valid_plane = true;
-		} else if (count == max_count) {
-			if (center_distance < min_cost) { best_plane = sh.cand_plane[t]; max_count = count; min_cost = center_distance; }
+	bool has_valid_plane = false;
+	{
+		DVP_LANES(l) {
+			int bt = -1, bstrong = 0, bcount = 0;
+			float bdist = 0.0f;
+			bool nan = false;
+			for (int t = l; t < kGnDraws; t += 64) {
+				const int info = sh.cand_info[t];
+				if (!(info & 1) || (info >> 8) < 6) continue;
+				const int strong = (info >> 1) & 1, count = info >> 8;
+				const float dist = sh.cand_dist[t];
+				nan = nan || dist != dist;
+				if (bt < 0 || strong > bstrong || (strong == bstrong && (count > bcount || (count == bcount && dist < bdist)))) { bt = t; bstrong = strong; bcount = count; bdist = dist; }
+			}
+			sh.part_t[l] = bt;
+			sh.part_nan[l] = nan ? 1 : 0;
+		}
+		wave_sync();
+		bool nan = false;
+		int bt = -1, bstrong = 0, bcount = 0;
+		float bdist = 0.0f;
+		for (int m = 0; m < 64; ++m) {
+			nan = nan || sh.part_nan[m] != 0;
+			const int t = sh.part_t[m];
+			if (t < 0) continue;
+			const int info = sh.cand_info[t];
+			const int strong = (info >> 1) & 1, count = info >> 8;
+			const float dist = sh.cand_dist[t];
+			const bool better = bt < 0 || strong > bstrong || (strong == bstrong && (count > bcount || (count == bcount && (dist < bdist || (dist == bdist && t < bt)))));
+			if (better) { bt = t; bstrong = strong; bcount = count; bdist = dist; }
+		}
+		if (!nan) {
+			if (bt >= 0) { best_plane = sh.cand_plane[bt]; has_valid_plane = true; }
+		} else {
+			bool has_strong_plane = false;
+			float min_cost = FLT_MAX;
+			int max_count = 3;
+			for (int t = 0; t < kGnDraws; ++t) {
+				const int info = sh.cand_info[t];
+				if (!(info & 1)) continue;
+				const bool strong = (info & 2) != 0;
+				if (has_strong_plane && !strong) continue;
+				const int count = info >> 8;
+				if (count < 6) continue;
+				const float center_distance = sh.cand_dist[t];
+				if (count > max_count || (!has_strong_plane && strong)) {
+					if (!has_strong_plane && strong) has_strong_plane = true;
+					best_plane = sh.cand_plane[t];
+					max_count = count;
+					min_cost = center_distance;
+					has_valid_plane = true;
+				} else if (count == max_count) {
+					if (center_distance < min_cost) { best_plane = sh.cand_plane[t]; max_count = count; min_cost = center_distance; }
+				}
+			}
 		}
 	}
 	if (!has_valid_plane) { if (DVP_LANE0) d.weak_reliable[center] = 0; return; }
