@@ -93,6 +93,11 @@ struct Dev {
 	uint32_t* edge_bits;       // the edge map as 32x32-pixel bit tiles (128 B each), see edge_bit()
 	int edge_tiles_x;
 	uint32_t* strong_bits;     // same tiling, bit = (weak_info == STRONG); valid during GenNeighbours
+	// summed-area table of edge-pixel counts over 8x8-pixel cells, (cells_y + 1) x (cells_x + 1) ints, first
+	// row / column zero: edge_sat[(cy + 1) * (cells_x + 1) + cx + 1] = #edge pixels in cells [0..cx] x [0..cy].
+	// Lets a line test prove "no edge pixel anywhere near this segment" with four loads.
+	int* edge_sat;
+	int sat_cells_x, sat_cells_y;
 	s2* edge_neigh;            // 8 per pixel
 	const int* label;
 	s2* label_boundary;        // 8 per WEAK pixel
@@ -320,6 +325,15 @@ DVP_HD unsigned edge_bit(const Dev& d, int x, int y) {   // 0 <= x < W, 0 <= y <
 DVP_HD unsigned strong_bit(const Dev& d, int x, int y) {
 	const unsigned w = d.strong_bits[(size_t)(((y >> 5) * d.edge_tiles_x + (x >> 5)) * 32 + (y & 31))];
 	return (w >> (x & 31)) & 1u;
+}
+DVP_HD int sat_cells(int n) { return (n + 7) >> 3; }
+// edge pixels in the pixel rectangle [x0, x1] x [y0, y1] widened to whole 8x8 cells (an upper bound that is 0
+// exactly when the widened rectangle holds no edge pixel); coordinates are clamped to the image
+DVP_HD int edge_count_upper(const Dev& d, int x0, int y0, int x1, int y1) {
+	const int cx0 = clampi(x0, 0, d.width - 1) >> 3, cx1 = clampi(x1, 0, d.width - 1) >> 3;
+	const int cy0 = clampi(y0, 0, d.height - 1) >> 3, cy1 = clampi(y1, 0, d.height - 1) >> 3;
+	const int P = d.sat_cells_x + 1;
+	return d.edge_sat[(cy1 + 1) * P + cx1 + 1] - d.edge_sat[cy0 * P + cx1 + 1] - d.edge_sat[(cy1 + 1) * P + cx0] + d.edge_sat[cy0 * P + cx0];
 }
 // one word of a bit-tiled map from a byte map (host loop / one thread per word):
 // bit = (byte != 0) when `equals` < 0, else (byte == equals)

@@ -205,6 +205,35 @@ extern "C" __global__ void __launch_bounds__(256) dvp_gen_candidates(const Dev d
 		gen_candidates_px(d, px, py, (int)blockIdx.y);
 }
 
+// cell table of the edge map (edge_count_upper): counts per 8x8 cell from the bit tiles, then the two prefix passes
+extern "C" __global__ void dvp_edge_cell_counts(const Dev d) {
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= d.sat_cells_x * d.sat_cells_y) return;
+	const int cy = c / d.sat_cells_x, cx = c - cy * d.sat_cells_x;
+	int n = 0;
+	for (int r = 0; r < 8; ++r) {
+		const int y = cy * 8 + r;
+		if (y >= d.height) break;
+		const unsigned w = d.edge_bits[(size_t)(((y >> 5) * d.edge_tiles_x + (cx >> 2)) * 32 + (y & 31))];
+		n += __popc((w >> ((cx & 3) * 8)) & 255u);
+	}
+	d.edge_sat[(cy + 1) * (d.sat_cells_x + 1) + cx + 1] = n;
+}
+extern "C" __global__ void dvp_edge_sat_rows(const Dev d) {   // one thread per table row: running sum along x
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r > d.sat_cells_y) return;
+	int* row = d.edge_sat + (size_t)r * (d.sat_cells_x + 1);
+	int acc = 0;
+	for (int x = 0; x <= d.sat_cells_x; ++x) { acc += (r == 0 || x == 0) ? 0 : row[x]; row[x] = acc; }
+}
+extern "C" __global__ void dvp_edge_sat_cols(const Dev d) {   // one thread per table column: running sum along y
+	const int x = blockIdx.x * blockDim.x + threadIdx.x;
+	if (x > d.sat_cells_x) return;
+	const int P = d.sat_cells_x + 1;
+	int acc = 0;
+	for (int r = 0; r <= d.sat_cells_y; ++r) { acc += d.edge_sat[(size_t)r * P + x]; d.edge_sat[(size_t)r * P + x] = acc; }
+}
+
 // sample search of the strong update (same red/black launch geometry, no LDS, small register footprint)
 extern "C" __global__ void __launch_bounds__(256) dvp_strong_search(const Dev d, const LaunchArgs a) {
 	int px, py;
@@ -275,6 +304,7 @@ struct dvp_ctx {
 	float* depths = nullptr;
 	uint32_t* edge_bits = nullptr;  // bit-tiled copy of `edge`, rebuilt before the launches that walk lines
 	uint32_t* strong_bits = nullptr; // bit-tiled (weak_info == STRONG), rebuilt before GenNeighbours
+	int* edge_sat = nullptr;         // cell table of the edge map (Dev::edge_sat), rebuilt with edge_bits
 	DvpCamera* cameras = nullptr; ViewConst* views = nullptr; int* sector_taps = nullptr; int* sector_start = nullptr;
 	f4* planes = nullptr; f4* planes_snap = nullptr; f4* fit_planes = nullptr;
 	int* search_pos = nullptr;   // [16][L]
@@ -334,7 +364,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.selected_views = c->selected_views; d.view_weight = c->view_weight; d.weak_info = c->weak_info;
 	d.weak_reliable = c->weak_reliable; d.weak_nearest_strong = c->weak_nearest_strong;
 	d.neighbours_map = c->neighbours_map; d.neighbours = c->neighbours; d.gn_points = c->gn_points; d.gn_count = c->gn_count; d.fit_planes = c->fit_planes;
-	d.candidate = c->candidate; d.edge = c->edge; d.edge_bits = c->edge_bits; d.strong_bits = c->strong_bits; d.edge_tiles_x = edge_tiles_x(c->W); d.edge_neigh = c->edge_neigh; d.label = c->label;
+	d.candidate = c->candidate; d.edge = c->edge; d.edge_bits = c->edge_bits; d.strong_bits = c->strong_bits; d.edge_sat = c->edge_sat; d.sat_cells_x = sat_cells(c->W); d.sat_cells_y = sat_cells(c->H); d.edge_tiles_x = edge_tiles_x(c->W); d.edge_neigh = c->edge_neigh; d.label = c->label;
 	d.label_boundary = c->label_boundary; d.label_stop = c->label_stop; d.complex_ = c->complex_; d.radius = c->radius;
 	d.weak_list = c->weak_list;
 	d.eval_counter = c->profiling ? c->eval_counter : nullptr;
@@ -390,6 +420,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	r |= dalloc(c, &c->edge, L);
 	r |= dalloc(c, &c->edge_bits, edge_bits_words(width, height));
 	r |= dalloc(c, &c->strong_bits, edge_bits_words(width, height));
+	r |= dalloc(c, &c->edge_sat, (size_t)(sat_cells(width) + 1) * (sat_cells(height) + 1));
 	r |= dalloc(c, &c->edge_neigh, L * 8);
 	r |= dalloc(c, &c->label, L);
 	r |= dalloc(c, &c->radius, L);
@@ -684,6 +715,11 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 	if (stage == DVP_ST_GEN_NEIGHBOURS || stage == DVP_ST_RANSAC_FIT) {   // the launch sites that walk lines over the edge map
 		const size_t words = edge_bits_words(c->W, c->H);
 		hipLaunchKernelGGL(dvp_pack_edge_bits, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c->stream, c->edge, c->edge_bits, c->W, c->H, edge_tiles_x(c->W), words, -1);
+		HIP_TRY(c, hipGetLastError());
+		const int cells = c->d.sat_cells_x * c->d.sat_cells_y;
+		hipLaunchKernelGGL(dvp_edge_cell_counts, dim3((cells + 255) / 256), dim3(256), 0, c->stream, c->d);
+		hipLaunchKernelGGL(dvp_edge_sat_rows, dim3((c->d.sat_cells_y + 1 + 63) / 64), dim3(64), 0, c->stream, c->d);
+		hipLaunchKernelGGL(dvp_edge_sat_cols, dim3((c->d.sat_cells_x + 1 + 63) / 64), dim3(64), 0, c->stream, c->d);
 		HIP_TRY(c, hipGetLastError());
 		if (stage == DVP_ST_GEN_NEIGHBOURS) {   // its anchor search probes "is this pixel STRONG" all over the image
 			hipLaunchKernelGGL(dvp_pack_edge_bits, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c->stream, c->weak_info, c->strong_bits, c->W, c->H, edge_tiles_x(c->W), words, (int)DVP_STRONG);

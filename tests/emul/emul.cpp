@@ -25,6 +25,7 @@ struct Emu {
 	std::vector<uint32_t> selected_views;
 	std::vector<uint8_t> view_weight, weak_info, weak_reliable, edge;
 	std::vector<uint32_t> edge_bits, strong_bits;
+	std::vector<int> edge_sat;
 	std::vector<s2> weak_nearest_strong, neighbours, candidate, edge_neigh, label_boundary, label_stop, gn_points;
 	std::vector<int> gn_count;
 	std::vector<int> neighbours_map, label, radius;
@@ -60,6 +61,9 @@ void refresh(Emu& e) {
 	d.candidate = e.candidate.data();
 	d.edge = e.edge.data();
 	d.edge_bits = e.edge_bits.data();
+	d.edge_sat = e.edge_sat.data();
+	d.sat_cells_x = sat_cells(e.W);
+	d.sat_cells_y = sat_cells(e.H);
 	d.strong_bits = e.strong_bits.data();
 	d.edge_tiles_x = edge_tiles_x(e.W);
 	d.edge_neigh = e.edge_neigh.data();
@@ -124,6 +128,7 @@ void* emu_create(int W, int H, int NI) {
 	e->candidate.assign(L * (size_t)(S > 0 ? S : 1) * 8, mks2(0, 0));
 	e->edge.assign(L, 0);
 	e->edge_bits.assign(edge_bits_words(W, H), 0u);
+	e->edge_sat.assign((size_t)(sat_cells(W) + 1) * (sat_cells(H) + 1), 0);
 	e->strong_bits.assign(edge_bits_words(W, H), 0u);
 	e->edge_neigh.assign(L * 8, mks2(-1, -1));
 	e->label_stop.assign(L * 8, mks2(-1, -1));
@@ -271,6 +276,16 @@ long long emu_tile_map_check(int W, int H, int half, int colour) {
 // dvp_pack_edge_bits
 static void pack_edge(Emu& e) {
 	for (size_t w = 0; w < e.edge_bits.size(); ++w) e.edge_bits[w] = pack_edge_word(e.edge.data(), e.W, e.H, edge_tiles_x(e.W), w);
+	// the cell table (dvp_edge_cell_counts + the two prefix passes)
+	const int CX = sat_cells(e.W), CY = sat_cells(e.H), P = CX + 1;
+	std::fill(e.edge_sat.begin(), e.edge_sat.end(), 0);
+	for (int y = 0; y < e.H; ++y)
+		for (int x = 0; x < e.W; ++x)
+			if (e.edge[(size_t)y * e.W + x]) e.edge_sat[(size_t)((y >> 3) + 1) * P + (x >> 3) + 1]++;
+	for (int r = 1; r <= CY; ++r)
+		for (int x = 1; x <= CX; ++x) e.edge_sat[(size_t)r * P + x] += e.edge_sat[(size_t)r * P + x - 1];
+	for (int r = 1; r <= CY; ++r)
+		for (int x = 0; x <= CX; ++x) e.edge_sat[(size_t)r * P + x] += e.edge_sat[(size_t)(r - 1) * P + x];
 }
 
 int emu_run_stage(void* c, int stage, int iter, int colour) {
