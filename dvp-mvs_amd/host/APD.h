@@ -25,6 +25,8 @@ std::string ToFormatIndex(int index);                                           
 template <typename TYPE>
 void RescaleMatToTargetSize(const Mat& src, Mat& dst, int target_width, int target_height);   // APD.cpp:1773-1795
 void RunFusion(const path& dense_folder, const std::vector<Problem>& problems);        // APD.cpp:1809-1960
+void RunFusion_TAT_Intermediate(const path& dense_folder, const std::vector<Problem>& problems);   // APD.cpp:1962-2130
+void RunFusion_TAT_advanced(const path& dense_folder, const std::vector<Problem>& problems);       // APD.cpp:2132-2279
 Mat EdgeSegment(const int scale, const Mat& srcImage, int mode = 0, bool useCanny = false);   // APD.cpp:348-499 (mode 0 + Canny only)
 void GetProblemEdges(const Problem& problem);                                           // main.cpp:193-246 (edge part)
 // Depth-Anything plane prior of a FIRST_INIT pass (APD.cpp:1210-1424), host/prior.cpp

@@ -12,6 +12,7 @@
 // produce a second copy when their own view's turn comes.  Claims make the result depend on the visiting
 // order, which is therefore the reference's (view order, rows, columns, sources).
 #include "APD.h"
+#include <cfloat>
 
 namespace {
 
@@ -68,6 +69,11 @@ Mat fit_colour(const Mat& bgr, int cols, int rows, Camera* cam) {
 	cam->K[4] *= sy; cam->K[5] *= sy;
 	cam->width = cols; cam->height = rows;
 	return out;
+}
+
+// blocks/mask_<id>.jpg (Tanks & Temples variants, APD.cpp:1991-2013): pixels below 128 are excluded
+Mat load_block_mask(const path& dense_folder, int image_id) {
+	return ReadImageGray(dense_folder / "blocks" / ("mask_" + std::to_string(image_id) + ".jpg"));
 }
 
 bool load_view(const path& dense_folder, const Problem& problem, FusionView* v) {
@@ -161,3 +167,101 @@ void RunFusion(const path& dense_folder, const std::vector<Problem>& problems) {
 	ExportPointCloud(ply_path, cloud);
 	std::cout << "Fusion: " << cloud.size() << " points -> " << ply_path << std::endl;
 }
+
+// ---- Tanks & Temples variants (RunFusion_TAT_Intermediate / _advanced, APD.cpp:1962-2279) ---------------------
+// Same witness geometry as RunFusion, different acceptance: a pixel needs k mutually consistent witnesses
+// for some k = 2..#sources, with thresholds that loosen with k (reprojection error < 0.25 k px, relative
+// depth difference < k / 3500 resp. k / 3000; the intermediate variant also wants the normals within
+// (4 + 3 k) degrees).  A kept pixel claims ITSELF (not its witnesses).  The intermediate variant averages
+// the colours of the pixel and its witnesses, the advanced one keeps the pixel's colour.
+// Reference quirk kept: the per-source residuals are one array reused across pixels and only overwritten
+// when a source yields a comparison, so a source that drops out keeps voting with the residuals of the
+// last pixel it was compared for (APD.cpp:2051, 2078-2090).
+namespace {
+void RunFusionGraded(const path& dense_folder, const std::vector<Problem>& problems, bool advanced) {
+	const float dist_base = 0.25f, depth_base = advanced ? 1.0f / 3000.0f : 1.0f / 3500.0f;
+	const float angle_base = 0.06981317007977318f, angle_grad = 0.05235987755982988f;   // 4 and 3 degrees
+	const int n_views = (int)problems.size();
+	std::vector<FusionView> views(n_views);
+	std::vector<Mat> blocks(n_views);
+	const bool use_block = std::filesystem::exists(dense_folder / "blocks");
+	int max_id = -1;
+	for (const Problem& p : problems) max_id = std::max(max_id, p.ref_image_id);
+	std::vector<int> slot_of_id(max_id + 1, -1);
+	for (int i = 0; i < n_views; ++i) {
+		std::cout << "Reading image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
+		load_view(dense_folder, problems[i], &views[i]);
+		if (use_block) blocks[i] = load_block_mask(dense_folder, problems[i].ref_image_id);
+		slot_of_id[problems[i].ref_image_id] = i;
+	}
+	struct Residual { float err = FLT_MAX, rel = FLT_MAX, ang = FLT_MAX; int x = 0, y = 0; };
+	std::vector<PointList> cloud;
+	for (int i = 0; i < n_views; ++i) {
+		std::cout << "Fusing image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
+		FusionView& R = views[i];
+		if (R.depth.empty()) continue;
+		const std::vector<int>& src_ids = problems[i].src_image_ids;
+		const int n_src = (int)src_ids.size();
+		std::vector<Residual> res(n_src);   // NOT reset per pixel (see above)
+		std::vector<char> agrees(n_src);
+		for (int y = 0; y < R.rows(); ++y)
+			for (int x = 0; x < R.cols(); ++x) {
+				if (use_block && !blocks[i].empty() && blocks[i].at<uint8_t>(y, x) < 128) continue;
+				const float z = R.depth.at<float>(y, x);
+				if (z <= 0.0) continue;
+				const float3 X = R.lift(x, y, z);
+				const Vec3f n_ref = R.normal.at<Vec3f>(y, x);
+				for (int j = 0; j < n_src; ++j) {
+					const int s = (src_ids[j] >= 0 && src_ids[j] <= max_id) ? slot_of_id[src_ids[j]] : -1;
+					if (s < 0 || views[s].depth.empty()) continue;
+					const FusionView& S = views[s];
+					float2 q;
+					float zq;
+					ProjectCamera(X, S.cam, q, zq);
+					const int sx = int(q.x + 0.5f), sy = int(q.y + 0.5f);
+					if (sx < 0 || sx >= S.cols() || sy < 0 || sy >= S.rows()) continue;
+					const float zs = S.depth.at<float>(sy, sx);
+					if (S.claimed.at<uint8_t>(sy, sx) == 1 || zs <= 0.0) continue;
+					float2 back;
+					float z_seen;
+					ProjectCamera(S.lift(sx, sy, zs), R.cam, back, z_seen);
+					res[j].err = (float)std::sqrt(std::pow(x - back.x, 2) + std::pow(y - back.y, 2));
+					res[j].rel = std::fabs(z_seen - z) / z;
+					res[j].ang = normal_angle(n_ref, S.normal.at<Vec3f>(sy, sx));
+					res[j].x = sx;
+					res[j].y = sy;
+				}
+				for (int k = 2; k <= n_src; ++k) {
+					int count = 0;
+					for (int j = 0; j < n_src; ++j) {
+						agrees[j] = res[j].err < k * dist_base && res[j].rel < k * depth_base && (advanced || res[j].ang < (k * angle_grad + angle_base));
+						count += agrees[j];
+					}
+					if (count < k) continue;
+					const uint8_t* c0 = R.bgr(x, y);
+					float sum[3] = { (float)c0[0], (float)c0[1], (float)c0[2] };
+					if (!advanced) {
+						for (int j = 0; j < n_src; ++j) {
+							if (!agrees[j]) continue;
+							const FusionView& S = views[slot_of_id[src_ids[j]]];
+							const uint8_t* cw = S.bgr(std::min(res[j].x, S.cols() - 1), std::min(res[j].y, S.rows() - 1));
+							sum[0] += cw[0]; sum[1] += cw[1]; sum[2] += cw[2];
+						}
+						sum[0] /= (count + 1.0f); sum[1] /= (count + 1.0f); sum[2] /= (count + 1.0f);
+					}
+					PointList pt;
+					pt.coord = X;
+					pt.color = float3{ sum[0], sum[1], sum[2] };
+					cloud.push_back(pt);
+					R.claimed.at<uint8_t>(y, x) = 1;
+					break;
+				}
+			}
+	}
+	const path ply_path = dense_folder / "APD" / "APD.ply";
+	ExportPointCloud(ply_path, cloud);
+	std::cout << "Fusion: " << cloud.size() << " points -> " << ply_path << std::endl;
+}
+}  // namespace
+void RunFusion_TAT_Intermediate(const path& dense_folder, const std::vector<Problem>& problems) { RunFusionGraded(dense_folder, problems, false); }
+void RunFusion_TAT_advanced(const path& dense_folder, const std::vector<Problem>& problems) { RunFusionGraded(dense_folder, problems, true); }

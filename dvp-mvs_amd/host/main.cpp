@@ -1,7 +1,7 @@
 // main.cpp — the driver: the reference's coarse-to-fine schedule (/root/reference/main.cpp:421-528) over
 // `class APD`, one process per GPU.
 //   apd <dense_folder> [gpu_index] [--max-src N] [--iters N] [--min-scale S] [--passes P] [--seed X]
-//       [--rank R --world N [--job ID]] [--jacobi] [--labels] [--no-fusion]
+//       [--rank R --world N [--job ID]] [--jacobi] [--labels] [--no-fusion | --fusion eth|tat-intermediate|tat-advanced]
 //
 // Schedule.  The image pyramid has round_num levels (the longer side is halved until <= 800).  Level i
 // runs one "A" pass without geometric consistency — FIRST_INIT from scratch / the Depth-Anything prior
@@ -30,7 +30,7 @@ struct Options {
 	int gpu = 0, max_src = 0, iters = 3, min_scale = 2, geom_passes = 3, rank = 0, world = 1;
 	uint64_t seed = 1234;
 	bool fusion = true, jacobi = false, label_files = false;
-	std::string job = "0";
+	std::string job = "0", fusion_kind = "eth";   // eth | tat-intermediate | tat-advanced (APD.h:52-54; the reference's main calls the first)
 };
 
 // pair.txt (written by colmap2mvsnet.py:442-448; read at main.cpp:127-170): a whitespace-separated
@@ -278,6 +278,7 @@ Options ParseOptions(int argc, char** argv) {
 		else if (s == "--jacobi") o.jacobi = true;
 		else if (s == "--labels") o.label_files = true;          // load labels_<s>.dmb (APD::SetUseLabelFiles)
 		else if (s == "--no-fusion") o.fusion = false;
+		else if (s == "--fusion") { if (a + 1 < argc) o.fusion_kind = argv[++a]; }
 	}
 	if (o.world > 1) o.jacobi = true;
 	return o;
@@ -338,7 +339,11 @@ int main(int argc, char** argv) {
 	exchange.reset();
 	APD::ReleasePooledContext();
 	comm.Barrier();
-	if (opt.fusion && opt.rank == 0) RunFusion(opt.dense_folder, problems);
+	if (opt.fusion && opt.rank == 0) {
+		if (opt.fusion_kind == "tat-intermediate") RunFusion_TAT_Intermediate(opt.dense_folder, problems);
+		else if (opt.fusion_kind == "tat-advanced") RunFusion_TAT_advanced(opt.dense_folder, problems);
+		else RunFusion(opt.dense_folder, problems);
+	}
 	std::cout << "All done\n";
 	return EXIT_SUCCESS;
 }
