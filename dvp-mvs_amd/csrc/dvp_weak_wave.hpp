@@ -41,14 +41,18 @@ DVP_HD void wave_sync() {}
 
 constexpr int kAnchors = DVP_NEIGHBOUR_NUM - 1;   // 11
 constexpr int kAnchorTaps = kAnchors * 9;         // 99
+#ifndef DVP_WEAK_BATCH
+#define DVP_WEAK_BATCH 8
+#endif
+constexpr int kWeakBatch = DVP_WEAK_BATCH;        // source views per shared-memory hand-over of the weak update
 
 // per-wave shared state (LDS on the device), ~11.5 KB
 struct WeakShared {
 	f2 ctab[kTaps * kTaps];        // centre patch: (w, w*ref) per tap, row-major
 	float caa[kTaps * kTaps];      // w*ref*ref per tap (reference moments only)
-	float rows[8][8][kTaps][3];    // centre-patch row sums (s_s, s_ss, s_rs) per (view slot, plane, row)
-	float acost[8][8][kAnchors];   // anchor cost per (view slot, plane, anchor), < 0: does not count
-	int inq[8][8];                 // (view slot, plane): the centre projects inside the source image
+	float rows[kWeakBatch][8][kTaps][3];    // centre-patch row sums (s_s, s_ss, s_rs) per (view slot, plane, row); the final-cost section uses slot 0 with 8 views in the plane index
+	float acost[kWeakBatch][8][kAnchors];   // anchor cost per (view slot, plane, anchor), < 0: does not count
+	int inq[kWeakBatch][8];                 // (view slot, plane): the centre projects inside the source image
 	float cost_array[8][32];
 	float ev[8][32];
 	float gtab[8][32];             // geometric-consistency cost per (plane, view)
@@ -161,7 +165,7 @@ DVP_HD void patch_row_sums(const Dev& d, const WeakShared& sh, const float* H, c
 
 // ComputeBilateralNCCNew (APD.cu:835-1021) for the live planes sh.pl[q] (q in pmask) and the source views
 // in vmask: sh.ev[q][view] = cost.  c = centre-patch context (colour-only weights) built by wave_patch_ctx.
-// Views are taken eight at a time with ONE shared-memory hand-over per batch:
+// Views are taken kWeakBatch at a time with ONE shared-memory hand-over per batch:
 //   section 1  per view of the batch, back to back:
 //              lane (plane q, anchor k): the whole anchor sub-patch of that pair in registers — the
 //              anchor's 9 reference taps (offsets, texels, weights, sums: identical in the 8 plane lanes
@@ -176,7 +180,7 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 	uint32_t rest = vmask;
 	while (rest) {
 		uint32_t batch = 0;
-		for (int n = 0; n < 8 && rest; ++n) { const uint32_t low = rest & (0u - rest); batch |= low; rest ^= low; }
+		for (int n = 0; n < kWeakBatch && rest; ++n) { const uint32_t low = rest & (0u - rest); batch |= low; rest ^= low; }
 		// lane -> (anchor k, plane q): item = round * 64 + lane, k = item / np, q = item % np with np = the
 		// number of plane slots in use (8 candidates in phase 0, 2 and 5 in the refinement phases): the 55 or
 		// 22 (anchor, plane) pairs of a refinement phase fit ONE round instead of two
@@ -691,18 +695,15 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 constexpr int kGnDraws = 200;
 constexpr int kGnPairWords = (kGnMaxPoints * (kGnMaxPoints - 1) / 2 + 31) / 32;
 struct FitShared {
-	s2 raw[kGnMaxPoints];          // the candidate list as handed over (holes = (-1,-1))
 	uint8_t slot_of[kGnMaxPoints]; // valid point j -> index in raw
 	s2 spv[kGnMaxPoints];
 	f3 sp3[kGnMaxPoints];          // camera-frame 3-D point
-	f3 spn[kGnMaxPoints];          // camera-frame normal
 	f2 fxy[kGnMaxPoints];          // ((x - cx) / fx, (y - cy) / fy)
-	float weight[kGnMaxPoints];
+	union { s2 raw[kGnMaxPoints]; float weight[kGnMaxPoints]; };   // the list as handed over (holes = (-1,-1)), dead once the tables are built; then the residuals
 	uint32_t trip[kGnDraws];       // a | b << 8 | c << 16 | passed << 24
 	uint32_t seen[kGnPairWords];   // unordered pair already queued for its line test
 	uint32_t hit[kGnPairWords];    // ... and the test found an edge pixel
 	uint16_t walk[3 * kGnDraws];   // queued tests: from | to << 8 (orientation of the first asker)
-	f4 cand_plane[kGnDraws];
 	float cand_dist[kGnDraws];
 	int cand_info[kGnDraws];       // bit 0 valid, bit 1 "strong plane", bits 8..: inlier count
 	uint8_t plist[kGnDraws];       // draws that passed the index and triangle tests (any order)
@@ -729,7 +730,28 @@ DVP_HD void wave_bits_or(uint32_t* word, uint32_t bits) {
 #endif
 }
 
+// plane through three camera-frame points, as the candidate step builds it (APD.cu:3609-3622)
+DVP_HD f4 gn_plane(const f3 A, const f3 B, const f3 C) {
+	const f3 AC = mk3(A.x - C.x, A.y - C.y, A.z - C.z);
+	const f3 BC = mk3(B.x - C.x, B.y - C.y, B.z - C.z);
+	f4 cv;
+	cv.x = AC.y * BC.z - BC.y * AC.z;
+	cv.y = -(AC.x * BC.z - BC.x * AC.z);
+	cv.z = AC.x * BC.y - BC.x * AC.y;
+	cv.w = 0.0f;
+	return cv;
+}
 DVP_HD int gn_pair_index(int a, int b) { const int hi = a > b ? a : b, lo = a > b ? b : a; return hi * (hi - 1) / 2 + lo; }
+
+// the plane of candidate draw t again (same operations on the same operands as the candidate step)
+DVP_HD f4 cand_plane_of(const FitShared& sh, int t) {
+	const uint32_t tr = sh.trip[t];
+	const f3 A = sh.sp3[tr & 255u];
+	f4 cv = gn_plane(A, sh.sp3[(tr >> 8) & 255u], sh.sp3[(tr >> 16) & 255u]);
+	normalize3(&cv);
+	cv.w = -(cv.x * A.x + cv.y * A.y + cv.z * A.z);
+	return cv;
+}
 
 DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh) {
 	const int W = d.width;
@@ -768,10 +790,8 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 			const f4 pl = d.planes[sp.x + sp.y * W];
 			float X[3];
 			get_3d_point(cam, sp.x, sp.y, pl.w, X);
-			const f4 n4 = normal_world_to_cam(cam, pl);
 			sh.spv[j] = sp;
 			sh.sp3[j] = mk3(X[0], X[1], X[2]);
-			sh.spn[j] = mk3(n4.x, n4.y, n4.z);
 			sh.fxy[j] = mk2((sp.x - cam.K[2]) / cam.K[0], (sp.y - cam.K[5]) / cam.K[4]);
 		}
 	}
@@ -861,16 +881,12 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 				const int i0 = gn_pair_index(ai, bi), i1 = gn_pair_index(bi, ci), i2 = gn_pair_index(ci, ai);
 				if (((sh.hit[i0 >> 5] >> (i0 & 31)) | (sh.hit[i1 >> 5] >> (i1 & 31)) | (sh.hit[i2 >> 5] >> (i2 & 31))) & 1u) continue;
 			}
-			const f3 AN = sh.spn[ai];   // the reference uses a_index for all three normals (APD.cu:3605-3607)
+			// camera-frame normal of point a — the reference uses a_index for all three normals (APD.cu:3605-3607);
+			// fetched again from the plane map instead of a 2 KB table (a third workgroup per CU fits)
+			const f4 AN = normal_world_to_cam(cam, d.planes[sh.spv[ai].x + sh.spv[ai].y * W]);
 			if (AN.x * AN.x + AN.y * AN.y + AN.z * AN.z < 0.9f) continue;
-			const f3 A = sh.sp3[ai], B = sh.sp3[bi], C = sh.sp3[ci];
-			const f3 AC = mk3(A.x - C.x, A.y - C.y, A.z - C.z);
-			const f3 BC = mk3(B.x - C.x, B.y - C.y, B.z - C.z);
-			f4 cv;
-			cv.x = AC.y * BC.z - BC.y * AC.z;
-			cv.y = -(AC.x * BC.z - BC.x * AC.z);
-			cv.z = AC.x * BC.y - BC.x * AC.y;
-			cv.w = 0.0f;
+			const f3 A = sh.sp3[ai];
+			f4 cv = gn_plane(A, sh.sp3[bi], sh.sp3[ci]);
 			if ((cv.x == 0 && cv.y == 0 && cv.z == 0) || cv.x != cv.x || cv.y != cv.y || cv.z != cv.z) continue;
 			normalize3(&cv);
 			cv.w = -(cv.x * A.x + cv.y * A.y + cv.z * A.z);
@@ -882,7 +898,6 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 				if (fabsf(fit_depth - sh.sp3[si].z) / depth_diff < P.ransac_threshold) count++;
 			}
 			const float fit_depth = -cv.w / (cv.x * fxc + cv.y * fyc + cv.z);
-			sh.cand_plane[t] = cv;
 			sh.cand_dist[t] = fabsf(fit_depth - center_z);
 			sh.cand_info[t] = 1 | (strong ? 2 : 0) | (count << 8);
 		}
@@ -928,7 +943,7 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 			if (better) { bt = t; bstrong = strong; bcount = count; bdist = dist; }
 		}
 		if (!nan) {
-			if (bt >= 0) { best_plane = sh.cand_plane[bt]; has_valid_plane = true; }
+			if (bt >= 0) { best_plane = cand_plane_of(sh, bt); has_valid_plane = true; }
 		} else {
 			bool has_strong_plane = false;
 			float min_cost = FLT_MAX;
@@ -943,12 +958,12 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 				const float center_distance = sh.cand_dist[t];
 				if (count > max_count || (!has_strong_plane && strong)) {
 					if (!has_strong_plane && strong) has_strong_plane = true;
-					best_plane = sh.cand_plane[t];
+					best_plane = cand_plane_of(sh, t);
 					max_count = count;
 					min_cost = center_distance;
 					has_valid_plane = true;
 				} else if (count == max_count) {
-					if (center_distance < min_cost) { best_plane = sh.cand_plane[t]; max_count = count; min_cost = center_distance; }
+					if (center_distance < min_cost) { best_plane = cand_plane_of(sh, t); max_count = count; min_cost = center_distance; }
 				}
 			}
 		}
