@@ -343,7 +343,8 @@ void GenNeighbours_px(Ctx& h, const int2 point) {
 		// symmetric first-evaluation-wins cache of the line tests (APD.cu:3574, 3588-3604): BresenhamLine
 		// walks from its second argument with a step limit, so the answer for an unordered pair is the
 		// one of the orientation in which the pair was first tested
-		std::vector<unsigned char> edge_test((size_t)max_pt_num * max_pt_num, 0);
+		static thread_local std::vector<unsigned char> edge_test((size_t)max_pt_num * max_pt_num, 0);
+		for (int a = 0; a < valid_count; ++a) std::memset(&edge_test[(size_t)a * max_pt_num], 0, (size_t)valid_count);   // only [0, valid_count)^2 is used
 		auto tested = [&](int a, int b) -> unsigned char& { return edge_test[(size_t)a * max_pt_num + b]; };
 		while (iteration > 0 && max_iter > 0) {
 			max_iter--;
