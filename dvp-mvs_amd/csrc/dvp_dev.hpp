@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <float.h>
+#include <string.h>
 #include "../../include/dvp_mvs.h"
 
 #if defined(__HIPCC__)
@@ -65,6 +66,11 @@ struct Dev {
 	float nb_cos, nb_sin, nb_thresh;
 	int nb_shift_range;
 	const float* images;       // [num_images][H + 2*PAD][pitch][2] row-pair planes {I(x,y), I(x,y+1)}, border replicated (== clamp addressing)
+	// the same planes as BYTES (uchar2 {I(x,y), I(x,y+1)}), or null: kept only when every texel of every image is
+	// an integer in [0, 255], i.e. images decoded from 8-bit files and used at their native size (APD.cpp:1057-1069,
+	// scale_size == 1).  A bilinear footprint is then 4 bytes instead of 16 and a 128-byte line holds 64 pixels
+	// of a row pair instead of 16: the gather-bound weak update reads these (same values, so same results).
+	const uint8_t* images8;
 	const float* depths;       // same layout (geom_consistency only)
 	const DvpCamera* cameras;  // [num_images]
 	const ViewConst* views;    // [num_images] (index 0 unused)
@@ -201,6 +207,33 @@ DVP_HD void load_quad(const float* base, unsigned byte_off, float* a, float* b, 
 	const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 	*a = p[0]; *b = p[1]; *c = p[2]; *e = p[3];
 #endif
+}
+// Image format of a kernel instantiation: FMT 0 = float row pairs (Dev::images), FMT 1 = byte row pairs
+// (Dev::images8).  `off` is always the byte offset inside a FLOAT plane (tex_offset); the byte plane has the
+// same geometry at a quarter of the size.
+template <int FMT> DVP_HD const void* img_plane(const Dev& d, int v);
+template <> DVP_HD const void* img_plane<0>(const Dev& d, int v) { return d.images + (size_t)v * d.plane_stride * 2; }
+template <> DVP_HD const void* img_plane<1>(const Dev& d, int v) { return d.images8 + (size_t)v * d.plane_stride * 2; }
+template <int FMT> DVP_HD void load_quad_t(const void* base, unsigned off, float* a, float* b, float* c, float* e);
+template <> DVP_HD void load_quad_t<0>(const void* base, unsigned off, float* a, float* b, float* c, float* e) {
+	load_quad(static_cast<const float*>(base), off, a, b, c, e);
+}
+template <> DVP_HD void load_quad_t<1>(const void* base, unsigned off, float* a, float* b, float* c, float* e) {
+	// one 4-byte load at a 2-byte aligned address, four v_cvt_f32_ubyteN
+	uint32_t t;
+#if defined(__HIP_DEVICE_COMPILE__)
+	typedef uint32_t u32_a2 __attribute__((aligned(2)));
+	t = *reinterpret_cast<const u32_a2*>(static_cast<const char*>(base) + (off >> 2));
+#else
+	memcpy(&t, static_cast<const char*>(base) + (off >> 2), 4);
+#endif
+	*a = (float)(t & 255u); *b = (float)((t >> 8) & 255u); *c = (float)((t >> 16) & 255u); *e = (float)(t >> 24);
+}
+// texel (ix, iy) of the reference image (plane 0), clamp-to-edge
+template <int FMT> DVP_HD float ref_texel_t(const Dev& d, int ix, int iy);
+template <> DVP_HD float ref_texel_t<0>(const Dev& d, int ix, int iy) { return img_texel(d.images, d.org, d.pitch, d.width, d.height, ix, iy); }
+template <> DVP_HD float ref_texel_t<1>(const Dev& d, int ix, int iy) {
+	return (float)d.images8[(size_t)(d.org + clampi(iy, 0, d.height - 1) * d.pitch + clampi(ix, 0, d.width - 1)) * 2];
 }
 // clamp(v, lo, hi) with NaN -> lo: fminf(fmaxf(v, lo), hi).  One v_med3_f32 on the device (with a
 // NaN operand the instruction returns min3 of the other two == lo).

@@ -6,6 +6,7 @@
 // stream (the reference calls cudaDeviceSynchronize after each of its 16+5*iters launches).
 #include "dvp_stages.hpp"
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include <cstdio>
@@ -123,7 +124,7 @@ DVP_KERNEL_LIST(dvp_ransac_fit_plane_list, DVP_ST_RANSAC_FIT, 1)
 
 // Black/RedPixelUpdateWeak (APD.cu:4487-4489): one WAVE per WEAK pixel of the list segment, four
 // pixels per workgroup, per-pixel state in LDS (dvp_weak_wave.hpp)
-template <int SMP>
+template <int SMP, int FMT>
 __device__ __forceinline__ void weak_wave_body(const Dev& d, const ListArgs& a) {
 	__shared__ WeakShared sh[4];
 	const int wave = threadIdx.x >> 6;
@@ -134,7 +135,7 @@ __device__ __forceinline__ void weak_wave_body(const Dev& d, const ListArgs& a) 
 	if (py >= a.covered_rows) return;   // rows beyond the reference's half grid (APD.cu:4421-4424)
 	if (d.weak_info[center] != DVP_WEAK) return;   // NeigbourUpdate turned it UNKNOWN since the list was built (APD.cu:3119-3123)
 	unsigned long long n = 0;
-	weak_update_wave<SMP>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, sh[wave]);
+	weak_update_wave<SMP, FMT>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, sh[wave]);
 	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
 }
 // second half of GenNeighbours (RANSAC plane + ranking): one wave per WEAK pixel, point tables in LDS
@@ -152,8 +153,11 @@ extern "C" __global__ void __launch_bounds__(256) dvp_gen_neighbours_fit(const D
 #ifndef DVP_LB_WEAK
 #define DVP_LB_WEAK 3   // waves per SIMD the wave kernel is compiled for (LDS: 42 KB per workgroup -> 3 workgroups per CU)
 #endif
-extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK) dvp_weak_update_wave(const Dev d, const ListArgs a) { weak_wave_body<0>(d, a); }
-extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK) dvp_weak_update_wave_exact(const Dev d, const ListArgs a) { weak_wave_body<1>(d, a); }
+extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK) dvp_weak_update_wave(const Dev d, const ListArgs a) { weak_wave_body<0, 0>(d, a); }
+extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK) dvp_weak_update_wave_exact(const Dev d, const ListArgs a) { weak_wave_body<1, 0>(d, a); }
+// the same launch site reading the byte planes (Dev::images8: all images 8-bit exact)
+extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK) dvp_weak_update_wave_u8(const Dev d, const ListArgs a) { weak_wave_body<0, 1>(d, a); }
+extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK) dvp_weak_update_wave_exact_u8(const Dev d, const ListArgs a) { weak_wave_body<1, 1>(d, a); }
 
 // replicate the image border into the kImgPad-wide frame of a padded plane set
 extern "C" __global__ void dvp_pad_replicate(float* planes, int W, int H, int pitch, size_t plane_stride, int n_planes) {
@@ -190,6 +194,16 @@ extern "C" __global__ void dvp_interleave_rows(const float* __restrict__ in, flo
 	const int y1 = y + 1 < PH ? y + 1 : y;
 	const float2 v = make_float2(p[(size_t)y * pitch + x], p[(size_t)y1 * pitch + x]);
 	reinterpret_cast<float2*>(out + (size_t)pl * plane_stride * 2)[(size_t)y * pitch + x] = v;
+}
+
+// row-pair float planes -> row-pair byte planes; *inexact is raised when a texel is not an integer in [0, 255]
+extern "C" __global__ void dvp_pairs_to_bytes(const float* __restrict__ pairs, uint8_t* __restrict__ out, size_t n, int* inexact) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float2 v = reinterpret_cast<const float2*>(pairs)[i];
+	const bool ok = v.x >= 0.0f && v.x <= 255.0f && v.y >= 0.0f && v.y <= 255.0f && v.x == floorf(v.x) && v.y == floorf(v.y);
+	if (!ok) { if (*inexact == 0) atomicOr(inexact, 1); return; }
+	reinterpret_cast<uchar2*>(out)[i] = make_uchar2((unsigned char)v.x, (unsigned char)v.y);
 }
 
 // byte edge map -> 32x32 bit tiles (one thread per 32-bit word)
@@ -300,6 +314,10 @@ struct dvp_ctx {
 	std::vector<void*> allocs;
 	// named device buffers
 	float* images = nullptr;        // row-pair planes (dvp_dev.hpp: img_texel / load_quad)
+	uint8_t* images8 = nullptr;     // the same as bytes; images8_ok says whether the last upload was 8-bit exact
+	int* images8_flag = nullptr;
+	bool images8_ok = false;
+	bool no_images8 = false;        // DVP_NO_IMAGES8 in the environment: keep the float planes for every kernel (A/B measurements)
 	float* image_stage = nullptr;   // plain padded planes the uploads land in before dvp_interleave_rows
 	float* depths = nullptr;
 	uint32_t* edge_bits = nullptr;  // bit-tiled copy of `edge`, rebuilt before the launches that walk lines
@@ -358,7 +376,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.width = c->W; d.height = c->H; d.num_images = c->NI; d.pitch = c->pitch;
 	d.org = kImgPad * c->pitch + kImgPad;
 	d.plane_stride = (size_t)c->pitch * (c->H + 2 * kImgPad);
-	d.images = c->images; d.depths = c->depths; d.cameras = c->cameras; d.views = c->views; d.sector_taps = c->sector_taps; d.sector_start = c->sector_start;
+	d.images = c->images; d.images8 = c->images8_ok ? c->images8 : nullptr; d.depths = c->depths; d.cameras = c->cameras; d.views = c->views; d.sector_taps = c->sector_taps; d.sector_start = c->sector_start;
 	d.search_pos = c->search_pos;
 	d.planes = c->planes; d.planes_snap = c->planes_snap; d.costs = c->costs; d.costs_snap = c->costs_snap;
 	d.selected_views = c->selected_views; d.view_weight = c->view_weight; d.weak_info = c->weak_info;
@@ -393,6 +411,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	}
 	dvp_ctx* c = new dvp_ctx();
 	c->device = device; c->W = width; c->H = height; c->NI = num_images;
+	c->no_images8 = getenv("DVP_NO_IMAGES8") != nullptr;
 	c->pitch = (width + 2 * kImgPad + 63) / 64 * 64;
 	c->L = (size_t)width * height;
 	auto fail = [&](int) { g_create_error = c->error; dvp_ctx_destroy(c); return 1; };
@@ -401,6 +420,8 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	const size_t L = c->L, S = (size_t)num_images - 1, plane = (size_t)c->pitch * (height + 2 * kImgPad);
 	int r = 0;
 	r |= dalloc(c, &c->images, plane * num_images * 2);
+	r |= dalloc(c, &c->images8, plane * num_images * 2 + 4);   // + slack: a 4-byte footprint load may start 2 bytes before the end
+	r |= dalloc(c, &c->images8_flag, (size_t)1);
 	r |= dalloc(c, &c->image_stage, plane * num_images);
 	r |= dalloc(c, &c->cameras, (size_t)num_images);
 	r |= dalloc(c, &c->views, (size_t)num_images);
@@ -481,6 +502,16 @@ static int upload_planes(dvp_ctx* c, float* dst, const float* const* src, int pi
 		hipLaunchKernelGGL(dvp_interleave_rows, dim3((unsigned)((c->pitch + 255) / 256), (unsigned)PH, (unsigned)c->NI), dim3(256), 0, c->stream,
 		                   dst, pairs, PH, c->pitch, stride, c->NI);
 		HIP_TRY(c, hipGetLastError());
+		// byte planes for 8-bit exact image sets (Dev::images8)
+		const size_t n = stride * c->NI;
+		HIP_TRY(c, hipMemsetAsync(c->images8_flag, 0, sizeof(int), c->stream));
+		hipLaunchKernelGGL(dvp_pairs_to_bytes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, pairs, c->images8, n, c->images8_flag);
+		HIP_TRY(c, hipGetLastError());
+		int inexact = 1;
+		HIP_TRY(c, hipMemcpyAsync(&inexact, c->images8_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		c->images8_ok = inexact == 0 && !c->no_images8;
+		sync_dev_struct(c);
 	}
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	return 0;
@@ -748,7 +779,10 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour) {
 				break;
 			case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(ex ? dvp_neighbour_update_list_exact : dvp_neighbour_update_list, lg, block, 0, c->stream, c->d, la); break;
 			case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(ex ? dvp_ransac_fit_plane_list_exact : dvp_ransac_fit_plane_list, lg, block, 0, c->stream, c->d, la); break;
-			case DVP_ST_WEAK_UPDATE: hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact : dvp_weak_update_wave, dim3((la.count + 3) / 4), block, 0, c->stream, c->d, la); break;
+			case DVP_ST_WEAK_UPDATE:
+				if (c->images8_ok) hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact_u8 : dvp_weak_update_wave_u8, dim3((la.count + 3) / 4), block, 0, c->stream, c->d, la);
+				else hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact : dvp_weak_update_wave, dim3((la.count + 3) / 4), block, 0, c->stream, c->d, la);
+				break;
 			}
 			HIP_TRY(c, hipGetLastError());
 		}

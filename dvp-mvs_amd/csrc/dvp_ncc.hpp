@@ -168,24 +168,23 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 		const float fx = (float)(px - c.radius + t * c.inc);
 		hx0[t] = H[0] * fx; hx3[t] = H[3] * fx; hx6[t] = H[6] * fx;
 	}
-	// Software pipeline over the three row PAIRS of the patch (12 taps each):
-	//   coords(p): 2 batched reciprocals + 12 footprint addresses / weights
-	//   issue(p) : 12 sixteen-byte gathers
-	//   consume(p): 12 blends + the row sums, rows in order (row-then-total accumulation)
-	// ordered  coords0 issue0 | coords1 | consume0 issue1 | coords2 | consume1 issue2 | consume2:
-	// the 12 gathers of a pair are issued back to back and fly while the next pair's addresses are
-	// computed (two IEEE divisions + 12 footprints).  (Issuing pair 2 before consume1 costs 40 spilled
-	// registers in the strong update and is slower; the last pair's latency stays exposed.)  Taps of one row land on the same source
-	// row pair (near-upright homographies): a lane with a hypothesis unrelated to its neighbours'
-	// touches 1-2 cache lines per row.
-	constexpr int kPair = 2 * kTaps;
-	unsigned off[2][kPair];
-	TapW<SMP> tw[2][kPair];
-	float q[2][kPair][4];
+	// Software pipeline over the six ROWS of the patch (6 taps each), three buffers deep:
+	//   coords(r): one batched reciprocal + 6 footprint addresses / weights
+	//   issue(r) : 6 sixteen-byte gathers
+	//   consume(r): 6 blends + the row sums, rows in order (row-then-total accumulation)
+	// ordered  coords0 issue0 coords1 issue1 | coords2 | consume0 issue2 | coords3 | consume1 issue3 | ... :
+	// the gathers of two rows (12) fly while the addresses of the row after them are computed, and
+	// only the last row's latency stays exposed.  (Round 1 ran the same pipeline over row PAIRS, two
+	// buffers deep: 256 VGPRs and 3 % slower; more rows in flight spill.)  Taps of one row land on
+	// the same source row pair (near-upright homographies): a lane with a hypothesis unrelated to
+	// its neighbours' touches 1-2 cache lines per row.
+	unsigned off[3][kTaps];
+	TapW<SMP> tw[3][kTaps];
+	float q[3][kTaps][4];
 	float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
-#define DVP_COORDS(PR, BUF)                                                                         \
-	_Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                 \
-		const float fy = (float)(py - c.radius + (2 * (PR) + r) * c.inc);                           \
+#define DVP_COORDS(R, BUF)                                                                          \
+	{                                                                                               \
+		const float fy = (float)(py - c.radius + (R) * c.inc);                                      \
 		const float hy1 = H[1] * fy, hy4 = H[4] * fy, hy7 = H[7] * fy;                              \
 		float X[kTaps], Y[kTaps], Z[kTaps], IZ[kTaps];                                              \
 		_Pragma("unroll") for (int tx = 0; tx < kTaps; ++tx) {                                      \
@@ -195,24 +194,22 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 		}                                                                                           \
 		batch_rcp(Z, kTaps, IZ);                                                                    \
 		_Pragma("unroll") for (int tx = 0; tx < kTaps; ++tx)                                        \
-			tex_coord(P, W, Hh, X[tx] * IZ[tx], Y[tx] * IZ[tx], &off[BUF][r * kTaps + tx],          \
-			          &tw[BUF][r * kTaps + tx]);                                                    \
+			tex_coord(P, W, Hh, X[tx] * IZ[tx], Y[tx] * IZ[tx], &off[BUF][tx], &tw[BUF][tx]);       \
 	}
 #define DVP_ISSUE(BUF)                                                                              \
-	_Pragma("unroll") for (int k = 0; k < kPair; ++k)                                               \
+	_Pragma("unroll") for (int k = 0; k < kTaps; ++k)                                               \
 		load_quad(src, off[BUF][k], &q[BUF][k][0], &q[BUF][k][1], &q[BUF][k][2], &q[BUF][k][3]);
-#define DVP_CONSUME(PR, BUF)                                                                        \
-	f2 tt##PR[kPair];   /* the pair's 12 table entries: all LDS reads issued before the first use */ \
-	_Pragma("unroll") for (int k = 0; k < kPair; ++k) tt##PR[k] = c.tab.get(2 * (PR) * kTaps + k);  \
-	sched_fence();                                                                                  \
-	_Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                 \
+#define DVP_CONSUME(R, BUF)                                                                         \
+	{                                                                                               \
+		f2 tt[kTaps];   /* the row's 6 table entries: all LDS reads issued before the first use */  \
+		_Pragma("unroll") for (int k = 0; k < kTaps; ++k) tt[k] = c.tab.get((R) * kTaps + k);       \
+		sched_fence();                                                                              \
 		float r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f;                                                 \
-		_Pragma("unroll") for (int tx = 0; tx < kTaps; ++tx) {                                      \
-			const int k = r * kTaps + tx;                                                           \
+		_Pragma("unroll") for (int k = 0; k < kTaps; ++k) {                                         \
 			float fa, fb;                                                                           \
 			tap_weights(tw[BUF][k], &fa, &fb);                                                      \
 			const float b = tex_lerp(fa, fb, q[BUF][k][0], q[BUF][k][1], q[BUF][k][2], q[BUF][k][3]); \
-			const f2 t = tt##PR[k];                                                                 \
+			const f2 t = tt[k];                                                                     \
 			const float wsb = t.x * b;                                                              \
 			r_s += wsb;                                                                             \
 			r_ss = fmaf(wsb, b, r_ss);                                                              \
@@ -223,11 +220,17 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 		s_rs += r_rs;                                                                               \
 	}
 	DVP_COORDS(0, 0) DVP_ISSUE(0) sched_fence();
-	DVP_COORDS(1, 1) sched_fence();
-	DVP_CONSUME(0, 0) DVP_ISSUE(1) sched_fence();
-	DVP_COORDS(2, 0) sched_fence();
+	DVP_COORDS(1, 1) DVP_ISSUE(1) sched_fence();
+	DVP_COORDS(2, 2) sched_fence();
+	DVP_CONSUME(0, 0) DVP_ISSUE(2) sched_fence();
+	DVP_COORDS(3, 0) sched_fence();
 	DVP_CONSUME(1, 1) DVP_ISSUE(0) sched_fence();
-	DVP_CONSUME(2, 0)
+	DVP_COORDS(4, 1) sched_fence();
+	DVP_CONSUME(2, 2) DVP_ISSUE(1) sched_fence();
+	DVP_COORDS(5, 2) sched_fence();
+	DVP_CONSUME(3, 0) DVP_ISSUE(2) sched_fence();
+	DVP_CONSUME(4, 1) sched_fence();
+	DVP_CONSUME(5, 2)
 #undef DVP_COORDS
 #undef DVP_ISSUE
 #undef DVP_CONSUME

@@ -92,7 +92,11 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 		// device: own launch shape (one wave per WEAK pixel, dvp_weak_update_wave); this branch is the
 		// host emulation of that wave (tests/emul): DVP_LANES loops over the 64 lanes
 #if !defined(__HIPCC__)
-		if (d.weak_info[center] == DVP_WEAK) { WeakShared sh; weak_update_wave<SMP>(d, px, py, iter, nevals, sh); }
+		if (d.weak_info[center] == DVP_WEAK) {
+			WeakShared sh;
+			if (d.images8) weak_update_wave<SMP, 1>(d, px, py, iter, nevals, sh);
+			else weak_update_wave<SMP, 0>(d, px, py, iter, nevals, sh);
+		}
 #endif
 	}
 	else if (STAGE == DVP_ST_GET_DEPTH_NORMAL) get_depth_normal_px(d, px, py);

@@ -86,6 +86,7 @@ DVP_HD float geom_cost_cams(const Dev& d, const DvpCamera& rc, const DvpCamera& 
 
 // build_patch_ctx (dvp_ncc.hpp) by the wave: lane t < 36 owns tap t; the reference moments are then
 // summed in the row-then-total order by every lane.
+template <int FMT>
 DVP_HD void wave_patch_ctx(const Dev& d, int px, int py, int radius, int inc, int colour_only, WeakShared& sh, PatchCtx* c) {
 	c->radius = radius;
 	c->inc = inc;
@@ -93,12 +94,12 @@ DVP_HD void wave_patch_ctx(const Dev& d, int px, int py, int radius, int inc, in
 	c->sum_ref = c->sum_ref_ref = c->wsum = 0.0f;
 	if (!c->fast) return;
 	const int W = d.width, H = d.height, P = d.pitch;
-	const float cpix = img_texel(d.images, d.org, P, W, H, px, py);
+	const float cpix = ref_texel_t<FMT>(d, px, py);
 	DVP_LANES(t) {
 		if (t >= kTaps * kTaps) continue;
 		const int ty = t / kTaps, tx = t - ty * kTaps;
 		const int i = -radius + tx * inc, j = -radius + ty * inc;
-		const float a = img_texel(d.images, d.org, P, W, H, px + i, py + j);
+		const float a = ref_texel_t<FMT>(d, px + i, py + j);
 		const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, colour_only);
 		const float wa = w * a;
 		sh.ctab[t] = mk2(w, wa);
@@ -125,8 +126,8 @@ DVP_HD void wave_patch_ctx(const Dev& d, int px, int py, int radius, int inc, in
 
 // one row (6 taps) of the 36-tap patch for homography H: the row's three source-side sums
 // (ncc_patch_fast, dvp_ncc.hpp: same products, same shared division per row, same order)
-template <int SMP>
-DVP_HD void patch_row_sums(const Dev& d, const WeakShared& sh, const float* H, const float* src, int px, int py, int radius, int inc, int row, float* out /*[3]*/) {
+template <int SMP, int FMT>
+DVP_HD void patch_row_sums(const Dev& d, const WeakShared& sh, const float* H, const void* src, int px, int py, int radius, int inc, int row, float* out /*[3]*/) {
 	const int W = d.width, Hh = d.height, P = d.pitch;
 	const float fy = (float)(py - radius + row * inc);
 	const float hy1 = H[1] * fy, hy4 = H[4] * fy, hy7 = H[7] * fy;
@@ -145,7 +146,7 @@ DVP_HD void patch_row_sums(const Dev& d, const WeakShared& sh, const float* H, c
 #pragma unroll
 	for (int tx = 0; tx < kTaps; ++tx) tex_coord(P, W, Hh, X[tx] * IZ[tx], Y[tx] * IZ[tx], &off[tx], &tw[tx]);
 #pragma unroll
-	for (int tx = 0; tx < kTaps; ++tx) load_quad(src, off[tx], &q[tx][0], &q[tx][1], &q[tx][2], &q[tx][3]);
+	for (int tx = 0; tx < kTaps; ++tx) load_quad_t<FMT>(src, off[tx], &q[tx][0], &q[tx][1], &q[tx][2], &q[tx][3]);
 	float r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f;
 #pragma unroll
 	for (int tx = 0; tx < kTaps; ++tx) {
@@ -174,7 +175,7 @@ DVP_HD void patch_row_sums(const Dev& d, const WeakShared& sh, const float* H, c
 //              The anchor pixel and its view mask do not depend on the view and are fetched once.
 //              Then lane (plane q, row r): one row of the 36-tap centre patch.
 //   section 2  lane (view slot, plane q): rows and anchors summed in the reference's order -> ev.
-template <int SMP>
+template <int SMP, int FMT>
 DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float cpix, int px, int py, uint32_t vmask, uint32_t pmask, WeakShared& sh) {
 	const int W = d.width, Hh = d.height, Pt = d.pitch;
 	uint32_t rest = vmask;
@@ -210,7 +211,8 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 			for (uint32_t todo = batch; todo; todo &= todo - 1, ++slot) {
 				const int v = __builtin_ctz(todo) + 1;   // 1-based image index of the source view
 				const ViewConst vc = load_view(d, v);
-				const float* src = d.images + (size_t)uniform_i(v) * d.plane_stride * 2;
+				const void* src = img_plane<FMT>(d, uniform_i(v));
+				const float* srcf = d.images + (size_t)uniform_i(v) * d.plane_stride * 2;   // generic (non-6-tap) patches sample the float planes
 				float H[9];
 				bool inside = false;
 				if (plane_on) {
@@ -266,10 +268,10 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 								tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t], &tw[t]);
 							}
 #pragma unroll
-							for (int t = 0; t < 9; ++t) load_quad(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
+							for (int t = 0; t < 9; ++t) load_quad_t<FMT>(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
 							float av[9];
 #pragma unroll
-							for (int t = 0; t < 9; ++t) av[t] = img_texel(d.images, d.org, Pt, W, Hh, tx[t], ty[t]);
+							for (int t = 0; t < 9; ++t) av[t] = ref_texel_t<FMT>(d, tx[t], ty[t]);
 							float a_sr = 0.0f, a_srr = 0.0f, a_sw = 0.0f;
 							float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
 #pragma unroll
@@ -302,12 +304,12 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 						if (!(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f)) {
 							if (c.fast) {
 								float o[3];
-								patch_row_sums<SMP>(d, sh, Hc, src, px, py, c.radius, c.inc, r, o);
+								patch_row_sums<SMP, FMT>(d, sh, Hc, src, px, py, c.radius, c.inc, r, o);
 								sh.rows[slot][cq][r][0] = o[0];
 								sh.rows[slot][cq][r][1] = o[1];
 								sh.rows[slot][cq][r][2] = o[2];
 							} else {
-								sh.rows[slot][cq][0][0] = ncc_patch_generic(d, Hc, src, px, py, c.radius, c.inc, 1);
+								sh.rows[slot][cq][0][0] = ncc_patch_generic(d, Hc, srcf, px, py, c.radius, c.inc, 1);
 							}
 						}
 					}
@@ -364,7 +366,7 @@ DVP_HD void wave_geom_table(const Dev& d, const DvpCamera& rc, int px, int py, u
 	wave_sync();
 }
 
-template <int SMP>
+template <int SMP, int FMT>
 DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned long long* nevals, WeakShared& sh) {
 	const int W = d.width, Hh = d.height;
 	const int center = py * W + px;
@@ -373,7 +375,7 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 	const int S = P.num_images - 1;
 	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
 	const s2* nbs = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
-	const float cpix = img_texel(d.images, d.org, d.pitch, W, Hh, px, py);
+	const float cpix = ref_texel_t<FMT>(d, px, py);
 	unsigned long long evals = 0;
 
 	PatchCtx c;
@@ -381,7 +383,7 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 	{
 		int radius, inc;
 		patch_geometry(d, center, &radius, &inc);
-		wave_patch_ctx(d, px, py, radius, inc, 1, sh, &c);
+		wave_patch_ctx<FMT>(d, px, py, radius, inc, 1, sh, &c);
 	}
 	DVP_LANES(l) {
 		for (int i = l; i < 8 * 32; i += 64) (&sh.cost_array[0][0])[i] = 0.0f;
@@ -525,7 +527,7 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 
 		// ---- evaluate: view by view ----------------------------------------------------------------------
 		if (pmask && vmask) {
-			wave_ncc_new<SMP>(d, c, nbs, cpix, px, py, vmask, pmask, sh);
+			wave_ncc_new<SMP, FMT>(d, c, nbs, cpix, px, py, vmask, pmask, sh);
 			evals += (unsigned long long)__builtin_popcount(pmask) * (unsigned long long)__builtin_popcount(vmask);
 		}
 
@@ -619,7 +621,7 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 	{
 		int r = P.strong_radius, inc = P.strong_increment;
 		if (P.use_radius) inc = DVP_MAX(2, (int)(2.0 * r / 5.0));
-		wave_patch_ctx(d, px, py, r, inc, 0, sh, &c2);
+		wave_patch_ctx<FMT>(d, px, py, r, inc, 0, sh, &c2);
 	}
 	for (int v0 = 0; v0 < S; v0 += 8) {
 		DVP_LANES(l) {
@@ -631,12 +633,12 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 			homography(vc, final_plane, H);
 			const f2 pt = apply_homography(H, px, py);
 			const bool in = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f);
-			const float* src = d.images + (size_t)(v + 1) * d.plane_stride * 2;
+			const void* src = img_plane<FMT>(d, v + 1);
 			if (!c2.fast) {
-				sh.ev[0][v] = in ? ncc_patch_generic(d, H, src, px, py, c2.radius, c2.inc, 0) : 2.0f;
+				sh.ev[0][v] = in ? ncc_patch_generic(d, H, d.images + (size_t)(v + 1) * d.plane_stride * 2, px, py, c2.radius, c2.inc, 0) : 2.0f;
 			} else if (in) {
 				float o[3];
-				patch_row_sums<SMP>(d, sh, H, src, px, py, c2.radius, c2.inc, r, o);
+				patch_row_sums<SMP, FMT>(d, sh, H, src, px, py, c2.radius, c2.inc, r, o);
 				sh.rows[0][vs][r][0] = o[0];
 				sh.rows[0][vs][r][1] = o[1];
 				sh.rows[0][vs][r][2] = o[2];

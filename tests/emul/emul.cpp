@@ -16,6 +16,8 @@ namespace {
 struct Emu {
 	int W, H, NI, pitch;
 	std::vector<float> images, depths;
+	std::vector<uint8_t> images8;       // byte row pairs (Dev::images8), valid when every image set so far is 8-bit exact
+	std::vector<char> image_exact;
 	std::vector<DvpCamera> cameras;
 	std::vector<ViewConst> views;
 	std::vector<int> sector_taps, sector_start;
@@ -40,6 +42,11 @@ void refresh(Emu& e) {
 	d.org = kImgPad * e.pitch + kImgPad;
 	d.plane_stride = (size_t)e.pitch * (e.H + 2 * kImgPad);
 	d.images = e.images.data();
+	{
+		bool all = !e.image_exact.empty();
+		for (char ok : e.image_exact) all = all && ok;
+		d.images8 = all ? e.images8.data() : nullptr;
+	}
 	d.depths = e.depths.data();
 	d.cameras = e.cameras.data();
 	d.views = e.views.data();
@@ -107,6 +114,8 @@ void* emu_create(int W, int H, int NI) {
 	const size_t L = (size_t)W * H;
 	const int S = NI - 1;
 	e->images.assign((size_t)e->pitch * (H + 2 * kImgPad) * NI * 2, 0.0f);   // row-pair planes
+	e->images8.assign((size_t)e->pitch * (H + 2 * kImgPad) * NI * 2 + 4, 0);
+	e->image_exact.assign(NI, 0);
 	e->depths.assign((size_t)e->pitch * (H + 2 * kImgPad) * NI, 0.0f);
 	e->cameras.resize(NI);
 	e->views.resize(NI);
@@ -159,6 +168,16 @@ void emu_set_image(void* c, int idx, const float* data) {
 			out[((size_t)y * e.pitch + x) * 2] = plain[(size_t)y * e.pitch + x];
 			out[((size_t)y * e.pitch + x) * 2 + 1] = plain[(size_t)(y + 1 < PH ? y + 1 : y) * e.pitch + x];
 		}
+	// byte planes (dvp_pairs_to_bytes)
+	uint8_t* out8 = &e.images8[(size_t)idx * e.d.plane_stride * 2];
+	bool exact = true;
+	for (size_t i = 0; i < e.d.plane_stride * 2; ++i) {
+		const float v = out[i];
+		if (!(v >= 0.0f && v <= 255.0f && v == floorf(v))) { exact = false; break; }
+		out8[i] = (uint8_t)v;
+	}
+	e.image_exact[idx] = exact ? 1 : 0;
+	refresh(e);
 }
 void emu_set_depth(void* c, int idx, const float* data) {
 	Emu& e = *(Emu*)c;
