@@ -39,14 +39,20 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # the NCC kernels hold 2 waves per SIMD (256 VGPRs + a 72 KB patch table per workgroup), whose ceiling is 756.2.
 VALU_PEAK_GINST = 974.6
 VALU_CEILING_BY_WAVES = {1: 502.9, 2: 756.2, 4: 893.4, 8: 974.6}
+GATHER_ROOF_GLINES = 51.5   # tools/gather_peak.hip on MI355X (profiles/r02_gather_peak.txt): 128-byte line requests per second of 16-byte gathers = 6.6 TB/s
 WAVES_PER_SIMD = {"strong_update": 2, "depth_to_weak": 2, "local_refine": 2, "random_init": 2, "weak_update": 3}
 PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_r02.json")
 
 # launch site -> kernel name in a rocprofv3 trace (list launches for the weak path; the narrow
 # strong-update instantiation when S <= 8)
+IMAGE_FORMAT = 0   # dvp_image_format of the timed context (1: the weak update reads byte planes)
+
+
 def kernel_name(stage, S):
     return {"strong_update": "dvp_strong_update_v8" if S <= 8 else ("dvp_strong_update_v16" if S <= 16 else "dvp_strong_update"),
-            "weak_update": "dvp_weak_update_wave", "gen_neighbours": "dvp_gen_neighbours_list",
+            "weak_update": "dvp_weak_update_wave_u8" if IMAGE_FORMAT else "dvp_weak_update_wave",
+            "depth_to_weak": "dvp_depth_to_weak_refine",   # dvp_run_patchmatch: DepthToWeak + LocalRefine in one launch
+            "gen_neighbours": "dvp_gen_neighbours_list",
             "ransac_fit": "dvp_ransac_fit_plane_list", "find_nearest_strong": "dvp_find_nearest_strong_list",
             "neighbour_update": "dvp_neighbour_update_list"}.get(stage, "dvp_" + stage)
 
@@ -182,6 +188,9 @@ def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
         for c in ("l2_hit_rate", "wait_any_frac"):
             if c in pmc:
                 r[c] = pmc[c]
+        if pmc.get("TCC_MISS"):   # L2 line misses per second against the measured gather roof
+            r["l2_miss_glines_s"] = round(pmc["TCC_MISS"] / sec / 1e9, 2)
+            r["gather_roof_frac"] = round(pmc["TCC_MISS"] / sec / 1e9 / GATHER_ROOF_GLINES, 4)
     else:
         r.update(bound="hbm", achieved=round(alg, 1) if alg else None, peak=HBM_PEAK_GBS, unit="GB/s",
                  frac=round(alg / HBM_PEAK_GBS, 4) if alg else None, traffic=None,
@@ -249,6 +258,8 @@ def main():
 
     ctx = capi.Context(W, H, NI, device=local_rank)
     ctx.set_images_device([imgs[i].data_ptr() for i in order], W)
+    global IMAGE_FORMAT
+    IMAGE_FORMAT = ctx.image_format()   # 1: 8-bit exact image set, the weak update reads the byte planes
     ctx.set_cameras(cams)
     p1 = wl.first_init_params(S, iters)
     ctx.set_params(p1)
@@ -334,7 +345,7 @@ def main():
             "metric": "Mpixels/sec/PatchMatch-iteration", "value": round(value, 3), "unit": "Mpx/s/iter",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (procedural texture quantised to 8-bit grey levels, as decoded image files are; image_format=%d)" % IMAGE_FORMAT,
             "config": {"workload": workload + ", one reference view per step per GPU", "baseline_config": args.config,
                        "width": W, "height": H, "src_views": S, "iterations": iters, "weak_fraction": round(weak_frac, 4),
                        "parallelism": "rank r takes view r mod %d of the scene as its reference view; %d rank(s), no data-path collective" % (NI, world)},

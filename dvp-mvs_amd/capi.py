@@ -29,7 +29,7 @@ BUFFERS = dict(planes=(0, np.float32, 4), costs=(1, np.float32, 1), selected_vie
 # every symbol include/dvp_mvs.h declares
 EXPORTS = ["dvp_ctx_create", "dvp_ctx_destroy", "dvp_last_error", "dvp_upload_images", "dvp_upload_depths",
            "dvp_upload_images_device", "dvp_upload_depths_device", "dvp_upload_cameras", "dvp_upload_state",
-           "dvp_reset_state", "dvp_save_state", "dvp_restore_state", "dvp_set_params", "dvp_set_seed", "dvp_set_sampler", "dvp_set_profiling", "dvp_run_patchmatch",
+           "dvp_reset_state", "dvp_save_state", "dvp_restore_state", "dvp_set_params", "dvp_set_seed", "dvp_set_sampler", "dvp_set_profiling", "dvp_image_format", "dvp_run_patchmatch",
            "dvp_run_stage", "dvp_synchronize", "dvp_download_state", "dvp_buffer_bytes", "dvp_download_buffer",
            "dvp_upload_buffer", "dvp_weak_count", "dvp_get_timings", "dvp_reset_timings", "dvp_eval_cost_vectors",
            "dvp_bench_cost_kernel"]
@@ -71,6 +71,7 @@ def lib():
         L.dvp_set_seed.argtypes = [vp, ctypes.c_uint64]
         L.dvp_set_sampler.argtypes = [vp, ci]
         L.dvp_set_profiling.argtypes = [vp, ci]
+        L.dvp_image_format.argtypes = [vp]
         L.dvp_run_patchmatch.argtypes = [vp]
         L.dvp_run_stage.argtypes = [vp, ci, ci, ci]
         L.dvp_synchronize.argtypes = [vp]
@@ -173,6 +174,10 @@ class Context:
 
     def reset_state(self):
         self._ck(self.L.dvp_reset_state(self.h))
+
+    def image_format(self):
+        """0: float planes, 1: byte planes (8-bit exact image set) — include/dvp_mvs.h dvp_image_format"""
+        return int(self.L.dvp_image_format(self.h))
 
     def save_state(self):
         self._ck(self.L.dvp_save_state(self.h))

@@ -68,6 +68,9 @@ DVP_HD bool block_to_pixel(int block, int lane, int wave, int tiles_x, int tiles
 
 // per-pixel predicate + body of launch site `STAGE` (DVP_ST_*), APD.cu:3091-3165, 3296-3328
 constexpr int kNarrowViews = 8;   // view capacity of the narrow strong-update instantiation
+// internal launch site: DepthToWeak with LocalRefine done by the same thread (dvp_run_patchmatch issues the two
+// back to back; depth_to_weak_px<SMP, true>).  dvp_run_stage keeps the two separate launches.
+constexpr int kStageSweeps = 100;
 template <int STAGE, int SMP, int MV = 32>
 DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long* nevals, PatchTab tab) {
 	const int center = px + py * d.width;
@@ -101,12 +104,13 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 	}
 	else if (STAGE == DVP_ST_GET_DEPTH_NORMAL) get_depth_normal_px(d, px, py);
 	else if (STAGE == DVP_ST_FILTER_STRONG) { if (d.weak_info[center] != DVP_WEAK) filter_strong_px(d, px, py); }
-	else if (STAGE == DVP_ST_DEPTH_TO_WEAK) depth_to_weak_px<SMP>(d, px, py, tab, nevals);
+	else if (STAGE == DVP_ST_DEPTH_TO_WEAK) depth_to_weak_px<SMP, false>(d, px, py, tab, nevals);
+	else if (STAGE == kStageSweeps) depth_to_weak_px<SMP, true>(d, px, py, tab, nevals);
 	else if (STAGE == DVP_ST_LOCAL_REFINE) local_refine_px<SMP>(d, px, py, tab, nevals);
 }
 // launch sites whose kernels need the per-lane patch table (LDS on the GPU)
 constexpr bool stage_uses_tab(int stage) {
-	return stage == DVP_ST_RANDOM_INIT || stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_DEPTH_TO_WEAK || stage == DVP_ST_LOCAL_REFINE;
+	return stage == DVP_ST_RANDOM_INIT || stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_DEPTH_TO_WEAK || stage == DVP_ST_LOCAL_REFINE || stage == kStageSweeps;
 }
 constexpr bool stage_is_half_c(int stage) {
 	return stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_WEAK_UPDATE || stage == DVP_ST_FILTER_STRONG;

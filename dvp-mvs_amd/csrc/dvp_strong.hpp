@@ -499,16 +499,15 @@ struct SweepCtx {
 	uint32_t sel;
 };
 
+// DepthToWeak (APD.cu:3892-4051).  REFINE: the same thread then does LocalRefine (APD.cu:4053-4139, the launch
+// that follows, local_refine_px below) for its pixel.  LocalRefine's sweep slots -5..5 are planes the DepthToWeak
+// sweep has just evaluated against the same views — same plane, same patch context, hence the same NCC and geometric
+// costs bit for bit — so the fused kernel only folds them a second time in LocalRefine's own order
+// ((ncc*w) + (factor*geom*w) per view) and adds LocalRefine's one extra slot, the current depth.  Neither kernel
+// reads anything another pixel writes, so running them back to back per pixel is the two launches' result.
 template <int SMP>
-DVP_HD float sweep_cost_view(const Dev& d, const PatchCtx& c, int px, int py, int v, const f4 pl, unsigned long long* nevals) {
-	float cst = ncc_old<SMP>(d, c, px, py, v + 1, pl);
-	if (nevals) *nevals += 1;
-	if (d.params.geom_consistency) cst += d.params.geom_factor * geom_cost(d, px, py, v + 1, pl);
-	return cst;
-}
-
-// DepthToWeak (APD.cu:3892-4051)
-template <int SMP>
+DVP_HD void local_refine_px(const Dev& d, int px, int py, PatchTab tab, unsigned long long* nevals);
+template <int SMP, bool REFINE>
 DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, PatchTab tab, unsigned long long* nevals) {
 	const int W = d.width, H = d.height;
 	const int center = px + py * W;
@@ -516,10 +515,14 @@ DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, PatchTab tab, unsigne
 	const DvpCamera rc = load_camera(d, 0);
 	const int S = P.num_images - 1;
 	if (P.use_radius && d.radius[center] == 0) d.radius[center] = P.strong_radius;
-	if (px < 6 || py < 6 || px >= W - 6 || py >= H - 6) { d.weak_info[center] = DVP_UNKNOWN; return; }
+	if (px < 6 || py < 6 || px >= W - 6 || py >= H - 6) {
+		d.weak_info[center] = DVP_UNKNOWN;
+		if (REFINE) local_refine_px<SMP>(d, px, py, tab, nevals);   // LocalRefine has no border rule
+		return;
+	}
 	const f4 origin = normal_world_to_cam(rc, d.planes[center]);
 	const float origin_depth = origin.w;
-	if (origin_depth == 0) { d.weak_info[center] = DVP_UNKNOWN; return; }
+	if (origin_depth == 0) { d.weak_info[center] = DVP_UNKNOWN; return; }   // (LocalRefine returns here too)
 	const uint32_t sel = d.selected_views[center];
 	const uint8_t* vw = d.view_weight + (size_t)center * 32;
 	PatchCtx c;
@@ -539,27 +542,41 @@ DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, PatchTab tab, unsigne
 		base_line += sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
 		valid++;
 	}
-	if (valid == 0) { d.weak_info[center] = DVP_UNKNOWN; return; }
+	if (valid == 0) { d.weak_info[center] = DVP_UNKNOWN; return; }   // (LocalRefine returns here too)
 	base_line /= valid;
 	const float disp = rc.K[0] * base_line / origin_depth;
+	const bool refine = REFINE && weight_normal != 0;   // LocalRefine's own guard (APD.cu:4075)
 	// the reference also evaluates cost_now at the current depth (APD.cu:3937-3941); its value
 	// is never used by DepthToWeak, so those evaluations are not issued.
 	float p_costs[61];
+	float lr_costs[11];            // LocalRefine's total of sweep slot pd = -5..5
+	unsigned lr_live = 0;          // ... bit pd+5: the slot is inside the depth range
 	for (int pd = -30; pd <= 30; ++pd) {
 		const float p_depth = rc.K[0] * base_line / (disp + pd);
 		if (p_depth < P.depth_min || p_depth > P.depth_max) { p_costs[pd + 30] = 2.0f; continue; }
 		f4 pl = origin;
 		pl.w = distance_to_origin(rc, px, py, p_depth, pl);
-		float pc = 0.0f;
+		const bool both = refine && pd >= -5 && pd <= 5;
+		float pc = 0.0f, lr = 0.0f;
 		for (int v = 0; v < S; ++v) {
 			if (!is_set(sel, v)) continue;
 			// a selected view with zero weight contributes cost*0 = +0: skipped (finite cost)
 			if (vw[v] == 0) continue;
-			const float tc = 0.0f + sweep_cost_view<SMP>(d, c, px, py, v, pl, nevals);
+			const float ncc = ncc_old<SMP>(d, c, px, py, v + 1, pl);
+			if (nevals) *nevals += 1;
+			const float gc = P.geom_consistency ? geom_cost(d, px, py, v + 1, pl) : 0.0f;
+			float cst = ncc;
+			if (P.geom_consistency) cst += P.geom_factor * gc;
+			const float tc = 0.0f + cst;
 			pc += tc * vw[v];
+			if (both) {   // ncc*w and (factor*geom)*w added separately, APD.cu:4124-4126
+				lr += ncc * vw[v];
+				if (P.geom_consistency) lr += (P.geom_factor * gc * vw[v]);
+			}
 		}
 		pc /= weight_normal;
 		p_costs[pd + 30] = DVP_MIN(2.0f, pc);
+		if (both) { lr_costs[pd + 5] = lr / weight_normal; lr_live |= 1u << (pd + 5); }
 	}
 	uint64_t is_peak = 0;
 	int peak_count = 0, min_peak = 0;
@@ -572,21 +589,47 @@ DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, PatchTab tab, unsigne
 		}
 	}
 	const int dpk = min_peak - 30;
-	if ((dpk < 0 ? -dpk : dpk) > P.weak_peak_radius || p_costs[min_peak] > 0.5f) { d.weak_info[center] = DVP_WEAK; return; }
-	if (peak_count == 1) {
-		d.weak_info[center] = (p_costs[min_peak] <= 0.15f) ? DVP_STRONG : DVP_WEAK;
-		return;
-	}
-	float var = 0.0f;
-	for (int i = 2; i < 59; ++i) {
-		if (((is_peak >> i) & 1) && i != min_peak) {
-			const float dist = p_costs[i] - min_cost;
-			var += dist * dist;
+	uint8_t state;
+	if ((dpk < 0 ? -dpk : dpk) > P.weak_peak_radius || p_costs[min_peak] > 0.5f) state = DVP_WEAK;
+	else if (peak_count == 1) state = (p_costs[min_peak] <= 0.15f) ? DVP_STRONG : DVP_WEAK;
+	else {
+		float var = 0.0f;
+		for (int i = 2; i < 59; ++i) {
+			if (((is_peak >> i) & 1) && i != min_peak) {
+				const float dist = p_costs[i] - min_cost;
+				var += dist * dist;
+			}
 		}
+		var = sqrtf(var);
+		var /= (peak_count - 1);
+		state = (var > 0.2f) ? DVP_STRONG : DVP_WEAK;
 	}
-	var = sqrtf(var);
-	var /= (peak_count - 1);
-	d.weak_info[center] = (var > 0.2f) ? DVP_STRONG : DVP_WEAK;
+	d.weak_info[center] = state;
+	if (!refine) return;
+	// ---- LocalRefine: the current depth (cost_now, APD.cu:4080-4090), then the minimum over the sweep slots ----
+	float cost_now = 0.0f;
+	{
+		f4 pl = origin;
+		pl.w = distance_to_origin(rc, px, py, origin_depth, pl);
+		for (int v = 0; v < S; ++v) {
+			if (!is_set(sel, v)) continue;
+			if (vw[v] == 0) continue;
+			const float ncc = ncc_old<SMP>(d, c, px, py, v + 1, pl);
+			if (nevals) *nevals += 1;
+			float t = ncc;   // (ncc + factor*geom) * w, APD.cu:4085-4089
+			if (P.geom_consistency) t += P.geom_factor * geom_cost(d, px, py, v + 1, pl);
+			cost_now += t * vw[v];
+		}
+		cost_now /= weight_normal;
+	}
+	float lr_min = 2.0f;
+	int best_pd = -6;
+	for (int pd = -5; pd <= 5; ++pd) {
+		if (!((lr_live >> (pd + 5)) & 1)) continue;
+		if (lr_costs[pd + 5] < lr_min) { lr_min = lr_costs[pd + 5]; best_pd = pd; }
+	}
+	const float best_depth = (best_pd == -6) ? origin_depth : rc.K[0] * base_line / (disp + best_pd);
+	if (cost_now - lr_min > 0.1) d.planes[center].w = best_depth;
 }
 
 // LocalRefine (APD.cu:4053-4139)

@@ -167,6 +167,11 @@ int dvp_set_seed(dvp_ctx* ctx, uint64_t seed);
 /* 0 = CUDA-texture-like 8-bit interpolation weights (default), 1 = exact fractions */
 int dvp_set_sampler(dvp_ctx* ctx, int sampler);
 int dvp_set_profiling(dvp_ctx* ctx, int count_evals);
+/* Image planes the gather-bound kernels read after the last dvp_upload_images*: 0 = the float planes,
+ * 1 = byte planes (kept besides the float planes when every texel of every image is an integer in
+ * [0, 255]: images decoded from 8-bit files at their native size, APD.cpp:1057-1069).  Same values
+ * either way, so results do not depend on it; DVP_NO_IMAGES8 in the environment forces 0. */
+int dvp_image_format(const dvp_ctx* ctx);
 
 /* ---- run (APD::RunPatchMatch, APD.cu:4406-4532) ---------------------------------------------- */
 int dvp_run_patchmatch(dvp_ctx* ctx);

@@ -353,6 +353,7 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 	case DVP_ST_FILTER_STRONG: launch<DVP_ST_FILTER_STRONG>(e, iter, colour); break;
 	case DVP_ST_DEPTH_TO_WEAK: launch<DVP_ST_DEPTH_TO_WEAK>(e, iter, colour); break;
 	case DVP_ST_LOCAL_REFINE: launch<DVP_ST_LOCAL_REFINE>(e, iter, colour); break;
+	case kStageSweeps: launch<kStageSweeps>(e, iter, colour); break;
 	default: return -1;
 	}
 	return 0;
@@ -375,8 +376,7 @@ int emu_run_patchmatch(void* c) {
 	emu_run_stage(c, DVP_ST_GET_DEPTH_NORMAL, 0, 0);
 	emu_run_stage(c, DVP_ST_FILTER_STRONG, 0, 0);
 	emu_run_stage(c, DVP_ST_FILTER_STRONG, 0, 1);
-	emu_run_stage(c, DVP_ST_DEPTH_TO_WEAK, 0, 0);
-	emu_run_stage(c, DVP_ST_LOCAL_REFINE, 0, 0);
+	emu_run_stage(c, kStageSweeps, 0, 0);   // DepthToWeak + LocalRefine in one launch, as dvp_run_patchmatch does
 	return 0;
 }
 

@@ -179,9 +179,10 @@ def _check_full_size(r):
     ok = np.abs(np.linalg.norm(n, axis=1) - 1) < 1e-3
     assert ok.mean() > 0.999
     t = g.timings()
-    # every launch site ran (REFINE_ITER with WEAK pixels): APD.cu:4430-4505
+    # every launch site ran (REFINE_ITER with WEAK pixels): APD.cu:4430-4505.  dvp_run_patchmatch does LocalRefine
+    # inside the DepthToWeak launch (depth_to_weak_px<SMP, true>), so that bucket stays empty.
     for k in ("gen_edge_inform", "find_nearest_strong", "gen_neighbours", "neighbour_update", "random_init", "strong_update",
-              "ransac_fit", "weak_update", "get_depth_normal", "filter_strong", "depth_to_weak", "local_refine"):
+              "ransac_fit", "weak_update", "get_depth_normal", "filter_strong", "depth_to_weak"):
         assert t["stage_launches"][k] > 0, k
     assert r["weak_count"] >= 0.05 * W * H
     # WEAK pixels that found anchors were updated towards the surface: their depth error is bounded too

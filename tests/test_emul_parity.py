@@ -35,11 +35,15 @@ def test_first_pass_strong_path(W, H, S, sampler):
     _run_and_compare(a, b, 2)
 
 
-def test_two_pass_weak_path_with_geom():
+@pytest.mark.parametrize("images", ["8bit", "float"])
+def test_two_pass_weak_path_with_geom(images):
     """pass 1 (FIRST_INIT) on the oracle, then a REFINE_ITER pass with WEAK pixels, labels, adaptive
-    radius and geometric consistency on both."""
+    radius and geometric consistency on both.  `images`: integer grey levels (the weak update reads the
+    byte planes) or non-integers (float planes)."""
     W, H, S = 112, 80, 3
     sc = synth.make_scene(W, H, S)
+    if images == "float":
+        sc["images"] = (sc["images"] * np.float32(0.97) + np.float32(1.3)).astype(np.float32)
     p1 = make_params(S + 1, max_iterations=2, state=synth.FIRST_INIT, use_APD=0)
     o = O.from_scene(sc, p1)
     o.upload_state(**first_pass_state(sc))
@@ -60,6 +64,32 @@ def test_two_pass_weak_path_with_geom():
     # the weak path really ran
     assert (a.get("weak_reliable") == 1).sum() > 0
     assert np.abs(a.get("fit_planes")).sum() > 0
+
+
+@pytest.mark.parametrize("geom", [0, 1])
+def test_fused_sweeps_equal_the_two_launches(geom):
+    """run_patchmatch does DepthToWeak + LocalRefine (APD.cu:4502-4505) per pixel in one launch; run_stage keeps them
+    apart.  Same bits either way, and both equal the oracle: border pixels, sweep slots outside the depth range
+    and the geometric term included."""
+    W, H, S = 90, 61, 3
+    sc = synth.make_scene(W, H, S)
+    p = make_params(S + 1, max_iterations=1, state=synth.FIRST_INIT, use_APD=0, geom_consistency=geom)
+    p["depth_min"] = np.float32(3.2)
+    st = first_pass_state(sc)
+    dm = sc["depth_gt"] if geom else None
+    ora = O.from_scene(sc, p, depths=dm, cls=O.Oracle)
+    whole = O.from_scene(sc, p, depths=dm, cls=E.Emul)
+    steps = O.from_scene(sc, p, depths=dm, cls=E.Emul)
+    for x in (ora, whole, steps):
+        x.upload_state(**st)
+    ora.run_patchmatch()
+    whole.run_patchmatch()
+    for stg, it, col in stage_sequence(1):
+        steps.run_stage(stg, it, col)
+    for n in ("planes", "weak_info", "radius", "costs", "selected_views"):
+        assert count_diff(whole.get(n), steps.get(n)) == 0, n
+        assert count_diff(whole.get(n), ora.get(n)) == 0, n
+    assert (whole.get("weak_info") == synth.WEAK).sum() > 0
 
 
 def test_refine_init_and_generic_radius():

@@ -100,9 +100,14 @@ def test_full_run_matches_and_converges():
     assert np.median(rel[m.reshape(-1)]) < 2e-3
 
 
-def test_two_pass_weak_path_with_geom():
+@pytest.mark.parametrize("images", ["8bit", "float"])
+def test_two_pass_weak_path_with_geom(images):
+    """`images`: the synthetic grey levels are integers (8-bit files) -> the weak update reads the byte planes
+    (Dev::images8); scaled to non-integers it reads the float planes.  Both against the oracle."""
     W, H, S = 112, 80, 3
     sc = synth.make_scene(W, H, S)
+    if images == "float":
+        sc["images"] = (sc["images"] * np.float32(0.97) + np.float32(1.3)).astype(np.float32)
     p1 = make_params(S + 1, max_iterations=2, state=synth.FIRST_INIT, use_APD=0)
     g = capi().from_scene(sc, p1)
     g.upload_state(**first_pass_state(sc))
@@ -115,9 +120,38 @@ def test_two_pass_weak_path_with_geom():
     p2 = make_params(S + 1, max_iterations=2, state=synth.REFINE_ITER, use_APD=1, geom_consistency=1,
                      weak_peak_radius=4, rotate_time=2, ransac_threshold=0.01)
     a, b = _pair(sc, p2, st, depths=sc["depth_gt"])
+    assert b.image_format() == (1 if images == "8bit" else 0)
     assert a.weak_count() == b.weak_count() > 50
     _run_and_compare(a, b, 2)
     assert (b.get("weak_reliable") == 1).sum() > 0
+
+
+@pytest.mark.parametrize("geom", [0, 1])
+def test_fused_sweeps_equal_the_two_launches(geom):
+    """dvp_run_patchmatch issues DepthToWeak + LocalRefine (APD.cu:4502-4505) as ONE launch; dvp_run_stage keeps
+    them separate.  Both must leave the same bits (and both equal the oracle's two functions, checked by the
+    full-run tests): border pixels, out-of-range sweep slots and the geometric term included."""
+    W, H, S = 150, 97, 4
+    sc = synth.make_scene(W, H, S)
+    p = make_params(S + 1, max_iterations=2, state=synth.FIRST_INIT, use_APD=0, geom_consistency=geom)
+    p["depth_min"] = np.float32(3.2)   # part of the +-30 disparity sweep leaves the depth range
+    st = first_pass_state(sc)
+    dm = sc["depth_gt"] if geom else None
+    whole = capi().from_scene(sc, p, depths=dm)
+    steps = capi().from_scene(sc, p, depths=dm)
+    ora = O.from_scene(sc, p, depths=dm)
+    for x in (whole, steps, ora):
+        x.upload_state(**st)
+    whole.run_patchmatch()
+    ora.run_patchmatch()
+    for stg, it, col in stage_sequence(2):
+        steps.run_stage(stg, it, col)
+    for n in ("planes", "weak_info", "radius", "costs", "selected_views"):
+        assert count_diff(whole.get(n), steps.get(n)) == 0, n
+        assert count_diff(whole.get(n), ora.get(n)) == 0, n
+    t = whole.timings()
+    assert t["stage_launches"]["depth_to_weak"] == 1 and t["stage_launches"]["local_refine"] == 0
+    assert steps.timings()["stage_launches"]["local_refine"] == 1
 
 
 def test_refine_init_generic_radius():
