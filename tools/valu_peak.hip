@@ -26,8 +26,8 @@ int main() {
 	float* out;
 	hipMalloc(&out, (size_t)cus * 4 * 8 * 64 * 4 * sizeof(float));
 	const int iters = 200000;
-	for (int wps : { 1, 2, 4, 8 }) {   // waves per SIMD
-		const int blocks = cus * wps, threads = 256;   // one 4-wave block per (CU, wave slot): one wave per SIMD each
+	for (int wps : { 1, 2, 3, 4, 6, 8 }) {   // waves per SIMD
+		const int blocks = cus * wps, threads = 256;   // one 4-wave block per (CU, wave slot): one wave per SIMD each (3, 6: as the dispatcher places them)
 		hipEvent_t a, b;
 		hipEventCreate(&a); hipEventCreate(&b);
 		fma_chain<<<blocks, threads>>>(out, 1000, 1.0001f, 0.5f);
