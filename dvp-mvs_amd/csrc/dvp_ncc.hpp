@@ -251,13 +251,17 @@ DVP_HD float ncc_old(const Dev& d, const PatchCtx& c, int px, int py, int v, con
 	return ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 0);
 }
 
-// ComputeGeomConsistencyCost (APD.cu:1218-1256)
-DVP_HD float geom_cost(const Dev& d, int px, int py, int v, const f4 plane) {
+// ComputeGeomConsistencyCost (APD.cu:1218-1256) in two pieces: the forward point depends on the pixel and the
+// plane only, so a caller that tests one plane against several views forms it once.
+DVP_HD f3 geom_forward_point(const Dev& d, int px, int py, const f4 plane) {
+	const DvpCamera rc = load_camera(d, 0);
+	const float depth = depth_from_plane(rc, plane, px, py);
+	return point_on_world((float)px, (float)py, depth, rc);
+}
+DVP_HD float geom_cost_of_point(const Dev& d, int px, int py, int v, const f3 fwd) {
 	const DvpCamera rc = load_camera(d, 0);
 	const DvpCamera sc = load_camera(d, v);
 	const float* dimg = d.depths + (size_t)v * d.plane_stride;
-	const float depth = depth_from_plane(rc, plane, px, py);
-	const f3 fwd = point_on_world((float)px, (float)py, depth, rc);
 	f2 sp;
 	float sd;
 	project_on_camera(fwd, sc, &sp, &sd);
@@ -271,6 +275,9 @@ DVP_HD float geom_cost(const Dev& d, int px, int py, int v, const f4 plane) {
 	project_on_camera(back, rc, &bp, &rd);
 	const float dc = px - bp.x, dr = py - bp.y;
 	return fminf(3.0f, sqrtf(dc * dc + dr * dr));
+}
+DVP_HD float geom_cost(const Dev& d, int px, int py, int v, const f4 plane) {
+	return geom_cost_of_point(d, px, py, v, geom_forward_point(d, px, py, plane));
 }
 
 }  // namespace dvp

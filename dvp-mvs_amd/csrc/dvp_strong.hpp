@@ -557,6 +557,8 @@ DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, PatchTab tab, unsigne
 		f4 pl = origin;
 		pl.w = distance_to_origin(rc, px, py, p_depth, pl);
 		const bool both = refine && pd >= -5 && pd <= 5;
+		f3 fwd;   // the plane's 3-D point, shared by the views' geometric terms
+		if (P.geom_consistency) fwd = geom_forward_point(d, px, py, pl);
 		float pc = 0.0f, lr = 0.0f;
 		for (int v = 0; v < S; ++v) {
 			if (!is_set(sel, v)) continue;
@@ -564,7 +566,7 @@ DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, PatchTab tab, unsigne
 			if (vw[v] == 0) continue;
 			const float ncc = ncc_old<SMP>(d, c, px, py, v + 1, pl);
 			if (nevals) *nevals += 1;
-			const float gc = P.geom_consistency ? geom_cost(d, px, py, v + 1, pl) : 0.0f;
+			const float gc = P.geom_consistency ? geom_cost_of_point(d, px, py, v + 1, fwd) : 0.0f;
 			float cst = ncc;
 			if (P.geom_consistency) cst += P.geom_factor * gc;
 			const float tc = 0.0f + cst;
