@@ -689,7 +689,7 @@ int dvp_restore_state(dvp_ctx* c) {
 int dvp_set_params(dvp_ctx* c, const DvpParams* p) {
 	if (set_device(c)) return 1;
 	if (p->num_images != c->NI) { c->error = "dvp_set_params: params.num_images != context num_images"; return 1; }
-	if (p->use_edge == 0) { c->error = "dvp_set_params: use_edge=false (legacy ACMH sampling, APD.cu:2142-2460) is not implemented"; return 1; }
+	if (p->use_edge == 0) { c->error = "dvp_set_params: use_edge=false is rejected: the reference's legacy ACMH branch (APD.cu:2142-2460) adopts planes through positions[], which only the use_edge branch assigns (APD.cu:2036, 2084, 2133 vs 2559-2563) - it has no defined result to reproduce"; return 1; }
 	if (p->weak_radius < 0 || p->weak_radius > 15) { c->error = "dvp_set_params: weak_radius out of range [0,15]"; return 1; }
 	c->d.params = *p;
 	set_neighbour_consts(&c->d);

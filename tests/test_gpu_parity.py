@@ -202,6 +202,10 @@ def test_error_paths():
     g.set_params(p)
     with pytest.raises(c.DvpError):    # geom on, no depth maps
         g.run_stage("depth_to_weak")
+    # use_edge=false: the reference's legacy branch reads an uninitialised positions[] (APD.cu:2036 vs 2559-2563);
+    # there is no result to reproduce, the engine says so instead of inventing one
+    with pytest.raises(c.DvpError, match="positions"):
+        g.set_params(make_params(3, use_edge=0))
 
 
 def test_size_independent_properties_at_bench_size():
