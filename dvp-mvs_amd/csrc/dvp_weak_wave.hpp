@@ -42,11 +42,11 @@ DVP_HD void wave_sync() {}
 constexpr int kAnchors = DVP_NEIGHBOUR_NUM - 1;   // 11
 constexpr int kAnchorTaps = kAnchors * 9;         // 99
 #ifndef DVP_WEAK_BATCH
-#define DVP_WEAK_BATCH 8
+#define DVP_WEAK_BATCH 9
 #endif
 constexpr int kWeakBatch = DVP_WEAK_BATCH;        // source views per shared-memory hand-over of the weak update
 
-// per-wave shared state (LDS on the device), ~11.5 KB
+// per-wave shared state (LDS on the device), ~12.3 KB
 struct WeakShared {
 	f2 ctab[kTaps * kTaps];        // centre patch: (w, w*ref) per tap, row-major
 	float caa[kTaps * kTaps];      // w*ref*ref per tap (reference moments only)
@@ -164,6 +164,81 @@ DVP_HD void patch_row_sums(const Dev& d, const WeakShared& sh, const float* H, c
 	out[2] = r_rs;
 }
 
+// index of the n-th set bit of m (n < popcount(m))
+DVP_HD int nth_set_bit(uint32_t m, int n) {
+	for (int i = 0; i < n; ++i) m &= m - 1;
+	return __builtin_ctz(m);
+}
+
+// One anchor sub-patch of ComputeBilateralNCCNew (APD.cu:905-1000): the anchor `nb` of the pixel against source
+// view v (1-based) under homography H.  < 0: the anchor does not count.  The anchor's 9 reference taps (the 8
+// visibility-prior offsets of (anchor, view) + the anchor itself: offsets, texels, weights, sums) and the 9 gathers
+// in the source image all stay in registers.
+template <int SMP, int FMT>
+DVP_HD float anchor_cost(const Dev& d, const float* H, const void* src, int v, s2 nb, float cpix) {
+	const int W = d.width, Hh = d.height, Pt = d.pitch;
+	if (nb.x == -1 || nb.y == -1) return -1.0f;
+	const int nbc = nb.x + nb.y * W;
+	const bool visible = is_set(d.selected_views[nbc], v - 1);
+	const f2 nsp = apply_homography(H, nb.x, nb.y);
+	const bool outside = nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh;
+	if (outside) return visible ? 2.0f : -1.0f;
+	if (!visible) return 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
+	const s2* cand = d.candidate + cand_index(d, nbc, v - 1);
+	int tx[9], ty[9];
+	float ti[9], tj[9];
+#pragma unroll
+	for (int t = 0; t < 9; ++t) {
+		int i = 0, j = 0;
+		if (t < 8) {
+			const s2 o = cand[t];
+			i = o.x;
+			j = o.y;
+			if (i == 0 && j == 0) {   // default +-5 ring (APD.cu:943-952): {-5,0,5}^2 without its centre, x-major
+				const int u = t + (t >= 4 ? 1 : 0);
+				i = (u / 3 - 1) * 5;
+				j = (u % 3 - 1) * 5;
+			}
+		}
+		tx[t] = nb.x + i;
+		ty[t] = nb.y + j;
+		ti[t] = (float)i;
+		tj[t] = (float)j;
+	}
+	// source side first (addresses need only the offsets): 9 gathers in flight
+	unsigned off[9];
+	TapW<SMP> tw[9];
+	float qd[9][4];
+#pragma unroll
+	for (int t = 0; t < 9; ++t) {
+		const f2 sp = apply_homography(H, tx[t], ty[t]);
+		tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t], &tw[t]);
+	}
+#pragma unroll
+	for (int t = 0; t < 9; ++t) load_quad_t<FMT>(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
+	float av[9];
+#pragma unroll
+	for (int t = 0; t < 9; ++t) av[t] = ref_texel_t<FMT>(d, tx[t], ty[t]);
+	float a_sr = 0.0f, a_srr = 0.0f, a_sw = 0.0f;
+	float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+#pragma unroll
+	for (int t = 0; t < 9; ++t) {
+		const float w = bilateral_weight(ti[t], tj[t], av[t], cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
+		const float wa = w * av[t];
+		a_sr += wa;
+		a_srr += wa * av[t];
+		a_sw += w;
+		float fa, fb;
+		tap_weights(tw[t], &fa, &fb);
+		const float b = tex_lerp(fa, fb, qd[t][0], qd[t][1], qd[t][2], qd[t][3]);
+		const float wb = w * b;
+		s_s += wb;
+		s_ss = fmaf(wb, b, s_ss);
+		s_rs = fmaf(wa, b, s_rs);
+	}
+	return ncc_from_sums(a_sr, a_srr, s_s, s_ss, s_rs, a_sw);
+}
+
 // ComputeBilateralNCCNew (APD.cu:835-1021) for the live planes sh.pl[q] (q in pmask) and the source views
 // in vmask: sh.ev[q][view] = cost.  c = centre-patch context (colour-only weights) built by wave_patch_ctx.
 // Views are taken kWeakBatch at a time with ONE shared-memory hand-over per batch:
@@ -182,147 +257,66 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 	while (rest) {
 		uint32_t batch = 0;
 		for (int n = 0; n < kWeakBatch && rest; ++n) { const uint32_t low = rest & (0u - rest); batch |= low; rest ^= low; }
-		// lane -> (anchor k, plane q): item = round * 64 + lane, k = item / np, q = item % np with np = the
-		// number of plane slots in use (8 candidates in phase 0, 2 and 5 in the refinement phases): the 55 or
-		// 22 (anchor, plane) pairs of a refinement phase fit ONE round instead of two
-		int np = 32 - __builtin_clz(pmask | 1u);
-		if (kAnchors * np > 64) np = 8;   // two rounds: 8 planes per anchor keep a lane on ONE plane in both
-		const int rounds = (kAnchors * np + 63) / 64;
+		// Work items of the batch, 64 per round over the lanes:
+		//   anchor items (view slot, anchor k, plane q), q fastest: the np planes of one (view, anchor) sit in
+		//   adjacent lanes, so a load instruction's lanes share lines; a round is full whatever np is (the 2- and
+		//   5-plane refinement phases and the second half of the 88 pairs of an 8-plane view used to leave
+		//   60-75 % of a round's lanes idle);
+		//   centre items (view slot, plane, patch row).
+		// A lane's view changes from item to item, so the per-view constants are per-lane loads here.
+		const int np = 32 - __builtin_clz(pmask | 1u);   // plane slots in use (8 candidates, then 2 and 5)
+		const int nv = __builtin_popcount(batch);
+		const int rows_per = c.fast ? kTaps : 1;
 		DVP_LANES(l) {
-			// the anchors this lane serves (one per round), fetched once for all views
-			s2 nb[2];
-			uint32_t sv[2];
-			int nbc[2], ak[2];
-			const int q = l % np;   // np == 8: the same plane in both rounds; np < 8: a single round
-			const bool plane_on = (pmask >> q) & 1;
-#pragma unroll
-			for (int rd = 0; rd < 2; ++rd) {
-				const int k = (rd * 64 + l) / np;
-				ak[rd] = (rd < rounds && k < kAnchors) ? k : kAnchors;
-				nb[rd] = mks2(-1, -1);
-				sv[rd] = 0;
-				nbc[rd] = 0;
-				if (ak[rd] < kAnchors && plane_on) {
-					nb[rd] = nbs[k + 1];
-					if (!(nb[rd].x == -1 || nb[rd].y == -1)) { nbc[rd] = nb[rd].x + nb[rd].y * W; sv[rd] = d.selected_views[nbc[rd]]; }
-				}
-			}
-			int slot = 0;
-			for (uint32_t todo = batch; todo; todo &= todo - 1, ++slot) {
-				const int v = __builtin_ctz(todo) + 1;   // 1-based image index of the source view
-				const ViewConst vc = load_view(d, v);
-				const void* src = img_plane<FMT>(d, uniform_i(v));
-				const float* srcf = d.images + (size_t)uniform_i(v) * d.plane_stride * 2;   // generic (non-6-tap) patches sample the float planes
+			const int n_anchor = nv * kAnchors * np;
+			for (int it0 = 0; it0 < n_anchor; it0 += 64) {
+				const int it = it0 + l;
+				if (it >= n_anchor) continue;
+				const int q = it % np, t2 = it / np;
+				const int k = t2 % kAnchors, slot = t2 / kAnchors;
+				if (!((pmask >> q) & 1)) continue;
+				const int v = nth_set_bit(batch, slot) + 1;   // 1-based image index of the source view
+				const ViewConst vc = d.views[v];
 				float H[9];
-				bool inside = false;
-				if (plane_on) {
-					homography(vc, sh.pl[q], H);
-					const f2 pt = apply_homography(H, px, py);
-					inside = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f);
-					if (l < np) sh.inq[slot][q] = inside ? 1 : 0;
-				}
-				// ---- anchors: 8 planes x 8 anchors per round ------------------------------------------------
-#pragma unroll
-				for (int rd = 0; rd < 2; ++rd) {
-					const int k = ak[rd];
-					if (k >= kAnchors || !inside) continue;
-					float cost = -1.0f;   // < 0: this anchor does not count
-					if (!(nb[rd].x == -1 || nb[rd].y == -1)) {
-						const bool visible = is_set(sv[rd], v - 1);
-						const f2 nsp = apply_homography(H, nb[rd].x, nb[rd].y);
-						const bool outside = nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh;
-						if (outside) {
-							if (visible) cost = 2.0f;
-						} else if (!visible) {
-							cost = 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
-						} else {
-							// reference side (APD.cu:905-1000): 8 visibility-prior offsets of the anchor + the anchor itself
-							const s2* cand = d.candidate + cand_index(d, nbc[rd], v - 1);
-							int tx[9], ty[9];
-							float ti[9], tj[9];
-#pragma unroll
-							for (int t = 0; t < 9; ++t) {
-								int i = 0, j = 0;
-								if (t < 8) {
-									const s2 o = cand[t];
-									i = o.x;
-									j = o.y;
-									if (i == 0 && j == 0) {   // default +-5 ring (APD.cu:943-952): {-5,0,5}^2 without its centre, x-major
-										const int u = t + (t >= 4 ? 1 : 0);
-										i = (u / 3 - 1) * 5;
-										j = (u % 3 - 1) * 5;
-									}
-								}
-								tx[t] = nb[rd].x + i;
-								ty[t] = nb[rd].y + j;
-								ti[t] = (float)i;
-								tj[t] = (float)j;
-							}
-							// source side first (addresses need only the offsets): 9 gathers in flight
-							unsigned off[9];
-							TapW<SMP> tw[9];
-							float qd[9][4];
-#pragma unroll
-							for (int t = 0; t < 9; ++t) {
-								const f2 sp = apply_homography(H, tx[t], ty[t]);
-								tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t], &tw[t]);
-							}
-#pragma unroll
-							for (int t = 0; t < 9; ++t) load_quad_t<FMT>(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
-							float av[9];
-#pragma unroll
-							for (int t = 0; t < 9; ++t) av[t] = ref_texel_t<FMT>(d, tx[t], ty[t]);
-							float a_sr = 0.0f, a_srr = 0.0f, a_sw = 0.0f;
-							float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
-#pragma unroll
-							for (int t = 0; t < 9; ++t) {
-								const float w = bilateral_weight(ti[t], tj[t], av[t], cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
-								const float wa = w * av[t];
-								a_sr += wa;
-								a_srr += wa * av[t];
-								a_sw += w;
-								float fa, fb;
-								tap_weights(tw[t], &fa, &fb);
-								const float b = tex_lerp(fa, fb, qd[t][0], qd[t][1], qd[t][2], qd[t][3]);
-								const float wb = w * b;
-								s_s += wb;
-								s_ss = fmaf(wb, b, s_ss);
-								s_rs = fmaf(wa, b, s_rs);
-							}
-							cost = ncc_from_sums(a_sr, a_srr, s_s, s_ss, s_rs, a_sw);
-						}
-					}
-					sh.acost[slot][q][k] = cost;
-				}
-				// ---- centre patch: lane = (plane, row) -----------------------------------------------------------
-				{
-					const int cq = l >> 3, r = l & 7;
-					if (((pmask >> cq) & 1) && (c.fast ? r < kTaps : r == 0)) {
-						float Hc[9];
-						homography(vc, sh.pl[cq], Hc);
-						const f2 pt = apply_homography(Hc, px, py);
-						if (!(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f)) {
-							if (c.fast) {
-								float o[3];
-								patch_row_sums<SMP, FMT>(d, sh, Hc, src, px, py, c.radius, c.inc, r, o);
-								sh.rows[slot][cq][r][0] = o[0];
-								sh.rows[slot][cq][r][1] = o[1];
-								sh.rows[slot][cq][r][2] = o[2];
-							} else {
-								sh.rows[slot][cq][0][0] = ncc_patch_generic(d, Hc, srcf, px, py, c.radius, c.inc, 1);
-							}
-						}
-					}
+				homography(vc, sh.pl[q], H);
+				const f2 pt = apply_homography(H, px, py);
+				const bool inside = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f);
+				if (k == 0) sh.inq[slot][q] = inside ? 1 : 0;
+				if (!inside) continue;
+				sh.acost[slot][q][k] = anchor_cost<SMP, FMT>(d, H, img_plane<FMT>(d, v), v, nbs[k + 1], cpix);
+			}
+			const int n_centre = nv * np * rows_per;
+			for (int it0 = 0; it0 < n_centre; it0 += 64) {
+				const int it = it0 + l;
+				if (it >= n_centre) continue;
+				const int r = it % rows_per, t2 = it / rows_per;
+				const int cq = t2 % np, slot = t2 / np;
+				if (!((pmask >> cq) & 1)) continue;
+				const int v = nth_set_bit(batch, slot) + 1;
+				const ViewConst vc = d.views[v];
+				float Hc[9];
+				homography(vc, sh.pl[cq], Hc);
+				const f2 pt = apply_homography(Hc, px, py);
+				if (pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f) continue;
+				if (c.fast) {
+					float o[3];
+					patch_row_sums<SMP, FMT>(d, sh, Hc, img_plane<FMT>(d, v), px, py, c.radius, c.inc, r, o);
+					sh.rows[slot][cq][r][0] = o[0];
+					sh.rows[slot][cq][r][1] = o[1];
+					sh.rows[slot][cq][r][2] = o[2];
+				} else {   // generic (non-6-tap) patches sample the float planes
+					sh.rows[slot][cq][0][0] = ncc_patch_generic(d, Hc, d.images + (size_t)v * d.plane_stride * 2, px, py, c.radius, c.inc, 1);
 				}
 			}
 		}
 		wave_sync();
 		DVP_LANES(l) {
-			const int slot = l >> 3, q = l & 7;
-			uint32_t todo = batch;
-			for (int n = 0; n < slot && todo; ++n) todo &= todo - 1;
-			if (!todo || !((pmask >> q) & 1)) continue;
-			const int v = __builtin_ctz(todo);   // 0-based view index
+		for (int it0 = 0; it0 < nv * np; it0 += 64) {   // items (view slot, plane)
+			const int it = it0 + l;
+			if (it >= nv * np) continue;
+			const int slot = it / np, q = it % np;
+			if (!((pmask >> q) & 1)) continue;
+			const int v = nth_set_bit(batch, slot);   // 0-based view index
 			if (!sh.inq[slot][q]) { sh.ev[q][v] = 2.0f; continue; }
 			float cc;
 			if (c.fast) {
@@ -348,6 +342,7 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 				out = (float)(0.25 * cc + 0.75 * sc2);
 			}
 			sh.ev[q][v] = out;
+		}
 		}
 		wave_sync();
 	}
