@@ -152,7 +152,7 @@ extern "C" __global__ void __launch_bounds__(256) dvp_gen_neighbours_fit(const D
 }
 
 #ifndef DVP_LB_WEAK
-#define DVP_LB_WEAK 3   // waves per SIMD the wave kernel is compiled for (LDS: 49 KB per workgroup -> 3 workgroups per CU)
+#define DVP_LB_WEAK 4   // waves per SIMD the wave kernel is compiled for (LDS: 34 KB per workgroup -> 4 workgroups per CU; 128 VGPRs)
 #endif
 extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK) dvp_weak_update_wave(const Dev d, const ListArgs a) { weak_wave_body<0, 0>(d, a); }
 extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK) dvp_weak_update_wave_exact(const Dev d, const ListArgs a) { weak_wave_body<1, 0>(d, a); }

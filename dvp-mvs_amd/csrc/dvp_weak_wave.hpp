@@ -41,18 +41,21 @@ DVP_HD void wave_sync() {}
 
 constexpr int kAnchors = DVP_NEIGHBOUR_NUM - 1;   // 11
 constexpr int kAnchorTaps = kAnchors * 9;         // 99
-#ifndef DVP_WEAK_BATCH
-#define DVP_WEAK_BATCH 9
+#ifndef DVP_WEAK_PAIRS
+#define DVP_WEAK_PAIRS 40
 #endif
-constexpr int kWeakBatch = DVP_WEAK_BATCH;        // source views per shared-memory hand-over of the weak update
+// (source view, plane) pairs per shared-memory hand-over of the weak update: a batch takes as many views as fit,
+// 5 with the 8 candidate planes, 20 / 8 with the 2 and 5 planes of the refinement phases (8.6 KB of LDS per wave:
+// four workgroups per CU)
+constexpr int kWeakPairs = DVP_WEAK_PAIRS;
 
-// per-wave shared state (LDS on the device), ~12.3 KB
+// per-wave shared state (LDS on the device), ~8.6 KB
 struct WeakShared {
 	f2 ctab[kTaps * kTaps];        // centre patch: (w, w*ref) per tap, row-major
 	float caa[kTaps * kTaps];      // w*ref*ref per tap (reference moments only)
-	float rows[kWeakBatch][8][kTaps][3];    // centre-patch row sums (s_s, s_ss, s_rs) per (view slot, plane, row); the final-cost section uses slot 0 with 8 views in the plane index
-	float acost[kWeakBatch][8][kAnchors];   // anchor cost per (view slot, plane, anchor), < 0: does not count
-	int inq[kWeakBatch][8];                 // (view slot, plane): the centre projects inside the source image
+	float rows[kWeakPairs][kTaps][3];    // centre-patch row sums (s_s, s_ss, s_rs) per pair (view slot * np + plane) and row; the final-cost section uses pairs 0..7 for 8 views
+	float acost[kWeakPairs][kAnchors];   // anchor cost per (pair, anchor), < 0: does not count
+	int inq[kWeakPairs];                 // pair: the centre projects inside the source image
 	float cost_array[8][32];
 	float ev[8][32];
 	float gtab[8][32];             // geometric-consistency cost per (plane, view)
@@ -241,7 +244,7 @@ DVP_HD float anchor_cost(const Dev& d, const float* H, const void* src, int v, s
 
 // ComputeBilateralNCCNew (APD.cu:835-1021) for the live planes sh.pl[q] (q in pmask) and the source views
 // in vmask: sh.ev[q][view] = cost.  c = centre-patch context (colour-only weights) built by wave_patch_ctx.
-// Views are taken kWeakBatch at a time with ONE shared-memory hand-over per batch:
+// Views are taken kWeakPairs / np at a time with ONE shared-memory hand-over per batch:
 //   section 1  per view of the batch, back to back:
 //              lane (plane q, anchor k): the whole anchor sub-patch of that pair in registers — the
 //              anchor's 9 reference taps (offsets, texels, weights, sums: identical in the 8 plane lanes
@@ -253,10 +256,11 @@ DVP_HD float anchor_cost(const Dev& d, const float* H, const void* src, int v, s
 template <int SMP, int FMT>
 DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float cpix, int px, int py, uint32_t vmask, uint32_t pmask, WeakShared& sh) {
 	const int W = d.width, Hh = d.height, Pt = d.pitch;
+	const int np = 32 - __builtin_clz(pmask | 1u);   // plane slots in use (8 candidates, then 2 and 5)
 	uint32_t rest = vmask;
 	while (rest) {
 		uint32_t batch = 0;
-		for (int n = 0; n < kWeakBatch && rest; ++n) { const uint32_t low = rest & (0u - rest); batch |= low; rest ^= low; }
+		for (int n = 0; n < kWeakPairs / np && rest; ++n) { const uint32_t low = rest & (0u - rest); batch |= low; rest ^= low; }
 		// Work items of the batch, 64 per round over the lanes:
 		//   anchor items (view slot, anchor k, plane q), q fastest: the np planes of one (view, anchor) sit in
 		//   adjacent lanes, so a load instruction's lanes share lines; a round is full whatever np is (the 2- and
@@ -264,7 +268,6 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 		//   60-75 % of a round's lanes idle);
 		//   centre items (view slot, plane, patch row).
 		// A lane's view changes from item to item, so the per-view constants are per-lane loads here.
-		const int np = 32 - __builtin_clz(pmask | 1u);   // plane slots in use (8 candidates, then 2 and 5)
 		const int nv = __builtin_popcount(batch);
 		const int rows_per = c.fast ? kTaps : 1;
 		DVP_LANES(l) {
@@ -281,9 +284,9 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 				homography(vc, sh.pl[q], H);
 				const f2 pt = apply_homography(H, px, py);
 				const bool inside = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f);
-				if (k == 0) sh.inq[slot][q] = inside ? 1 : 0;
+				if (k == 0) sh.inq[slot * np + q] = inside ? 1 : 0;
 				if (!inside) continue;
-				sh.acost[slot][q][k] = anchor_cost<SMP, FMT>(d, H, img_plane<FMT>(d, v), v, nbs[k + 1], cpix);
+				sh.acost[slot * np + q][k] = anchor_cost<SMP, FMT>(d, H, img_plane<FMT>(d, v), v, nbs[k + 1], cpix);
 			}
 			const int n_centre = nv * np * rows_per;
 			for (int it0 = 0; it0 < n_centre; it0 += 64) {
@@ -301,11 +304,11 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 				if (c.fast) {
 					float o[3];
 					patch_row_sums<SMP, FMT>(d, sh, Hc, img_plane<FMT>(d, v), px, py, c.radius, c.inc, r, o);
-					sh.rows[slot][cq][r][0] = o[0];
-					sh.rows[slot][cq][r][1] = o[1];
-					sh.rows[slot][cq][r][2] = o[2];
+					sh.rows[slot * np + cq][r][0] = o[0];
+					sh.rows[slot * np + cq][r][1] = o[1];
+					sh.rows[slot * np + cq][r][2] = o[2];
 				} else {   // generic (non-6-tap) patches sample the float planes
-					sh.rows[slot][cq][0][0] = ncc_patch_generic(d, Hc, d.images + (size_t)v * d.plane_stride * 2, px, py, c.radius, c.inc, 1);
+					sh.rows[slot * np + cq][0][0] = ncc_patch_generic(d, Hc, d.images + (size_t)v * d.plane_stride * 2, px, py, c.radius, c.inc, 1);
 				}
 			}
 		}
@@ -317,22 +320,22 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 			const int slot = it / np, q = it % np;
 			if (!((pmask >> q) & 1)) continue;
 			const int v = nth_set_bit(batch, slot);   // 0-based view index
-			if (!sh.inq[slot][q]) { sh.ev[q][v] = 2.0f; continue; }
+			if (!sh.inq[slot * np + q]) { sh.ev[q][v] = 2.0f; continue; }
 			float cc;
 			if (c.fast) {
 				float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
 				for (int r = 0; r < kTaps; ++r) {
-					s_s += sh.rows[slot][q][r][0];
-					s_ss += sh.rows[slot][q][r][1];
-					s_rs += sh.rows[slot][q][r][2];
+					s_s += sh.rows[slot * np + q][r][0];
+					s_ss += sh.rows[slot * np + q][r][1];
+					s_rs += sh.rows[slot * np + q][r][2];
 				}
 				cc = ncc_from_sums(c.sum_ref, c.sum_ref_ref, s_s, s_ss, s_rs, c.wsum);
 			} else {
-				cc = sh.rows[slot][q][0][0];
+				cc = sh.rows[slot * np + q][0][0];
 			}
 			float scost = 0.0f, scnt = 0.0f;
 			for (int k = 0; k < kAnchors; ++k) {
-				const float ac = sh.acost[slot][q][k];
+				const float ac = sh.acost[slot * np + q][k];
 				if (ac >= 0.0f) { scost += ac; scnt += 1.0f; }
 			}
 			float out = cc;
@@ -634,25 +637,25 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 			} else if (in) {
 				float o[3];
 				patch_row_sums<SMP, FMT>(d, sh, H, src, px, py, c2.radius, c2.inc, r, o);
-				sh.rows[0][vs][r][0] = o[0];
-				sh.rows[0][vs][r][1] = o[1];
-				sh.rows[0][vs][r][2] = o[2];
+				sh.rows[vs][r][0] = o[0];
+				sh.rows[vs][r][1] = o[1];
+				sh.rows[vs][r][2] = o[2];
 			} else if (r == 0) {
 				sh.ev[0][v] = 2.0f;
-				sh.inq[0][vs] = 0;   // "outside" for the totalling lane
+				sh.inq[vs] = 0;   // "outside" for the totalling lane
 			}
-			if (c2.fast && in && r == 0) sh.inq[0][vs] = 1;
+			if (c2.fast && in && r == 0) sh.inq[vs] = 1;
 		}
 		wave_sync();
 		if (c2.fast) {
 			DVP_LANES(l) {
 				const int v = v0 + l;
-				if (l >= 8 || v >= S || sh.vw[v] == 0 || !sh.inq[0][l]) continue;
+				if (l >= 8 || v >= S || sh.vw[v] == 0 || !sh.inq[l]) continue;
 				float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
 				for (int r = 0; r < kTaps; ++r) {
-					s_s += sh.rows[0][l][r][0];
-					s_ss += sh.rows[0][l][r][1];
-					s_rs += sh.rows[0][l][r][2];
+					s_s += sh.rows[l][r][0];
+					s_ss += sh.rows[l][r][1];
+					s_rs += sh.rows[l][r][2];
 				}
 				sh.ev[0][v] = ncc_from_sums(c2.sum_ref, c2.sum_ref_ref, s_s, s_ss, s_rs, c2.wsum);
 			}
