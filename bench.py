@@ -35,12 +35,12 @@ NCC_BYTES = 724            # algorithmic bytes of one bilateral-NCC evaluation (
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # non-packed fp32 VALU issue rate of MI355X, MEASURED with tools/valu_peak.hip (independent v_fma_f32 chains,
 # profiles/r02_valu_peak.txt): G wave64 instructions/s by waves per SIMD.  The ceiling needs >= 8 waves per SIMD
-# (974.6 = one instruction per ~2.5 cycles per SIMD at the nominal 2.4 GHz; MI355X_MICROARCH.md gives 2 cycles);
-# the NCC kernels hold 2 waves per SIMD (256 VGPRs + a 72 KB patch table per workgroup), whose ceiling is 756.2.
-VALU_PEAK_GINST = 974.6
-VALU_CEILING_BY_WAVES = {1: 502.9, 2: 756.2, 4: 893.4, 8: 974.6}
-GATHER_ROOF_GLINES = 51.5   # tools/gather_peak.hip on MI355X (profiles/r02_gather_peak.txt): 128-byte line requests per second of 16-byte gathers = 6.6 TB/s
-WAVES_PER_SIMD = {"strong_update": 2, "depth_to_weak": 2, "local_refine": 2, "random_init": 2, "weak_update": 3}
+# (977.5 = one instruction per ~2.5 cycles per SIMD at the nominal 2.4 GHz; MI355X_MICROARCH.md gives 2 cycles);
+# the NCC kernels hold 2 waves per SIMD (256 VGPRs + a 72 KB patch table per workgroup), whose ceiling is 761.6.
+VALU_PEAK_GINST = 977.5
+VALU_CEILING_BY_WAVES = {1: 501.6, 2: 761.6, 3: 852.3, 4: 896.1, 6: 943.3, 8: 977.5}
+GATHER_ROOF_GLINES = 51.4   # tools/gather_peak.hip on MI355X (profiles/r02_gather_peak.txt): 128-byte line requests per second of 16-byte gathers = 6.6 TB/s
+WAVES_PER_SIMD = {"strong_update": 2, "depth_to_weak": 2, "local_refine": 2, "random_init": 2, "weak_update": 4}
 PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_r02.json")
 
 # launch site -> kernel name in a rocprofv3 trace (list launches for the weak path; the narrow
@@ -143,9 +143,9 @@ def pmc_lookup(kernel, W, H, S):
 def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
     """Roofline entry of one launch site.  `bound` = the limiter with the larger fraction of its peak:
       valu: wave64 VALU instructions per second (PMC SQ_INSTS_VALU of this kernel at this size / live launch
-            time) over the MEASURED issue peak of the part (tools/valu_peak.hip: 974.6 G/s with 8 waves per
+            time) over the MEASURED issue peak of the part (tools/valu_peak.hip: 977.5 G/s with 8 waves per
             SIMD).  `valu_frac_of_occupancy_ceiling` relates the same rate to the measured ceiling at the
-            kernel's own occupancy (2 waves per SIMD: 756.2 G/s) — what is left without freeing registers/LDS;
+            kernel's own occupancy (2 waves per SIMD: 761.6 G/s) — what is left without freeing registers/LDS;
       hbm:  physical traffic (PMC FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md)
             over 8 TB/s.
     Both are <= 1 by construction and need the PMC entry of this (kernel, size) in profiles/pmc_r02.json;
