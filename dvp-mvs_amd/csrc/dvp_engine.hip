@@ -710,7 +710,9 @@ int dvp_set_sampler(dvp_ctx* c, int s) { c->d.sampler = s ? 1 : 0; return 0; }
 int dvp_set_profiling(dvp_ctx* c, int on) { c->profiling = on != 0; sync_dev_struct(c); return 0; }
 
 // ---- launches ---------------------------------------------------------------------------------
-static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool with_refine = false) {
+// `fused` (dvp_run_patchmatch only): DepthToWeak does LocalRefine too; GenEdgeInform skips the visibility-prior
+// candidates when the pass has no WEAK pixel (their only reader is the weak update's anchor_cost)
+static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused = false) {
 	if (stage < 0 || stage >= DVP_ST_LAUNCHABLE) { c->error = "bad stage id"; return 1; }
 	if (!c->sector_taps) { c->error = "dvp_set_params must be called before running kernels"; return 1; }
 	if (c->d.params.geom_consistency && !c->have_depths) { c->error = "geom_consistency is on but no depth maps were uploaded"; return 1; }
@@ -803,7 +805,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool with_r
 	}
 	switch (stage) {
 	case DVP_ST_GEN_EDGE_INFORM:
-		hipLaunchKernelGGL(dvp_gen_candidates, dim3(g.grid(), (unsigned)(c->NI - 1)), block, 0, c->stream, c->d, a);
+		if (!fused || c->d.weak_count > 0) hipLaunchKernelGGL(dvp_gen_candidates, dim3(g.grid(), (unsigned)(c->NI - 1)), block, 0, c->stream, c->d, a);
 		hipLaunchKernelGGL(c->d.sampler ? dvp_gen_edge_inform_exact : dvp_gen_edge_inform, grid, block, 0, c->stream, c->d, a);
 		break;
 	case DVP_ST_RANDOM_INIT: hipLaunchKernelGGL(c->d.sampler ? dvp_random_init_exact : dvp_random_init, grid, block, 0, c->stream, c->d, a); break;
@@ -815,7 +817,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool with_r
 	case DVP_ST_GET_DEPTH_NORMAL: hipLaunchKernelGGL(c->d.sampler ? dvp_get_depth_normal_exact : dvp_get_depth_normal, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_FILTER_STRONG: hipLaunchKernelGGL(c->d.sampler ? dvp_filter_strong_exact : dvp_filter_strong, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_DEPTH_TO_WEAK:
-		if (with_refine) hipLaunchKernelGGL(c->d.sampler ? dvp_depth_to_weak_refine_exact : dvp_depth_to_weak_refine, grid, block, 0, c->stream, c->d, a);
+		if (fused) hipLaunchKernelGGL(c->d.sampler ? dvp_depth_to_weak_refine_exact : dvp_depth_to_weak_refine, grid, block, 0, c->stream, c->d, a);
 		else hipLaunchKernelGGL(c->d.sampler ? dvp_depth_to_weak_exact : dvp_depth_to_weak, grid, block, 0, c->stream, c->d, a);
 		break;
 	case DVP_ST_LOCAL_REFINE: hipLaunchKernelGGL(c->d.sampler ? dvp_local_refine_exact : dvp_local_refine, grid, block, 0, c->stream, c->d, a); break;
@@ -852,7 +854,7 @@ int dvp_run_patchmatch(dvp_ctx* c) {
 	HIP_TRY(c, hipEventCreate(&tot.a)); HIP_TRY(c, hipEventCreate(&tot.b));
 	HIP_TRY(c, hipEventCreate(&itl.a)); HIP_TRY(c, hipEventCreate(&itl.b));
 	HIP_TRY(c, hipEventRecord(tot.a, c->stream));
-	if (launch_stage(c, DVP_ST_GEN_EDGE_INFORM, 0, 0)) return 1;
+	if (launch_stage(c, DVP_ST_GEN_EDGE_INFORM, 0, 0, true)) return 1;
 	if (launch_stage(c, DVP_ST_FIND_NEAREST_STRONG, 0, 0)) return 1;
 	if (launch_stage(c, DVP_ST_GEN_NEIGHBOURS, 0, 0)) return 1;
 	if (launch_stage(c, DVP_ST_NEIGHBOUR_UPDATE, 0, 0)) return 1;
