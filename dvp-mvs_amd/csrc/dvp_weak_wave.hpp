@@ -706,12 +706,12 @@ struct FitShared {
 	uint16_t walk[3 * kGnDraws];   // queued tests: from | to << 8 (orientation of the first asker)
 	float cand_dist[kGnDraws];
 	int cand_info[kGnDraws];       // bit 0 valid, bit 1 "strong plane", bits 8..: inlier count
-	uint8_t plist[kGnDraws];       // draws that passed the index and triangle tests (any order)
+	uint8_t plist[kGnDraws];       // draws that passed the index and triangle tests, in draw order
 	int req_idx[64], mark[64];     // one batch of line-test requests: pair index / pair to mark
 	uint8_t req_from[64], req_to[64];
 	int part_t[64];                // per-lane winner of the running best
 	uint8_t part_nan[64];
-	int n_pass, n_walk;
+	int n_pass, n_walk, n_valid;
 };
 
 // shared-memory counters / bit sets touched by several lanes of the wave in one section
@@ -720,6 +720,22 @@ DVP_HD int wave_counter_add(int* counter) {
 	return atomicAdd(counter, 1);
 #else
 	return (*counter)++;
+#endif
+}
+// Slot of the calling lane in a list that the lanes with `pred` append to IN LANE ORDER; *counter (shared memory) is the
+// list length.  Every lane of the wave must call it (no early exit before it inside the section).
+DVP_HD int wave_ordered_slot(bool pred, int* counter) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	const unsigned long long m = __ballot(pred);
+	const int base = *counter;
+	const unsigned lane = threadIdx.x & 63u;
+	wave_sync();
+	if (lane == 0) *counter = base + __popcll(m);
+	return base + __popcll(m & ((1ull << lane) - 1ull));
+#else
+	const int r = *counter;
+	if (pred) (*counter)++;
+	return r;
 #endif
 }
 DVP_HD void wave_bits_or(uint32_t* word, uint32_t bits) {
@@ -774,14 +790,19 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 	}
 
 	// ---- the point tables -------------------------------------------------------------------------------
+	if (DVP_LANE0) sh.n_valid = 0;
+	wave_sync();
 	for (int i0 = 0; i0 < listed; i0 += 64) {
-		DVP_LANES(l) { if (i0 + l < listed) sh.raw[i0 + l] = d.gn_points[(size_t)wi * kGnMaxPoints + i0 + l]; }
+		DVP_LANES(l) {
+			s2 r = mks2(-1, -1);
+			if (i0 + l < listed) { r = d.gn_points[(size_t)wi * kGnMaxPoints + i0 + l]; sh.raw[i0 + l] = r; }
+			const bool valid = r.x != -1;
+			const int slot = wave_ordered_slot(valid, &sh.n_valid);   // the list without its holes, order kept
+			if (valid) sh.slot_of[slot] = (uint8_t)(i0 + l);
+		}
 	}
 	wave_sync();
-	int valid_count = 0;
-	for (int i = 0; i < listed; ++i)
-		if (sh.raw[i].x != -1) { if (DVP_LANE0) sh.slot_of[valid_count] = (uint8_t)i; ++valid_count; }
-	wave_sync();
+	const int valid_count = sh.n_valid;
 	for (int j0 = 0; j0 < valid_count; j0 += 64) {
 		DVP_LANES(l) {
 			const int j = j0 + l;
@@ -807,14 +828,17 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 	for (int t0 = 0; t0 < kGnDraws; t0 += 64) {
 		DVP_LANES(l) {
 			const int t = t0 + l;
-			if (t >= kGnDraws) continue;
-			const int ai = (int)(rand_u32(d.seed, (uint32_t)center, site, 3u * t) % (uint32_t)valid_count);
-			const int bi = (int)(rand_u32(d.seed, (uint32_t)center, site, 3u * t + 1u) % (uint32_t)valid_count);
-			const int ci = (int)(rand_u32(d.seed, (uint32_t)center, site, 3u * t + 2u) % (uint32_t)valid_count);
-			const bool pass = !(ai == bi || bi == ci || ai == ci) && point_in_triangle(sh.spv[ai], sh.spv[bi], sh.spv[ci], px, py);
-			sh.trip[t] = (uint32_t)ai | ((uint32_t)bi << 8) | ((uint32_t)ci << 16) | (pass ? 1u << 24 : 0u);
-			sh.cand_info[t] = 0;
-			if (pass) sh.plist[wave_counter_add(&sh.n_pass)] = (uint8_t)t;
+			bool pass = false;
+			if (t < kGnDraws) {
+				const int ai = (int)(rand_u32(d.seed, (uint32_t)center, site, 3u * t) % (uint32_t)valid_count);
+				const int bi = (int)(rand_u32(d.seed, (uint32_t)center, site, 3u * t + 1u) % (uint32_t)valid_count);
+				const int ci = (int)(rand_u32(d.seed, (uint32_t)center, site, 3u * t + 2u) % (uint32_t)valid_count);
+				pass = !(ai == bi || bi == ci || ai == ci) && point_in_triangle(sh.spv[ai], sh.spv[bi], sh.spv[ci], px, py);
+				sh.trip[t] = (uint32_t)ai | ((uint32_t)bi << 8) | ((uint32_t)ci << 16) | (pass ? 1u << 24 : 0u);
+				sh.cand_info[t] = 0;
+			}
+			const int slot = wave_ordered_slot(pass, &sh.n_pass);   // plist in draw order
+			if (pass) sh.plist[slot] = (uint8_t)t;
 		}
 	}
 	wave_sync();
@@ -824,12 +848,12 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 	// a first asker when its pair is neither marked from an earlier batch nor asked by a lower lane of this
 	// batch; first askers mark the pair and queue the walk in THEIR orientation.
 	if (edge_limit) {
-		for (int r0 = 0; r0 < 3 * kGnDraws; r0 += 64) {
+		for (int r0 = 0; r0 < 3 * n_pass; r0 += 64) {   // only the draws that passed ask; plist keeps their order
 			DVP_LANES(l) {
-				const int r = r0 + l, t = r / 3, e = r - 3 * t;
+				const int r = r0 + l, j = r / 3, e = r - 3 * j;
 				int idx = -1;
-				if (r < 3 * kGnDraws && (sh.trip[t] >> 24)) {
-					const uint32_t tr = sh.trip[t];
+				if (r < 3 * n_pass) {
+					const uint32_t tr = sh.trip[sh.plist[j]];
 					const int p[4] = { (int)(tr & 255u), (int)((tr >> 8) & 255u), (int)((tr >> 16) & 255u), (int)(tr & 255u) };
 					idx = gn_pair_index(p[e], p[e + 1]);
 					sh.req_from[l] = (uint8_t)p[e];
