@@ -156,7 +156,7 @@ def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
     sec = avg_ms * 1e-3
     alg = evals_per_launch * NCC_BYTES / sec / 1e9 if (sec > 0 and evals_per_launch) else None
     pmc = pmc_lookup(k, W, H, S)
-    second = {"gen_neighbours": "dvp_gen_neighbours_fit", "gen_edge_inform": "dvp_gen_candidates"}.get(stage)
+    second = {"gen_neighbours": "dvp_gen_neighbours_fit"}.get(stage)   # (dvp_gen_candidates runs on the side stream, outside its launch site's timer)
     if pmc and second:   # a launch site with two kernels is timed as one: its counters are the sum of both
         p2 = pmc_lookup(second, W, H, S)
         if p2:

@@ -311,6 +311,10 @@ struct dvp_ctx {
 	int W = 0, H = 0, NI = 0, pitch = 0;
 	size_t L = 0;
 	hipStream_t stream = nullptr;
+	// second stream of dvp_run_patchmatch: the visibility-prior candidates (VALU-bound, read by the weak updates only)
+	// run beside the latency-bound list kernels of the weak path's preparation
+	hipStream_t side = nullptr;
+	hipEvent_t side_fork = nullptr, side_join = nullptr;
 	Dev d{};
 	std::vector<void*> allocs;
 	// named device buffers
@@ -418,6 +422,8 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	auto fail = [&](int) { g_create_error = c->error; dvp_ctx_destroy(c); return 1; };
 	if (set_device(c)) return fail(0);
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->error = "hipStreamCreate failed"; return fail(0); }
+	if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->side_join, hipEventDisableTiming) != hipSuccess) { c->error = "hipStreamCreate failed"; return fail(0); }
 	const size_t L = c->L, S = (size_t)num_images - 1, plane = (size_t)c->pitch * (height + 2 * kImgPad);
 	int r = 0;
 	r |= dalloc(c, &c->images, plane * num_images * 2);
@@ -476,6 +482,9 @@ int dvp_ctx_destroy(dvp_ctx* c) {
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	for (void* p : c->allocs) (void)hipFree(p);
+	if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+	if (c->side_fork) (void)hipEventDestroy(c->side_fork);
+	if (c->side_join) (void)hipEventDestroy(c->side_join);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return 0;
@@ -710,8 +719,9 @@ int dvp_set_sampler(dvp_ctx* c, int s) { c->d.sampler = s ? 1 : 0; return 0; }
 int dvp_set_profiling(dvp_ctx* c, int on) { c->profiling = on != 0; sync_dev_struct(c); return 0; }
 
 // ---- launches ---------------------------------------------------------------------------------
-// `fused` (dvp_run_patchmatch only): DepthToWeak does LocalRefine too; GenEdgeInform skips the visibility-prior
-// candidates when the pass has no WEAK pixel (their only reader is the weak update's anchor_cost)
+// `fused` (dvp_run_patchmatch only): DepthToWeak does LocalRefine too; GenEdgeInform leaves the visibility-prior
+// candidates to dvp_run_patchmatch (side stream; not computed at all when the pass has no WEAK pixel: their only
+// reader is the weak update's anchor_cost)
 static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused = false) {
 	if (stage < 0 || stage >= DVP_ST_LAUNCHABLE) { c->error = "bad stage id"; return 1; }
 	if (!c->sector_taps) { c->error = "dvp_set_params must be called before running kernels"; return 1; }
@@ -805,7 +815,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 	}
 	switch (stage) {
 	case DVP_ST_GEN_EDGE_INFORM:
-		if (!fused || c->d.weak_count > 0) hipLaunchKernelGGL(dvp_gen_candidates, dim3(g.grid(), (unsigned)(c->NI - 1)), block, 0, c->stream, c->d, a);
+		if (!fused) hipLaunchKernelGGL(dvp_gen_candidates, dim3(g.grid(), (unsigned)(c->NI - 1)), block, 0, c->stream, c->d, a);   // fused: dvp_run_patchmatch issued them on the side stream
 		hipLaunchKernelGGL(c->d.sampler ? dvp_gen_edge_inform_exact : dvp_gen_edge_inform, grid, block, 0, c->stream, c->d, a);
 		break;
 	case DVP_ST_RANDOM_INIT: hipLaunchKernelGGL(c->d.sampler ? dvp_random_init_exact : dvp_random_init, grid, block, 0, c->stream, c->d, a); break;
@@ -854,10 +864,25 @@ int dvp_run_patchmatch(dvp_ctx* c) {
 	HIP_TRY(c, hipEventCreate(&tot.a)); HIP_TRY(c, hipEventCreate(&tot.b));
 	HIP_TRY(c, hipEventCreate(&itl.a)); HIP_TRY(c, hipEventCreate(&itl.b));
 	HIP_TRY(c, hipEventRecord(tot.a, c->stream));
+	// The candidates read the images, the sector tables and selected_views (which RandomInitialization is the first
+	// to write) and are read by the weak updates: they run on the side stream from here to just before RandomInit.
+	const bool side_work = c->d.weak_count > 0;
+	if (side_work) {
+		if (!c->sector_taps) { c->error = "dvp_set_params must be called before running kernels"; return 1; }
+		HIP_TRY(c, hipEventRecord(c->side_fork, c->stream));
+		HIP_TRY(c, hipStreamWaitEvent(c->side, c->side_fork, 0));
+		const LaunchGeom g = make_geom(c->W, c->H, false);
+		LaunchArgs a;
+		a.tiles_x = g.tiles_x; a.tiles = g.tiles; a.rows = g.rows; a.half = 0; a.colour = 0; a.iter = 0;
+		hipLaunchKernelGGL(dvp_gen_candidates, dim3(g.grid(), (unsigned)(c->NI - 1)), dim3(256), 0, c->side, c->d, a);
+		HIP_TRY(c, hipGetLastError());
+		HIP_TRY(c, hipEventRecord(c->side_join, c->side));
+	}
 	if (launch_stage(c, DVP_ST_GEN_EDGE_INFORM, 0, 0, true)) return 1;
 	if (launch_stage(c, DVP_ST_FIND_NEAREST_STRONG, 0, 0)) return 1;
 	if (launch_stage(c, DVP_ST_GEN_NEIGHBOURS, 0, 0)) return 1;
 	if (launch_stage(c, DVP_ST_NEIGHBOUR_UPDATE, 0, 0)) return 1;
+	if (side_work) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_join, 0));
 	if (launch_stage(c, DVP_ST_RANDOM_INIT, 0, 0)) return 1;
 	HIP_TRY(c, hipEventRecord(itl.a, c->stream));
 	for (int i = 0; i < c->d.params.max_iterations; ++i) {
