@@ -98,7 +98,8 @@ struct Dev {
 	int* search_pos;           // [16][L]: sample positions of the strong update's 16 propagation slots (strong_search_px)
 	uint32_t* edge_bits;       // the edge map as 32x32-pixel bit tiles (128 B each), see edge_bit()
 	int edge_tiles_x;
-	uint32_t* strong_bits;     // same tiling, bit = (weak_info == STRONG); valid during GenNeighbours
+	uint32_t* strong_bits;     // same tiling, bit = (weak_info == STRONG); valid during FindNearestStrongPoint / GenNeighbours
+	uint32_t* strong_bits_t;   // the same map with the tiles transposed: word c of a tile = its column c, bit r = row r (column segments in 1-2 words)
 	// summed-area table of edge-pixel counts over 8x8-pixel cells, (cells_y + 1) x (cells_x + 1) ints, first
 	// row / column zero: edge_sat[(cy + 1) * (cells_x + 1) + cx + 1] = #edge pixels in cells [0..cx] x [0..cy].
 	// Lets a line test prove "no edge pixel anywhere near this segment" with four loads.
@@ -382,6 +383,36 @@ DVP_HD uint32_t pack_edge_word(const uint8_t* edge, int W, int H, int tiles_x, s
 			if (x < W && (equals < 0 ? edge[(size_t)y * W + x] != 0 : edge[(size_t)y * W + x] == equals)) v |= 1u << b;
 		}
 	return v;
+}
+
+// transposed tiles: word = column of the tile, bit = row
+DVP_HD uint32_t pack_edge_word_t(const uint8_t* edge, int W, int H, int tiles_x, size_t word, int equals) {
+	const int cidx = (int)(word & 31);
+	const size_t tile = word >> 5;
+	const int ty = (int)(tile / tiles_x), tx = (int)(tile - (size_t)ty * tiles_x);
+	const int x = tx * 32 + cidx;
+	uint32_t v = 0;
+	if (x < W)
+		for (int b = 0; b < 32; ++b) {
+			const int y = ty * 32 + b;
+			if (y < H && edge[(size_t)y * W + x] == equals) v |= 1u << b;
+		}
+	return v;
+}
+// smallest t in [a, b] (a <= b, both inside the image) with the bit of (t, fixed) set, or -1.  TRANSPOSED = false:
+// t runs along x in row `fixed` of the row-major tiles; true: t runs along y in column `fixed` of the transposed tiles.
+template <bool TRANSPOSED>
+DVP_HD int first_set_bit_in(const uint32_t* bits, int tiles_x, int fixed, int a, int b) {
+	for (int w0 = a >> 5; w0 <= (b >> 5); ++w0) {
+		const size_t word = TRANSPOSED ? (size_t)((w0 * tiles_x + (fixed >> 5)) * 32 + (fixed & 31))
+		                               : (size_t)(((fixed >> 5) * tiles_x + w0) * 32 + (fixed & 31));
+		uint32_t v = bits[word];
+		const int lo = w0 * 32;
+		if (a > lo) v &= 0xFFFFFFFFu << (a - lo);
+		if (b < lo + 31) v &= 0xFFFFFFFFu >> (lo + 31 - b);
+		if (v) return lo + __builtin_ctz(v);
+	}
+	return -1;
 }
 
 // ---- small geometry helpers (APD.cu:181-194, 331-422, 467-499, 750-768) ----------------------

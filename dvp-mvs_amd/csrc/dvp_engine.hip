@@ -220,6 +220,11 @@ extern "C" __global__ void __launch_bounds__(256) dvp_gen_candidates(const Dev d
 		gen_candidates_px(d, px, py, (int)blockIdx.y);
 }
 
+extern "C" __global__ void dvp_pack_bits_transposed(const uint8_t* __restrict__ map, uint32_t* __restrict__ bits, int W, int H, int tiles_x, size_t words, int equals) {
+	const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w < words) bits[w] = pack_edge_word_t(map, W, H, tiles_x, w, equals);
+}
+
 // cell table of the edge map (edge_count_upper): counts per 8x8 cell from the bit tiles, then the two prefix passes
 extern "C" __global__ void dvp_edge_cell_counts(const Dev d) {
 	const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,7 +331,8 @@ struct dvp_ctx {
 	float* image_stage = nullptr;   // plain padded planes the uploads land in before dvp_interleave_rows
 	float* depths = nullptr;
 	uint32_t* edge_bits = nullptr;  // bit-tiled copy of `edge`, rebuilt before the launches that walk lines
-	uint32_t* strong_bits = nullptr; // bit-tiled (weak_info == STRONG), rebuilt before GenNeighbours
+	uint32_t* strong_bits = nullptr; // bit-tiled (weak_info == STRONG), rebuilt before FindNearestStrongPoint and GenNeighbours
+	uint32_t* strong_bits_t = nullptr;   // ... with transposed tiles (FindNearestStrongPoint's column segments)
 	int* edge_sat = nullptr;         // cell table of the edge map (Dev::edge_sat), rebuilt with edge_bits
 	DvpCamera* cameras = nullptr; ViewConst* views = nullptr; int* sector_taps = nullptr; int* sector_start = nullptr;
 	f4* planes = nullptr; f4* planes_snap = nullptr; f4* fit_planes = nullptr;
@@ -387,7 +393,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.selected_views = c->selected_views; d.view_weight = c->view_weight; d.weak_info = c->weak_info;
 	d.weak_reliable = c->weak_reliable; d.weak_nearest_strong = c->weak_nearest_strong;
 	d.neighbours_map = c->neighbours_map; d.neighbours = c->neighbours; d.gn_points = c->gn_points; d.gn_count = c->gn_count; d.fit_planes = c->fit_planes;
-	d.candidate = c->candidate; d.edge = c->edge; d.edge_bits = c->edge_bits; d.strong_bits = c->strong_bits; d.edge_sat = c->edge_sat; d.sat_cells_x = sat_cells(c->W); d.sat_cells_y = sat_cells(c->H); d.edge_tiles_x = edge_tiles_x(c->W); d.edge_neigh = c->edge_neigh; d.label = c->label;
+	d.candidate = c->candidate; d.edge = c->edge; d.edge_bits = c->edge_bits; d.strong_bits = c->strong_bits; d.strong_bits_t = c->strong_bits_t; d.edge_sat = c->edge_sat; d.sat_cells_x = sat_cells(c->W); d.sat_cells_y = sat_cells(c->H); d.edge_tiles_x = edge_tiles_x(c->W); d.edge_neigh = c->edge_neigh; d.label = c->label;
 	d.label_boundary = c->label_boundary; d.label_stop = c->label_stop; d.complex_ = c->complex_; d.radius = c->radius;
 	d.weak_list = c->weak_list;
 	d.eval_counter = c->profiling ? c->eval_counter : nullptr;
@@ -448,6 +454,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	r |= dalloc(c, &c->edge, L);
 	r |= dalloc(c, &c->edge_bits, edge_bits_words(width, height));
 	r |= dalloc(c, &c->strong_bits, edge_bits_words(width, height));
+	r |= dalloc(c, &c->strong_bits_t, edge_bits_words(width, height));
 	r |= dalloc(c, &c->edge_sat, (size_t)(sat_cells(width) + 1) * (sat_cells(height) + 1));
 	r |= dalloc(c, &c->edge_neigh, L * 8);
 	r |= dalloc(c, &c->label, L);
@@ -757,6 +764,12 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 	const dim3 grid(g.grid()), block(256);
 	const bool list_stage = stage == DVP_ST_FIND_NEAREST_STRONG || stage == DVP_ST_GEN_NEIGHBOURS || stage == DVP_ST_NEIGHBOUR_UPDATE ||
 	                        stage == DVP_ST_RANSAC_FIT || stage == DVP_ST_WEAK_UPDATE;
+	if (stage == DVP_ST_FIND_NEAREST_STRONG && c->d.weak_black + c->d.weak_red > 0) {   // its ring search reads row and column segments of the STRONG map
+		const size_t words = edge_bits_words(c->W, c->H);
+		hipLaunchKernelGGL(dvp_pack_edge_bits, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c->stream, c->weak_info, c->strong_bits, c->W, c->H, edge_tiles_x(c->W), words, (int)DVP_STRONG);
+		hipLaunchKernelGGL(dvp_pack_bits_transposed, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c->stream, c->weak_info, c->strong_bits_t, c->W, c->H, edge_tiles_x(c->W), words, (int)DVP_STRONG);
+		HIP_TRY(c, hipGetLastError());
+	}
 	if (stage == DVP_ST_GEN_NEIGHBOURS || stage == DVP_ST_RANSAC_FIT) {   // the launch sites that walk lines over the edge map
 		const size_t words = edge_bits_words(c->W, c->H);
 		hipLaunchKernelGGL(dvp_pack_edge_bits, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c->stream, c->edge, c->edge_bits, c->W, c->H, edge_tiles_x(c->W), words, -1);

@@ -205,23 +205,30 @@ DVP_HD void find_nearest_strong_px(const Dev& d, int px, int py) {
 	const int center = px + py * W;
 	s2 res = mks2(-1, -1);
 	if (d.weak_info[center] == DVP_WEAK) {
-		// The reference scans the whole (2r+1)^2 square of every ring and skips the interior
-		// (APD.cu:4176-4179): O(r^3).  Only the perimeter is visited here, in the same order
-		// (x ascending; for the two outer columns every y, otherwise y = -r then y = +r).
-		bool found = false;
-		for (int radius = 0; radius <= 100 && !found; ++radius) {
-			for (int x = -radius; x <= radius && !found; ++x) {
-				const bool full = (x == -radius || x == radius);
-				const int ystep = full ? 1 : 2 * radius;   // radius >= 1 whenever !full
-				for (int y = -radius; y <= radius; y += ystep) {
-					const int nx = px + x, ny = py + y;
-					if (!(nx < 0 || ny < 0 || nx >= W || ny >= H) && d.weak_info[nx + ny * W] == DVP_STRONG) {
-						res = mks2(nx, ny);
-						found = true;
-						break;
-					}
-					if (ystep == 0) break;   // radius == 0: single point
-				}
+		// The reference scans the whole (2r+1)^2 square of every ring and skips the interior (APD.cu:4176-4179):
+		// O(r^3) dependent loads.  Its visiting order on a ring is x ascending — the whole left column (y
+		// ascending), then per inner column the top pixel before the bottom one, then the whole right column — so
+		// the first hit is: the first set bit of the left column segment, else the smaller of the first set bits
+		// of the top and bottom row segments (top wins a tie), else the first set bit of the right column segment.
+		// Row segments come from the row-major bit tiles of (weak_info == STRONG), column segments from the
+		// transposed tiles: a ring costs 4-8 word loads instead of 8r byte loads.
+		for (int radius = 1; radius <= 100; ++radius) {   // (ring 0 is the WEAK pixel itself)
+			const int xl = px - radius, xr = px + radius, yt = py - radius, yb = py + radius;
+			const int ya = DVP_MAX(yt, 0), yz = DVP_MIN(yb, H - 1);
+			if (xl >= 0) {
+				const int y = first_set_bit_in<true>(d.strong_bits_t, d.edge_tiles_x, xl, ya, yz);
+				if (y >= 0) { res = mks2(xl, y); break; }
+			}
+			const int xa = DVP_MAX(xl + 1, 0), xz = DVP_MIN(xr - 1, W - 1);
+			if (xa <= xz) {
+				const int xt = yt >= 0 ? first_set_bit_in<false>(d.strong_bits, d.edge_tiles_x, yt, xa, xz) : -1;
+				const int xb = yb < H ? first_set_bit_in<false>(d.strong_bits, d.edge_tiles_x, yb, xa, xz) : -1;
+				if (xt >= 0 && (xb < 0 || xt <= xb)) { res = mks2(xt, yt); break; }
+				if (xb >= 0) { res = mks2(xb, yb); break; }
+			}
+			if (xr < W) {
+				const int y = first_set_bit_in<true>(d.strong_bits_t, d.edge_tiles_x, xr, ya, yz);
+				if (y >= 0) { res = mks2(xr, y); break; }
 			}
 		}
 	}

@@ -26,7 +26,7 @@ struct Emu {
 	std::vector<float> costs, costs_snap, complex_;
 	std::vector<uint32_t> selected_views;
 	std::vector<uint8_t> view_weight, weak_info, weak_reliable, edge;
-	std::vector<uint32_t> edge_bits, strong_bits;
+	std::vector<uint32_t> edge_bits, strong_bits, strong_bits_t;
 	std::vector<int> edge_sat;
 	std::vector<s2> weak_nearest_strong, neighbours, candidate, edge_neigh, label_boundary, label_stop, gn_points;
 	std::vector<int> gn_count;
@@ -72,6 +72,7 @@ void refresh(Emu& e) {
 	d.sat_cells_x = sat_cells(e.W);
 	d.sat_cells_y = sat_cells(e.H);
 	d.strong_bits = e.strong_bits.data();
+	d.strong_bits_t = e.strong_bits_t.data();
 	d.edge_tiles_x = edge_tiles_x(e.W);
 	d.edge_neigh = e.edge_neigh.data();
 	d.label = e.label.data();
@@ -139,6 +140,7 @@ void* emu_create(int W, int H, int NI) {
 	e->edge_bits.assign(edge_bits_words(W, H), 0u);
 	e->edge_sat.assign((size_t)(sat_cells(W) + 1) * (sat_cells(H) + 1), 0);
 	e->strong_bits.assign(edge_bits_words(W, H), 0u);
+	e->strong_bits_t.assign(edge_bits_words(W, H), 0u);
 	e->edge_neigh.assign(L * 8, mks2(-1, -1));
 	e->label_stop.assign(L * 8, mks2(-1, -1));
 	e->label.assign(L, 0);
@@ -323,7 +325,13 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 		}
 		launch<DVP_ST_GEN_EDGE_INFORM>(e, iter, colour);
 		break;
-	case DVP_ST_FIND_NEAREST_STRONG: launch<DVP_ST_FIND_NEAREST_STRONG>(e, iter, colour); break;
+	case DVP_ST_FIND_NEAREST_STRONG:
+		for (size_t w = 0; w < e.strong_bits.size(); ++w) {
+			e.strong_bits[w] = pack_edge_word(e.weak_info.data(), e.W, e.H, edge_tiles_x(e.W), w, (int)DVP_STRONG);
+			e.strong_bits_t[w] = pack_edge_word_t(e.weak_info.data(), e.W, e.H, edge_tiles_x(e.W), w, (int)DVP_STRONG);
+		}
+		launch<DVP_ST_FIND_NEAREST_STRONG>(e, iter, colour);
+		break;
 	case DVP_ST_GEN_NEIGHBOURS:
 		pack_edge(e);
 		for (size_t w = 0; w < e.strong_bits.size(); ++w) e.strong_bits[w] = pack_edge_word(e.weak_info.data(), e.W, e.H, edge_tiles_x(e.W), w, (int)DVP_STRONG);
