@@ -92,6 +92,37 @@ def test_fused_sweeps_equal_the_two_launches(geom):
     assert (whole.get("weak_info") == synth.WEAK).sum() > 0
 
 
+def find_nearest_strong_case(seed, pair):
+    """FindNearestStrongPoint alone (APD.cu:4159-4193) on adversarial maps: the engine finds the first hit of a ring from
+    row / column segments of bit tiles, the oracle walks the ring pixel by pixel.  WEAK blobs larger than a 32x32
+    tile (segments spanning several words), sparse STRONG pixels (ties between the columns and rows of a ring,
+    hits at distance > 64), image borders, and pixels with no STRONG pixel within the 100 rings."""
+    rng = np.random.default_rng(seed)
+    W, H, S = 300, 170, 1
+    sc = synth.make_scene(W, H, S)
+    p = make_params(S + 1, max_iterations=1, state=synth.REFINE_ITER, use_APD=1)
+    st = first_pass_state(sc)
+    weak = np.full((H, W), synth.WEAK, np.uint8)
+    n_strong = [40, 6, 400][seed]
+    weak.reshape(-1)[rng.choice(W * H, n_strong, replace=False)] = synth.STRONG
+    weak[rng.random((H, W)) < 0.05] = synth.UNKNOWN
+    if seed == 1:
+        weak[:, :120] = np.where(weak[:, :120] == synth.STRONG, synth.UNKNOWN, weak[:, :120])   # nothing within 100 rings on the left
+    st["weak"] = weak.reshape(-1)
+    a, b = pair(sc, p, st)
+    for x in (a, b):
+        x.run_stage("find_nearest_strong", 0, 0)
+    na, nb = a.get("weak_nearest_strong"), b.get("weak_nearest_strong")
+    assert count_diff(na, nb) == 0
+    found = (na.reshape(-1, 2)[:, 0] >= 0)
+    assert found.any() and (~found[weak.reshape(-1) == synth.WEAK]).any() == (seed == 1)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_find_nearest_strong_ring_order(seed):
+    find_nearest_strong_case(seed, _pair)
+
+
 def test_refine_init_and_generic_radius():
     """REFINE_INIT acceptance rule (cost must improve by 0.1) + radii that are not multiples of 5
     (generic tap loop) + use_radius off."""

@@ -154,6 +154,12 @@ def test_fused_sweeps_equal_the_two_launches(geom):
     assert steps.timings()["stage_launches"]["local_refine"] == 1
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_find_nearest_strong_ring_order(seed):
+    from test_emul_parity import find_nearest_strong_case
+    find_nearest_strong_case(seed, _pair)
+
+
 def test_refine_init_generic_radius():
     W, H, S = 80, 64, 2
     sc = synth.make_scene(W, H, S)
