@@ -351,13 +351,21 @@ DVP_HD void batch_rcp(const float* z, int n, float* iz) {
 // r of the tile, bit b = column b.  A walk of ~100 pixels in any direction touches 4-6 tiles
 // (128 B each; the whole map is W*H/8 bytes and stays in L2) instead of one cache line per step.
 DVP_HD int edge_tiles_x(int W) { return (W + 31) >> 5; }
+// word of pixel (x, y) in a bit-tiled map; tile row * tiles_x < 2^24: a 24-bit multiply (full rate; v_mul_lo_u32 is quarter rate)
+DVP_HD int tile_word(int tiles_x, int x, int y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return ((__mul24(y >> 5, tiles_x) + (x >> 5)) << 5) + (y & 31);
+#else
+	return (((y >> 5) * tiles_x + (x >> 5)) << 5) + (y & 31);
+#endif
+}
 DVP_HD size_t edge_bits_words(int W, int H) { return (size_t)edge_tiles_x(W) * ((H + 31) >> 5) * 32; }
 DVP_HD unsigned edge_bit(const Dev& d, int x, int y) {   // 0 <= x < W, 0 <= y < H
-	const unsigned w = d.edge_bits[(size_t)(((y >> 5) * d.edge_tiles_x + (x >> 5)) * 32 + (y & 31))];
+	const unsigned w = d.edge_bits[tile_word(d.edge_tiles_x, x, y)];
 	return (w >> (x & 31)) & 1u;
 }
 DVP_HD unsigned strong_bit(const Dev& d, int x, int y) {
-	const unsigned w = d.strong_bits[(size_t)(((y >> 5) * d.edge_tiles_x + (x >> 5)) * 32 + (y & 31))];
+	const unsigned w = d.strong_bits[tile_word(d.edge_tiles_x, x, y)];
 	return (w >> (x & 31)) & 1u;
 }
 DVP_HD int sat_cells(int n) { return (n + 7) >> 3; }

@@ -294,7 +294,7 @@ DVP_HD bool bresenham_hits_edge(const Dev& d, int Ax, int Ay, int Bx, int By) {
 				if (e2 > -dx) { erro -= dy; x0 += sx; }
 				if (e2 < dy) { erro += dx; y0 += sy; }
 				if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H) {
-					wi[k] = ((y0 >> 5) * d.edge_tiles_x + (x0 >> 5)) * 32 + (y0 & 31);
+					wi[k] = tile_word(d.edge_tiles_x, x0, y0);
 					sh[k] = x0 & 31;
 				}
 				step += 1;
