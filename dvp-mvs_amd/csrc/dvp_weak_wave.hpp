@@ -48,6 +48,7 @@ constexpr int kAnchorTaps = kAnchors * 9;         // 99
 // 5 with the 8 candidate planes, 20 / 8 with the 2 and 5 planes of the refinement phases (8.6 KB of LDS per wave:
 // four workgroups per CU)
 constexpr int kWeakPairs = DVP_WEAK_PAIRS;
+constexpr int kWeakViews = 7;   // ... and at most this many views (size of the (view, anchor) prefetch table)
 
 // per-wave shared state (LDS on the device), ~8.6 KB
 struct WeakShared {
@@ -56,6 +57,10 @@ struct WeakShared {
 	float rows[kWeakPairs][kTaps][3];    // centre-patch row sums (s_s, s_ss, s_rs) per pair (view slot * np + plane) and row; the final-cost section uses pairs 0..7 for 8 views
 	float acost[kWeakPairs][kAnchors];   // anchor cost per (pair, anchor), < 0: does not count
 	int inq[kWeakPairs];                 // pair: the centre projects inside the source image
+	// (view slot, anchor) of the batch, fetched once before the items run: the anchor's 8 visibility-prior offsets
+	// for that view as signed bytes (x, y) and what anchor_cost has to do with the pair
+	uint32_t aoff[kWeakViews * kAnchors][4];
+	uint8_t astate[kWeakViews * kAnchors];   // 0: no anchor; 1: the anchor did not select the view; 2: sub-patch
 	float cost_array[8][32];
 	float ev[8][32];
 	float gtab[8][32];             // geometric-consistency cost per (plane, view)
@@ -178,25 +183,23 @@ DVP_HD int nth_set_bit(uint32_t m, int n) {
 // visibility-prior offsets of (anchor, view) + the anchor itself: offsets, texels, weights, sums) and the 9 gathers
 // in the source image all stay in registers.
 template <int SMP, int FMT>
-DVP_HD float anchor_cost(const Dev& d, const float* H, const void* src, int v, s2 nb, float cpix) {
+DVP_HD float anchor_cost(const Dev& d, const float* H, const void* src, s2 nb, int state, const uint32_t* offs, float cpix) {
 	const int W = d.width, Hh = d.height, Pt = d.pitch;
-	if (nb.x == -1 || nb.y == -1) return -1.0f;
-	const int nbc = nb.x + nb.y * W;
-	const bool visible = is_set(d.selected_views[nbc], v - 1);
+	if (state == 0) return -1.0f;
+	const bool visible = state == 2;
 	const f2 nsp = apply_homography(H, nb.x, nb.y);
 	const bool outside = nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh;
 	if (outside) return visible ? 2.0f : -1.0f;
 	if (!visible) return 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
-	const s2* cand = d.candidate + cand_index(d, nbc, v - 1);
 	int tx[9], ty[9];
 	float ti[9], tj[9];
 #pragma unroll
 	for (int t = 0; t < 9; ++t) {
 		int i = 0, j = 0;
 		if (t < 8) {
-			const s2 o = cand[t];
-			i = o.x;
-			j = o.y;
+			const uint32_t o = offs[t >> 1] >> (16 * (t & 1));
+			i = (int)(int8_t)(o & 255u);
+			j = (int)(int8_t)((o >> 8) & 255u);
 			if (i == 0 && j == 0) {   // default +-5 ring (APD.cu:943-952): {-5,0,5}^2 without its centre, x-major
 				const int u = t + (t >= 4 ? 1 : 0);
 				i = (u / 3 - 1) * 5;
@@ -260,7 +263,7 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 	uint32_t rest = vmask;
 	while (rest) {
 		uint32_t batch = 0;
-		for (int n = 0; n < kWeakPairs / np && rest; ++n) { const uint32_t low = rest & (0u - rest); batch |= low; rest ^= low; }
+		for (int n = 0; n < kWeakPairs / np && n < kWeakViews && rest; ++n) { const uint32_t low = rest & (0u - rest); batch |= low; rest ^= low; }
 		// Work items of the batch, 64 per round over the lanes:
 		//   anchor items (view slot, anchor k, plane q), q fastest: the np planes of one (view, anchor) sit in
 		//   adjacent lanes, so a load instruction's lanes share lines; a round is full whatever np is (the 2- and
@@ -270,6 +273,34 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 		// A lane's view changes from item to item, so the per-view constants are per-lane loads here.
 		const int nv = __builtin_popcount(batch);
 		const int rows_per = c.fast ? kTaps : 1;
+		// the (view, anchor) pairs of the batch: what the anchor is worth in that view and its offsets, loaded by 64
+		// lanes at a time BEFORE the items (every item used to start with two dependent loads — the anchor's
+		// selected_views word, then its offsets — in front of its gathers)
+		for (int i0 = 0; i0 < nv * kAnchors; i0 += 64) {
+			DVP_LANES(l) {
+				const int i = i0 + l;
+				if (i >= nv * kAnchors) continue;
+				const int slot = i / kAnchors, k = i - slot * kAnchors;
+				const s2 nb = nbs[k + 1];
+				int state = 0;
+				if (!(nb.x == -1 || nb.y == -1)) {
+					const int nbc = nb.x + nb.y * W;
+					const int v0 = nth_set_bit(batch, slot);   // 0-based view
+					state = is_set(d.selected_views[nbc], v0) ? 2 : 1;
+					if (state == 2) {
+						const s2* cand = d.candidate + cand_index(d, nbc, v0);
+#pragma unroll
+						for (int t = 0; t < 4; ++t) {
+							const s2 a = cand[2 * t], b = cand[2 * t + 1];
+							sh.aoff[i][t] = ((uint32_t)(uint8_t)(int8_t)a.x) | ((uint32_t)(uint8_t)(int8_t)a.y << 8) |
+							                ((uint32_t)(uint8_t)(int8_t)b.x << 16) | ((uint32_t)(uint8_t)(int8_t)b.y << 24);
+						}
+					}
+				}
+				sh.astate[i] = (uint8_t)state;
+			}
+		}
+		wave_sync();
 		DVP_LANES(l) {
 			const int n_anchor = nv * kAnchors * np;
 			for (int it0 = 0; it0 < n_anchor; it0 += 64) {
@@ -286,7 +317,7 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 				const bool inside = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f);
 				if (k == 0) sh.inq[slot * np + q] = inside ? 1 : 0;
 				if (!inside) continue;
-				sh.acost[slot * np + q][k] = anchor_cost<SMP, FMT>(d, H, img_plane<FMT>(d, v), v, nbs[k + 1], cpix);
+				sh.acost[slot * np + q][k] = anchor_cost<SMP, FMT>(d, H, img_plane<FMT>(d, v), nbs[k + 1], sh.astate[slot * kAnchors + k], sh.aoff[slot * kAnchors + k], cpix);
 			}
 			const int n_centre = nv * np * rows_per;
 			for (int it0 = 0; it0 < n_centre; it0 += 64) {
