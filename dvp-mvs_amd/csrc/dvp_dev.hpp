@@ -66,11 +66,16 @@ struct Dev {
 	float nb_cos, nb_sin, nb_thresh;
 	int nb_shift_range;
 	const float* images;       // [num_images][H + 2*PAD][pitch][2] row-pair planes {I(x,y), I(x,y+1)}, border replicated (== clamp addressing)
-	// the same planes as BYTES (uchar2 {I(x,y), I(x,y+1)}), or null: kept only when every texel of every image is
-	// an integer in [0, 255], i.e. images decoded from 8-bit files and used at their native size (APD.cpp:1057-1069,
-	// scale_size == 1).  A bilinear footprint is then 4 bytes instead of 16 and a 128-byte line holds 64 pixels
-	// of a row pair instead of 16: the gather-bound weak update reads these (same values, so same results).
+	// the same images as BYTES (uchar2 {I(x,y), I(x,y+1)}) in 128-byte TILES, or null: kept only when every texel of
+	// every image is an integer in [0, 255], i.e. images decoded from 8-bit files and used at their native size
+	// (APD.cpp:1057-1069, scale_size == 1).  A bilinear footprint is then 4 bytes instead of 16.  A tile is 8 rows of
+	// 8 elements = 7 pixels + the first pixel of the right-hand neighbour again (so that every footprint x, x+1 lies
+	// inside one tile row): the 9 taps of an anchor sub-patch — arbitrary offsets in an 11x11 window — land in 3.7 tiles
+	// on average instead of 6.6 lines of a row-major plane (they rarely share an image row).  The gather-bound weak
+	// update reads these (same values, so same results).
 	const uint8_t* images8;
+	int img8_tiles_x;            // tiles per tile row
+	size_t img8_plane_bytes;     // bytes of one image
 	const float* depths;       // same layout (geom_consistency only)
 	const DvpCamera* cameras;  // [num_images]
 	const ViewConst* views;    // [num_images] (index 0 unused)
@@ -209,12 +214,27 @@ DVP_HD void load_quad(const float* base, unsigned byte_off, float* a, float* b, 
 	*a = p[0]; *b = p[1]; *c = p[2]; *e = p[3];
 #endif
 }
-// Image format of a kernel instantiation: FMT 0 = float row pairs (Dev::images), FMT 1 = byte row pairs
-// (Dev::images8).  `off` is always the byte offset inside a FLOAT plane (tex_offset); the byte plane has the
-// same geometry at a quarter of the size.
+// Image format of a kernel instantiation: FMT 0 = float row pairs (Dev::images), FMT 1 = tiled byte pairs
+// (Dev::images8).
+DVP_HD int img8_tiles_x(int W) { return (W + 2 * kImgPad + 6) / 7; }
+DVP_HD int img8_tiles_y(int H) { return (H + 2 * kImgPad + 7) / 8; }
+// byte offset of the footprint {I(i0,j0), I(i0,j0+1), I(i0+1,j0), I(i0+1,j0+1)} inside a tiled byte plane;
+// i0 >= -PAD, j0 >= -PAD (pixel coordinates; the PAD frame is part of the plane)
+DVP_HD unsigned img8_offset(int tiles_x, int i0, int j0) {
+	const unsigned px = (unsigned)(i0 + kImgPad), py = (unsigned)(j0 + kImgPad);
+	const unsigned tx = (px * 74899u) >> 19;   // px / 7, exact for px < 70000
+	const unsigned ex = px - 7u * tx;
+#if defined(__HIP_DEVICE_COMPILE__)
+	const unsigned tile = __umul24(py >> 3, (unsigned)tiles_x) + tx;
+#else
+	const unsigned tile = (py >> 3) * (unsigned)tiles_x + tx;
+#endif
+	return (tile << 7) + ((py & 7u) << 4) + (ex << 1);
+}
 template <int FMT> DVP_HD const void* img_plane(const Dev& d, int v);
 template <> DVP_HD const void* img_plane<0>(const Dev& d, int v) { return d.images + (size_t)v * d.plane_stride * 2; }
-template <> DVP_HD const void* img_plane<1>(const Dev& d, int v) { return d.images8 + (size_t)v * d.plane_stride * 2; }
+template <> DVP_HD const void* img_plane<1>(const Dev& d, int v) { return d.images8 + (size_t)v * d.img8_plane_bytes; }
+// `off`: byte offset of the footprint inside the plane of the format (tex_coord_t)
 template <int FMT> DVP_HD void load_quad_t(const void* base, unsigned off, float* a, float* b, float* c, float* e);
 template <> DVP_HD void load_quad_t<0>(const void* base, unsigned off, float* a, float* b, float* c, float* e) {
 	load_quad(static_cast<const float*>(base), off, a, b, c, e);
@@ -224,9 +244,9 @@ template <> DVP_HD void load_quad_t<1>(const void* base, unsigned off, float* a,
 	uint32_t t;
 #if defined(__HIP_DEVICE_COMPILE__)
 	typedef uint32_t u32_a2 __attribute__((aligned(2)));
-	t = *reinterpret_cast<const u32_a2*>(static_cast<const char*>(base) + (off >> 2));
+	t = *reinterpret_cast<const u32_a2*>(static_cast<const char*>(base) + off);
 #else
-	memcpy(&t, static_cast<const char*>(base) + (off >> 2), 4);
+	memcpy(&t, static_cast<const char*>(base) + off, 4);
 #endif
 	*a = (float)(t & 255u); *b = (float)((t >> 8) & 255u); *c = (float)((t >> 16) & 255u); *e = (float)(t >> 24);
 }
@@ -234,7 +254,7 @@ template <> DVP_HD void load_quad_t<1>(const void* base, unsigned off, float* a,
 template <int FMT> DVP_HD float ref_texel_t(const Dev& d, int ix, int iy);
 template <> DVP_HD float ref_texel_t<0>(const Dev& d, int ix, int iy) { return img_texel(d.images, d.org, d.pitch, d.width, d.height, ix, iy); }
 template <> DVP_HD float ref_texel_t<1>(const Dev& d, int ix, int iy) {
-	return (float)d.images8[(size_t)(d.org + clampi(iy, 0, d.height - 1) * d.pitch + clampi(ix, 0, d.width - 1)) * 2];
+	return (float)d.images8[img8_offset(d.img8_tiles_x, clampi(ix, 0, d.width - 1), clampi(iy, 0, d.height - 1))];
 }
 // clamp(v, lo, hi) with NaN -> lo: fminf(fmaxf(v, lo), hi).  One v_med3_f32 on the device (with a
 // NaN operand the instruction returns min3 of the other two == lo).
@@ -295,21 +315,37 @@ DVP_HD unsigned tex_offset(int pitch, int i0, int j0) {
 #endif
 	return ((unsigned)e << 3) + (unsigned)((kImgPad * pitch + kImgPad) * 8);
 }
-DVP_HD void tex_coord(int pitch, int W, int H, float x, float y, unsigned* off, TapW<0>* w) {
+// coordinate -> integer footprint origin (i0, j0) + the two interpolation weights
+DVP_HD void tex_origin(int W, int H, float x, float y, int* i0, int* j0, TapW<0>* w) {
 	const float xb = clampf_nan_lo(x, -1.0f, (float)W);
 	const float yb = clampf_nan_lo(y, -1.0f, (float)H);
 	const int qx = floor_to_int(fmaf(xb, 256.0f, 0.5f));   // in [-256, 256 W]
 	const int qy = floor_to_int(fmaf(yb, 256.0f, 0.5f));
 	w->pk = ((unsigned)qx & 255u) | ((unsigned)qy << 8);    // bits 8..15 = fraction of y
-	*off = tex_offset(pitch, qx >> 8, qy >> 8);
+	*i0 = qx >> 8;
+	*j0 = qy >> 8;
 }
-DVP_HD void tex_coord(int pitch, int W, int H, float x, float y, unsigned* off, TapW<1>* w) {
+DVP_HD void tex_origin(int W, int H, float x, float y, int* i0, int* j0, TapW<1>* w) {
 	const float xb = clampf_nan_lo(x, -1.0f, (float)W);
 	const float yb = clampf_nan_lo(y, -1.0f, (float)H);
 	const float fx = floorf(xb), fy = floorf(yb);
 	w->a = xb - fx;
 	w->b = yb - fy;
-	*off = tex_offset(pitch, (int)fx, (int)fy);
+	*i0 = (int)fx;
+	*j0 = (int)fy;
+}
+template <int SMP>
+DVP_HD void tex_coord(int pitch, int W, int H, float x, float y, unsigned* off, TapW<SMP>* w) {
+	int i0, j0;
+	tex_origin(W, H, x, y, &i0, &j0, w);
+	*off = tex_offset(pitch, i0, j0);
+}
+// the same for a plane of format FMT
+template <int FMT, int SMP>
+DVP_HD void tex_coord_t(const Dev& d, float x, float y, unsigned* off, TapW<SMP>* w) {
+	int i0, j0;
+	tex_origin(d.width, d.height, x, y, &i0, &j0, w);
+	*off = FMT ? img8_offset(d.img8_tiles_x, i0, j0) : tex_offset(d.pitch, i0, j0);
 }
 // q = {I(i,j), I(i,j+1), I(i+1,j), I(i+1,j+1)}
 DVP_HD float tex_lerp(float a, float b, float t00, float t01, float t10, float t11) {

@@ -197,11 +197,20 @@ extern "C" __global__ void dvp_interleave_rows(const float* __restrict__ in, flo
 	reinterpret_cast<float2*>(out + (size_t)pl * plane_stride * 2)[(size_t)y * pitch + x] = v;
 }
 
-// row-pair float planes -> row-pair byte planes; *inexact is raised when a texel is not an integer in [0, 255]
-extern "C" __global__ void dvp_pairs_to_bytes(const float* __restrict__ pairs, uint8_t* __restrict__ out, size_t n, int* inexact) {
+// row-pair float planes -> tiled byte planes (Dev::images8); *inexact is raised when a texel is not an integer in [0, 255].
+// One thread per tile element: tile (tx, ty), element (ex, ey) = padded pixel (tx*7 + ex, ty*8 + ey), clamped to the
+// padded plane (the right-most column of a tile repeats the first pixel of the next tile).
+extern "C" __global__ void dvp_pairs_to_tiles(const float* __restrict__ pairs, uint8_t* __restrict__ out, int PW, int PH, int pitch, size_t plane_stride,
+                                              int tiles_x, int tiles_y, int n_planes, int* inexact) {
+	const size_t per_plane = (size_t)tiles_x * tiles_y * 64;
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const float2 v = reinterpret_cast<const float2*>(pairs)[i];
+	if (i >= per_plane * n_planes) return;
+	const int pl = (int)(i / per_plane);
+	const size_t r = i - (size_t)pl * per_plane;
+	const int tile = (int)(r >> 6), e = (int)(r & 63);
+	const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+	const int sx = min(tx * 7 + (e & 7), PW - 1), sy = min(ty * 8 + (e >> 3), PH - 1);
+	const float2 v = reinterpret_cast<const float2*>(pairs + (size_t)pl * plane_stride * 2)[(size_t)sy * pitch + sx];
 	const bool ok = v.x >= 0.0f && v.x <= 255.0f && v.y >= 0.0f && v.y <= 255.0f && v.x == floorf(v.x) && v.y == floorf(v.y);
 	if (!ok) { if (*inexact == 0) atomicOr(inexact, 1); return; }
 	reinterpret_cast<uchar2*>(out)[i] = make_uchar2((unsigned char)v.x, (unsigned char)v.y);
@@ -387,7 +396,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.width = c->W; d.height = c->H; d.num_images = c->NI; d.pitch = c->pitch;
 	d.org = kImgPad * c->pitch + kImgPad;
 	d.plane_stride = (size_t)c->pitch * (c->H + 2 * kImgPad);
-	d.images = c->images; d.images8 = c->images8_ok ? c->images8 : nullptr; d.depths = c->depths; d.cameras = c->cameras; d.views = c->views; d.sector_taps = c->sector_taps; d.sector_start = c->sector_start;
+	d.images = c->images; d.images8 = c->images8_ok ? c->images8 : nullptr; d.img8_tiles_x = img8_tiles_x(c->W); d.img8_plane_bytes = (size_t)img8_tiles_x(c->W) * img8_tiles_y(c->H) * 128; d.depths = c->depths; d.cameras = c->cameras; d.views = c->views; d.sector_taps = c->sector_taps; d.sector_start = c->sector_start;
 	d.search_pos = c->search_pos;
 	d.planes = c->planes; d.planes_snap = c->planes_snap; d.costs = c->costs; d.costs_snap = c->costs_snap;
 	d.selected_views = c->selected_views; d.view_weight = c->view_weight; d.weak_info = c->weak_info;
@@ -433,7 +442,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	const size_t L = c->L, S = (size_t)num_images - 1, plane = (size_t)c->pitch * (height + 2 * kImgPad);
 	int r = 0;
 	r |= dalloc(c, &c->images, plane * num_images * 2);
-	r |= dalloc(c, &c->images8, plane * num_images * 2 + 4);   // + slack: a 4-byte footprint load may start 2 bytes before the end
+	r |= dalloc(c, &c->images8, (size_t)img8_tiles_x(width) * img8_tiles_y(height) * 128 * num_images);
 	r |= dalloc(c, &c->images8_flag, (size_t)1);
 	r |= dalloc(c, &c->image_stage, plane * num_images);
 	r |= dalloc(c, &c->cameras, (size_t)num_images);
@@ -520,9 +529,11 @@ static int upload_planes(dvp_ctx* c, float* dst, const float* const* src, int pi
 		                   dst, pairs, PH, c->pitch, stride, c->NI);
 		HIP_TRY(c, hipGetLastError());
 		// byte planes for 8-bit exact image sets (Dev::images8)
-		const size_t n = stride * c->NI;
 		HIP_TRY(c, hipMemsetAsync(c->images8_flag, 0, sizeof(int), c->stream));
-		hipLaunchKernelGGL(dvp_pairs_to_bytes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, pairs, c->images8, n, c->images8_flag);
+		const int t8x = img8_tiles_x(c->W), t8y = img8_tiles_y(c->H);
+		const size_t n = (size_t)t8x * t8y * 64 * c->NI;
+		hipLaunchKernelGGL(dvp_pairs_to_tiles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, pairs, c->images8, c->W + 2 * kImgPad, PH, c->pitch, stride,
+		                   t8x, t8y, c->NI, c->images8_flag);
 		HIP_TRY(c, hipGetLastError());
 		int inexact = 1;
 		HIP_TRY(c, hipMemcpyAsync(&inexact, c->images8_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -152,7 +152,7 @@ DVP_HD void patch_row_sums(const Dev& d, const WeakShared& sh, const float* H, c
 	TapW<SMP> tw[kTaps];
 	float q[kTaps][4];
 #pragma unroll
-	for (int tx = 0; tx < kTaps; ++tx) tex_coord(P, W, Hh, X[tx] * IZ[tx], Y[tx] * IZ[tx], &off[tx], &tw[tx]);
+	for (int tx = 0; tx < kTaps; ++tx) tex_coord_t<FMT>(d, X[tx] * IZ[tx], Y[tx] * IZ[tx], &off[tx], &tw[tx]);
 #pragma unroll
 	for (int tx = 0; tx < kTaps; ++tx) load_quad_t<FMT>(src, off[tx], &q[tx][0], &q[tx][1], &q[tx][2], &q[tx][3]);
 	float r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f;
@@ -218,7 +218,7 @@ DVP_HD float anchor_cost(const Dev& d, const float* H, const void* src, s2 nb, i
 #pragma unroll
 	for (int t = 0; t < 9; ++t) {
 		const f2 sp = apply_homography(H, tx[t], ty[t]);
-		tex_coord(Pt, W, Hh, sp.x, sp.y, &off[t], &tw[t]);
+		tex_coord_t<FMT>(d, sp.x, sp.y, &off[t], &tw[t]);
 	}
 #pragma unroll
 	for (int t = 0; t < 9; ++t) load_quad_t<FMT>(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);

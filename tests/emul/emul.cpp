@@ -42,6 +42,8 @@ void refresh(Emu& e) {
 	d.org = kImgPad * e.pitch + kImgPad;
 	d.plane_stride = (size_t)e.pitch * (e.H + 2 * kImgPad);
 	d.images = e.images.data();
+	d.img8_tiles_x = img8_tiles_x(e.W);
+	d.img8_plane_bytes = (size_t)img8_tiles_x(e.W) * img8_tiles_y(e.H) * 128;
 	{
 		bool all = !e.image_exact.empty();
 		for (char ok : e.image_exact) all = all && ok;
@@ -115,7 +117,7 @@ void* emu_create(int W, int H, int NI) {
 	const size_t L = (size_t)W * H;
 	const int S = NI - 1;
 	e->images.assign((size_t)e->pitch * (H + 2 * kImgPad) * NI * 2, 0.0f);   // row-pair planes
-	e->images8.assign((size_t)e->pitch * (H + 2 * kImgPad) * NI * 2 + 4, 0);
+	e->images8.assign((size_t)img8_tiles_x(W) * img8_tiles_y(H) * 128 * NI, 0);
 	e->image_exact.assign(NI, 0);
 	e->depths.assign((size_t)e->pitch * (H + 2 * kImgPad) * NI, 0.0f);
 	e->cameras.resize(NI);
@@ -170,14 +172,21 @@ void emu_set_image(void* c, int idx, const float* data) {
 			out[((size_t)y * e.pitch + x) * 2] = plain[(size_t)y * e.pitch + x];
 			out[((size_t)y * e.pitch + x) * 2 + 1] = plain[(size_t)(y + 1 < PH ? y + 1 : y) * e.pitch + x];
 		}
-	// byte planes (dvp_pairs_to_bytes)
-	uint8_t* out8 = &e.images8[(size_t)idx * e.d.plane_stride * 2];
+	// tiled byte planes (dvp_pairs_to_tiles)
+	const int t8x = img8_tiles_x(e.W), t8y = img8_tiles_y(e.H), PW = e.W + 2 * kImgPad;
+	uint8_t* out8 = &e.images8[(size_t)idx * t8x * t8y * 128];
 	bool exact = true;
-	for (size_t i = 0; i < e.d.plane_stride * 2; ++i) {
-		const float v = out[i];
-		if (!(v >= 0.0f && v <= 255.0f && v == floorf(v))) { exact = false; break; }
-		out8[i] = (uint8_t)v;
-	}
+	for (int ty = 0; ty < t8y && exact; ++ty)
+		for (int tx = 0; tx < t8x && exact; ++tx)
+			for (int el = 0; el < 64; ++el) {
+				const int sx = std::min(tx * 7 + (el & 7), PW - 1), sy = std::min(ty * 8 + (el >> 3), PH - 1);
+				for (int c2 = 0; c2 < 2; ++c2) {
+					const float v = out[((size_t)sy * e.pitch + sx) * 2 + c2];
+					if (!(v >= 0.0f && v <= 255.0f && v == floorf(v))) { exact = false; break; }
+					out8[((size_t)(ty * t8x + tx) * 64 + el) * 2 + c2] = (uint8_t)v;
+				}
+				if (!exact) break;
+			}
 	e.image_exact[idx] = exact ? 1 : 0;
 	refresh(e);
 }
