@@ -216,20 +216,28 @@ DVP_HD void load_quad(const float* base, unsigned byte_off, float* a, float* b, 
 }
 // Image format of a kernel instantiation: FMT 0 = float row pairs (Dev::images), FMT 1 = tiled byte pairs
 // (Dev::images8).
-DVP_HD int img8_tiles_x(int W) { return (W + 2 * kImgPad + 6) / 7; }
-DVP_HD int img8_tiles_y(int H) { return (H + 2 * kImgPad + 7) / 8; }
+#ifndef DVP_IMG8_TW
+#define DVP_IMG8_TW 7
+#endif
+constexpr int kT8W = DVP_IMG8_TW;              // unique pixels per tile row (7 or 15)
+constexpr int kT8E = kT8W + 1;                 // elements per tile row
+constexpr int kT8H = 64 / kT8E;                // tile rows (8 or 4)
+constexpr unsigned kT8Mul = kT8W == 7 ? 74899u : 34953u;   // x / kT8W == (x * kT8Mul) >> 19 for x < 70000
+DVP_HD int img8_tiles_x(int W) { return (W + 2 * kImgPad + kT8W - 1) / kT8W; }
+DVP_HD int img8_tiles_y(int H) { return (H + 2 * kImgPad + kT8H - 1) / kT8H; }
 // byte offset of the footprint {I(i0,j0), I(i0,j0+1), I(i0+1,j0), I(i0+1,j0+1)} inside a tiled byte plane;
 // i0 >= -PAD, j0 >= -PAD (pixel coordinates; the PAD frame is part of the plane)
 DVP_HD unsigned img8_offset(int tiles_x, int i0, int j0) {
 	const unsigned px = (unsigned)(i0 + kImgPad), py = (unsigned)(j0 + kImgPad);
-	const unsigned tx = (px * 74899u) >> 19;   // px / 7, exact for px < 70000
-	const unsigned ex = px - 7u * tx;
+	const unsigned tx = (px * kT8Mul) >> 19;   // px / kT8W
+	const unsigned ex = px - (unsigned)kT8W * tx;
+	const unsigned ty = py / (unsigned)kT8H, ey = py % (unsigned)kT8H;
 #if defined(__HIP_DEVICE_COMPILE__)
-	const unsigned tile = __umul24(py >> 3, (unsigned)tiles_x) + tx;
+	const unsigned tile = __umul24(ty, (unsigned)tiles_x) + tx;
 #else
-	const unsigned tile = (py >> 3) * (unsigned)tiles_x + tx;
+	const unsigned tile = ty * (unsigned)tiles_x + tx;
 #endif
-	return (tile << 7) + ((py & 7u) << 4) + (ex << 1);
+	return (tile << 7) + ey * (unsigned)(2 * kT8E) + (ex << 1);
 }
 template <int FMT> DVP_HD const void* img_plane(const Dev& d, int v);
 template <> DVP_HD const void* img_plane<0>(const Dev& d, int v) { return d.images + (size_t)v * d.plane_stride * 2; }

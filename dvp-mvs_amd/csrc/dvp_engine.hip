@@ -209,7 +209,7 @@ extern "C" __global__ void dvp_pairs_to_tiles(const float* __restrict__ pairs, u
 	const size_t r = i - (size_t)pl * per_plane;
 	const int tile = (int)(r >> 6), e = (int)(r & 63);
 	const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-	const int sx = min(tx * 7 + (e & 7), PW - 1), sy = min(ty * 8 + (e >> 3), PH - 1);
+	const int sx = min(tx * kT8W + (e % kT8E), PW - 1), sy = min(ty * kT8H + (e / kT8E), PH - 1);
 	const float2 v = reinterpret_cast<const float2*>(pairs + (size_t)pl * plane_stride * 2)[(size_t)sy * pitch + sx];
 	const bool ok = v.x >= 0.0f && v.x <= 255.0f && v.y >= 0.0f && v.y <= 255.0f && v.x == floorf(v.x) && v.y == floorf(v.y);
 	if (!ok) { if (*inexact == 0) atomicOr(inexact, 1); return; }

@@ -179,7 +179,7 @@ void emu_set_image(void* c, int idx, const float* data) {
 	for (int ty = 0; ty < t8y && exact; ++ty)
 		for (int tx = 0; tx < t8x && exact; ++tx)
 			for (int el = 0; el < 64; ++el) {
-				const int sx = std::min(tx * 7 + (el & 7), PW - 1), sy = std::min(ty * 8 + (el >> 3), PH - 1);
+				const int sx = std::min(tx * kT8W + (el % kT8E), PW - 1), sy = std::min(ty * kT8H + (el / kT8E), PH - 1);
 				for (int c2 = 0; c2 < 2; ++c2) {
 					const float v = out[((size_t)sy * e.pitch + sx) * 2 + c2];
 					if (!(v >= 0.0f && v <= 255.0f && v == floorf(v))) { exact = false; break; }
