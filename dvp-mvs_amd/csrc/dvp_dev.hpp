@@ -219,10 +219,14 @@ DVP_HD void load_quad(const float* base, unsigned byte_off, float* a, float* b, 
 #ifndef DVP_IMG8_TW
 #define DVP_IMG8_TW 7
 #endif
-constexpr int kT8W = DVP_IMG8_TW;              // unique pixels per tile row (7 or 15)
-constexpr int kT8E = kT8W + 1;                 // elements per tile row
-constexpr int kT8H = 64 / kT8E;                // tile rows (8 or 4)
-constexpr unsigned kT8Mul = kT8W == 7 ? 74899u : 34953u;   // x / kT8W == (x * kT8Mul) >> 19 for x < 70000
+// DVP_IMG8_TW = 7 / 15: uchar2 elements, tile rows of TW pixels + one repeated; 8: QUAD elements (uchar4
+// {I(x,y), I(x,y+1), I(x+1,y), I(x+1,y+1)}, nothing repeated, 8 x 4 pixels per tile, power-of-two addressing)
+constexpr bool kT8Quad = DVP_IMG8_TW == 8;
+constexpr int kT8W = DVP_IMG8_TW;                            // unique pixels per tile row
+constexpr int kT8E = kT8Quad ? 8 : kT8W + 1;                 // elements per tile row
+constexpr int kT8B = kT8Quad ? 4 : 2;                        // bytes per element
+constexpr int kT8H = 128 / (kT8E * kT8B);                    // tile rows
+constexpr unsigned kT8Mul = kT8W == 7 ? 74899u : (kT8W == 15 ? 34953u : 65536u);   // x / kT8W == (x * kT8Mul) >> 19 for x < 70000
 DVP_HD int img8_tiles_x(int W) { return (W + 2 * kImgPad + kT8W - 1) / kT8W; }
 DVP_HD int img8_tiles_y(int H) { return (H + 2 * kImgPad + kT8H - 1) / kT8H; }
 // byte offset of the footprint {I(i0,j0), I(i0,j0+1), I(i0+1,j0), I(i0+1,j0+1)} inside a tiled byte plane;
@@ -237,7 +241,7 @@ DVP_HD unsigned img8_offset(int tiles_x, int i0, int j0) {
 #else
 	const unsigned tile = ty * (unsigned)tiles_x + tx;
 #endif
-	return (tile << 7) + ey * (unsigned)(2 * kT8E) + (ex << 1);
+	return (tile << 7) + ey * (unsigned)(kT8B * kT8E) + ex * (unsigned)kT8B;
 }
 template <int FMT> DVP_HD const void* img_plane(const Dev& d, int v);
 template <> DVP_HD const void* img_plane<0>(const Dev& d, int v) { return d.images + (size_t)v * d.plane_stride * 2; }

@@ -210,10 +210,16 @@ extern "C" __global__ void dvp_pairs_to_tiles(const float* __restrict__ pairs, u
 	const int tile = (int)(r >> 6), e = (int)(r & 63);
 	const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
 	const int sx = min(tx * kT8W + (e % kT8E), PW - 1), sy = min(ty * kT8H + (e / kT8E), PH - 1);
-	const float2 v = reinterpret_cast<const float2*>(pairs + (size_t)pl * plane_stride * 2)[(size_t)sy * pitch + sx];
+	if (e >= kT8E * kT8H) return;
+	const float* plane = pairs + (size_t)pl * plane_stride * 2;
+	const float2 v = reinterpret_cast<const float2*>(plane)[(size_t)sy * pitch + sx];
+	const float2 u = reinterpret_cast<const float2*>(plane)[(size_t)sy * pitch + min(sx + 1, PW - 1)];
 	const bool ok = v.x >= 0.0f && v.x <= 255.0f && v.y >= 0.0f && v.y <= 255.0f && v.x == floorf(v.x) && v.y == floorf(v.y);
 	if (!ok) { if (*inexact == 0) atomicOr(inexact, 1); return; }
-	reinterpret_cast<uchar2*>(out)[i] = make_uchar2((unsigned char)v.x, (unsigned char)v.y);
+	uint8_t* dst = out + ((size_t)pl * tiles_x * tiles_y + tile) * 128 + (size_t)e * kT8B;
+	dst[0] = (uint8_t)v.x;
+	dst[1] = (uint8_t)v.y;
+	if (kT8Quad) { dst[2] = (uint8_t)u.x; dst[3] = (uint8_t)u.y; }
 }
 
 // byte edge map -> 32x32 bit tiles (one thread per 32-bit word)

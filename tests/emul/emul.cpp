@@ -178,12 +178,14 @@ void emu_set_image(void* c, int idx, const float* data) {
 	bool exact = true;
 	for (int ty = 0; ty < t8y && exact; ++ty)
 		for (int tx = 0; tx < t8x && exact; ++tx)
-			for (int el = 0; el < 64; ++el) {
+			for (int el = 0; el < kT8E * kT8H; ++el) {
 				const int sx = std::min(tx * kT8W + (el % kT8E), PW - 1), sy = std::min(ty * kT8H + (el / kT8E), PH - 1);
-				for (int c2 = 0; c2 < 2; ++c2) {
-					const float v = out[((size_t)sy * e.pitch + sx) * 2 + c2];
+				const int sx1 = std::min(sx + 1, PW - 1);
+				uint8_t* dst = &out8[(size_t)(ty * t8x + tx) * 128 + (size_t)el * kT8B];
+				for (int c2 = 0; c2 < kT8B; ++c2) {
+					const float v = out[((size_t)sy * e.pitch + (c2 < 2 ? sx : sx1)) * 2 + (c2 & 1)];
 					if (!(v >= 0.0f && v <= 255.0f && v == floorf(v))) { exact = false; break; }
-					out8[((size_t)(ty * t8x + tx) * 64 + el) * 2 + c2] = (uint8_t)v;
+					dst[c2] = (uint8_t)v;
 				}
 				if (!exact) break;
 			}
