@@ -200,6 +200,11 @@ def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
 
 def main():
     args = parse()
+    # stdout carries ONE JSON line (rank 0).  Libraries write there too (RCCL prints its NCCL_DEBUG=VERSION banner and
+    # its warnings on stdout): from here on file descriptor 1 is stderr, the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -365,7 +370,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, args, cfg, S, iters, device=local_rank)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
