@@ -34,9 +34,12 @@ PARAMS_DTYPE = np.dtype({
 FIRST_INIT, REFINE_INIT, REFINE_ITER = 0, 1, 2   # main.h:74-78
 WEAK, STRONG, UNKNOWN = 0, 1, 2                  # main.h:80-84
 
-# the 9 source-view offsets on the baseline ring (unit: 0.4 world units)
+# source-view offsets on the baseline ring (unit: 0.4 world units): the 9 of the BASELINE configurations, then more
+# (tests of the > 9 and > 16 view code paths); a scene with S views uses the first S
 _RING = [(1.0, 0.0), (-1.0, 0.0), (0.0, 1.0), (0.0, -1.0), (0.7, 0.7), (-0.7, 0.7), (0.7, -0.7),
-         (-0.7, -0.7), (0.5, -0.2)]
+         (-0.7, -0.7), (0.5, -0.2),
+         (0.3, 0.9), (-0.3, 0.9), (0.9, 0.3), (-0.9, -0.3), (0.35, 0.35), (-0.35, 0.35), (0.35, -0.35),
+         (-0.35, -0.35), (0.85, -0.5), (-0.85, 0.5), (0.15, 0.6)]
 
 
 def default_params(num_images, **kw):

@@ -123,6 +123,32 @@ def test_find_nearest_strong_ring_order(seed):
     find_nearest_strong_case(seed, _pair)
 
 
+def many_views_case(S, pair, make_engine):
+    W, H = 88, 64
+    sc = synth.make_scene(W, H, S)
+    p1 = make_params(S + 1, max_iterations=1, state=synth.FIRST_INIT, use_APD=0)
+    g = make_engine(sc, p1)
+    g.upload_state(**first_pass_state(sc))
+    g.run_patchmatch()
+    st = second_pass_inputs(g, sc)
+    weak = st["weak"].reshape(H, W)
+    weak[sc["flat"] & (weak == synth.STRONG)] = synth.WEAK
+    weak[20:30, 40:60] = np.where(weak[20:30, 40:60] == synth.STRONG, synth.WEAK, weak[20:30, 40:60])
+    st["weak"] = weak.reshape(-1)
+    p2 = make_params(S + 1, max_iterations=1, state=synth.REFINE_ITER, use_APD=1, geom_consistency=1,
+                     weak_peak_radius=4, rotate_time=2, ransac_threshold=0.01)
+    a, b = pair(sc, p2, st, depths=sc["depth_gt"])
+    assert a.weak_count() == b.weak_count() > 50
+    _run_and_compare(a, b, 1)
+    assert (b.get("weak_reliable") == 1).sum() > 0
+
+
+@pytest.mark.parametrize("S", [12, 18])
+def test_many_views_weak_path(S):
+    """More than 9 and more than 16 source views (see tests/test_gpu_parity.py for the device kernels this selects)."""
+    many_views_case(S, _pair, lambda sc, p: O.from_scene(sc, p, cls=O.Oracle))
+
+
 def test_refine_init_and_generic_radius():
     """REFINE_INIT acceptance rule (cost must improve by 0.1) + radii that are not multiples of 5
     (generic tap loop) + use_radius off."""

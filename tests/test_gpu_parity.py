@@ -160,6 +160,14 @@ def test_find_nearest_strong_ring_order(seed):
     find_nearest_strong_case(seed, _pair)
 
 
+@pytest.mark.parametrize("S", [12, 18])
+def test_many_views_weak_path(S):
+    """More than 9 and more than 16 source views: the 16- and 32-view instantiations of the strong update, several
+    batches of (view, plane) pairs per phase of the weak update, view selection over 12 / 18 candidates."""
+    from test_emul_parity import many_views_case
+    many_views_case(S, _pair, lambda sc, p: capi().from_scene(sc, p))
+
+
 def test_refine_init_generic_radius():
     W, H, S = 80, 64, 2
     sc = synth.make_scene(W, H, S)
