@@ -54,7 +54,8 @@ namespace ora {
 
 // numerics == 1 ("literal", Oracle.set_numerics): every site the numerics contract restates is evaluated
 // as the reference's SOURCE TEXT says instead — true divisions in ComputeHomography /
-// ComputeCorrespondingPoint, column-major single-chain moment sums, tex2D(x + 0.5f), libm expf, the
+// ComputeCorrespondingPoint, x-offset-outer tap order with per-outer-index partial moment sums
+// (APD.cu:1059-1089, 904-926), one division per tap, tex2D(x + 0.5f), libm expf, the
 // `complex` sigmoid in double.  Process-wide switch (the free functions below take no context); used by
 // tests only, to measure how far the contract is from a literal reading (tests/test_literal_mode.py).
 inline int& literal_mode() { static int v = 0; return v; }

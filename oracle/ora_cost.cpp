@@ -8,8 +8,9 @@ namespace ora {
 //   numerics 0 (contract): taps row by row (y offset outer, x offset inner) with per-row partial
 //     sums; the projective divide of a row is taken six taps at a time (batch_rcp); the three
 //     source-side sums use one fused multiply-add per tap; the sampler takes pixel coordinates.
-//   numerics 1 (literal): the reference's own order — x offset outer, y offset inner, one running
-//     sum per moment, one division per tap, tex2D(x + 0.5f, y + 0.5f) — every operator rounded once.
+//   numerics 1 (literal): the reference's own order — x offset outer, y offset inner, the six taps of
+//     one x offset summed into per-outer-index partials ("sum_*_row") that are then added to the
+//     totals, one division per tap, tex2D(x + 0.5f, y + 0.5f) — every operator rounded once.
 struct PatchSums { float ref, ref_ref, src, src_src, ref_src, w; };
 template <class WeightFn>
 static PatchSums patch_sums(const Ctx& h, const float* ref_image, const float* src_image, const float* H, const int2 c,
@@ -18,19 +19,21 @@ static PatchSums patch_sums(const Ctx& h, const float* ref_image, const float* s
 	PatchSums s = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
 	if (h.numerics == 1) {
 		for (int i = -radius; i <= radius; i += increment) {
+			PatchSums r = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };   // sum_*_row of APD.cu:1060-1065 / 906-911
 			for (int j = -radius; j <= radius; j += increment) {
 				const int2 ref_pt = make_int2(c.x + i, c.y + j);
 				const float ref_pix = tex_texel(ref_image, W, Hh, ref_pt.x, ref_pt.y);
 				const float2 src_pt = ComputeCorrespondingPoint(H, ref_pt);
 				const float src_pix = tex_linear_literal(src_image, W, Hh, src_pt.x + 0.5f, src_pt.y + 0.5f, h.sampler);
 				const float weight = weight_of((float)i, (float)j, ref_pix);
-				s.ref += weight * ref_pix;
-				s.ref_ref += weight * ref_pix * ref_pix;
-				s.src += weight * src_pix;
-				s.src_src += weight * src_pix * src_pix;
-				s.ref_src += weight * ref_pix * src_pix;
-				s.w += weight;
+				r.ref += weight * ref_pix;
+				r.ref_ref += weight * ref_pix * ref_pix;
+				r.src += weight * src_pix;
+				r.src_src += weight * src_pix * src_pix;
+				r.ref_src += weight * ref_pix * src_pix;
+				r.w += weight;
 			}
+			s.ref += r.ref; s.ref_ref += r.ref_ref; s.src += r.src; s.src_src += r.src_src; s.ref_src += r.ref_src; s.w += r.w;   // APD.cu:1083-1088 / 920-925
 		}
 		return s;
 	}

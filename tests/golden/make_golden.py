@@ -26,9 +26,9 @@ depth = rng.uniform(1.5, 7.8, n).astype(np.float32)
 nrm = rng.normal(size=(n, 3)).astype(np.float32)
 nrm[:, 2] = -np.abs(nrm[:, 2]) - 0.3
 nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
-K = sc["cameras"][0]["K"]
-d = -(nrm[:, 0] * depth * (px[:, 0] - K[2]) / K[0] + nrm[:, 1] * depth * (px[:, 1] - K[5]) / K[4] + nrm[:, 2] * depth)
-planes = np.concatenate([nrm, d[:, None]], 1).astype(np.float32)
+
+
+planes = synth.planes_in_ref_cam(sc["cameras"][0], px, depth, nrm)
 costs = o.eval_cost_vectors(px, planes)
 o.run_patchmatch()
 np.savez_compressed(os.path.join(os.path.dirname(__file__), "golden_small.npz"), W=W, H=H, S=S, seed=seed,

@@ -1,0 +1,277 @@
+"""An INDEPENDENT float64 numpy reading of the reference's cost functions, written from the source
+text of /root/reference/APD.cu (not from oracle/): ComputeHomography (:679-739),
+ComputeCorrespondingPoint (:741-748), ComputeBilateralNCCOld (:1023-1113), ComputeBilateralNCCNew
+(:835-1021), ComputeGeomConsistencyCost (:1218-1256) with Get3DPointonWorld_cu (:467-487) and
+ProjectonCamera_cu (:489-499), and DepthToWeak's cost line + peak rule (:3892-4051).
+
+TEST INFRASTRUCTURE.  It shares no code with the oracle or the engine and uses none of the
+numerics contract (no batched reciprocal, no fmaf, no 8-bit sampler, libm exp, float64 throughout),
+so agreement with the oracle to float32 accuracy on ROTATED cameras with per-view K is evidence that
+the oracle reads R, t, c and K the way the reference's source does — the one thing the
+oracle-vs-engine bit comparisons cannot show.  Scalar loops: use on a few hundred samples."""
+import math
+
+import numpy as np
+
+
+def cam64(cam):
+    return dict(K=cam["K"].astype(np.float64), R=cam["R"].astype(np.float64), t=cam["t"].astype(np.float64),
+                c=cam["c"].astype(np.float64), width=int(cam["width"]), height=int(cam["height"]))
+
+
+def homography(ref, src, pl):
+    """APD.cu:679-739, written out index by index like the source (R is row-major R[3*r + c])."""
+    R, t = ref["R"], ref["t"]
+    S, u = src["R"], src["t"]
+    ref_C = [-(R[0 + k] * t[0] + R[3 + k] * t[1] + R[6 + k] * t[2]) for k in range(3)]
+    src_C = [-(S[0 + k] * u[0] + S[3 + k] * u[1] + S[6 + k] * u[2]) for k in range(3)]
+    Rrel = [S[3 * (m // 3) + 0] * R[3 * (m % 3) + 0] + S[3 * (m // 3) + 1] * R[3 * (m % 3) + 1] + S[3 * (m // 3) + 2] * R[3 * (m % 3) + 2]
+            for m in range(9)]
+    Crel = [ref_C[k] - src_C[k] for k in range(3)]
+    trel = [S[3 * r + 0] * Crel[0] + S[3 * r + 1] * Crel[1] + S[3 * r + 2] * Crel[2] for r in range(3)]
+    n = (pl[0], pl[1], pl[2])
+    H = [Rrel[3 * r + c] - trel[r] * n[c] / pl[3] for r in range(3) for c in range(3)]
+    K = ref["K"]
+    tmp = [0.0] * 9
+    for r in range(3):
+        tmp[3 * r + 0] = H[3 * r + 0] / K[0]
+        tmp[3 * r + 1] = H[3 * r + 1] / K[4]
+        tmp[3 * r + 2] = -H[3 * r + 0] * K[2] / K[0] - H[3 * r + 1] * K[5] / K[4] + H[3 * r + 2]
+    Ks = src["K"]
+    out = [Ks[0] * tmp[0] + Ks[2] * tmp[6], Ks[0] * tmp[1] + Ks[2] * tmp[7], Ks[0] * tmp[2] + Ks[2] * tmp[8],
+           Ks[4] * tmp[3] + Ks[5] * tmp[6], Ks[4] * tmp[4] + Ks[5] * tmp[7], Ks[4] * tmp[5] + Ks[5] * tmp[8],
+           Ks[8] * tmp[6], Ks[8] * tmp[7], Ks[8] * tmp[8]]
+    return out
+
+
+def corresponding_point(H, x, y):
+    z = H[6] * x + H[7] * y + H[8]
+    return (H[0] * x + H[1] * y + H[2]) / z, (H[3] * x + H[4] * y + H[5]) / z
+
+
+def tex_point(img, ix, iy):
+    """tex2D(img, ix + 0.5, iy + 0.5), integer ix, iy: the texel itself, clamp addressing."""
+    h, w = img.shape
+    return float(img[min(max(iy, 0), h - 1), min(max(ix, 0), w - 1)])
+
+
+def tex_linear(img, x, y):
+    """tex2D(img, x + 0.5, y + 0.5), cudaFilterModeLinear, clamp (APD.cpp:1501-1517): bilinear between
+    the texel centres around pixel coordinate (x, y); exact fractions (the texture unit's 8-bit weights
+    are third-party arithmetic: the oracle is compared with its sampler 1)."""
+    h, w = img.shape
+    x = min(max(x, -1.0), float(w))
+    y = min(max(y, -1.0), float(h))
+    i0, j0 = math.floor(x), math.floor(y)
+    a, b = x - i0, y - j0
+    t00, t10 = tex_point(img, i0, j0), tex_point(img, i0 + 1, j0)
+    t01, t11 = tex_point(img, i0, j0 + 1), tex_point(img, i0 + 1, j0 + 1)
+    return (1 - b) * ((1 - a) * t00 + a * t10) + b * ((1 - a) * t01 + a * t11)
+
+
+def _ncc(sr, srr, ss, sss, srs, sw):
+    """APD.cu:1091-1109 (and 975-994).  min/max are CUDA's: a NaN operand is dropped."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = np.float64(1.0) / np.float64(sw)
+        sr, srr, ss, sss, srs = sr * inv, srr * inv, ss * inv, sss * inv, srs * inv
+        var_ref = srr - sr * sr
+        var_src = sss - ss * ss
+        if var_ref < 1e-5 or var_src < 1e-5:
+            return 2.0
+        v = 1.0 - (srs - sr * ss) / math.sqrt(var_ref * var_src) if var_ref * var_src >= 0 else float("nan")
+    if v != v:
+        return 2.0     # max(0, min(2, NaN)) with fminf/fmaxf semantics = 2
+    return max(0.0, min(2.0, v))
+
+
+def ncc_old(images, cams, x, y, v, pl, radius=5, increment=2, sigma_spatial=5.0, sigma_color=3.0):
+    ref, src = cams[0], cams[v]
+    H = homography(ref, src, pl)
+    px, py = corresponding_point(H, x, y)
+    if px >= src["width"] or px < 0.0 or py >= src["height"] or py < 0.0:
+        return 2.0
+    centre = tex_point(images[0], x, y)
+    sr = srr = ss = sss = srs = sw = 0.0
+    for i in range(-radius, radius + 1, increment):
+        for j in range(-radius, radius + 1, increment):
+            a = tex_point(images[0], x + i, y + j)
+            qx, qy = corresponding_point(H, x + i, y + j)
+            b = tex_linear(images[v], qx, qy)
+            w = math.exp(-math.sqrt(i * i + j * j) / (2.0 * sigma_spatial * sigma_spatial) - abs(a - centre) / (2.0 * sigma_color * sigma_color))
+            sr += w * a
+            srr += w * a * a
+            ss += w * b
+            sss += w * b * b
+            srs += w * a * b
+            sw += w
+    return _ncc(sr, srr, ss, sss, srs, sw)
+
+
+_RING5 = [(-5, -5), (-5, 0), (-5, 5), (0, -5), (0, 5), (5, -5), (5, 0), (5, 5)]
+
+
+def ncc_new(images, cams, x, y, v, pl, anchors, anchor_views, anchor_offsets, radius=5, increment=2, sigma_color=3.0):
+    """APD.cu:835-1021 for a WEAK pixel.  anchors: 12 (x, y), anchors[0] = the pixel, (-1, -1) = absent;
+    anchor_views[k]: selected_views word of anchor k; anchor_offsets[k]: the 8 candidate offsets of anchor k
+    for THIS view."""
+    W, Hh = cams[0]["width"], cams[0]["height"]
+    ref, src = cams[0], cams[v]
+    H = homography(ref, src, pl)
+    px, py = corresponding_point(H, x, y)
+    if px >= src["width"] or px < 0.0 or py >= src["height"] or py < 0.0:
+        return 2.0
+    centre = tex_point(images[0], x, y)
+    centre_cost, strong_cost, strong_count = 0.0, 0.0, 0
+    for k in range(12):
+        ax, ay = anchors[k]
+        if ax == -1 or ay == -1:
+            continue
+        qx, qy = corresponding_point(H, ax, ay)
+        if qx < 0 or qy < 0 or qx >= W or qy >= Hh:
+            if k != 0:
+                if (anchor_views[k] >> (v - 1)) & 1:
+                    strong_cost += 2.0
+                    strong_count += 1
+                continue
+            return 2.0
+        taps = []
+        if k == 0:
+            taps = [(i, j) for i in range(-radius, radius + 1, increment) for j in range(-radius, radius + 1, increment)]
+        elif (anchor_views[k] >> (v - 1)) & 1:
+            for m in range(9):
+                i, j = (0, 0) if m == 8 else anchor_offsets[k][m]
+                if i == 0 and j == 0 and m < 8:
+                    i, j = _RING5[m]
+                taps.append((int(i), int(j)))
+        sr = srr = ss = sss = srs = sw = 0.0
+        for i, j in taps:
+            a = tex_point(images[0], ax + i, ay + j)
+            tx, ty = corresponding_point(H, ax + i, ay + j)
+            b = tex_linear(images[v], tx, ty)
+            w = math.exp(-abs(a - centre) / (2.0 * sigma_color * sigma_color))
+            sr += w * a
+            srr += w * a * a
+            ss += w * b
+            sss += w * b * b
+            srs += w * a * b
+            sw += w
+        c = _ncc(sr, srr, ss, sss, srs, sw)    # no taps: 0/0 -> NaN -> 2 (the anchor is charged the maximum)
+        if k == 0:
+            centre_cost = c
+        else:
+            strong_cost += c
+            strong_count += 1
+    if strong_count == 0:
+        return centre_cost
+    return 0.25 * centre_cost + 0.75 * min(strong_cost / strong_count, 2.0)
+
+
+def point_on_world(x, y, depth, cam):
+    """APD.cu:467-487: R^T (depth K^-1 p) + c, K without skew."""
+    K, R, c = cam["K"], cam["R"], cam["c"]
+    X = (depth * (x - K[2]) / K[0], depth * (y - K[5]) / K[4], depth)
+    return tuple(R[0 + k] * X[0] + R[3 + k] * X[1] + R[6 + k] * X[2] + c[k] for k in range(3))
+
+
+def project_on_camera(P, cam):
+    """APD.cu:489-499: K (R X + t) with the full K (skew included)."""
+    K, R, t = cam["K"], cam["R"], cam["t"]
+    T = [R[3 * r] * P[0] + R[3 * r + 1] * P[1] + R[3 * r + 2] * P[2] + t[r] for r in range(3)]
+    d = K[6] * T[0] + K[7] * T[1] + K[8] * T[2]
+    return (K[0] * T[0] + K[1] * T[1] + K[2] * T[2]) / d, (K[3] * T[0] + K[4] * T[1] + K[5] * T[2]) / d, d
+
+
+def depth_from_plane(cam, pl, x, y):
+    K = cam["K"]   # APD.cu:419-422
+    return -pl[3] * K[0] / ((x - K[2]) * pl[0] + (K[0] / K[4]) * (y - K[5]) * pl[1] + K[0] * pl[2])
+
+
+def distance_to_origin(cam, x, y, depth, n):
+    K = cam["K"]   # APD.cu:400-405
+    X = (depth * (x - K[2]) / K[0], depth * (y - K[5]) / K[4], depth)
+    return -(n[0] * X[0] + n[1] * X[1] + n[2] * X[2])
+
+
+def geom_cost(depth_maps, cams, x, y, v, pl):
+    """APD.cu:1218-1256."""
+    ref, src = cams[0], cams[v]
+    z = depth_from_plane(ref, pl, x, y)
+    fwd = point_on_world(x, y, z, ref)
+    sx, sy, _ = project_on_camera(fwd, src)
+    if not (math.isfinite(sx) and math.isfinite(sy)):
+        return None
+    zs = tex_point(depth_maps[v], int(sx), int(sy))      # (int) truncates toward zero
+    if zs == 0.0:
+        return 3.0
+    back = point_on_world(sx, sy, zs, src)
+    bx, by, _ = project_on_camera(back, ref)
+    return min(3.0, math.hypot(x - bx, y - by))
+
+
+def depth_to_weak(images, depth_maps, cams, x, y, plane_world, views, weights, depth_min, depth_max, geom, geom_factor=0.2,
+                  weak_peak_radius=2, radius=5, increment=2):
+    """APD.cu:3892-4051 for one pixel.  Returns (state, cost line [61], min_peak) with state 0 WEAK, 1 STRONG,
+    2 UNKNOWN; None where the pixel sits within 1e-4 of a decision threshold (float32 vs float64 may differ)."""
+    W, Hh = cams[0]["width"], cams[0]["height"]
+    if x < 6 or y < 6 or x >= W - 6 or y >= Hh - 6:
+        return 2, None, None
+    R = cams[0]["R"]
+    n = tuple(R[3 * r] * plane_world[0] + R[3 * r + 1] * plane_world[1] + R[3 * r + 2] * plane_world[2] for r in range(3))   # TransformNormal2RefCam
+    z0 = float(plane_world[3])
+    if z0 == 0:
+        return 2, None, None
+    S = len(cams) - 1
+    sel = [s for s in range(1, S + 1) if (views >> (s - 1)) & 1]
+    if not sel:
+        return 2, None, None
+    base = sum(math.sqrt(sum((cams[0]["c"][k] - cams[s]["c"][k]) ** 2 for k in range(3))) for s in sel) / len(sel)
+    wn = float(sum(weights[s - 1] for s in sel))
+    disp = cams[0]["K"][0] * base / z0
+    line = []
+    for pd in range(-30, 31):
+        with np.errstate(divide="ignore"):
+            z = float(np.float64(cams[0]["K"][0] * base) / np.float64(disp + pd))
+        if z < depth_min or z > depth_max:
+            line.append(2.0)
+            continue
+        pl = (n[0], n[1], n[2], distance_to_origin(cams[0], x, y, z, n))
+        acc = 0.0
+        for s in sel:
+            c = ncc_old(images, cams, x, y, s, pl, radius, increment)
+            if geom:
+                c += geom_factor * geom_cost(depth_maps, cams, x, y, s, pl)
+            acc += c * weights[s - 1]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            pc = float(np.float64(acc) / np.float64(wn))
+        line.append(pc if 2.0 > pc else 2.0)     # MIN(2.0f, p_cost) = (2 > p ? p : 2): NaN -> 2
+    eps = 1e-4
+    fragile = False
+    peaks = []
+    min_peak, min_cost = 0, 2.0
+    for i in range(2, 59):
+        a, b, c = line[i - 1], line[i], line[i + 1]
+        if 0 < abs(a - b) < eps or 0 < abs(c - b) < eps:     # (equal entries are saturated at 2.0 on both sides)
+            fragile = True
+        if a > b and c > b:
+            peaks.append(i)
+            if b < min_cost:
+                if abs(b - min_cost) < eps:
+                    fragile = True
+                min_peak, min_cost = i, b
+    for i in peaks:
+        if i != min_peak and abs(line[i] - min_cost) < eps:
+            fragile = True
+    if abs(min_peak - 30) > weak_peak_radius or line[min_peak] > 0.5:
+        st = 0
+        if abs(line[min_peak] - 0.5) < eps:
+            fragile = True
+    elif len(peaks) == 1:
+        st = 1 if line[min_peak] <= 0.15 else 0
+        if abs(line[min_peak] - 0.15) < eps:
+            fragile = True
+    else:
+        var = math.sqrt(sum((line[i] - min_cost) ** 2 for i in peaks if i != min_peak)) / (len(peaks) - 1)
+        st = 1 if var > 0.2 else 0
+        if abs(var - 0.2) < eps:
+            fragile = True
+    return (None if fragile else st), line, min_peak

@@ -24,8 +24,8 @@ def scene_with_views(W, H, S, seed=7):
     while len(images) < S + 1:
         a, b = synth._RING[k % len(synth._RING)]
         base = 0.15 + 0.05 * (k // len(synth._RING))
-        cam = synth.make_camera(W, H, (base * a, base * b, 0.01 * k))
-        img, dep, _ = synth.render_view(W, H, cam, px_world, with_step=True, with_flat=True)
+        cam = synth.make_camera(W, H, (base * a, base * b, 0.01 * k), R=synth._rot(0.02 * a, -0.03 * b, 0.1 * (k % 5 - 2)))
+        img, dep, _, _ = synth.render_view(W, H, cam, px_world, with_step=True, with_flat=True)
         images.append(img)
         depths.append(dep)
         cams.append(cam)
