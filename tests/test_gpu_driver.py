@@ -69,7 +69,10 @@ def test_apd_with_depth_prior(tmp_path):
         rel = np.abs(dep - gt[0])[8:-8, 8:-8][m] / gt[0][8:-8, 8:-8][m]
         med[tag] = (float(np.mean(rel < 1e-2)), float(np.mean(rel < 1e-3)), float(m.mean()))
     print(med)
-    assert med["prior"][0] > 0.7 and med["prior"][0] >= med["random"][0] and med["prior"][1] > med["random"][1] + 0.15, med
+    # With rotated reference cameras the prior helps less than it did with R = I: FIRST_INIT keeps the prior plane as
+    # (WORLD normal, depth) and the kernels then read it as (camera normal, offset) — the reference's own behaviour
+    # (APD.cpp:1393-1420 + APD.cu:1289-1298, quirk ledger in DESIGN.md) — so its normals are off by the camera rotation.
+    assert med["prior"][0] > 0.7 and med["prior"][0] >= med["random"][0] and med["prior"][1] > med["random"][1] + 0.05, med
 
 
 def test_apd_first_pass_equals_capi(tmp_path):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Fold the PMC passes of tools/pmc_collect.sh into profiles/pmc_r02.json.
-usage: pmc_table.py OUTDIR [TABLE=profiles/pmc_r02.json]
+"""Fold the PMC passes of tools/pmc_collect.sh into profiles/pmc_r03.json.
+usage: pmc_table.py OUTDIR [TABLE=profiles/pmc_r03.json]
 
 Per kernel only the launches of the bench's LAST step are averaged (the untimed FIRST_INIT pass and
 the counting warm-up step launch the same kernels earlier): the last `launches_per_step[kernel]`
@@ -42,10 +42,15 @@ def per_kernel_last(path, launches_per_step):
 
 def main():
     out = sys.argv[1]
-    table_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_r02.json")
-    table = {"notes": __doc__.split("Units and corrections")[1].strip(), "kernels": {}}
+    table_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_r03.json")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    sha = bench.csrc_sha256()
+    table = {"notes": __doc__.split("Units and corrections")[1].strip(), "kernels": {}, "csrc_sha256": sha}
     if os.path.exists(table_path):
-        table = json.load(open(table_path))
+        old = json.load(open(table_path))
+        if old.get("csrc_sha256") == sha:      # counters of other kernel sources are never mixed in
+            table = old
     merged = collections.defaultdict(dict)
     cfg = None
     for name in ("fetch", "write", "sq1", "sq2"):
