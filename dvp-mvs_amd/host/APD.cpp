@@ -23,9 +23,25 @@ APD::APD(const Problem& problem) {   // APD.cpp:984-987
 // context whose shape (device, W, H, images) matches the next view's is recycled instead: one pooled
 // context per process, reset on the device (dvp_reset_state) and re-filled by the uploads.
 namespace {
-struct ImageEntry { Mat image; int orig_cols = 0, orig_rows = 0; };
+struct ImageEntry { Mat image; int orig_cols = 0, orig_rows = 0; uint64_t used = 0; };
 using ImageKey = std::tuple<std::string, int, int, int>;   // file, scale, pad width, pad height
 std::map<ImageKey, ImageEntry> g_img_cache;
+size_t g_img_cache_capacity = 96;
+uint64_t g_img_cache_clock = 0;
+// Room for one more entry: images of other pyramid levels go first (a level never comes back), then the least
+// recently used one — never the whole cache (a scene with more views than the capacity would otherwise re-read
+// every file for every view).
+void make_room(int scale) {
+	if (g_img_cache.size() < g_img_cache_capacity) return;
+	for (auto it = g_img_cache.begin(); it != g_img_cache.end();)
+		it = (std::get<1>(it->first) != scale) ? g_img_cache.erase(it) : std::next(it);
+	while (g_img_cache.size() >= g_img_cache_capacity) {
+		auto lru = g_img_cache.begin();
+		for (auto it = g_img_cache.begin(); it != g_img_cache.end(); ++it)
+			if (it->second.used < lru->second.used) lru = it;
+		g_img_cache.erase(lru);
+	}
+}
 struct PooledCtx {
 	dvp_ctx* ctx = nullptr;
 	int device = 0, w = 0, h = 0, ni = 0;
@@ -33,6 +49,7 @@ struct PooledCtx {
 	// calls APD::ReleasePooledContext() before it returns
 } g_pool;
 }
+void APD::ReserveImageCache(size_t views) { g_img_cache_capacity = std::max<size_t>(96, 2 * views + 8); }   // reference + padded source role
 void APD::ReleasePooledContext() {
 	if (g_pool.ctx) dvp_ctx_destroy(g_pool.ctx);
 	g_pool.ctx = nullptr;
@@ -50,17 +67,14 @@ static ImageKey image_key(const Problem& problem, int image_id, int pad_w, int p
 static const ImageEntry& load_image(const Problem& problem, int image_id, int pad_w, int pad_h, bool is_ref) {
 	const ImageKey key = image_key(problem, image_id, pad_w, pad_h);
 	auto it = g_img_cache.find(key);
-	if (it != g_img_cache.end()) return it->second;
+	if (it != g_img_cache.end()) { it->second.used = ++g_img_cache_clock; return it->second; }
 	if (!is_ref) {   // the same file cached in its reference role needs no padding when the sizes agree
 		auto ir = g_img_cache.find(image_key(problem, image_id, 0, 0));
-		if (ir != g_img_cache.end() && ir->second.orig_cols == pad_w && ir->second.orig_rows == pad_h) return ir->second;
+		if (ir != g_img_cache.end() && ir->second.orig_cols == pad_w && ir->second.orig_rows == pad_h) { ir->second.used = ++g_img_cache_clock; return ir->second; }
 	}
-	if (g_img_cache.size() >= 96) g_img_cache.clear();
+	make_room(problem.scale_size);
 	const Mat image_uint = ReadImageGray(std::get<0>(key));
-	if (image_uint.empty()) {
-		std::cerr << "Can't read " << (is_ref ? "reference" : "source") << " image " << image_id << std::endl;
-		exit(EXIT_FAILURE);
-	}
+	if (image_uint.empty()) DvpFatal(std::string("Can't read ") + (is_ref ? "reference" : "source") + " image " + std::to_string(image_id));
 	// uint8 -> float; a source image is zero-padded / cropped to the reference size (APD.cpp:1059, 1071-1079)
 	const int fw = is_ref ? image_uint.cols : pad_w, fh = is_ref ? image_uint.rows : pad_h;
 	Mat f = Mat::zeros(fh, fw, CV_32FC1);
@@ -77,6 +91,7 @@ static const ImageEntry& load_image(const Problem& problem, int image_id, int pa
 		f = ResizeLinear(f, (int)std::round(f.cols * factor), (int)std::round(f.rows * factor));
 	}
 	ci.image = f;
+	ci.used = ++g_img_cache_clock;
 	return g_img_cache.emplace(key, ci).first->second;
 }
 const Mat& APD::CachedImage(const Problem& problem, int image_id, int* orig_cols, int* orig_rows) {
@@ -90,7 +105,8 @@ void APD::InsertCachedImage(const Problem& problem, int image_id, const Mat& ima
 	ci.image = image;
 	ci.orig_cols = orig_cols;
 	ci.orig_rows = orig_rows;
-	if (g_img_cache.size() >= 96) g_img_cache.clear();
+	ci.used = ++g_img_cache_clock;
+	make_room(problem.scale_size);
 	g_img_cache[image_key(problem, image_id, 0, 0)] = ci;
 }
 
@@ -132,8 +148,7 @@ void APD::InuputInitialization() {
 		orig_sizes.emplace_back(ci.orig_cols, ci.orig_rows);
 	}
 	if (images.size() > MAX_IMAGES) {
-		std::cerr << "Can't process so much images: " << images.size() << std::endl;
-		exit(EXIT_FAILURE);
+		DvpFatal("Can't process so much images: " + std::to_string(images.size()));
 	}
 	{
 		Camera cam;
@@ -198,8 +213,7 @@ void APD::InuputInitialization() {
 	if (params_host.use_APD) {            // APD.cpp:1169-1195
 		path weak_info_path = problem.result_folder / path("weak.bin");
 		if (!std::filesystem::exists(weak_info_path)) {
-			std::cerr << "Can't find weak info file: " << weak_info_path.string() << std::endl;
-			exit(EXIT_FAILURE);
+			DvpFatal("Can't find weak info file: " + weak_info_path.string());
 		}
 		ReadBinMat(weak_info_path, weak_info_host);
 		if (weak_info_host.cols != width || weak_info_host.rows != height) {
@@ -309,8 +323,7 @@ void APD::CudaSpaceInitialization() {
 		DVP_SAFE_CALL(ctx, dvp_reset_state(ctx));
 		DVP_SAFE_CALL(ctx, dvp_reset_timings(ctx));
 	} else if (dvp_ctx_create(g_device, width, height, num_images, &ctx) != 0) {
-		fprintf(stderr, "dvp_ctx_create failed: %s\n", dvp_last_error(nullptr));
-		exit(EXIT_FAILURE);
+		DvpFatal(std::string("dvp_ctx_create failed: ") + dvp_last_error(nullptr));
 	}
 	std::vector<const float*> ptrs(num_images);
 	for (int i = 0; i < num_images; ++i) ptrs[i] = images[i].ptr<float>(0);

@@ -43,7 +43,10 @@ Mat LabelSegment(const int scale, const Mat& src_image);   // EdgeSegment mode 1
 Mat ReadImageGray(const path& image_path_jpg);      // stands in for cv::imread(IMREAD_GRAYSCALE), APD.cpp:1057
 Mat ReadImageColor(const path& image_path_jpg);     // cv::imread(IMREAD_COLOR) (BGR), APD.cpp:1842
 Mat ResizeLinear(const Mat& src_f32, int new_cols, int new_rows);   // cv::resize(INTER_LINEAR), APD.cpp:1129
-// error convention of the reference (CudaSafeCall, APD.cpp:943-951): message on stderr + exit
+// error convention of the reference (CudaSafeCall, APD.cpp:943-951): message on stderr + exit.  Every such exit of the
+// host library goes through DvpFatal; a multi-rank driver installs a hook that turns it into an agreed abort (comm.h).
+[[noreturn]] void DvpFatal(const std::string& message);
+void DvpSetFatalHook(void (*hook)(const char* message));
 void DvpSafeCall(int rc, dvp_ctx* ctx, const char* what, const char* file, int line);
 #define DVP_SAFE_CALL(ctx, expr) DvpSafeCall((expr), (ctx), #expr, __FILE__, __LINE__)
 
@@ -80,6 +83,7 @@ public:
 	// its reference role at the problem's scale — rank 0 fills it from disk, the others from a broadcast.
 	static const Mat& CachedImage(const Problem& problem, int image_id, int* orig_cols, int* orig_rows);
 	static void InsertCachedImage(const Problem& problem, int image_id, const Mat& image, int orig_cols, int orig_rows);
+	static void ReserveImageCache(size_t views);   // the cache holds at least this many images before it evicts
 	// Depth maps of the previous pass resident on this process' device (row-major, pitch = width).  When
 	// the maps of a view and all its sources are registered, a geometric-consistency pass takes them from
 	// there (dvp_upload_depths_device) instead of reading APD/<id>/depths.dmb (APD.cpp:1147-1166).

@@ -232,9 +232,18 @@ Mat ResizeLinear(const Mat& src, int new_cols, int new_rows) {
 	return dst;
 }
 
+static void (*g_fatal_hook)(const char*) = nullptr;
+void DvpSetFatalHook(void (*hook)(const char*)) { g_fatal_hook = hook; }
+void DvpFatal(const std::string& message) {
+	std::cerr << message << std::endl;
+	if (g_fatal_hook) g_fatal_hook(message.c_str());
+	exit(EXIT_FAILURE);
+}
+
 void DvpSafeCall(int rc, dvp_ctx* ctx, const char* what, const char* file, int line) {
 	if (rc != 0) {
-		fprintf(stderr, "DvpSafeCall() failed at %s:%i : %s : %s\n", file, line, what, dvp_last_error(ctx));
-		exit(EXIT_FAILURE);
+		char buf[1024];
+		snprintf(buf, sizeof(buf), "DvpSafeCall() failed at %s:%i : %s : %s", file, line, what, dvp_last_error(ctx));
+		DvpFatal(buf);
 	}
 }

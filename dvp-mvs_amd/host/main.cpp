@@ -1,7 +1,8 @@
 // main.cpp — the driver: the reference's coarse-to-fine schedule (/root/reference/main.cpp:421-528) over
 // `class APD`, one process per GPU.
 //   apd <dense_folder> [gpu_index] [--max-src N] [--iters N] [--min-scale S] [--passes P] [--seed X]
-//       [--rank R --world N [--job ID]] [--jacobi] [--labels] [--no-fusion | --fusion eth|tat-intermediate|tat-advanced]
+//       [--rank R --world N --job ID [--transport rccl|host] [--collective-timeout SEC]] [--jacobi] [--labels]
+//       [--no-fusion | --fusion eth|tat-intermediate|tat-advanced]
 //
 // Schedule.  The image pyramid has round_num levels (the longer side is halved until <= 800).  Level i
 // runs one "A" pass without geometric consistency — FIRST_INIT from scratch / the Depth-Anything prior
@@ -9,10 +10,12 @@
 // `passes` REFINE_ITER passes with geometric consistency against the source views' depth maps.  The
 // reference stops before the finest level (`i < round_num - 1`); --min-scale 1 adds it.
 //
-// Multi-GPU.  Views of a pass are independent: view v belongs to rank v % world.  Rank 0 decodes and
-// resizes the images of a level and broadcasts them (RCCL); after every pass each view's new depth map is
+// Multi-GPU.  Views of a pass are independent: view v belongs to rank v % world.  Every rank decodes and
+// resizes the images of ITS views at a level and broadcasts them (RCCL), so that the decode work scales with the
+// rank count and every file is read once; after every pass each view's new depth map is
 // broadcast by its owner and kept resident on every GPU, which is where the next pass' geometric term
-// reads it (Jacobi: a pass sees the previous pass' maps only).  With one rank the default is the
+// reads it (Jacobi: a pass sees the previous pass' maps only).  --job must be unique per run (default: $DVP_JOB_ID,
+// $TORCHELASTIC_RUN_ID or $SLURM_JOB_ID); a rank that fails takes the whole job down (comm.h, "Failure model").  With one rank the default is the
 // reference's in-place order (a view sees the maps its predecessors wrote in the same pass, through the
 // result files); --jacobi selects the exchange semantics there too, which makes a run independent of the
 // number of ranks.  Result files are always written to a temporary name and renamed, so a reader never
@@ -30,7 +33,9 @@ struct Options {
 	int gpu = 0, max_src = 0, iters = 3, min_scale = 2, geom_passes = 3, rank = 0, world = 1;
 	uint64_t seed = 1234;
 	bool fusion = true, jacobi = false, label_files = false;
-	std::string job = "0", fusion_kind = "eth";   // eth | tat-intermediate | tat-advanced (APD.h:52-54; the reference's main calls the first)
+	int collective_timeout_s = 600;
+	std::string job, transport = "rccl";
+	std::string fusion_kind = "eth";   // eth | tat-intermediate | tat-advanced (APD.h:52-54; the reference's main calls the first)
 };
 
 // pair.txt (written by colmap2mvsnet.py:442-448; read at main.cpp:127-170): a whitespace-separated
@@ -76,7 +81,7 @@ struct Pass {
 	int geom_index;   // -1: the A pass, else the REFINE_ITER pass number
 };
 
-void ConfigurePass(Problem& problem, const Pass& pass, int iteration, int iters) {   // main.cpp:457-478, 488-502
+void ConfigurePass(Problem& problem, const Pass& pass, int iteration, int iters, int round_num) {   // main.cpp:457-478, 488-502
 	PatchMatchParams& q = problem.params;
 	problem.iteration = iteration;
 	problem.scale_size = pass.scale;
@@ -88,7 +93,9 @@ void ConfigurePass(Problem& problem, const Pass& pass, int iteration, int iters)
 	if (pass.geom_index < 0) {
 		q.state = pass.level == 0 ? FIRST_INIT : REFINE_INIT;
 		q.use_APD = pass.level != 0;
-		if (pass.level != 0) q.use_detail = true;
+		// main.cpp:465-470: on below the finest pyramid level only (the reference never runs the finest one; with
+		// --min-scale 1 its own rule, i < round_num - 1, leaves use_detail off there)
+		if (pass.level != 0) q.use_detail = pass.level < round_num - 1;
 		q.geom_consistency = false;
 		q.weak_peak_radius = 6;
 	} else {
@@ -103,7 +110,7 @@ void ConfigurePass(Problem& problem, const Pass& pass, int iteration, int iters)
 void PublishBinMat(const path& file, const Mat& m) {
 	path tmp = file;
 	tmp += ".part";
-	if (!WriteBinMat(tmp, m)) { std::cerr << "cannot write " << tmp << std::endl; exit(EXIT_FAILURE); }
+	if (!WriteBinMat(tmp, m)) DvpFatal("cannot write " + tmp.string());
 	std::filesystem::rename(tmp, file);
 }
 
@@ -200,62 +207,74 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	return ViewResult{ depth };
 }
 
-// depth maps of every view, resident on this rank's device, refreshed after each pass
+// depth maps of every view, resident on this rank's device, refreshed after each pass.  Views may differ in size
+// (the reference pads / crops source images and rescales source depth maps, APD.cpp:1071-1079, 1147-1166): every
+// map travels with its own dimensions.
 class DepthExchange {
 public:
 	DepthExchange(RankComm& comm, const std::vector<Problem>& problems) : comm_(comm), problems_(problems) {}
 	~DepthExchange() { Release(); }
 	// `mine`: view index -> the depth map this rank computed in the pass just finished
 	void Publish(const std::map<int, Mat>& mine) {
-		// every rank must agree on the map size: taken from the owner of view 0
-		int dims[2] = { 0, 0 };
-		if (!mine.empty()) { dims[0] = mine.begin()->second.cols; dims[1] = mine.begin()->second.rows; }
-		int owner0_dims[2] = { dims[0], dims[1] };
-		comm_.BroadcastHost(owner0_dims, sizeof(owner0_dims), 0 % comm_.world());
-		if (owner0_dims[0] != w_ || owner0_dims[1] != h_) { Release(); w_ = owner0_dims[0]; h_ = owner0_dims[1]; }
-		const size_t count = (size_t)w_ * h_;
+		// agreed check first: a rank that lacks one of its maps must not leave the others inside a collective
+		bool ok = true;
+		for (size_t v = 0; v < problems_.size(); ++v)
+			if ((int)(v % (size_t)comm_.world()) == comm_.rank() && (mine.find((int)v) == mine.end() || mine.at((int)v).empty())) ok = false;
+		if (!comm_.AllOk(ok)) {
+			std::cerr << "DepthExchange: a rank is missing a depth map of the pass" << std::endl;
+			if (comm_.world() > 1) comm_.Abort("DepthExchange: missing depth map");
+			exit(EXIT_FAILURE);
+		}
 		for (size_t v = 0; v < problems_.size(); ++v) {
-			float*& dev = maps_[problems_[v].ref_image_id];
-			if (!dev) dev = RankComm::DeviceAlloc(count);
 			const int owner = (int)(v % (size_t)comm_.world());
-			if (owner == comm_.rank()) {
-				auto it = mine.find((int)v);
-				if (it == mine.end() || it->second.cols != w_ || it->second.rows != h_) { std::cerr << "DepthExchange: view " << v << " has no " << w_ << "x" << h_ << " map" << std::endl; exit(EXIT_FAILURE); }
-				RankComm::HostToDevice(dev, it->second.ptr<float>(0), count);
+			int dims[2] = { 0, 0 };
+			if (owner == comm_.rank()) { dims[0] = mine.at((int)v).cols; dims[1] = mine.at((int)v).rows; }
+			comm_.BroadcastHost(dims, sizeof(dims), owner);
+			Slot& s = maps_[problems_[v].ref_image_id];
+			const size_t count = (size_t)dims[0] * dims[1];
+			if (s.w != dims[0] || s.h != dims[1]) {
+				RankComm::DeviceFree(s.dev);
+				s.dev = RankComm::DeviceAlloc(count);
+				s.w = dims[0];
+				s.h = dims[1];
 			}
-			comm_.BroadcastDevice(dev, count, owner);
-			APD::SetResidentDepth(problems_[v].ref_image_id, dev, w_, h_);
+			if (owner == comm_.rank()) RankComm::HostToDevice(s.dev, mine.at((int)v).ptr<float>(0), count);
+			comm_.BroadcastDevice(s.dev, count, owner);
+			APD::SetResidentDepth(problems_[v].ref_image_id, s.dev, s.w, s.h);
 		}
 	}
 	void Release() {
 		APD::ClearResidentDepths();
-		for (auto& kv : maps_) RankComm::DeviceFree(kv.second);
+		for (auto& kv : maps_) RankComm::DeviceFree(kv.second.dev);
 		maps_.clear();
 	}
 private:
+	struct Slot { float* dev = nullptr; int w = 0, h = 0; };
 	RankComm& comm_;
 	const std::vector<Problem>& problems_;
-	std::map<int, float*> maps_;
-	int w_ = 0, h_ = 0;
+	std::map<int, Slot> maps_;
 };
 
-// rank 0 decodes + resizes every view's image at this level and broadcasts it; the others take it from
-// the broadcast into their image cache (so that only one process touches the image files)
+// The owner of a view (rank v % world) decodes + resizes its image at this level and broadcasts it; the others
+// take it from the broadcast into their image cache: every image file is read by exactly one process and the
+// decode work is spread over the ranks.
 void ShareLevelImages(RankComm& comm, std::vector<Problem>& problems, int scale) {
 	if (comm.world() <= 1) return;
+	APD::ReserveImageCache(problems.size());
 	for (Problem& p : problems) {
 		p.scale_size = scale;
+		const int owner = p.index % comm.world();
 		int meta[4] = { 0, 0, 0, 0 };   // cols, rows, original cols, original rows
 		Mat img;
-		if (comm.rank() == 0) {
+		if (comm.rank() == owner) {
 			img = APD::CachedImage(p, p.ref_image_id, &meta[2], &meta[3]);
 			meta[0] = img.cols;
 			meta[1] = img.rows;
 		}
-		comm.BroadcastHost(meta, sizeof(meta), 0);
-		if (comm.rank() != 0) img = Mat(meta[1], meta[0], CV_32FC1);
-		comm.BroadcastHost(img.data, (size_t)meta[0] * meta[1] * sizeof(float), 0);
-		if (comm.rank() != 0) APD::InsertCachedImage(p, p.ref_image_id, img, meta[2], meta[3]);
+		comm.BroadcastHost(meta, sizeof(meta), owner);
+		if (comm.rank() != owner) img = Mat(meta[1], meta[0], CV_32FC1);
+		comm.BroadcastHost(img.data, (size_t)meta[0] * meta[1] * sizeof(float), owner);
+		if (comm.rank() != owner) APD::InsertCachedImage(p, p.ref_image_id, img, meta[2], meta[3]);
 	}
 }
 
@@ -275,12 +294,17 @@ Options ParseOptions(int argc, char** argv) {
 		else if (s == "--rank") o.rank = (int)val();
 		else if (s == "--world") o.world = (int)val();
 		else if (s == "--job") { if (a + 1 < argc) o.job = argv[++a]; }
+		else if (s == "--transport") { if (a + 1 < argc) o.transport = argv[++a]; }
+		else if (s == "--collective-timeout") o.collective_timeout_s = (int)val();
 		else if (s == "--jacobi") o.jacobi = true;
 		else if (s == "--labels") o.label_files = true;          // load labels_<s>.dmb (APD::SetUseLabelFiles)
 		else if (s == "--no-fusion") o.fusion = false;
 		else if (s == "--fusion") { if (a + 1 < argc) o.fusion_kind = argv[++a]; }
 	}
 	if (o.world > 1) o.jacobi = true;
+	if (o.job.empty())   // a launcher-provided id; with --world > 1 RankComm refuses to start without one
+		for (const char* e : { "DVP_JOB_ID", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID" })
+			if (const char* v = std::getenv(e)) { o.job = v; break; }
 	return o;
 }
 
@@ -296,7 +320,10 @@ int main(int argc, char** argv) {
 	APD::SetDevice(opt.gpu);
 	APD::SetSeed(opt.seed);
 	APD::SetUseLabelFiles(opt.label_files);
-	RankComm comm(opt.rank, opt.world, opt.gpu, (opt.dense_folder / "APD" / ".rccl_id").string(), opt.job);
+	RankComm comm(opt.rank, opt.world, opt.gpu, (opt.dense_folder / "APD" / ".rccl_id").string(), opt.job, opt.collective_timeout_s, opt.transport);
+	// every print-and-exit of the host library (unreadable image, missing weak.bin, engine error ...) becomes an agreed
+	// abort of the whole job when there are peers
+	DvpSetFatalHook([](const char* msg) { if (RankComm* c = RankComm::Current()) if (c->world() > 1) c->Abort(msg); });
 
 	std::vector<Problem> problems = ReadViewGraph(opt.dense_folder, opt.max_src);
 	std::cout << "There are " << problems.size() << " problems needed to be processed!" << std::endl;
@@ -325,7 +352,7 @@ int main(int argc, char** argv) {
 		}
 		std::map<int, Mat> mine;
 		for (Problem& problem : problems) {
-			ConfigurePass(problem, pass, (int)it, opt.iters);
+			ConfigurePass(problem, pass, (int)it, opt.iters, round_num);
 			if (problem.index % opt.world != opt.rank) continue;
 			if (pass.geom_index < 0) GetProblemEdges(problem);   // main.cpp:480
 			ViewResult r = ProcessProblem(problem);

@@ -172,3 +172,94 @@ def test_apd_jpeg_folder_with_label_files(tmp_path):
         rel = np.abs(dep - gt[v])[10:-10, 10:-10][m] / gt[v][10:-10, 10:-10][m]
         assert m.mean() > 0.7 and np.median(rel) < 2e-2, (v, m.mean(), np.median(rel))
     assert os.path.exists(os.path.join(d, "APD", "APD.ply"))
+
+
+def _apd(d, *args, **kw):
+    return subprocess.Popen([os.path.join(ROOT, "dvp-mvs_amd", "apd"), d, "0"] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, **kw)
+
+
+def test_apd_two_ranks_equal_single_rank_jacobi(tmp_path):
+    """world = 2 through the WHOLE multi-rank code path of the driver — rendezvous file, view v -> rank v % 2, every rank
+    decoding its own share of the images and broadcasting it (ShareLevelImages), the per-pass DepthExchange with per-view
+    dimensions, AllOk, atomic result files — against the single-rank --jacobi run of the same folder: every view's depth
+    map bit-identical.  Two processes share the one GPU of the box, so the collectives run over the host transport
+    (--transport host: TCP, star through rank 0); RCCL refuses two ranks on one device, and a multi-GPU box has never
+    been available.  Only the ncclBroadcast / ncclAllReduce calls themselves stay unexercised."""
+    W, H, NV = 128, 96, 5
+    outs = {}
+    for tag in ("single", "world2"):
+        d = str(tmp_path / tag)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), "3"])
+        common = ["--iters", "2", "--passes", "2", "--min-scale", "1", "--seed", "5", "--no-fusion"]
+        if tag == "single":
+            procs = [_apd(d, "--jacobi", *common)]
+        else:
+            # a stale rendezvous record of an "earlier run" with the same job id must not be picked up
+            os.makedirs(os.path.join(d, "APD"), exist_ok=True)
+            with open(os.path.join(d, "APD", ".rccl_id"), "wb") as f:
+                f.write(b"dvp-host-id job42\n" + b"127.0.0.1:1\0" + bytes(52))
+            os.utime(os.path.join(d, "APD", ".rccl_id"), (1, 1))
+            procs = [_apd(d, "--rank", str(r), "--world", "2", "--job", "job42", "--transport", "host", "--collective-timeout", "120", *common) for r in (1, 0)]
+        for p in procs:
+            so, se = p.communicate(timeout=900)
+            assert p.returncode == 0, so[-1500:] + se[-1500:]
+        outs[tag] = [read_binmat(os.path.join(d, "APD", "%08d" % v, "depths.dmb")) for v in range(NV)]
+        assert not os.path.exists(os.path.join(d, "APD", ".rccl_id"))
+    for v in range(NV):
+        assert np.array_equal(outs["single"][v], outs["world2"][v]), v
+
+
+def test_apd_rank_failure_takes_the_job_down(tmp_path):
+    """A rank that hits a fatal error (here: the image of one of ITS views is unreadable) must not leave its peer hanging
+    in a collective: DvpFatal -> RankComm::Abort drops the .abort marker, the peer's wait sees it and exits non-zero too."""
+    import time
+    W, H, NV = 96, 64, 4
+    d = str(tmp_path / "scene")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), "2"])
+    with open(os.path.join(d, "images", "%08d.pgm" % 1), "wb") as f:      # view 1 belongs to rank 1
+        f.write(b"not an image")
+    t0 = time.time()
+    procs = [_apd(d, "--rank", str(r), "--world", "2", "--job", "jobX", "--transport", "host", "--collective-timeout", "300",
+                  "--iters", "1", "--passes", "1", "--min-scale", "1", "--no-fusion") for r in (0, 1)]
+    for p in procs:
+        so, se = p.communicate(timeout=120)
+        assert p.returncode != 0, so[-800:]
+    assert time.time() - t0 < 100           # far below the collective timeout: the marker, not the watchdog
+    assert "rank 1" in open(os.path.join(d, "APD", ".rccl_id.abort")).read()
+    # and without a job id a multi-rank run refuses to start
+    p = _apd(d, "--rank", "0", "--world", "2", "--transport", "host", env={k: v for k, v in os.environ.items() if k not in ("DVP_JOB_ID", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID")})
+    so, se = p.communicate(timeout=60)
+    assert p.returncode != 0 and "--job" in se
+
+
+def test_apd_source_image_smaller_than_the_reference(tmp_path):
+    """APD.cpp:1066-1082: a source image of another size is copied into a zero image of the reference's size (cropped
+    if larger, zero-padded if smaller).  View 2's file is 24 columns / 16 rows short; view 0 uses it as a source: the
+    driver's first pass on view 0 must equal a C-ABI run on the explicitly zero-padded image, bit for bit."""
+    W, H, NV = 96, 64, 3
+    d = str(tmp_path / "scene")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), "2"])
+    sc = synth.make_scene(W, H, NV - 1)
+    small = sc["images"][2][:H - 16, :W - 24].astype(np.uint8)
+    with open(os.path.join(d, "images", "%08d.pgm" % 2), "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (W - 24, H - 16))
+        f.write(small.tobytes())
+    out = subprocess.run([os.path.join(ROOT, "dvp-mvs_amd", "apd"), d, "0", "--iters", "1", "--passes", "0", "--min-scale", "1", "--seed", "5", "--no-fusion"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-1500:]
+    dep = read_binmat(os.path.join(d, "APD", "00000000", "depths.dmb"))
+    toks = open(os.path.join(d, "pair.txt")).read().split("\n")[2].split()
+    src = [int(toks[1 + 2 * i]) for i in range(int(toks[0]))]
+    assert 2 in src
+    padded = sc["images"].copy()
+    padded[2] = 0
+    padded[2][:H - 16, :W - 24] = small
+    order = [0] + src
+    sub = dict(sc, images=padded[order], cameras=sc["cameras"][order].copy())
+    p = make_params(len(order), max_iterations=1, state=synth.FIRST_INIT, use_APD=0, weak_peak_radius=6)
+    g = pkg("capi").from_scene(sub, p, seed=5)
+    g.upload_state(planes=np.zeros((H * W, 4), np.float32), radius=np.full(H * W, 5, np.int32))
+    g.run_patchmatch()
+    d2 = g.get("planes")[:, 3].reshape(H, W).copy()
+    d2[(d2 < p["depth_min"]) | (d2 > p["depth_max"])] = 0
+    assert count_diff(dep, d2) == 0
