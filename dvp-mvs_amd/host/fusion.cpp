@@ -24,14 +24,18 @@ struct FusionView {
 	int cols() const { return depth.cols; }
 	int rows() const { return depth.rows; }
 
+	float centre[3] = { 0, 0, 0 };      // -R^T t in binary32: the fusion recomputes it instead of using Camera::c (APD.cpp:515-518)
+	void set_centre() {
+		for (int k = 0; k < 3; ++k) centre[k] = -(cam.R[0 + k] * cam.t[0] + cam.R[3 + k] * cam.t[1] + cam.R[6 + k] * cam.t[2]);
+	}
 	// pixel + depth -> world (camera frame through K^-1, then R^T . + C; APD.cpp:502-523)
 	float3 lift(int x, int y, float z) const {
 		const float cx = z * (x - cam.K[2]) / cam.K[0];
 		const float cy = z * (y - cam.K[5]) / cam.K[4];
 		float3 w;
-		w.x = cam.R[0] * cx + cam.R[3] * cy + cam.R[6] * z + cam.c[0];
-		w.y = cam.R[1] * cx + cam.R[4] * cy + cam.R[7] * z + cam.c[1];
-		w.z = cam.R[2] * cx + cam.R[5] * cy + cam.R[8] * z + cam.c[2];
+		w.x = (cam.R[0] * cx + cam.R[3] * cy + cam.R[6] * z) + centre[0];
+		w.y = (cam.R[1] * cx + cam.R[4] * cy + cam.R[7] * z) + centre[1];
+		w.z = (cam.R[2] * cx + cam.R[5] * cy + cam.R[8] * z) + centre[2];
 		return w;
 	}
 	const uint8_t* bgr(int x, int y) const { return colour.data + (size_t)y * colour.step + 3 * (size_t)x; }
@@ -71,7 +75,8 @@ Mat fit_colour(const Mat& bgr, int cols, int rows, Camera* cam) {
 	return out;
 }
 
-// blocks/mask_<id>.jpg (Tanks & Temples variants, APD.cpp:1991-2013): pixels below 128 are excluded
+// blocks/mask_<id>.jpg: reference pixels below 128 are excluded whenever a blocks/ folder exists — in all three
+// variants (APD.cpp:1831-1835 + 1885-1887, 1991-2013)
 Mat load_block_mask(const path& dense_folder, int image_id) {
 	return ReadImageGray(dense_folder / "blocks" / ("mask_" + std::to_string(image_id) + ".jpg"));
 }
@@ -80,6 +85,7 @@ bool load_view(const path& dense_folder, const Problem& problem, FusionView* v) 
 	const std::string id = ToFormatIndex(problem.ref_image_id);
 	v->image_id = problem.ref_image_id;
 	ReadCamera(dense_folder / "cams" / (id + "_cam.txt"), v->cam);
+	v->set_centre();
 	if (!ReadBinMat(problem.result_folder / "depths.dmb", v->depth) || !ReadBinMat(problem.result_folder / "APD_normals.dmb", v->normal)) return false;
 	Mat weak;
 	ReadBinMat(problem.result_folder / "weak.bin", weak);
@@ -100,12 +106,15 @@ bool load_view(const path& dense_folder, const Problem& problem, FusionView* v) 
 void RunFusion(const path& dense_folder, const std::vector<Problem>& problems) {
 	const int n_views = (int)problems.size();
 	std::vector<FusionView> views(n_views);
+	std::vector<Mat> blocks(n_views);
+	const bool use_block = std::filesystem::exists(dense_folder / "blocks");
 	int max_id = -1;
 	for (const Problem& p : problems) max_id = std::max(max_id, p.ref_image_id);
 	std::vector<int> slot_of_id(max_id + 1, -1);   // image id -> position in `views`
 	for (int i = 0; i < n_views; ++i) {
 		std::cout << "Reading image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
 		if (!load_view(dense_folder, problems[i], &views[i])) std::cerr << "RunFusion: no depth/normal maps for view " << problems[i].ref_image_id << std::endl;
+		if (use_block) blocks[i] = load_block_mask(dense_folder, problems[i].ref_image_id);
 		slot_of_id[problems[i].ref_image_id] = i;
 	}
 
@@ -120,6 +129,7 @@ void RunFusion(const path& dense_folder, const std::vector<Problem>& problems) {
 			if (id >= 0 && id <= max_id && slot_of_id[id] >= 0 && !views[slot_of_id[id]].depth.empty()) sources.push_back(slot_of_id[id]);
 		for (int y = 0; y < R.rows(); ++y) {
 			for (int x = 0; x < R.cols(); ++x) {
+				if (use_block && !blocks[i].empty() && blocks[i].at<uint8_t>(y, x) < 128) continue;
 				const float z = R.depth.at<float>(y, x);
 				if (R.claimed.at<uint8_t>(y, x) == 1 || z <= 0.0) continue;
 				const float3 X = R.lift(x, y, z);

@@ -2,6 +2,7 @@
 // BinMat (APD.cpp:548-573, 630-649), ACMM dmb (APD.cpp:575-628), MVSNet camera text
 // (APD.cpp:651-692), binary PLY (APD.cpp:842-882), PNM images, bilinear resize, nearest rescale.
 #include "APD.h"
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 
@@ -70,38 +71,63 @@ static int write_dmb(const path& p, const Mat& m, int32_t nb) {
 int writeDepthDmb(const path& mat_path, const Mat& depth) { return write_dmb(mat_path, depth, 1); }
 int writeNormalDmb(const path& mat_path, const Mat& normal) { return write_dmb(mat_path, normal, 3); }
 
+// cams/<id>_cam.txt (MVSNet layout, written by colmap2mvsnet.py:429-441; reference reader APD.cpp:651-692):
+//   "extrinsic" + 4x4 world-to-camera matrix, "intrinsic" + 3x3 K, then `depth_min interval depth_num depth_max`.
+// Parsed as blocks with their keywords checked; a file that is short or mislabelled is rejected (the reference
+// reads whatever the stream yields).
 bool ReadCamera(const path& cam_path, Camera& cam) {
 	std::ifstream in(cam_path);
 	if (!in.good()) return false;
-	std::string line;
-	in >> line;   // "extrinsic"
-	for (int i = 0; i < 3; ++i) in >> cam.R[3 * i + 0] >> cam.R[3 * i + 1] >> cam.R[3 * i + 2] >> cam.t[i];
-	float tmp[4];
-	in >> tmp[0] >> tmp[1] >> tmp[2] >> tmp[3];
-	in >> line;   // "intrinsic"
-	for (int i = 0; i < 3; ++i) in >> cam.K[3 * i + 0] >> cam.K[3 * i + 1] >> cam.K[3 * i + 2];
-	const auto& R = cam.R;
-	const auto& t = cam.t;
-	for (int j = 0; j < 3; ++j)   // camera centre in world coordinates, in double (APD.cpp:673-677)
-		cam.c[j] = -float(double(R[0 + j]) * double(t[0]) + double(R[3 + j]) * double(t[1]) + double(R[6 + j]) * double(t[2]));
-	float depth_num, interval;   // TAT & ETH layout: depth_min interval depth_num depth_max (APD.cpp:680-682)
-	in >> cam.depth_min >> interval >> depth_num >> cam.depth_max;
+	auto block = [&in](const char* keyword, double* dst, int n) {
+		std::string word;
+		if (!(in >> word) || word != keyword) return false;
+		for (int i = 0; i < n; ++i)
+			if (!(in >> dst[i])) return false;
+		return true;
+	};
+	double E[16], K[9], range[4];
+	if (!block("extrinsic", E, 16) || !block("intrinsic", K, 9)) return false;
+	for (double& v : range)
+		if (!(in >> v)) return false;
+	for (int r = 0; r < 3; ++r) {
+		for (int c = 0; c < 3; ++c) {
+			cam.R[3 * r + c] = (float)E[4 * r + c];
+			cam.K[3 * r + c] = (float)K[3 * r + c];
+		}
+		cam.t[r] = (float)E[4 * r + 3];
+	}
+	// camera centre C = -R^T t from the float32 R and t, accumulated in double (APD.cpp:673-677)
+	for (int c = 0; c < 3; ++c) {
+		double acc = 0.0;
+		for (int r = 0; r < 3; ++r) acc += (double)cam.R[3 * r + c] * (double)cam.t[r];
+		cam.c[c] = -(float)acc;
+	}
+	cam.depth_min = (float)range[0];   // TAT & ETH layout (APD.cpp:680-682); interval and depth_num are not used
+	cam.depth_max = (float)range[3];
 	return true;
 }
 
+// binary little-endian PLY: x y z float + diffuse_blue/green/red uchar per vertex (APD.cpp:842-882); PointList::color
+// is already in that (B, G, R) order
 bool ExportPointCloud(const path& point_cloud_path, std::vector<PointList>& pointcloud) {
+	static const char* const kProperties[] = { "float x", "float y", "float z", "uchar diffuse_blue", "uchar diffuse_green", "uchar diffuse_red" };
 	std::ofstream out(point_cloud_path, std::ios::binary);
 	if (!out.good()) return false;
-	out << "ply\n" << "format binary_little_endian 1.0\n" << "element vertex " << int(pointcloud.size()) << "\n"
-	    << "property float x\n" << "property float y\n" << "property float z\n"
-	    << "property uchar diffuse_blue\n" << "property uchar diffuse_green\n" << "property uchar diffuse_red\n" << "end_header\n";
-	for (size_t idx = 0; idx < pointcloud.size(); idx++) {
-		float p[3] = { pointcloud[idx].coord.x, pointcloud[idx].coord.y, pointcloud[idx].coord.z };
-		unsigned char c[3] = { static_cast<unsigned char>(pointcloud[idx].color.x), static_cast<unsigned char>(pointcloud[idx].color.y),
-		                       static_cast<unsigned char>(pointcloud[idx].color.z) };
-		out.write((char*)p, 12);
-		out.write((char*)c, 3);
+	out << "ply\nformat binary_little_endian 1.0\nelement vertex " << (int)pointcloud.size() << "\n";
+	for (const char* prop : kProperties) out << "property " << prop << "\n";
+	out << "end_header\n";
+	constexpr size_t kRecord = 3 * sizeof(float) + 3;
+	std::vector<char> records(pointcloud.size() * kRecord);
+	char* w = records.data();
+	for (const PointList& pt : pointcloud) {
+		const float xyz[3] = { pt.coord.x, pt.coord.y, pt.coord.z };
+		memcpy(w, xyz, sizeof(xyz));
+		w += sizeof(xyz);
+		*w++ = (char)(unsigned char)pt.color.x;
+		*w++ = (char)(unsigned char)pt.color.y;
+		*w++ = (char)(unsigned char)pt.color.z;
 	}
+	out.write(records.data(), (std::streamsize)records.size());
 	return out.good();
 }
 

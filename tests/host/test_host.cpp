@@ -106,8 +106,33 @@ static int dump_labels(const path& in, int scale, const path& out) {
 	return WriteBinMat(out, EdgeSegment(scale, img, 1)) ? 0 : 3;
 }
 
+// `test_host --edges image.pgm scale out.dmb`: EdgeSegment(scale, image, mode 0, Canny) -> BinMat (CV_8UC1)
+static int dump_edges(const path& in, int scale, const path& out) {
+	const Mat img = ReadImageGray(in);
+	if (img.empty()) return 2;
+	return WriteBinMat(out, EdgeSegment(scale, img, 0, true)) ? 0 : 3;
+}
+// `test_host --prior dense_folder image_id W H out.bin`: BuildPlanePrior (dep/ + sfm/ + cams/) -> W*H float4 (world normal, metric depth)
+static int dump_prior(const path& folder, int id, int W, int H, const path& out) {
+	Problem p;
+	p.ref_image_id = id;
+	p.dense_folder = folder;
+	p.result_folder = folder / "APD" / ToFormatIndex(id);
+	Camera cam;
+	if (!ReadCamera(folder / "cams" / (ToFormatIndex(id) + "_cam.txt"), cam)) return 2;
+	cam.width = W;
+	cam.height = H;
+	std::vector<float4> planes((size_t)W * H, float4{ 0, 0, 0, 0 });
+	if (!BuildPlanePrior(p, cam, W, H, planes.data())) return 3;
+	std::ofstream f(out, std::ios::binary);
+	f.write((const char*)planes.data(), (std::streamsize)(planes.size() * sizeof(float4)));
+	return f.good() ? 0 : 4;
+}
+
 int main(int argc, char** argv) {
 	if (argc > 2 && std::string(argv[1]) == "--fuse") return fuse_folder(argv[2]);
+	if (argc > 4 && std::string(argv[1]) == "--edges") return dump_edges(argv[2], std::atoi(argv[3]), argv[4]);
+	if (argc > 6 && std::string(argv[1]) == "--prior") return dump_prior(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), argv[6]);
 	if (argc > 4 && std::string(argv[1]) == "--jpeg") return dump_jpeg(argv[2], argv[3], std::atoi(argv[4]));
 	if (argc > 4 && std::string(argv[1]) == "--labels") return dump_labels(argv[2], std::atoi(argv[3]), argv[4]);
 	path tmp = argc > 1 ? path(argv[1]) : std::filesystem::temp_directory_path();

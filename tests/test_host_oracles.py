@@ -1,0 +1,264 @@
+"""The host stages next to the hot path against something OTHER than themselves:
+  * RunFusion (host/fusion.cpp) vs oracle/ora_host.cpp::ora_run_fusion, a sequential restatement of
+    APD.cpp:1809-1960 — the point LIST (order, coordinates bit for bit, colours) must be identical, including the
+    order-dependent claims, WEAK thresholds, zero depths, failing witnesses and blocks/ masks;
+  * the Canny edge map (host/edges.cpp) vs an independent numpy/scipy Canny with the reference's thresholds;
+  * the Depth-Anything prior's ratio map (host/prior.cpp) on a hand-built sparse point file vs the closed form.
+CPU only (the host library needs no GPU for these)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, synth
+from oracle import oracle as O
+
+
+def _write_binmat(path, a, typ):
+    with open(path, "wb") as f:
+        f.write(np.array([1, a.shape[0], a.shape[1], typ], np.int32).tobytes())
+        f.write(np.ascontiguousarray(a).tobytes())
+
+
+def _host_tool(*args, env=None):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "dvp-mvs_amd", "host")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "host")])
+    return subprocess.run([os.path.join(ROOT, "tests", "host", "test_host")] + [str(a) for a in args], capture_output=True, text=True, env=env)
+
+
+def _read_ply(path):
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    n = int(head.decode().split("element vertex ")[1].split("\n")[0])
+    pts = np.frombuffer(body, np.dtype([("xyz", "<f4", 3), ("bgr", "u1", 3)]))
+    assert len(pts) == n
+    return pts
+
+
+@pytest.mark.parametrize("with_blocks", [False, True])
+def test_fusion_equals_sequential_restatement(tmp_path, with_blocks):
+    W, H, NV, NSRC = 80, 56, 5, 3
+    d = str(tmp_path / "scene")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), str(NSRC)], stdout=subprocess.DEVNULL)
+    sc = synth.make_scene(W, H, NV - 1)
+    rng = np.random.default_rng(21)
+    n_true = sc["normal_gt"].astype(np.float64)
+    depths, normals, weaks, colours, blocks = [], [], [], [], []
+    for v in range(NV):
+        dep = sc["depth_gt"][v].astype(np.float64)
+        dep *= 1.0 + rng.normal(0, 0.0012, dep.shape)            # part of the pixels fail the 1 % depth test
+        dep[rng.random(dep.shape) < 0.05] = 0.0                  # holes
+        dep[rng.random(dep.shape) < 0.01] = -1.0                 # and negative depths
+        nrm = np.tile(n_true, (H, W, 1)) + rng.normal(0, 0.025, (H, W, 3))   # some beyond 10 degrees
+        nrm /= np.linalg.norm(nrm, axis=2, keepdims=True)
+        weak = rng.integers(0, 3, (H, W)).astype(np.uint8)
+        rgb = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        r = os.path.join(d, "APD", "%08d" % v)
+        os.makedirs(r, exist_ok=True)
+        _write_binmat(os.path.join(r, "depths.dmb"), dep.astype(np.float32), 5)
+        _write_binmat(os.path.join(r, "APD_normals.dmb"), nrm.astype(np.float32), 21)
+        _write_binmat(os.path.join(r, "weak.bin"), weak, 0)
+        os.remove(os.path.join(d, "images", "%08d.pgm" % v))
+        with open(os.path.join(d, "images", "%08d.ppm" % v), "wb") as f:
+            f.write(b"P6\n%d %d\n255\n" % (W, H))
+            f.write(rgb.tobytes())
+        depths.append(np.ascontiguousarray(dep.astype(np.float32)))
+        normals.append(np.ascontiguousarray(nrm.astype(np.float32)))
+        weaks.append(weak)
+        colours.append(np.ascontiguousarray(rgb[:, :, ::-1]))   # BGR, as cv::imread returns it
+        if with_blocks:
+            from PIL import Image
+            os.makedirs(os.path.join(d, "blocks"), exist_ok=True)
+            m = np.full((H, W), 255, np.uint8)
+            m[:, : W // 3 + 4 * v] = 0
+            fn = os.path.join(d, "blocks", "mask_%d.jpg" % v)
+            Image.fromarray(m, "L").save(fn, quality=95)
+            blocks.append(np.ascontiguousarray(np.array(Image.open(fn).convert("L"))))
+    out = _host_tool("--fuse", d)
+    assert out.returncode == 0, out.stdout[-600:] + out.stderr[-600:]
+    got = _read_ply(os.path.join(d, "APD", "APD.ply"))
+
+    # the same inputs through the restatement
+    lines = open(os.path.join(d, "pair.txt")).read().split("\n")
+    src = np.full((NV, NSRC + 1), -1, np.int32)
+    for v in range(NV):
+        toks = lines[2 + 2 * v].split()
+        ids = [int(toks[1 + 2 * i]) for i in range(int(toks[0])) if float(toks[2 + 2 * i]) > 0]
+        src[v, :len(ids)] = ids
+    cams = sc["cameras"].copy()
+    # the driver parses cams/*.txt: R, t, K from "%.9g" text (exact for float32), c recomputed — same values
+    L = O.lib()
+    arr = lambda lst: (ctypes.c_void_p * NV)(*[a.ctypes.data for a in lst])
+    cap = NV * W * H
+    xyz = np.zeros((cap, 3), np.float32)
+    bgr = np.zeros((cap, 3), np.float32)
+    L.ora_run_fusion.restype = ctypes.c_int
+    L.ora_run_fusion.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    n = L.ora_run_fusion(NV, H, W, cams.ctypes.data, arr(depths), arr(normals), arr(weaks), arr(colours),
+                         arr(blocks) if with_blocks else None, src.ctypes.data, NSRC + 1, xyz.ctypes.data, bgr.ctypes.data, cap)
+    print("fusion: %d points (oracle), %d (host)" % (n, len(got)))
+    assert 0.2 * W * H < n < cap
+    assert n == len(got), (n, len(got))
+    assert np.array_equal(xyz[:n].view(np.uint32), got["xyz"].view(np.uint32))        # same points, same order, same bits
+    assert np.array_equal(bgr[:n].astype(np.uint8), got["bgr"])                        # static_cast<uchar> of the mean colour
+    # the data really exercise the rules: WEAK reference pixels, rejected witnesses, claimed pixels, masked columns
+    assert n < 0.9 * sum((dp > 0).sum() for dp in depths)
+    if with_blocks:
+        assert n < 0.75 * W * H * 1.6
+
+
+def _np_canny(img, low, high):
+    """Canny as OpenCV documents it for 8-bit input, aperture 3, L2gradient = true — written independently of
+    host/edges.cpp with array operations: Sobel with replicated border, squared magnitude against squared thresholds,
+    non-maximum suppression by gradient sector (boundaries tan 22.5 / tan 67.5 degrees; the comparison is `>` towards
+    the left / upper neighbour and `>=` towards the right / lower one on the horizontal / vertical sectors, `>` both
+    ways on the diagonals), hysteresis = 8-connected components of (candidate | strong) that contain a strong pixel."""
+    from scipy import ndimage
+    a = np.pad(img.astype(np.int64), 1, mode="edge")
+    gx = (a[:-2, 2:] + 2 * a[1:-1, 2:] + a[2:, 2:]) - (a[:-2, :-2] + 2 * a[1:-1, :-2] + a[2:, :-2])
+    gy = (a[2:, :-2] + 2 * a[2:, 1:-1] + a[2:, 2:]) - (a[:-2, :-2] + 2 * a[:-2, 1:-1] + a[:-2, 2:])
+    mag = gx * gx + gy * gy
+    m = np.pad(mag, 1)
+    c = m[1:-1, 1:-1]
+    ax, ay = np.abs(gx).astype(np.float64), np.abs(gy).astype(np.float64)
+    t22, t67 = np.tan(np.pi / 8), np.tan(3 * np.pi / 8)
+    horiz = ay < ax * t22
+    vert = ay > ax * t67
+    same_sign = (gx ^ gy) >= 0          # diagonal towards (+1, +1) when the signs agree
+    keep_h = (c > m[1:-1, :-2]) & (c >= m[1:-1, 2:])
+    keep_v = (c > m[:-2, 1:-1]) & (c >= m[2:, 1:-1])
+    keep_d1 = (c > m[:-2, :-2]) & (c > m[2:, 2:])      # s = +1
+    keep_d2 = (c > m[:-2, 2:]) & (c > m[2:, :-2])      # s = -1
+    keep = np.where(horiz, keep_h, np.where(vert, keep_v, np.where(same_sign, keep_d1, keep_d2)))
+    lo2, hi2 = int(np.floor(low * low)) if low > 0 else int(low), int(np.floor(high * high)) if high > 0 else int(high)
+    cand = keep & (mag > lo2)
+    strong = cand & (mag > hi2)
+    lab, n = ndimage.label(cand, structure=np.ones((3, 3)))
+    good = np.zeros(n + 1, bool)
+    good[np.unique(lab[strong])] = True
+    good[0] = False
+    return good[lab]
+
+
+def test_canny_edge_map_vs_independent_canny(tmp_path):
+    """host/edges.cpp (EdgeSegment mode 0: median-adaptive Canny low = (1 - 0.67) median, high = median, aperture 3, L2
+    gradient, APD.cpp:404-433, + the border fix-ups :452-463) on the synthetic views against _np_canny."""
+    W, H = 160, 120
+    sc = synth.make_scene(W, H, 2)
+    rng = np.random.default_rng(3)
+    for k, img in enumerate([sc["images"][0], sc["images"][1], np.clip(sc["images"][2] + rng.normal(0, 6, (H, W)), 0, 255)]):
+        u8 = np.rint(img).astype(np.uint8)
+        fn = str(tmp_path / ("v%d.pgm" % k))
+        with open(fn, "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (W, H))
+            f.write(u8.tobytes())
+        out = _host_tool("--edges", fn, 0, str(tmp_path / "e.dmb"))
+        assert out.returncode == 0, out.stderr
+        raw = open(str(tmp_path / "e.dmb"), "rb").read()
+        hdr = np.frombuffer(raw[:16], np.int32)
+        assert tuple(hdr) == (1, H, W, 0)
+        got = np.frombuffer(raw[16:], np.uint8).reshape(H, W) > 0
+        # thresholds exactly as APD.cpp:420-431 (histogram median over grey levels 0..254)
+        hist = np.bincount(u8.ravel(), minlength=256)
+        cum, med = 0, -1
+        for i in range(255):
+            cum += hist[i]
+            if cum > (H * W) // 2:
+                med = i
+                break
+        t1, t2 = int(np.float32(1 - np.float32(0.67)) * med), med
+        want = _np_canny(u8, t1, t2)
+        # border fix-ups of APD.cpp:452-463 (sequential, columns first then rows — the corners see both)
+        w2 = want.copy()
+        for y in range(H):
+            if not w2[y, 1]:
+                w2[y, 0] = False
+            if not w2[y, W - 2]:
+                w2[y, W - 1] = False
+        for x in range(W):
+            if not w2[1, x]:
+                w2[0, x] = False
+            if not w2[H - 2, x]:
+                w2[H - 1, x] = False
+        assert 0.01 < w2.mean() < 0.5
+        diff = int((w2 != got).sum())
+        print("canny view %d: %d edge pixels, %d differ" % (k, int(w2.sum()), diff))
+        assert diff == 0, (k, diff, int(w2.sum()))
+
+
+def test_prior_ratio_map_on_a_hand_built_point_file(tmp_path):
+    """The Depth-Anything prior (APD.cpp:1210-1424, host/prior.cpp) on a hand-built sfm/ file of 5 points: the metric depth
+    inside the triangulated hull must be (255 - raw) / (barycentric interpolation of the per-point ratio
+    raw'/projected depth) — triangulation by scipy.spatial.Delaunay, interpolation in float64, nothing shared with the host
+    code —, outside the hull (255 - raw) / rates[n / 2]; the planes' normals must be the finite-difference normals of
+    that depth map turned towards the camera and rotated to the world (R^T n)."""
+    from scipy.spatial import Delaunay
+    W, H = 96, 72
+    d = str(tmp_path / "scene")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), "3", "2"], stdout=subprocess.DEVNULL)
+    sc = synth.make_scene(W, H, 2)
+    cam = sc["cameras"][0]
+    K, R, t = cam["K"].astype(np.float64).reshape(3, 3), cam["R"].astype(np.float64).reshape(3, 3), cam["t"].astype(np.float64)
+    gt = sc["depth_gt"][0].astype(np.float64)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    scale = 20.0 * (1.0 + 0.3 * xx / W - 0.2 * yy / H)            # the unknown, slowly varying scale of the relative map
+    raw = (255.0 - scale * gt).astype(np.float32)
+    os.makedirs(os.path.join(d, "dep"), exist_ok=True)
+    os.makedirs(os.path.join(d, "sfm"), exist_ok=True)
+    _write_binmat(os.path.join(d, "dep", "%08d.dmb" % 0), raw, 5)
+    pts = [(12, 10), (80, 14), (70, 60), (15, 55), (44, 33)]       # integer pixels, no four cocircular
+    lines, rates = [], []
+    for (x, y) in pts:
+        z = gt[y, x]
+        Xc = np.array([z * (x - K[0, 2]) / K[0, 0], z * (y - K[1, 2]) / K[1, 1], z])
+        Xw = R.T @ (Xc - t)
+        lines.append("%d %d %.9f %.9f %.9f 10 20 30" % (x, y, Xw[0], Xw[1], Xw[2]))
+        rates.append((255.0 - float(raw[y, x])) / z)              # dep'(pixel) / projected depth (the point projects onto its own pixel)
+    open(os.path.join(d, "sfm", "%08d.txt" % 0), "w").write("\n".join(lines) + "\n")
+    out = _host_tool("--prior", d, 0, W, H, str(tmp_path / "planes.bin"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    planes = np.fromfile(str(tmp_path / "planes.bin"), np.float32).reshape(H, W, 4)
+    dep = planes[:, :, 3].astype(np.float64)
+
+    P = np.array(pts, np.float64)
+    tri = Delaunay(P)
+    q = np.stack([xx.ravel(), yy.ravel()], 1)
+    simplex = tri.find_simplex(q)
+    Tm = tri.transform[np.maximum(simplex, 0)]
+    b2 = np.einsum("nij,nj->ni", Tm[:, :2, :], q - Tm[:, 2, :])
+    bary = np.concatenate([b2, 1 - b2.sum(1, keepdims=True)], 1)
+    rate_tri = (bary * np.array(rates)[tri.simplices[np.maximum(simplex, 0)]]).sum(1).reshape(H, W)
+    inside = (simplex >= 0).reshape(H, W) & (bary.min(1).reshape(H, W) > 0.04)       # away from the triangle edges
+    want_in = (255.0 - raw.astype(np.float64)) / rate_tri
+    rel = np.abs(dep - want_in) / want_in
+    assert inside.sum() > 1500
+    ok = rel[inside] < 2e-5
+    print("prior: %d interior pixels, %.4f within 2e-5 of the closed form, worst of those %.2e" % (inside.sum(), ok.mean(), rel[inside][ok].max()))
+    assert ok.mean() > 0.995        # the reference's barycentric sweep with truncating casts leaves a few pixels unvisited
+    # far outside the hull: the median-position ratio (rates[n / 2], APD.cpp:1279)
+    outside = np.zeros((H, W), bool)
+    outside[:6, :] = True
+    outside[-6:, :] = True
+    want_out = (255.0 - raw.astype(np.float64)) / np.float32(rates[len(rates) // 2])
+    assert np.abs(dep - want_out)[outside].max() / want_out[outside].max() < 2e-6
+    # and the interpolated metric depth is close to the truth where the scale is interpolated linearly
+    assert np.median(np.abs(dep - gt)[inside] / gt[inside]) < 0.02
+    # normals: finite differences of `dep` in the camera frame, flipped towards the camera, rotated by R^T (APD.cpp:1365-1409)
+    Kf = cam["K"].astype(np.float64)
+
+    def X3(x, y):
+        z = dep[y, x]
+        return np.array([z * (x - Kf[2]) / Kf[0], z * (y - Kf[5]) / Kf[4], z])
+    worst = 0.0
+    for (x, y) in [(30, 20), (50, 40), (60, 25), (25, 45), (44, 30)]:
+        X = X3(x, y)
+        n = np.cross(X3(x + 1, y) - X, X3(x, y + 1) - X)
+        n /= np.linalg.norm(n)
+        if n @ X > 0:
+            n = -n
+        worst = max(worst, float(np.abs(R.T @ n - planes[y, x, :3]).max()))
+    assert worst < 1e-3, worst
+    assert np.all(planes[0, :, :3] == 0) and np.all(planes[:, 0, :3] == 0)     # border pixels keep a zero normal
