@@ -281,6 +281,105 @@ extern "C" __global__ void __launch_bounds__(256) dvp_edge_rays(const Dev d, int
 	edge_ray_line(d, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, what);
 }
 
+// ---- WEAK-pixel bookkeeping on the device (dvp_upload_state) -------------------------------------------------
+// neighbours_map (running index of WEAK pixels in raster order, APD.cpp:1182-1193) and the compacted WEAK list of the
+// list kernels used to be built by serial host loops over all L pixels per pass (25.6 M at full resolution: 0.2 s, plus a
+// 26 MB download when the weak map was already on the device).  Three small launches instead: ballot counts per unit,
+// one exclusive scan, ballot-rank scatter.
+// List order: 64 x 64 super-tiles row-major over the image, 16 x 16 tiles row-major inside them, rows inside those; black
+// ((x + y) even) pixels first, then red.  "Slot" = (super-tile, tile position 0..15); a slot outside the image counts zero.
+constexpr int kWeakTile = 16, kWeakSuper = 64, kWeakChunk = 1024;   // raster chunk of the neighbours_map scan
+DVP_HD void weak_slot_origin(int slot, int supers_x, int* tx, int* ty) {
+	const int super = slot >> 4, t = slot & 15;
+	*tx = (super % supers_x) * kWeakSuper + (t & 3) * kWeakTile;
+	*ty = (super / supers_x) * kWeakSuper + (t >> 2) * kWeakTile;
+}
+// one wave per slot: counts[slot] = black WEAK pixels, counts[n_slots + slot] = red ones;
+// one wave per raster chunk: counts[2 * n_slots + chunk] = WEAK pixels of the chunk
+extern "C" __global__ void __launch_bounds__(256) dvp_weak_counts(const uint8_t* __restrict__ weak, int W, int H, int supers_x, int n_slots, int n_chunks, int* __restrict__ counts) {
+	const int lane = threadIdx.x & 63;
+	const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (unit < n_slots) {
+		int tx, ty;
+		weak_slot_origin(unit, supers_x, &tx, &ty);
+		int nb = 0, nr = 0;
+		for (int step = 0; step < 4; ++step) {
+			const int x = tx + (lane & 15), y = ty + step * 4 + (lane >> 4);
+			const bool wk = x < W && y < H && weak[(size_t)y * W + x] == DVP_WEAK;
+			nb += __popcll(__ballot(wk && !((x + y) & 1)));
+			nr += __popcll(__ballot(wk && ((x + y) & 1)));
+		}
+		if (lane == 0) { counts[unit] = nb; counts[n_slots + unit] = nr; }
+	} else if (unit < n_slots + n_chunks) {
+		const int chunk = unit - n_slots;
+		const size_t L = (size_t)W * H;
+		int n = 0;
+		for (int step = 0; step < kWeakChunk / 64; ++step) {
+			const size_t i = (size_t)chunk * kWeakChunk + step * 64 + lane;
+			n += __popcll(__ballot(i < L && weak[i] == DVP_WEAK));
+		}
+		if (lane == 0) counts[2 * n_slots + chunk] = n;
+	}
+}
+// exclusive scan of three int arrays in place (one workgroup each): blockIdx.x selects [start[b], start[b + 1]); totals[b] = sum
+extern "C" __global__ void __launch_bounds__(1024) dvp_scan3(int* __restrict__ data, int s0, int s1, int s2, int s3, int* __restrict__ totals) {
+	__shared__ int part[1024];
+	__shared__ int carry;
+	const int starts[4] = { s0, s1, s2, s3 };
+	const int lo = starts[blockIdx.x], hi = starts[blockIdx.x + 1];
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (int base = lo; base < hi; base += 1024) {
+		const int i = base + (int)threadIdx.x;
+		const int v = i < hi ? data[i] : 0;
+		part[threadIdx.x] = v;
+		__syncthreads();
+		for (int off = 1; off < 1024; off <<= 1) {
+			const int add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
+			__syncthreads();
+			part[threadIdx.x] += add;
+			__syncthreads();
+		}
+		if (i < hi) data[i] = carry + part[threadIdx.x] - v;
+		__syncthreads();
+		if (threadIdx.x == 1023) carry += part[1023];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+// scatter: the list entries of a slot / the running indices of a chunk, in pixel order, by ballot rank
+extern "C" __global__ void __launch_bounds__(256) dvp_weak_fill(const uint8_t* __restrict__ weak, int W, int H, int supers_x, int n_slots, int n_chunks,
+                                                               const int* __restrict__ offs, const int* __restrict__ totals, int* __restrict__ list, int* __restrict__ map) {
+	const int lane = threadIdx.x & 63;
+	const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const unsigned long long below = (1ull << lane) - 1ull;
+	if (unit < n_slots) {
+		int tx, ty;
+		weak_slot_origin(unit, supers_x, &tx, &ty);
+		int ob = offs[unit], orr = totals[0] + offs[n_slots + unit];   // red entries follow all black ones
+		for (int step = 0; step < 4; ++step) {
+			const int x = tx + (lane & 15), y = ty + step * 4 + (lane >> 4);
+			const bool wk = x < W && y < H && weak[(size_t)y * W + x] == DVP_WEAK;
+			const bool red = (x + y) & 1;
+			const unsigned long long mb = __ballot(wk && !red), mr = __ballot(wk && red);
+			if (wk) list[red ? orr + __popcll(mr & below) : ob + __popcll(mb & below)] = y * W + x;
+			ob += __popcll(mb);
+			orr += __popcll(mr);
+		}
+	} else if (unit < n_slots + n_chunks) {
+		const int chunk = unit - n_slots;
+		const size_t L = (size_t)W * H;
+		int o = offs[2 * n_slots + chunk];
+		for (int step = 0; step < kWeakChunk / 64; ++step) {
+			const size_t i = (size_t)chunk * kWeakChunk + step * 64 + lane;
+			const bool wk = i < L && weak[i] == DVP_WEAK;
+			const unsigned long long m = __ballot(wk);
+			if (i < L) map[i] = wk ? o + __popcll(m & below) : 0;
+			o += __popcll(m);
+		}
+	}
+}
+
 extern "C" __global__ void dvp_prepare_views(const DvpCamera* cams, ViewConst* views, int n) {
 	const int v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= 1 && v < n) compute_view_const(cams[0], cams[v], &views[v]);
@@ -362,6 +461,8 @@ struct dvp_ctx {
 	size_t weak_alloc = 0;       // capacity (in WEAK pixels) of the per-WEAK buffers
 	int* weak_list = nullptr;    // compacted WEAK pixel indices (black first, then red)
 	size_t weak_list_alloc = 0;
+	int* weak_counts = nullptr;  // scratch of the device-side compaction: per-slot black / red counts, per-chunk counts, then 3 totals
+	int* weak_totals_host = nullptr;   // pinned: (black, red, all)
 	// dvp_save_state / dvp_restore_state: device-side copy of the per-pixel input state
 	f4* saved_planes = nullptr; uint32_t* saved_views = nullptr; uint8_t* saved_weak = nullptr; int* saved_radius = nullptr;
 	bool have_saved = false;
@@ -395,6 +496,16 @@ static int dalloc(dvp_ctx* c, T** p, size_t count, bool zero = true) {
 	if (zero) HIP_TRY(c, hipMemsetAsync(q, 0, bytes, c->stream));
 	*p = (T*)q;
 	return 0;
+}
+
+// give a superseded block back (the caller has made sure no queued work still uses it)
+template <class T>
+static void dfree(dvp_ctx* c, T** p) {
+	if (!*p) return;
+	for (size_t i = 0; i < c->allocs.size(); ++i)
+		if (c->allocs[i] == (void*)*p) { c->allocs[i] = c->allocs.back(); c->allocs.pop_back(); break; }
+	(void)hipFree((void*)*p);
+	*p = nullptr;
 }
 
 static void sync_dev_struct(dvp_ctx* c) {
@@ -504,6 +615,7 @@ int dvp_ctx_destroy(dvp_ctx* c) {
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	for (void* p : c->allocs) (void)hipFree(p);
+	if (c->weak_totals_host) (void)hipHostFree(c->weak_totals_host);
 	if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
 	if (c->side_fork) (void)hipEventDestroy(c->side_fork);
 	if (c->side_join) (void)hipEventDestroy(c->side_join);
@@ -586,12 +698,17 @@ int dvp_upload_cameras(dvp_ctx* c, const DvpCamera* cams, int n) {
 static int ensure_weak_buffers(dvp_ctx* c, size_t weak_count) {
 	const size_t need = weak_count ? weak_count : 1;
 	if (need > c->weak_alloc) {
-		// grow (old blocks stay owned by the context until destroy; growth is rare)
-		if (dalloc(c, &c->neighbours, need * DVP_NEIGHBOUR_NUM, false)) return 1;
-		if (dalloc(c, &c->gn_points, need * kGnMaxPoints, false) || dalloc(c, &c->gn_count, need)) return 1;
-		if (dalloc(c, &c->complex_, need)) return 1;
-		if (dalloc(c, &c->label_boundary, need * 8, false)) return 1;
-		c->weak_alloc = need;
+		// The host driver recycles one context over all views and passes (APD.cpp pool): grow geometrically and give the
+		// superseded blocks back (at 160 * 4 B of gn_points per WEAK pixel they are gigabytes at full resolution).
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		if (c->side) HIP_TRY(c, hipStreamSynchronize(c->side));
+		dfree(c, &c->neighbours); dfree(c, &c->gn_points); dfree(c, &c->gn_count); dfree(c, &c->complex_); dfree(c, &c->label_boundary);
+		const size_t cap = std::min<size_t>(c->L, std::max(need, c->weak_alloc + c->weak_alloc / 2));
+		if (dalloc(c, &c->neighbours, cap * DVP_NEIGHBOUR_NUM, false)) return 1;
+		if (dalloc(c, &c->gn_points, cap * kGnMaxPoints, false) || dalloc(c, &c->gn_count, cap)) return 1;
+		if (dalloc(c, &c->complex_, cap)) return 1;
+		if (dalloc(c, &c->label_boundary, cap * 8, false)) return 1;
+		c->weak_alloc = cap;
 	}
 	HIP_TRY(c, hipMemsetAsync(c->neighbours, 0xFF, need * DVP_NEIGHBOUR_NUM * sizeof(s2), c->stream));   // (-1,-1)
 	HIP_TRY(c, hipMemsetAsync(c->label_boundary, 0xFF, need * 8 * sizeof(s2), c->stream));
@@ -608,55 +725,44 @@ int dvp_upload_state(dvp_ctx* c, const float* planes, const uint32_t* views, con
 	if (edge) HIP_TRY(c, hipMemcpyAsync(c->edge, edge, L, hipMemcpyHostToDevice, c->stream));
 	if (label) HIP_TRY(c, hipMemcpyAsync(c->label, label, L * 4, hipMemcpyHostToDevice, c->stream));
 	if (radius) HIP_TRY(c, hipMemcpyAsync(c->radius, radius, L * 4, hipMemcpyHostToDevice, c->stream));
-	// weak_info -> neighbours_map: running index of WEAK pixels (APD.cpp:1182-1193)
-	std::vector<uint8_t> wi(L);
-	if (weak) {
-		std::memcpy(wi.data(), weak, L);
-		HIP_TRY(c, hipMemcpyAsync(c->weak_info, weak, L, hipMemcpyHostToDevice, c->stream));
-	} else {
-		HIP_TRY(c, hipMemcpyAsync(wi.data(), c->weak_info, L, hipMemcpyDeviceToHost, c->stream));
-		HIP_TRY(c, hipStreamSynchronize(c->stream));
+	// weak_info -> neighbours_map (running index of WEAK pixels, APD.cpp:1182-1193) and the compacted WEAK lists of the
+	// list kernels (black, then red; rows the reference's half grid never reaches, APD.cu:4421-4424, are kept like in the
+	// full-grid launch), all on the device: see dvp_weak_counts / dvp_scan3 / dvp_weak_fill.  List order = 64 x 64
+	// super-tiles, 16 x 16 tiles inside them, rows inside those: the lanes of a wave are neighbours in both directions and
+	// the ~8 consecutive workgroups of a super-tile share their anchors and the source lines those touch; stage_body_list
+	// hands such runs to ONE XCD.  (16x16 vs 16x8 / 32x4 / row-major: 592.7 / 599 / 609 / 622 ms per REFINE pass, r01.)
+	// Every list kernel is order-independent (a WEAK pixel only reads STRONG pixels' state).
+	if (weak) HIP_TRY(c, hipMemcpyAsync(c->weak_info, weak, L, hipMemcpyHostToDevice, c->stream));
+	const int supers_x = (c->W + kWeakSuper - 1) / kWeakSuper, supers_y = (c->H + kWeakSuper - 1) / kWeakSuper;
+	const int n_slots = supers_x * supers_y * 16, n_chunks = (int)((L + kWeakChunk - 1) / kWeakChunk);
+	const int n_units = n_slots + n_chunks;
+	if (!c->weak_counts) {
+		if (dalloc(c, &c->weak_counts, (size_t)2 * n_slots + n_chunks + 4)) return 1;
+		HIP_TRY(c, hipHostMalloc((void**)&c->weak_totals_host, 4 * sizeof(int)));
 	}
-	std::vector<int> map(L, 0);
-	std::vector<int> list, red;   // function scope: source of an async copy, alive until the stream sync below
-	int wc = 0;
-	for (size_t i = 0; i < L; ++i)
-		if (wi[i] == DVP_WEAK) map[i] = wc++;
+	int* totals = c->weak_counts + 2 * (size_t)n_slots + n_chunks;
+	hipLaunchKernelGGL(dvp_weak_counts, dim3((n_units + 3) / 4), dim3(256), 0, c->stream, c->weak_info, c->W, c->H, supers_x, n_slots, n_chunks, c->weak_counts);
+	hipLaunchKernelGGL(dvp_scan3, dim3(3), dim3(1024), 0, c->stream, c->weak_counts, 0, n_slots, 2 * n_slots, 2 * n_slots + n_chunks, totals);
+	HIP_TRY(c, hipMemcpyAsync(c->weak_totals_host, totals, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	const int nb = c->weak_totals_host[0], nr = c->weak_totals_host[1], wc = c->weak_totals_host[2];
+	if (nb + nr != wc) { c->error = "dvp_upload_state: WEAK list / map counts disagree"; return 1; }
 	c->d.weak_count = wc;
-	{
-		// compacted pixel lists per checkerboard colour; rows the reference's half grid never
-		// reaches (APD.cu:4421-4424) are left out like in the full-grid launch
-		list.reserve((size_t)wc);
-		red.reserve((size_t)wc / 2 + 1);
-		// Order: 64 x 64 super-tiles (row-major over the image), inside them 16 x 16 tiles, inside those
-		// rows: the lanes of a wave are neighbours in both directions and the ~8 consecutive workgroups of
-		// a super-tile share their anchors (the STRONG points around a WEAK region) and the source lines
-		// those touch; stage_body_list hands such runs of consecutive workgroups to ONE XCD (one L2).
-		// Every list kernel is order-independent (a WEAK pixel only reads STRONG pixels' state).
-		constexpr int kTW = 16, kTH = 16, kSuper = 64;   // 16x16 vs 16x8 / 32x4 / row-major: 592.7 / 599 / 609 / 622 ms per REFINE pass (r01)
-		for (int sy = 0; wc > 0 && sy < c->H; sy += kSuper)   // (no WEAK pixel, e.g. a FIRST_INIT pass: nothing to list)
-			for (int sx = 0; sx < c->W; sx += kSuper)
-				for (int ty = sy; ty < sy + kSuper && ty < c->H; ty += kTH)
-					for (int tx = sx; tx < sx + kSuper && tx < c->W; tx += kTW) {
-						const int y1 = ty + kTH < c->H ? ty + kTH : c->H, x1 = tx + kTW < c->W ? tx + kTW : c->W;
-						for (int y = ty; y < y1; ++y) {
-							const uint8_t* row = wi.data() + (size_t)y * c->W;
-							for (int x = tx; x < x1; ++x)
-								if (row[x] == DVP_WEAK) (((x + y) & 1) ? red : list).push_back(y * c->W + x);
-						}
-					}
-		const int nb = (int)list.size();
-		list.insert(list.end(), red.begin(), red.end());
-		if (list.size() > c->weak_list_alloc) {
-			if (dalloc(c, &c->weak_list, list.size(), false)) return 1;
-			c->weak_list_alloc = list.size();
-		}
-		if (!list.empty()) HIP_TRY(c, hipMemcpyAsync(c->weak_list, list.data(), list.size() * 4, hipMemcpyHostToDevice, c->stream));
-		c->d.weak_black = nb;
-		c->d.weak_red = (int)list.size() - nb;
+	c->d.weak_black = nb;
+	c->d.weak_red = nr;
+	if ((size_t)wc > c->weak_list_alloc) {
+		dfree(c, &c->weak_list);
+		const size_t cap = std::min<size_t>(L, std::max<size_t>((size_t)wc, c->weak_list_alloc + c->weak_list_alloc / 2));
+		if (dalloc(c, &c->weak_list, cap, false)) return 1;
+		c->weak_list_alloc = cap;
 	}
-	if (wc > 0) HIP_TRY(c, hipMemcpyAsync(c->neighbours_map, map.data(), L * 4, hipMemcpyHostToDevice, c->stream));
-	else HIP_TRY(c, hipMemsetAsync(c->neighbours_map, 0, L * 4, c->stream));
+	if (wc > 0) {
+		hipLaunchKernelGGL(dvp_weak_fill, dim3((n_units + 3) / 4), dim3(256), 0, c->stream, c->weak_info, c->W, c->H, supers_x, n_slots, n_chunks,
+		                   c->weak_counts, totals, c->weak_list, c->neighbours_map);
+		HIP_TRY(c, hipGetLastError());
+	} else {
+		HIP_TRY(c, hipMemsetAsync(c->neighbours_map, 0, L * 4, c->stream));
+	}
 	if (ensure_weak_buffers(c, (size_t)wc)) return 1;
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	sync_dev_struct(c);

@@ -4,7 +4,8 @@
 pair.txt.  With --prior also the inputs of the FIRST_INIT plane prior (APD.cpp:1210-1424):
 dep/%08d.dmb = 255 - s(x,y) * true depth (a stand-in for a Depth-Anything map: right up to a slowly
 varying unknown scale) and sfm/%08d.txt = sparse points "x2d y2d X Y Z r g b".
-usage: make_dataset.py OUT W H NUM_VIEWS [SRC_PER_VIEW] [--prior] [--jpg]"""
+usage: make_dataset.py OUT W H NUM_VIEWS [SRC_PER_VIEW] [--prior] [--jpg] [--torch]
+--torch renders on cuda:0 (full-resolution folders: the numpy renderer needs ~30 s per 25 Mpx view)."""
 import importlib
 import os
 import sys
@@ -58,13 +59,22 @@ def main():
     prior = "--prior" in sys.argv
     if prior:
         sys.argv.remove("--prior")
+    use_torch = "--torch" in sys.argv
+    if use_torch:
+        sys.argv.remove("--torch")
     jpg = "--jpg" in sys.argv     # images/%08d.jpg (colour, like colmap2mvsnet.py:424-430 writes) instead of .pgm
     if jpg:
         sys.argv.remove("--jpg")
     out, W, H, NV = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     nsrc = int(sys.argv[5]) if len(sys.argv) > 5 else min(NV - 1, 4)
     synth = importlib.import_module("dvp-mvs_amd.synth")
-    sc = synth.make_scene(W, H, NV - 1)
+    if use_torch:
+        import torch
+        st = synth.make_scene_torch(W, H, NV - 1, torch.device("cuda", 0))
+        sc = dict(images=st["images"].cpu().numpy(), depth_gt=st["depth_gt"].cpu().numpy(), cameras=st["cameras"])
+        del st
+    else:
+        sc = synth.make_scene(W, H, NV - 1)
     os.makedirs(os.path.join(out, "images"), exist_ok=True)
     os.makedirs(os.path.join(out, "cams"), exist_ok=True)
     for i in range(NV):
