@@ -3,6 +3,7 @@
 // CudaSpaceInitialization -> SetDataPassHelperInCuda -> RunPatchMatch, main.cpp:276-280), same
 // files read per pass.
 #include "APD.h"
+#include <mutex>
 #include <cstdlib>
 #include <map>
 #include <tuple>
@@ -26,6 +27,7 @@ namespace {
 struct ImageEntry { Mat image; int orig_cols = 0, orig_rows = 0; uint64_t used = 0; };
 using ImageKey = std::tuple<std::string, int, int, int>;   // file, scale, pad width, pad height
 std::map<ImageKey, ImageEntry> g_img_cache;
+std::recursive_mutex g_img_cache_mutex;   // the driver's background worker (edge maps of the next view) shares the cache
 size_t g_img_cache_capacity = 96;
 uint64_t g_img_cache_clock = 0;
 // Room for one more entry: images of other pyramid levels go first (a level never comes back), then the least
@@ -49,10 +51,11 @@ struct PooledCtx {
 	// calls APD::ReleasePooledContext() before it returns
 } g_pool;
 }
-void APD::ReserveImageCache(size_t views) { g_img_cache_capacity = std::max<size_t>(96, 2 * views + 8); }   // reference + padded source role
+void APD::ReserveImageCache(size_t views) { std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex); g_img_cache_capacity = std::max<size_t>(96, 2 * views + 8); }   // reference + padded source role
 void APD::ReleasePooledContext() {
 	if (g_pool.ctx) dvp_ctx_destroy(g_pool.ctx);
 	g_pool.ctx = nullptr;
+	std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
 	g_img_cache.clear();
 }
 
@@ -64,7 +67,8 @@ static ImageKey image_key(const Problem& problem, int image_id, int pad_w, int p
 	const path file = problem.dense_folder / path("images") / path(ToFormatIndex(image_id) + ".jpg");
 	return ImageKey{ file.string(), problem.scale_size, pad_w, pad_h };
 }
-static const ImageEntry& load_image(const Problem& problem, int image_id, int pad_w, int pad_h, bool is_ref) {
+static ImageEntry load_image(const Problem& problem, int image_id, int pad_w, int pad_h, bool is_ref) {
+	std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
 	const ImageKey key = image_key(problem, image_id, pad_w, pad_h);
 	auto it = g_img_cache.find(key);
 	if (it != g_img_cache.end()) { it->second.used = ++g_img_cache_clock; return it->second; }
@@ -94,13 +98,14 @@ static const ImageEntry& load_image(const Problem& problem, int image_id, int pa
 	ci.used = ++g_img_cache_clock;
 	return g_img_cache.emplace(key, ci).first->second;
 }
-const Mat& APD::CachedImage(const Problem& problem, int image_id, int* orig_cols, int* orig_rows) {
-	const auto& ci = load_image(problem, image_id, 0, 0, true);
+Mat APD::CachedImage(const Problem& problem, int image_id, int* orig_cols, int* orig_rows) {
+	const ImageEntry ci = load_image(problem, image_id, 0, 0, true);
 	*orig_cols = ci.orig_cols;
 	*orig_rows = ci.orig_rows;
 	return ci.image;
 }
 void APD::InsertCachedImage(const Problem& problem, int image_id, const Mat& image, int orig_cols, int orig_rows) {
+	std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
 	ImageEntry ci;
 	ci.image = image;
 	ci.orig_cols = orig_cols;
@@ -131,19 +136,19 @@ void APD::InuputInitialization() {
 	cameras.clear();
 	path image_folder = problem.dense_folder / path("images");
 	path cam_folder = problem.dense_folder / path("cams");
-	auto load = [&](int image_id, int pad_w, int pad_h, bool is_ref) -> const ImageEntry& {
+	auto load = [&](int image_id, int pad_w, int pad_h, bool is_ref) -> ImageEntry {
 		return load_image(problem, image_id, pad_w, pad_h, is_ref);
 	};
 	std::vector<std::pair<int, int>> orig_sizes;   // (cols, rows) before scaling, per image
 	{
-		const ImageEntry& ci = load(problem.ref_image_id, 0, 0, true);
+		const ImageEntry ci = load(problem.ref_image_id, 0, 0, true);
 		images.push_back(ci.image);
 		orig_sizes.emplace_back(ci.orig_cols, ci.orig_rows);
 		width = ci.orig_cols;
 		height = ci.orig_rows;
 	}
 	for (const auto& src_idx : problem.src_image_ids) {
-		const ImageEntry& ci = load(src_idx, width, height, false);
+		const ImageEntry ci = load(src_idx, width, height, false);
 		images.push_back(ci.image);
 		orig_sizes.emplace_back(ci.orig_cols, ci.orig_rows);
 	}
@@ -203,7 +208,7 @@ void APD::InuputInitialization() {
 		} else {
 			for (int id : ids) {
 				Mat depth;
-				ReadBinMat(problem.dense_folder / path("APD") / path(ToFormatIndex(id)) / path("depths.dmb"), depth);
+				LoadResult(problem.dense_folder / path("APD") / path(ToFormatIndex(id)) / path("depths.dmb"), depth);
 				if (depth.empty()) depth = Mat::zeros(height, width, CV_32FC1);
 				if (depth.cols != width || depth.rows != height) RescaleMatToTargetSize<float>(depth, depth, width, height);
 				depths.push_back(depth);
@@ -212,28 +217,30 @@ void APD::InuputInitialization() {
 	}
 	if (params_host.use_APD) {            // APD.cpp:1169-1195
 		path weak_info_path = problem.result_folder / path("weak.bin");
-		if (!std::filesystem::exists(weak_info_path)) {
+		if (!ResultExists(weak_info_path)) {
 			DvpFatal("Can't find weak info file: " + weak_info_path.string());
 		}
-		ReadBinMat(weak_info_path, weak_info_host);
+		LoadResult(weak_info_path, weak_info_host, true);   // RunPatchMatch downloads the new states into this buffer
 		if (weak_info_host.cols != width || weak_info_host.rows != height) {
 			std::cerr << "Weak info doesn't match the images' size!\n";
 			RescaleMatToTargetSize<uint8_t>(weak_info_host, weak_info_host, width, height);
 			std::cout << "Scale done\n";
 		}
-		weak_count = 0;
-		for (int r = 0; r < height; ++r)
-			for (int c = 0; c < width; ++c)
-				if (weak_info_host.at<uint8_t>(r, c) == WEAK) weak_count++;
+		long long wc = 0;
+#pragma omp parallel for reduction(+ : wc) schedule(static) num_threads(8)
+		for (int r = 0; r < height; ++r) {
+			const uint8_t* row = weak_info_host.ptr<uint8_t>(r);
+			for (int c = 0; c < width; ++c) wc += row[c] == WEAK;
+		}
+		weak_count = (int)wc;
 		std::cout << "Weak count: " << weak_count << " / " << width * height << " = " << (float)weak_count / (float)(width * height) * 100 << "%" << std::endl;
 	} else {                              // APD.cpp:1196-1204
-		weak_info_host = Mat::zeros(height, width, CV_8UC1);
+		weak_info_host = Mat(height, width, CV_8UC1);
 		weak_count = 0;
-		for (int r = 0; r < height; ++r)
-			for (int c = 0; c < width; ++c) weak_info_host.at<uint8_t>(r, c) = STRONG;
+		std::memset(weak_info_host.data, STRONG, weak_info_host.step * (size_t)height);
 	}
 	plane_hypotheses_host = new float4[(size_t)width * height];
-	std::memset(plane_hypotheses_host, 0, sizeof(float4) * (size_t)width * height);
+	if (params_host.state == FIRST_INIT) std::memset(plane_hypotheses_host, 0, sizeof(float4) * (size_t)width * height);   // (else every entry is assigned below)
 	// FIRST_INIT: plane prior from the Depth-Anything map + sparse SfM points (dep/<id>.dmb,
 	// sfm/<id>.txt, APD.cpp:1210-1424; host/prior.cpp).  Without those inputs the planes stay zero
 	// (.w out of range) and RandomInitialization draws random planes (APD.cu:1289-1291).
@@ -244,9 +251,10 @@ void APD::InuputInitialization() {
 	selected_views_host = Mat::zeros(height, width, CV_32SC1);
 	if (params_host.state != FIRST_INIT) {   // APD.cpp:1428-1456: the previous pass' maps are this pass' start
 		Mat depth, normal;
-		ReadBinMat(problem.result_folder / path("depths.dmb"), depth);
-		ReadBinMat(problem.result_folder / path("APD_normals.dmb"), normal);
-		ReadBinMat(problem.result_folder / path("selected_views.bin"), selected_views_host);
+		LoadResult(problem.result_folder / path("depths.dmb"), depth);
+		LoadResult(problem.result_folder / path("APD_normals.dmb"), normal);
+		LoadResult(problem.result_folder / path("selected_views.bin"), selected_views_host, true);   // downloaded into by RunPatchMatch
+		if (depth.empty() || normal.empty() || selected_views_host.empty()) DvpFatal("Can't find the previous pass' maps in " + problem.result_folder.string());
 		const bool fits = depth.cols == width && depth.rows == height && normal.cols == width && normal.rows == height;
 		if (!fits) {
 			std::cerr << "Depth and Normal doesn't match the images' size!\n";
@@ -257,11 +265,12 @@ void APD::InuputInitialization() {
 			std::cerr << "Select view doesn't match the images' size!\n";
 			RescaleMatToTargetSize<unsigned int>(selected_views_host, selected_views_host, width, height);
 		}
-		float4* out = plane_hypotheses_host;
+#pragma omp parallel for schedule(static) num_threads(8)
 		for (int row = 0; row < height; ++row) {
 			const float* z = depth.ptr<float>(row);
 			const Vec3f* n = normal.ptr<Vec3f>(row);
-			for (int col = 0; col < width; ++col, ++out) *out = float4{ n[col][0], n[col][1], n[col][2], z[col] };
+			float4* out = plane_hypotheses_host + (size_t)row * width;
+			for (int col = 0; col < width; ++col) out[col] = float4{ n[col][0], n[col][1], n[col][2], z[col] };
 		}
 	}
 }
@@ -272,7 +281,7 @@ void APD::SupportInitialization() {
 	while ((1 << scale) < problem.scale_size) scale++;
 	if (problem.params.use_edge || problem.params.use_limit) {
 		path edge_path = problem.result_folder / path("edges_" + std::to_string(scale) + ".dmb");
-		if (!std::filesystem::exists(edge_path) || !ReadBinMat(edge_path, edge_host) || edge_host.cols != width || edge_host.rows != height) {
+		if (!LoadResult(edge_path, edge_host) || edge_host.cols != width || edge_host.rows != height) {
 			// edges_<s>.dmb is written by GetProblemEdges (edges.cpp) before the first pass; a caller
 			// that skipped it gets an empty edge map (no edge pixels)
 			edge_host = Mat::zeros(height, width, CV_8UC1);
@@ -290,7 +299,7 @@ void APD::SupportInitialization() {
 			std::memcpy(label_host.data, tmp.data, (size_t)width * height * 4);   // float bits reinterpreted, as the reference does
 		} else if (g_use_label_files) {   // the commented-out load of APD.cpp:1630-1633
 			Mat lab;
-			if (ReadBinMat(problem.result_folder / path("labels_" + std::to_string(scale) + ".dmb"), lab) && lab.type() == CV_32SC1) {
+			if (LoadResult(problem.result_folder / path("labels_" + std::to_string(scale) + ".dmb"), lab) && lab.type() == CV_32SC1) {
 				if (lab.cols != width || lab.rows != height) RescaleMatToTargetSize<int>(lab, lab, width, height);
 				label_host = lab;
 			}
@@ -298,7 +307,7 @@ void APD::SupportInitialization() {
 	}
 	if (problem.params.use_radius) {   // APD.cpp:1648-1667: the first pass starts at strong_radius, later ones at the stored map
 		const int fallback = problem.params.strong_radius;
-		if (problem.params.state != FIRST_INIT) ReadBinMat(problem.result_folder / path("radius.bin"), radius_host);
+		if (problem.params.state != FIRST_INIT) LoadResult(problem.result_folder / path("radius.bin"), radius_host, true);
 		if (problem.params.state == FIRST_INIT || radius_host.empty()) {
 			radius_host = Mat(height, width, CV_32S);
 			std::fill(radius_host.ptr<int>(0), radius_host.ptr<int>(0) + (size_t)width * height, fallback);
@@ -309,7 +318,9 @@ void APD::SupportInitialization() {
 		}
 		const uint8_t* state = weak_info_host.ptr<uint8_t>(0);
 		int* rad = radius_host.ptr<int>(0);
-		for (size_t i = 0, n = (size_t)width * height; i < n; ++i)
+		const long long npx = (long long)width * height;
+#pragma omp parallel for schedule(static) num_threads(8)
+		for (long long i = 0; i < npx; ++i)
 			if (state[i] == UNKNOWN) rad[i] = fallback;   // a pixel that lost its estimate restarts with the default patch
 	}
 }

@@ -7,6 +7,7 @@
 #ifndef _APD_H_
 #define _APD_H_
 #include "main.h"
+#include <functional>
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -29,6 +30,7 @@ void RunFusion_TAT_Intermediate(const path& dense_folder, const std::vector<Prob
 void RunFusion_TAT_advanced(const path& dense_folder, const std::vector<Problem>& problems);       // APD.cpp:2132-2279
 Mat EdgeSegment(const int scale, const Mat& srcImage, int mode = 0, bool useCanny = false);   // APD.cpp:348-499 (mode 0 + Canny only)
 void GetProblemEdges(const Problem& problem);                                           // main.cpp:193-246 (edge part)
+std::vector<path> ProblemEdgeOutputs(const Problem& problem);   // the files GetProblemEdges would still have to produce
 // Depth-Anything plane prior of a FIRST_INIT pass (APD.cpp:1210-1424), host/prior.cpp
 std::vector<Triangle> DelaunayTriangulation(int cols, int rows, const Rect boundRC, std::vector<float2> xy_temps, std::vector<float> rates);   // APD.cpp:51-80
 double calculateZ(const double A[3], const double B[3], const double C[3], double X, double Y);   // APD.cpp:30-49
@@ -43,6 +45,15 @@ Mat LabelSegment(const int scale, const Mat& src_image);   // EdgeSegment mode 1
 Mat ReadImageGray(const path& image_path_jpg);      // stands in for cv::imread(IMREAD_GRAYSCALE), APD.cpp:1057
 Mat ReadImageColor(const path& image_path_jpg);     // cv::imread(IMREAD_COLOR) (BGR), APD.cpp:1842
 Mat ResizeLinear(const Mat& src_f32, int new_cols, int new_rows);   // cv::resize(INTER_LINEAR), APD.cpp:1129
+// write-back cache of the per-view result files + background workers (host/store.cpp)
+void SetResultCache(bool enabled, size_t limit_bytes = 0);   // default: on, 32 GiB
+void PublishResult(const path& file, const Mat& m);          // keep in memory + write in the background (.part + rename); `m` must not be modified afterwards
+void ExpectResult(const path& file);                         // a background job will publish this path: loads of it wait
+bool LoadResult(const path& file, Mat& m, bool will_modify = false);   // memory first, then the file
+bool ResultExists(const path& file);
+void RunInBackground(std::function<void()> job);             // one worker, at most two jobs queued
+void FlushResults(bool drop_cache = false);                  // join jobs and writes
+void ShutdownResultStore();
 // error convention of the reference (CudaSafeCall, APD.cpp:943-951): message on stderr + exit.  Every such exit of the
 // host library goes through DvpFatal; a multi-rank driver installs a hook that turns it into an agreed abort (comm.h).
 [[noreturn]] void DvpFatal(const std::string& message);
@@ -81,7 +92,7 @@ public:
 	static void SetUseLabelFiles(bool on);
 	// multi-GPU hooks of the driver (comm.h).  Image cache: the decoded + rescaled float image of a view in
 	// its reference role at the problem's scale — rank 0 fills it from disk, the others from a broadcast.
-	static const Mat& CachedImage(const Problem& problem, int image_id, int* orig_cols, int* orig_rows);
+	static Mat CachedImage(const Problem& problem, int image_id, int* orig_cols, int* orig_rows);
 	static void InsertCachedImage(const Problem& problem, int image_id, const Mat& image, int orig_cols, int orig_rows);
 	static void ReserveImageCache(size_t views);   // the cache holds at least this many images before it evicts
 	// Depth maps of the previous pass resident on this process' device (row-major, pitch = width).  When

@@ -114,28 +114,53 @@ Mat EdgeSegment(const int scale, const Mat& src_image, int mode, bool use_canny)
 }
 
 // GetProblemEdges (main.cpp:193-225): Canny edge map of the reference image at the current scale,
-// cached as <result_folder>/edges_<scale>.dmb
-void GetProblemEdges(const Problem& problem) {
+// cached as <result_folder>/edges_<scale>.dmb (+ labels_<scale>.dmb)
+static int scale_level(const Problem& problem) {
 	int scale = 0;
 	while ((1 << scale) < problem.scale_size) scale++;
+	return scale;
+}
+std::vector<path> ProblemEdgeOutputs(const Problem& problem) {
+	const int scale = scale_level(problem);
+	std::vector<path> out;
 	const path edge_path = problem.result_folder / path("edges_" + std::to_string(scale) + ".dmb");
 	const path label_path = problem.result_folder / path("labels_" + std::to_string(scale) + ".dmb");
-	const bool need_edge = problem.params.use_edge && !std::filesystem::exists(edge_path);
-	const bool need_label = problem.params.use_label && !std::filesystem::exists(label_path);
+	if (problem.params.use_edge && !ResultExists(edge_path)) out.push_back(edge_path);
+	if (problem.params.use_label && !ResultExists(label_path)) out.push_back(label_path);
+	return out;
+}
+void GetProblemEdges(const Problem& problem) {
+	const int scale = scale_level(problem);
+	const path edge_path = problem.result_folder / path("edges_" + std::to_string(scale) + ".dmb");
+	const path label_path = problem.result_folder / path("labels_" + std::to_string(scale) + ".dmb");
+	bool need_edge = false, need_label = false;
+	for (const path& p : ProblemEdgeOutputs(problem)) {
+		need_edge = need_edge || p == edge_path;
+		need_label = need_label || p == label_path;
+	}
 	if (!need_edge && !need_label) return;
-	Mat image_uint = ReadImageGray(problem.dense_folder / path("images") / path(ToFormatIndex(problem.ref_image_id) + ".jpg"));
-	if (image_uint.empty()) return;
-	if (need_label) WriteBinMat(label_path, EdgeSegment(scale, image_uint, 1));   // from the full-size image (main.cpp:236)
+	// whatever happens below, every announced output is published (an empty map stands for "no priors")
+	auto publish_empty = [&]() {
+		if (need_label) PublishResult(label_path, Mat());
+		if (need_edge) PublishResult(edge_path, Mat());
+	};
+	if (need_label) {   // from the full-size image (main.cpp:236)
+		Mat image_uint = ReadImageGray(problem.dense_folder / path("images") / path(ToFormatIndex(problem.ref_image_id) + ".jpg"));
+		if (image_uint.empty()) { publish_empty(); return; }
+		PublishResult(label_path, EdgeSegment(scale, image_uint, 1));
+		need_label = false;
+	}
 	if (!need_edge) return;
-	Mat f(image_uint.rows, image_uint.cols, CV_32FC1);
-	for (int r = 0; r < f.rows; ++r)
-		for (int c = 0; c < f.cols; ++c) f.at<float>(r, c) = image_uint.at<uint8_t>(r, c);
-	const float factor = 1.0f / (float)(problem.scale_size);
-	const int new_cols = (int)std::round(f.cols * factor), new_rows = (int)std::round(f.rows * factor);
-	Mat scaled = (new_cols == f.cols && new_rows == f.rows) ? f : ResizeLinear(f, new_cols, new_rows);
+	// the reference image at this scale: uint8 -> float -> cv::resize(INTER_LINEAR) (main.cpp:205-214) is exactly what
+	// the driver's image cache holds for this view (APD.cpp load_image), decoded and resized once
+	int oc = 0, orow = 0;
+	const Mat scaled = APD::CachedImage(problem, problem.ref_image_id, &oc, &orow);
+	if (scaled.empty()) { publish_empty(); return; }
+	const int new_cols = scaled.cols, new_rows = scaled.rows;
 	Mat u8(new_rows, new_cols, CV_8UC1);   // convertTo(CV_8UC1): round to nearest, saturate
+#pragma omp parallel for schedule(static) num_threads(8)
 	for (int r = 0; r < new_rows; ++r)
 		for (int c = 0; c < new_cols; ++c) u8.at<uint8_t>(r, c) = (uint8_t)std::min(255L, std::max(0L, std::lrintf(scaled.at<float>(r, c))));
 	Mat edge = EdgeSegment(scale, u8, 0, true);
-	WriteBinMat(edge_path, edge);
+	PublishResult(edge_path, edge);
 }

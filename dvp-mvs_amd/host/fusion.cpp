@@ -86,9 +86,9 @@ bool load_view(const path& dense_folder, const Problem& problem, FusionView* v) 
 	v->image_id = problem.ref_image_id;
 	ReadCamera(dense_folder / "cams" / (id + "_cam.txt"), v->cam);
 	v->set_centre();
-	if (!ReadBinMat(problem.result_folder / "depths.dmb", v->depth) || !ReadBinMat(problem.result_folder / "APD_normals.dmb", v->normal)) return false;
+	if (!LoadResult(problem.result_folder / "depths.dmb", v->depth) || !LoadResult(problem.result_folder / "APD_normals.dmb", v->normal)) return false;
 	Mat weak;
-	ReadBinMat(problem.result_folder / "weak.bin", weak);
+	LoadResult(problem.result_folder / "weak.bin", weak);
 	if (weak.empty()) weak = Mat(v->rows(), v->cols(), CV_8UC1), std::memset(weak.data, STRONG, weak.step * weak.rows);
 	v->weak = weak;
 	RescaleMatToTargetSize<uint8_t>(weak, v->weak, v->cols(), v->rows());   // no-op when the sizes agree

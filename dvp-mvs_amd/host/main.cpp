@@ -34,6 +34,7 @@ struct Options {
 	uint64_t seed = 1234;
 	bool fusion = true, jacobi = false, label_files = false;
 	int collective_timeout_s = 600;
+	bool sync_io = false;
 	std::string job, transport = "rccl";
 	std::string fusion_kind = "eth";   // eth | tat-intermediate | tat-advanced (APD.h:52-54; the reference's main calls the first)
 };
@@ -106,14 +107,6 @@ void ConfigurePass(Problem& problem, const Pass& pass, int iteration, int iters,
 	}
 }
 
-// BinMat written under a temporary name, then renamed into place
-void PublishBinMat(const path& file, const Mat& m) {
-	path tmp = file;
-	tmp += ".part";
-	if (!WriteBinMat(tmp, m)) DvpFatal("cannot write " + tmp.string());
-	std::filesystem::rename(tmp, file);
-}
-
 struct ViewResult { Mat depth; };   // what the exchange step needs from a finished view
 
 ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
@@ -146,6 +139,7 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	Mat depth(height, width, CV_32FC1), normal(height, width, CV_32FC3);
 	Mat pixel_states = APD.GetPixelStates();
 	Mat views = APD.GetSelectedViews();
+	Mat radius = problem.params.use_radius ? APD.GetRadiusMap() : Mat();
 	// planes -> depth / normal maps; depths outside the admissible range are dropped and the pixel loses
 	// its state (main.cpp:300-309)
 #pragma omp parallel for schedule(static) num_threads(8)
@@ -162,43 +156,57 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 		}
 	}
 	lap("unpack planes");
-	// Visibility clean-up (main.cpp:311-363): per source view, every 4-connected region of pixels that do
-	// NOT select the view and is smaller than 20 * (8 / scale)^2 pixels is switched to "selected".
-	const int min_region = 20 * (8 / problem.scale_size) * (8 / problem.scale_size);
-	std::vector<Mat> fill(nsrc);   // per source: 1 where the bit has to be set
+	// The depth map is what OTHER views read next (geometric term of their pass): it is published now.  Everything else
+	// of this view — the visibility clean-up and the remaining four files — is only read by this view's own next pass:
+	// it runs in the background while the GPU is already on the next view (store.cpp).
+	const path folder = problem.result_folder;
+	PublishResult(folder / "depths.dmb", depth);
+	for (const char* name : { "APD_normals.dmb", "weak.bin", "selected_views.bin" }) ExpectResult(folder / name);
+	if (problem.params.use_radius) ExpectResult(folder / "radius.bin");
+	const int scale_size = problem.scale_size;
+	const bool timing = host_timing;
+	RunInBackground([=]() mutable {
+		const auto t0 = std::chrono::steady_clock::now();
+		// Visibility clean-up (main.cpp:311-363): per source view, every 4-connected region of pixels that do
+		// NOT select the view and is smaller than 20 * (8 / scale)^2 pixels is switched to "selected".
+		const int min_region = 20 * (8 / scale_size) * (8 / scale_size);
+		std::vector<Mat> fill(nsrc);   // per source: 1 where the bit has to be set
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nsrc < 8 ? (nsrc > 0 ? nsrc : 1) : 8)
-	for (int i = 0; i < nsrc; ++i) {
-		Mat visible(height, width, CV_8UC1);
-		for (int r = 0; r < height; ++r) {
-			const uint32_t* w = views.ptr<uint32_t>(r);
-			uint8_t* v = visible.ptr<uint8_t>(r);
-			for (int c = 0; c < width; ++c) v[c] = ((w[c] >> i) & 1u) ? 255 : 0;
+		for (int i = 0; i < nsrc; ++i) {
+			Mat visible(height, width, CV_8UC1);
+			for (int r = 0; r < height; ++r) {
+				const uint32_t* w = views.ptr<uint32_t>(r);
+				uint8_t* v = visible.ptr<uint8_t>(r);
+				for (int c = 0; c < width; ++c) v[c] = ((w[c] >> i) & 1u) ? 255 : 0;
+			}
+			Mat region(height, width, CV_32S);
+			std::vector<int> region_size;
+			Connect(visible, region, region_size);
+			Label_Update(region, region_size);
+			fill[i] = Mat(height, width, CV_8UC1);
+			for (int r = 0; r < height; ++r) {
+				const int* lab = region.ptr<int>(r);
+				uint8_t* f = fill[i].ptr<uint8_t>(r);
+				for (int c = 0; c < width; ++c) f[c] = (lab[c] != 0 && region_size[lab[c]] >= min_region) ? 0 : 1;
+			}
 		}
-		Mat region(height, width, CV_32S);
-		std::vector<int> region_size;
-		Connect(visible, region, region_size);
-		Label_Update(region, region_size);
-		fill[i] = Mat(height, width, CV_8UC1);
-		for (int r = 0; r < height; ++r) {
-			const int* lab = region.ptr<int>(r);
-			uint8_t* f = fill[i].ptr<uint8_t>(r);
-			for (int c = 0; c < width; ++c) f[c] = (lab[c] != 0 && region_size[lab[c]] >= min_region) ? 0 : 1;
-		}
-	}
 #pragma omp parallel for schedule(static) num_threads(8)
-	for (int r = 0; r < height; ++r)
-		for (int c = 0; c < width; ++c) {
-			unsigned int mask = 0;
-			for (int i = 0; i < nsrc; ++i) mask |= (unsigned int)fill[i].at<uint8_t>(r, c) << i;
-			APD.SetPixelSelectedViews(r, c, (int)mask);
+		for (int r = 0; r < height; ++r) {
+			uint32_t* w = views.ptr<uint32_t>(r);
+			for (int c = 0; c < width; ++c) {
+				unsigned int mask = 0;
+				for (int i = 0; i < nsrc; ++i) mask |= (unsigned int)fill[i].at<uint8_t>(r, c) << i;
+				w[c] = mask;                      // APD.SetPixelSelectedViews(r, c, mask)
+			}
 		}
-	lap("visibility-mask clean-up");
-	PublishBinMat(problem.result_folder / "depths.dmb", depth);
-	PublishBinMat(problem.result_folder / "APD_normals.dmb", normal);
-	PublishBinMat(problem.result_folder / "weak.bin", pixel_states);
-	PublishBinMat(problem.result_folder / "selected_views.bin", APD.GetSelectedViews());
-	if (problem.params.use_radius) PublishBinMat(problem.result_folder / "radius.bin", APD.GetRadiusMap());
-	lap("write results");
+		PublishResult(folder / "APD_normals.dmb", normal);
+		PublishResult(folder / "weak.bin", pixel_states);
+		PublishResult(folder / "selected_views.bin", views);
+		if (!radius.empty()) PublishResult(folder / "radius.bin", radius);
+		if (timing) std::cout << "  [background] visibility-mask clean-up + publish: "
+		                      << std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() / 1000.0 << " ms" << std::endl;
+	});
+	lap("hand-over to the background worker");
 	const auto end = std::chrono::steady_clock::now();
 	const DvpTimings& t = APD.GetTimings();
 	std::cout << "Processing image: " << std::setw(8) << std::setfill('0') << problem.ref_image_id << " done!" << std::endl;
@@ -255,6 +263,33 @@ private:
 	std::map<int, Slot> maps_;
 };
 
+// Single-rank, in-place order (the reference's): a finished view's depth map goes to the device right away and stays
+// there, so that the views after it — which see it as a source map in the same pass, exactly as they would through
+// APD/<id>/depths.dmb — take it with a device-to-device copy instead of a 100 MB file read + upload per source.
+class InPlaceDepths {
+public:
+	~InPlaceDepths() { Release(); }
+	void Update(int image_id, const Mat& depth) {
+		Slot& s = maps_[image_id];
+		if (s.w != depth.cols || s.h != depth.rows) {
+			RankComm::DeviceFree(s.dev);
+			s.dev = RankComm::DeviceAlloc((size_t)depth.cols * depth.rows);
+			s.w = depth.cols;
+			s.h = depth.rows;
+		}
+		RankComm::HostToDevice(s.dev, depth.ptr<float>(0), (size_t)s.w * s.h);
+		APD::SetResidentDepth(image_id, s.dev, s.w, s.h);
+	}
+	void Release() {
+		APD::ClearResidentDepths();
+		for (auto& kv : maps_) RankComm::DeviceFree(kv.second.dev);
+		maps_.clear();
+	}
+private:
+	struct Slot { float* dev = nullptr; int w = 0, h = 0; };
+	std::map<int, Slot> maps_;
+};
+
 // The owner of a view (rank v % world) decodes + resizes its image at this level and broadcasts it; the others
 // take it from the broadcast into their image cache: every image file is read by exactly one process and the
 // decode work is spread over the ranks.
@@ -299,6 +334,7 @@ Options ParseOptions(int argc, char** argv) {
 		else if (s == "--jacobi") o.jacobi = true;
 		else if (s == "--labels") o.label_files = true;          // load labels_<s>.dmb (APD::SetUseLabelFiles)
 		else if (s == "--no-fusion") o.fusion = false;
+		else if (s == "--sync-io") o.sync_io = true;               // no result cache / background worker: the reference's synchronous file flow
 		else if (s == "--fusion") { if (a + 1 < argc) o.fusion_kind = argv[++a]; }
 	}
 	if (o.world > 1) o.jacobi = true;
@@ -320,6 +356,7 @@ int main(int argc, char** argv) {
 	APD::SetDevice(opt.gpu);
 	APD::SetSeed(opt.seed);
 	APD::SetUseLabelFiles(opt.label_files);
+	SetResultCache(!opt.sync_io);
 	RankComm comm(opt.rank, opt.world, opt.gpu, (opt.dense_folder / "APD" / ".rccl_id").string(), opt.job, opt.collective_timeout_s, opt.transport);
 	// every print-and-exit of the host library (unreadable image, missing weak.bin, engine error ...) becomes an agreed
 	// abort of the whole job when there are peers
@@ -341,7 +378,9 @@ int main(int argc, char** argv) {
 	}
 
 	std::unique_ptr<DepthExchange> exchange;
+	std::unique_ptr<InPlaceDepths> inplace;
 	if (opt.jacobi) exchange.reset(new DepthExchange(comm, problems));
+	else if (!opt.sync_io) inplace.reset(new InPlaceDepths());
 	int shared_scale = -1;
 	for (size_t it = 0; it < plan.size(); ++it) {
 		const Pass& pass = plan[it];
@@ -351,12 +390,25 @@ int main(int argc, char** argv) {
 			if (exchange) exchange->Release();   // maps of the coarser level do not fit this one (and its A pass has no geometric term)
 		}
 		std::map<int, Mat> mine;
+		std::vector<Problem*> owned;
 		for (Problem& problem : problems) {
 			ConfigurePass(problem, pass, (int)it, opt.iters, round_num);
-			if (problem.index % opt.world != opt.rank) continue;
-			if (pass.geom_index < 0) GetProblemEdges(problem);   // main.cpp:480
+			if (problem.index % opt.world == opt.rank) owned.push_back(&problem);
+		}
+		for (size_t k = 0; k < owned.size(); ++k) {
+			Problem& problem = *owned[k];
+			if (pass.geom_index < 0) {   // main.cpp:480
+				GetProblemEdges(problem);      // (already there when the previous view's turn prefetched it)
+				if (k + 1 < owned.size()) {    // the next view's edge / label maps are made while the GPU works on this one
+					const Problem next = *owned[k + 1];
+					const std::vector<path> outs = ProblemEdgeOutputs(next);
+					for (const path& p : outs) ExpectResult(p);
+					if (!outs.empty()) RunInBackground([next]() { GetProblemEdges(next); });
+				}
+			}
 			ViewResult r = ProcessProblem(problem);
 			if (exchange) mine[problem.index] = r.depth;
+			if (inplace) inplace->Update(problem.ref_image_id, r.depth);
 		}
 		if (exchange) exchange->Publish(mine);   // collective: also the barrier between passes
 		else comm.Barrier();
@@ -364,13 +416,16 @@ int main(int argc, char** argv) {
 	}
 	if (exchange) exchange->Release();
 	exchange.reset();
+	inplace.reset();
 	APD::ReleasePooledContext();
+	FlushResults();          // every result file of this rank is on disk before anyone (rank 0's fusion) reads the folder
 	comm.Barrier();
 	if (opt.fusion && opt.rank == 0) {
 		if (opt.fusion_kind == "tat-intermediate") RunFusion_TAT_Intermediate(opt.dense_folder, problems);
 		else if (opt.fusion_kind == "tat-advanced") RunFusion_TAT_advanced(opt.dense_folder, problems);
 		else RunFusion(opt.dense_folder, problems);
 	}
+	ShutdownResultStore();
 	std::cout << "All done\n";
 	return EXIT_SUCCESS;
 }
