@@ -157,7 +157,9 @@ DVP_HD float ncc_patch_generic(const Dev& d, const float* H, const float* src, i
 
 // 36-tap patch with the hoisted context.  H is the pixel->source homography.  The sampler mode is
 // a template parameter so that the unrolled tap body is one branch-free basic block.
-template <int SMP>
+// CLAMP = false: every tap's source coordinate is known to lie in [-1, W] x [-1, H] (patch_stays_inside) — the sampler's
+// clamp is then the identity and is left out; results are the same bits.
+template <int SMP, bool CLAMP = true>
 DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, const float* src, int px, int py) {
 	const int W = d.width, Hh = d.height, P = d.pitch;
 	// H[k]*x and H[k]*y products for the 6 distinct tap columns / rows: same products the
@@ -193,7 +195,7 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 		}                                                                                           \
 		batch_rcp(Z, kTaps, IZ);                                                                    \
 		_Pragma("unroll") for (int tx = 0; tx < kTaps; ++tx)                                        \
-			tex_coord(P, W, Hh, X[tx] * IZ[tx], Y[tx] * IZ[tx], &off[BUF][tx], &tw[BUF][tx]);       \
+			tex_coord<SMP, CLAMP>(P, W, Hh, X[tx] * IZ[tx], Y[tx] * IZ[tx], &off[BUF][tx], &tw[BUF][tx]); \
 	}
 #define DVP_ISSUE(BUF)                                                                              \
 	_Pragma("unroll") for (int k = 0; k < kTaps; ++k)                                               \
@@ -236,6 +238,28 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 	return ncc_from_sums(c.sum_ref, c.sum_ref_ref, s_s, s_ss, s_rs, c.wsum);
 }
 
+// the clamped evaluation as a real function call: taken by the few waves whose patches reach the image border, it keeps
+// the second copy of the 36-tap body (and its register pressure) out of the callers
+template <int SMP>
+DVP_HD_NOINLINE float ncc_patch_clamped(const Dev& d, const PatchCtx& c, const float* H, const float* src, int px, int py) {
+	return ncc_patch_fast<SMP, true>(d, c, H, src, px, py);
+}
+
+// Does the whole patch (|dx|, |dy| <= r around the pixel) project at least one pixel inside the source image?  With
+// q(p) = (X, Y) / z, q(p + D) - q(p) = ((dX, dY) - q(p) dz) / (z + dz) where (dX, dY, dz) = H D, so
+// |q.x(p + D) - q.x(p)| <= (r (|H0| + |H1|) + |q.x| r (|H6| + |H7|)) / (|z| - r (|H6| + |H7|)) whenever the denominator is
+// positive (and likewise in y).  The test asks for a full pixel of slack on every side, far more than the rounding of
+// the bound and of the tap coordinates themselves (< 1e-2 px at any image size the engine accepts); NaN / inf anywhere
+// makes a comparison false, i.e. the clamped path.  The sampler's clamp range is [-1, W] x [-1, H].
+DVP_HD bool patch_stays_inside(const float* H, const f2 pt, int px, int py, float r, float fw, float fh) {
+	const float z = H[6] * px + H[7] * py + H[8];
+	const float ez = r * (fabsf(H[6]) + fabsf(H[7]));
+	const float zl = fabsf(z) - ez;
+	const float bx = r * (fabsf(H[0]) + fabsf(H[1])) + fabsf(pt.x) * ez;
+	const float by = r * (fabsf(H[3]) + fabsf(H[4])) + fabsf(pt.y) * ez;
+	return zl > 0.0f && (pt.x - 1.0f) * zl >= bx && (fw - 2.0f - pt.x) * zl >= bx && (pt.y - 1.0f) * zl >= by && (fh - 2.0f - pt.y) * zl >= by;
+}
+
 // ComputeBilateralNCCOld (APD.cu:1023-1113) for source view `v` (1-based image index).
 template <int SMP>
 DVP_HD float ncc_old(const Dev& d, const PatchCtx& c, int px, int py, int v, const f4 plane) {
@@ -246,6 +270,13 @@ DVP_HD float ncc_old(const Dev& d, const PatchCtx& c, int px, int py, int v, con
 	const f2 pt = apply_homography(H, px, py);
 	if (pt.x >= fw || pt.x < 0.0f || pt.y >= fh || pt.y < 0.0f) return 2.0f;
 	const float* src = d.images + (size_t)uniform_i(v) * d.plane_stride * 2;   // wave-uniform base
+#ifndef DVP_NO_CLAMP_FREE
+	if (c.fast && wave_all(patch_stays_inside(H, pt, px, py, (float)c.radius, (float)d.width, (float)d.height)))
+		return ncc_patch_fast<SMP, false>(d, c, H, src, px, py);
+#ifdef DVP_CLAMP_SLOW_NOINLINE
+	if (c.fast) return ncc_patch_clamped<SMP>(d, c, H, src, px, py);
+#endif
+#endif
 	if (c.fast) return ncc_patch_fast<SMP>(d, c, H, src, px, py);
 	return ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 0);
 }

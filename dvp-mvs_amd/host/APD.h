@@ -30,6 +30,7 @@ void RunFusion_TAT_Intermediate(const path& dense_folder, const std::vector<Prob
 void RunFusion_TAT_advanced(const path& dense_folder, const std::vector<Problem>& problems);       // APD.cpp:2132-2279
 Mat EdgeSegment(const int scale, const Mat& srcImage, int mode = 0, bool useCanny = false);   // APD.cpp:348-499 (mode 0 + Canny only)
 void GetProblemEdges(const Problem& problem);                                           // main.cpp:193-246 (edge part)
+void GetProblemEdges(const Problem& problem, const std::vector<path>& outputs);
 std::vector<path> ProblemEdgeOutputs(const Problem& problem);   // the files GetProblemEdges would still have to produce
 // Depth-Anything plane prior of a FIRST_INIT pass (APD.cpp:1210-1424), host/prior.cpp
 std::vector<Triangle> DelaunayTriangulation(int cols, int rows, const Rect boundRC, std::vector<float2> xy_temps, std::vector<float> rates);   // APD.cpp:51-80

@@ -129,12 +129,15 @@ std::vector<path> ProblemEdgeOutputs(const Problem& problem) {
 	if (problem.params.use_label && !ResultExists(label_path)) out.push_back(label_path);
 	return out;
 }
-void GetProblemEdges(const Problem& problem) {
+void GetProblemEdges(const Problem& problem) { GetProblemEdges(problem, ProblemEdgeOutputs(problem)); }
+// `outputs`: what ProblemEdgeOutputs said BEFORE the caller announced the files with ExpectResult (an announced file
+// counts as existing)
+void GetProblemEdges(const Problem& problem, const std::vector<path>& outputs) {
 	const int scale = scale_level(problem);
 	const path edge_path = problem.result_folder / path("edges_" + std::to_string(scale) + ".dmb");
 	const path label_path = problem.result_folder / path("labels_" + std::to_string(scale) + ".dmb");
 	bool need_edge = false, need_label = false;
-	for (const path& p : ProblemEdgeOutputs(problem)) {
+	for (const path& p : outputs) {
 		need_edge = need_edge || p == edge_path;
 		need_label = need_label || p == label_path;
 	}

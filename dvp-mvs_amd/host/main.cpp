@@ -403,7 +403,7 @@ int main(int argc, char** argv) {
 					const Problem next = *owned[k + 1];
 					const std::vector<path> outs = ProblemEdgeOutputs(next);
 					for (const path& p : outs) ExpectResult(p);
-					if (!outs.empty()) RunInBackground([next]() { GetProblemEdges(next); });
+					if (!outs.empty()) RunInBackground([next, outs]() { GetProblemEdges(next, outs); });
 				}
 			}
 			ViewResult r = ProcessProblem(problem);

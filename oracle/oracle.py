@@ -139,7 +139,7 @@ class Oracle:
 
     def set_numerics(self, n):
         """0 = the numerics contract (default); 1 = literal per-operator evaluation of the reference's
-        NCC expressions (column-major single-chain sums, one division per tap, tex2D(x+0.5) with the
+        NCC expressions (the source's per-x-offset partial sums, one division per tap, tex2D(x+0.5) with the
         add/subtract pair rounded).  Oracle only: a cross-check of how far the contract is from it."""
         self.L.ora_set_numerics.argtypes = [ctypes.c_void_p, ctypes.c_int]
         self.L.ora_set_numerics(self.h, n)

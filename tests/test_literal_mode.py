@@ -1,6 +1,6 @@
 """End-to-end distance between the numerics CONTRACT (what the oracle and the HIP engine implement bit
 for bit) and a LITERAL reading of the reference's source (Oracle.set_numerics(1): true divisions in
-ComputeHomography / ComputeCorrespondingPoint, column-major single-chain moment sums, one division
+ComputeHomography / ComputeCorrespondingPoint, the source's tap order with its per-x-offset partial sums, one division
 per tap, tex2D(x + 0.5f) with the add/subtract pair rounded, libm expf, the `complex` sigmoid in
 double — APD.cu:679-748, 1059-1089, 905-1000, 3844).
 
@@ -11,9 +11,9 @@ pass with geometric consistency, WEAK pixels and priors.  PatchMatch amplifies u
 differences wherever two hypotheses tie, so agreement is a statement about the distribution:
 SURVEY.md §8c measured, for the reference's own code: 0.4 % of pixels beyond 1e-3 run twice with the same
 seed (its data races), 48 % with another seed, 21 % with the other bilinear weight rounding.
-Measured here (printed with pytest -s, recorded in DESIGN.md §2): contract vs literal 1-2 % of pixels
-beyond 1e-3, <= 0.06 % beyond 1e-2, mean relative depth difference 0.7e-4 .. 2.2e-4, p99 ~1e-3; the same
-pipeline with another seed: 12-17 % beyond 1e-3, mean 2e-3 .. 4e-3 (an order of magnitude more).  The gates below are those measurements with
+Measured here on the rotated camera rig (printed with pytest -s, recorded in DESIGN.md §2): contract vs literal
+0.4-2.6 % of pixels beyond 1e-3, <= 0.07 % beyond 1e-2, mean relative depth difference 0.4e-4 .. 2.2e-4, p99 ~1e-3; the
+same pipeline with another seed: 14-25 % beyond 1e-3, mean 1e-2 (two orders of magnitude more).  The gates below are those measurements with
 a 1.5-2x margin: the test pins the DISTANCE, it does not claim per-pixel agreement."""
 import numpy as np
 import pytest
@@ -75,6 +75,6 @@ def test_contract_vs_literal_end_to_end(W, H, S):
         assert s["median"] <= 3e-4, s
         assert s["mean"] <= 5e-4, s
         assert s["p99"] <= 3e-3, s
-        assert s["over_1e3"] <= 0.035, s
+        assert s["over_1e3"] <= 0.04, s
         assert s["over_1e2"] <= 0.002, s
-    assert states <= 0.002
+    assert states <= 0.003
