@@ -109,6 +109,7 @@ def parse():
     ap.add_argument("--src", type=int, default=0)
     ap.add_argument("--iters", type=int, default=0)
     ap.add_argument("--weak-frac", type=float, default=0.05, help="share of 32x32 tiles handed over as WEAK (refine configs)")
+    ap.add_argument("--rig", default="rotated", choices=["rotated", "axis"], help="camera rig of the synthetic scene: per-view rotations and intrinsics (default) or the round-1/2 rig (R = I, one K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=str, default="auto", help="WxH of the CPU-baseline view (auto: scaled to the core count)")
     return ap.parse_args()
@@ -137,7 +138,7 @@ def cpu_baseline(pkg, args, cfg, S, iters, device=0):
         w = h * 4 // 3
     else:
         w, h = [int(v) for v in args.cpu_size.split("x")]
-    sc = synth.make_scene(w, h, S)
+    sc = synth.make_scene(w, h, S, rig=args.rig)
     L = w * h
     p1 = wl.first_init_params(S, iters)
     first = dict(planes=np.zeros((L, 4), np.float32), edge=sc["edge"], label=sc["label"], radius=np.full(L, 5, np.int32))
@@ -282,7 +283,7 @@ def main():
     flats = torch.empty((NI, H, W), dtype=torch.bool, device=dev)
     cams_t = torch.empty(NI * 112, dtype=torch.uint8, device=dev)
     if rank == 0:
-        sc = synth.make_scene_torch(W, H, S, dev)
+        sc = synth.make_scene_torch(W, H, S, dev, rig=args.rig)
         imgs.copy_(sc["images"])
         deps.copy_(sc["depth_gt"])
         for i in range(NI):

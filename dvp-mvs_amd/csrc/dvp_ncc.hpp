@@ -6,7 +6,7 @@
 // samples.  Everything that touches only the reference image depends on the pixel alone, yet the
 // reference recomputes it for each of the ~20·S evaluations per pixel and iteration.  Here a
 // PatchCtx is built once per pixel per kernel (weights w[t], w[t]*ref[t], the three reference
-// moments in the reference's partial-then-total accumulation order) and each evaluation only does the
+// moments in the reference's row-then-total accumulation order) and each evaluation only does the
 // homography, the 36 gathers and three accumulations.  Results are bit-identical to the direct
 // form because every floating-point operation that remains is the same operation on the same
 // operands in the same order.
@@ -31,8 +31,8 @@ struct PatchTab {
 };
 
 struct PatchCtx {
-	PatchTab tab;              // (bilateral weight w, w * ref_pix) of the tap at x-offset index g, y-offset index k: entry g*6+k (the reference's visiting order, APD.cu:1059-1067)
-	float sum_ref, sum_ref_ref, wsum;   // un-normalised reference sums (per-x-offset partial sums, then totals: APD.cu:1060-1088)
+	PatchTab tab;              // (bilateral weight w, w * ref_pix) of tap (tx, ty) at index ty*6+tx (row-major: ty = y offset index)
+	float sum_ref, sum_ref_ref, wsum;   // un-normalised reference sums (row-then-total order)
 	int radius, inc;
 	int fast;                  // 1: exactly 6 taps per axis (register path); 0: generic loops
 };
@@ -69,23 +69,23 @@ DVP_HD void build_patch_ctx(const Dev& d, int px, int py, int radius, int inc, i
 	// the 36 reference texels first (independent loads, all in flight together), then the weights
 	float av[kTaps * kTaps];
 #pragma unroll
-	for (int g = 0; g < kTaps; ++g)
+	for (int ty = 0; ty < kTaps; ++ty)
 #pragma unroll
-		for (int k = 0; k < kTaps; ++k)
-			av[g * kTaps + k] = img_texel(ref, d.org, P, W, H, px - radius + g * inc, py - radius + k * inc);
+		for (int tx = 0; tx < kTaps; ++tx)
+			av[ty * kTaps + tx] = img_texel(ref, d.org, P, W, H, px - radius + tx * inc, py - radius + ty * inc);
 	sched_fence();
 	float sr = 0.0f, srr = 0.0f, ws = 0.0f;
 #pragma unroll
-	for (int g = 0; g < kTaps; ++g) {          // x offset outer, y offset inner (APD.cu:1059-1067)
-		const int i = -radius + g * inc;
+	for (int ty = 0; ty < kTaps; ++ty) {          // rows outer, columns inner (tap order)
+		const int j = -radius + ty * inc;
 		float sr_row = 0.0f, srr_row = 0.0f, ws_row = 0.0f;
 #pragma unroll
-		for (int k = 0; k < kTaps; ++k) {
-			const int j = -radius + k * inc;
-			const float a = av[g * kTaps + k];
+		for (int tx = 0; tx < kTaps; ++tx) {
+			const int i = -radius + tx * inc;
+			const float a = av[ty * kTaps + tx];
 			const float w = bilateral_weight((float)i, (float)j, a, cpix, sig_s, sig_c, colour_only);
 			const float wa = w * a;
-			tab.set(g * kTaps + k, mk2(w, wa));
+			tab.set(ty * kTaps + tx, mk2(w, wa));
 			sr_row += wa;
 			srr_row += wa * a;
 			ws_row += w;
@@ -117,19 +117,19 @@ DVP_HD float ncc_from_sums(float sum_ref, float sum_ref_ref, float sum_src, floa
 }
 
 // Generic (non-hoisted) patch loop for tap counts other than 6 per axis; restatement of
-// APD.cu:1059-1089 with the weight variant selected by `colour_only` (same visiting order).
+// APD.cu:1059-1089 with the weight variant selected by `colour_only` (taps visited row by row).
 DVP_HD float ncc_patch_generic(const Dev& d, const float* H, const float* src, int px, int py, int radius, int inc, int colour_only) {
 	const float* ref = d.images;
 	const int W = d.width, Hh = d.height, P = d.pitch;
 	const float cpix = img_texel(ref, d.org, P, W, Hh, px, py);
 	float s_r = 0.0f, s_rr = 0.0f, s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f, s_w = 0.0f;
 	if (inc <= 0) inc = 1;
-	for (int i = -radius; i <= radius; i += inc) {        // x offset outer, y offset inner (APD.cu:1059-1067)
+	for (int j = -radius; j <= radius; j += inc) {        // rows outer, columns inner
 		float r_r = 0.0f, r_rr = 0.0f, r_s = 0.0f, r_ss = 0.0f, r_rs = 0.0f, r_w = 0.0f;
-		for (int j0 = -radius; j0 <= radius; j0 += 6 * inc) {   // projective divide: six taps at a time
+		for (int i0 = -radius; i0 <= radius; i0 += 6 * inc) {   // projective divide: six taps at a time
 			float X[6], Y[6], Z[6], IZ[6];
 			int n = 0;
-			for (int j = j0; j <= radius && n < 6; j += inc, ++n) {
+			for (int i = i0; i <= radius && n < 6; i += inc, ++n) {
 				const int qx = px + i, qy = py + j;
 				X[n] = H[0] * qx + H[1] * qy + H[2];
 				Y[n] = H[3] * qx + H[4] * qy + H[5];
@@ -137,7 +137,7 @@ DVP_HD float ncc_patch_generic(const Dev& d, const float* H, const float* src, i
 			}
 			batch_rcp(Z, n, IZ);
 			for (int k = 0; k < n; ++k) {
-				const int j = j0 + k * inc;
+				const int i = i0 + k * inc;
 				const float a = img_texel(ref, d.org, P, W, Hh, px + i, py + j);
 				const float b = tex_linear(src, P, W, Hh, X[k] * IZ[k], Y[k] * IZ[k], d.sampler);
 				const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, colour_only);
@@ -164,34 +164,35 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 	const int W = d.width, Hh = d.height, P = d.pitch;
 	// H[k]*x and H[k]*y products for the 6 distinct tap columns / rows: same products the
 	// reference forms per tap (H[0]*p.x + H[1]*p.y + H[2], APD.cu:744-746), formed once.
-	float hy1[kTaps], hy4[kTaps], hy7[kTaps];
+	float hx0[kTaps], hx3[kTaps], hx6[kTaps];
 #pragma unroll
 	for (int t = 0; t < kTaps; ++t) {
-		const float fy = (float)(py - c.radius + t * c.inc);
-		hy1[t] = H[1] * fy; hy4[t] = H[4] * fy; hy7[t] = H[7] * fy;
+		const float fx = (float)(px - c.radius + t * c.inc);
+		hx0[t] = H[0] * fx; hx3[t] = H[3] * fx; hx6[t] = H[6] * fx;
 	}
-	// Software pipeline over the six GROUPS of the patch (one x offset, its six y offsets: the reference's outer
-	// loop index, APD.cu:1059), three buffers deep:
-	//   coords(g): one batched reciprocal + 6 footprint addresses / weights
-	//   issue(g) : 6 sixteen-byte gathers
-	//   consume(g): 6 blends + the group's partial sums, groups in order (partial-then-total accumulation)
+	// Software pipeline over the six ROWS of the patch (6 taps each), three buffers deep:
+	//   coords(r): one batched reciprocal + 6 footprint addresses / weights
+	//   issue(r) : 6 sixteen-byte gathers
+	//   consume(r): 6 blends + the row sums, rows in order (row-then-total accumulation)
 	// ordered  coords0 issue0 coords1 issue1 | coords2 | consume0 issue2 | coords3 | consume1 issue3 | ... :
-	// the gathers of two groups (12) fly while the addresses of the group after them are computed, and
-	// only the last group's latency stays exposed.  (Round 1 ran the same pipeline over PAIRS, two
-	// buffers deep: 256 VGPRs and 3 % slower; more groups in flight spill.)
+	// the gathers of two rows (12) fly while the addresses of the row after them are computed, and
+	// only the last row's latency stays exposed.  (Round 1 ran the same pipeline over row PAIRS, two
+	// buffers deep: 256 VGPRs and 3 % slower; more rows in flight spill.)  Taps of one row land on
+	// the same source row pair (near-upright homographies): a lane with a hypothesis unrelated to
+	// its neighbours' touches 1-2 cache lines per row.
 	unsigned off[3][kTaps];
 	TapW<SMP> tw[3][kTaps];
 	float q[3][kTaps][4];
 	float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
 #define DVP_COORDS(R, BUF)                                                                          \
 	{                                                                                               \
-		const float fx = (float)(px - c.radius + (R) * c.inc);                                      \
-		const float hx0 = H[0] * fx, hx3 = H[3] * fx, hx6 = H[6] * fx;                              \
+		const float fy = (float)(py - c.radius + (R) * c.inc);                                      \
+		const float hy1 = H[1] * fy, hy4 = H[4] * fy, hy7 = H[7] * fy;                              \
 		float X[kTaps], Y[kTaps], Z[kTaps], IZ[kTaps];                                              \
 		_Pragma("unroll") for (int tx = 0; tx < kTaps; ++tx) {                                      \
-			X[tx] = hx0 + hy1[tx] + H[2];                                                           \
-			Y[tx] = hx3 + hy4[tx] + H[5];                                                           \
-			Z[tx] = hx6 + hy7[tx] + H[8];                                                           \
+			X[tx] = hx0[tx] + hy1 + H[2];                                                           \
+			Y[tx] = hx3[tx] + hy4 + H[5];                                                           \
+			Z[tx] = hx6[tx] + hy7 + H[8];                                                           \
 		}                                                                                           \
 		batch_rcp(Z, kTaps, IZ);                                                                    \
 		_Pragma("unroll") for (int tx = 0; tx < kTaps; ++tx)                                        \
@@ -238,19 +239,15 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 	return ncc_from_sums(c.sum_ref, c.sum_ref_ref, s_s, s_ss, s_rs, c.wsum);
 }
 
-// the clamped evaluation as a real function call: taken by the few waves whose patches reach the image border, it keeps
-// the second copy of the 36-tap body (and its register pressure) out of the callers
-template <int SMP>
-DVP_HD_NOINLINE float ncc_patch_clamped(const Dev& d, const PatchCtx& c, const float* H, const float* src, int px, int py) {
-	return ncc_patch_fast<SMP, true>(d, c, H, src, px, py);
-}
-
 // Does the whole patch (|dx|, |dy| <= r around the pixel) project at least one pixel inside the source image?  With
 // q(p) = (X, Y) / z, q(p + D) - q(p) = ((dX, dY) - q(p) dz) / (z + dz) where (dX, dY, dz) = H D, so
 // |q.x(p + D) - q.x(p)| <= (r (|H0| + |H1|) + |q.x| r (|H6| + |H7|)) / (|z| - r (|H6| + |H7|)) whenever the denominator is
 // positive (and likewise in y).  The test asks for a full pixel of slack on every side, far more than the rounding of
-// the bound and of the tap coordinates themselves (< 1e-2 px at any image size the engine accepts); NaN / inf anywhere
-// makes a comparison false, i.e. the clamped path.  The sampler's clamp range is [-1, W] x [-1, H].
+// the bound and of the tap coordinates themselves; NaN / inf anywhere makes a comparison false, i.e. the clamped path.
+// NOT ENABLED (build with -DDVP_CLAMP_FREE): the clamp is 2 of ~42 VALU instructions per tap, but a second inlined copy
+// of the 36-tap body next to the first pushes the 256-VGPR kernels into spilling (strong update 7 -> 83 spilled VGPRs,
+// DepthToWeak 0 -> 91): measured at cfg3 (r03) 31.2 Mpx/s/iter with this path against 38.9 without (strong update 712 ->
+// 804 ms, DepthToWeak 633 -> 1032 ms per pass); the clamped copy as a real function call is worse still (1098 / 953 ms).
 DVP_HD bool patch_stays_inside(const float* H, const f2 pt, int px, int py, float r, float fw, float fh) {
 	const float z = H[6] * px + H[7] * py + H[8];
 	const float ez = r * (fabsf(H[6]) + fabsf(H[7]));
@@ -270,12 +267,9 @@ DVP_HD float ncc_old(const Dev& d, const PatchCtx& c, int px, int py, int v, con
 	const f2 pt = apply_homography(H, px, py);
 	if (pt.x >= fw || pt.x < 0.0f || pt.y >= fh || pt.y < 0.0f) return 2.0f;
 	const float* src = d.images + (size_t)uniform_i(v) * d.plane_stride * 2;   // wave-uniform base
-#ifndef DVP_NO_CLAMP_FREE
+#ifdef DVP_CLAMP_FREE
 	if (c.fast && wave_all(patch_stays_inside(H, pt, px, py, (float)c.radius, (float)d.width, (float)d.height)))
 		return ncc_patch_fast<SMP, false>(d, c, H, src, px, py);
-#ifdef DVP_CLAMP_SLOW_NOINLINE
-	if (c.fast) return ncc_patch_clamped<SMP>(d, c, H, src, px, py);
-#endif
 #endif
 	if (c.fast) return ncc_patch_fast<SMP>(d, c, H, src, px, py);
 	return ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 0);

@@ -52,7 +52,7 @@ constexpr int kWeakViews = 7;   // ... and at most this many views (size of the 
 
 // per-wave shared state (LDS on the device), ~8.6 KB
 struct WeakShared {
-	f2 ctab[kTaps * kTaps];        // centre patch: (w, w*ref) per tap, entry g*6+k = x-offset index g, y-offset index k (PatchCtx order)
+	f2 ctab[kTaps * kTaps];        // centre patch: (w, w*ref) per tap, row-major
 	float caa[kTaps * kTaps];      // w*ref*ref per tap (reference moments only)
 	float rows[kWeakPairs][kTaps][3];    // centre-patch row sums (s_s, s_ss, s_rs) per pair (view slot * np + plane) and row; the final-cost section uses pairs 0..7 for 8 views
 	float acost[kWeakPairs][kAnchors];   // anchor cost per (pair, anchor), < 0: does not count
@@ -105,8 +105,8 @@ DVP_HD void wave_patch_ctx(const Dev& d, int px, int py, int radius, int inc, in
 	const float cpix = ref_texel_t<FMT>(d, px, py);
 	DVP_LANES(t) {
 		if (t >= kTaps * kTaps) continue;
-		const int g = t / kTaps, k = t - g * kTaps;      // x-offset index (outer), y-offset index (inner)
-		const int i = -radius + g * inc, j = -radius + k * inc;
+		const int ty = t / kTaps, tx = t - ty * kTaps;
+		const int i = -radius + tx * inc, j = -radius + ty * inc;
 		const float a = ref_texel_t<FMT>(d, px + i, py + j);
 		const float w = bilateral_weight((float)i, (float)j, a, cpix, d.params.sigma_spatial, d.params.sigma_color, colour_only);
 		const float wa = w * a;
@@ -132,20 +132,20 @@ DVP_HD void wave_patch_ctx(const Dev& d, int px, int py, int radius, int inc, in
 	c->wsum = ws;
 }
 
-// one group (one x offset `row`, its 6 y offsets) of the 36-tap patch for homography H: the group's three source-side sums
-// (ncc_patch_fast, dvp_ncc.hpp: same products, same shared division per group, same order)
+// one row (6 taps) of the 36-tap patch for homography H: the row's three source-side sums
+// (ncc_patch_fast, dvp_ncc.hpp: same products, same shared division per row, same order)
 template <int SMP, int FMT>
 DVP_HD void patch_row_sums(const Dev& d, const WeakShared& sh, const float* H, const void* src, int px, int py, int radius, int inc, int row, float* out /*[3]*/) {
 	const int W = d.width, Hh = d.height, P = d.pitch;
-	const float fx = (float)(px - radius + row * inc);
-	const float hx0 = H[0] * fx, hx3 = H[3] * fx, hx6 = H[6] * fx;
+	const float fy = (float)(py - radius + row * inc);
+	const float hy1 = H[1] * fy, hy4 = H[4] * fy, hy7 = H[7] * fy;
 	float X[kTaps], Y[kTaps], Z[kTaps], IZ[kTaps];
 #pragma unroll
 	for (int tx = 0; tx < kTaps; ++tx) {
-		const float fy = (float)(py - radius + tx * inc);
-		X[tx] = hx0 + H[1] * fy + H[2];
-		Y[tx] = hx3 + H[4] * fy + H[5];
-		Z[tx] = hx6 + H[7] * fy + H[8];
+		const float fx = (float)(px - radius + tx * inc);
+		X[tx] = H[0] * fx + hy1 + H[2];
+		Y[tx] = H[3] * fx + hy4 + H[5];
+		Z[tx] = H[6] * fx + hy7 + H[8];
 	}
 	batch_rcp(Z, kTaps, IZ);
 	unsigned off[kTaps];

@@ -23,11 +23,11 @@
 //    divisions of ComputeHomography (by plane.w, K[0], K[4]) and ComputeCorrespondingPoint (by the
 //    projective z) are evaluated as a * (1.0f / b) with a correctly rounded reciprocal, one
 //    reciprocal per distinct divisor.  Every other division is a correctly rounded a / b.
-//  * the NCC tap loops (APD.cu:1059-1089, 905-935) keep the reference's order and structure: x offset
-//    outer, y offset inner, the taps of one x offset summed into partial sums that are then added to
-//    the totals (round 3; rounds 1-2 walked the patch y-outer).  Inside such a group the projective
-//    divide of the six taps is taken through ONE division (batch_rcp, ora_core.h) and the three
-//    source-side moments use one fmaf per tap.  ctx.numerics = 1 switches these loops (and the sampler) to the literal
+//  * the NCC tap loops (APD.cu:1059-1089, 905-935) keep the source's structure (six partial sums of six
+//    taps, added to the totals in order) on the TRANSPOSED walk: row by row (y offset outer, x offset inner;
+//    the source walks x outer, y inner) — see ora_cost.cpp for the measured reason; the projective divide of a row is taken six taps
+//    at a time through ONE division (batch_rcp, ora_core.h); the three source-side moments use one
+//    fmaf per tap.  ctx.numerics = 1 switches these loops (and the sampler) to the literal
 //    per-operator evaluation in the reference's own order; tests/test_oracle_kat.py measures the
 //    distance between the two (NCC costs: 4e-6 median, 5e-4 max).
 //  * exp() is the polynomial dvp_expf below (<= 1 ulp on the ranges used).

@@ -5,10 +5,13 @@
 namespace ora {
 
 // Weighted moments of one square patch around `c` (the tap loops of APD.cu:1059-1089 and 905-935).
-//   numerics 0 (contract): the reference's order — x offset outer, y offset inner, per-x-offset partial
-//     sums added to the totals; the projective divide of the six taps of one x offset is taken through
-//     ONE division (batch_rcp); the three source-side sums use one fused multiply-add per tap (what nvcc's
-//     default -fmad contraction does to `sum += w * b * b`); the sampler takes pixel coordinates.
+//   numerics 0 (contract): the source's STRUCTURE — six partial sums of six taps each, added to the totals in order —
+//     applied to the TRANSPOSED walk: y offset outer, x offset inner (the source walks x outer, y inner).  The walk
+//     is transposed because a row of taps lies in ONE row-pair line of the image planes: walking columns re-fetches
+//     every line six times for lanes with unrelated hypotheses (measured on MI355X, r03: strong update 592 -> 686 ms per
+//     cfg3 pass; NCC costs move by 3e-6 median, contract-vs-literal end to end 2.7 % -> 2.6 % of pixels > 1e-3, i.e.
+//     nothing).  The projective divide of a row is taken six taps at a time (batch_rcp); the three source-side sums use
+//     one fused multiply-add per tap; the sampler takes pixel coordinates.
 //   numerics 1 (literal): the reference's own order — x offset outer, y offset inner, the six taps of
 //     one x offset summed into per-outer-index partials ("sum_*_row") that are then added to the
 //     totals, one division per tap, tex2D(x + 0.5f, y + 0.5f) — every operator rounded once.
@@ -38,26 +41,24 @@ static PatchSums patch_sums(const Ctx& h, const float* ref_image, const float* s
 		}
 		return s;
 	}
-	// contract: the reference's own tap order and partial-sum structure (x offset outer, y offset inner, one partial sum
-	// per x offset added to the totals, APD.cu:1059-1089); what differs from the literal reading is inside a group only
-	for (int i = -radius; i <= radius; i += increment) {
+	for (int j = -radius; j <= radius; j += increment) {
 		PatchSums r = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
-		for (int j0 = -radius; j0 <= radius; j0 += 6 * increment) {
+		for (int i0 = -radius; i0 <= radius; i0 += 6 * increment) {
 			float X[6], Y[6], Z[6], IZ[6];
 			int off[6];
 			int n = 0;
-			for (int j = j0; j <= radius && n < 6; j += increment, ++n) {
+			for (int i = i0; i <= radius && n < 6; i += increment, ++n) {
 				const int2 q = make_int2(c.x + i, c.y + j);
 				X[n] = H[0] * q.x + H[1] * q.y + H[2];   // ComputeCorrespondingPoint, APD.cu:744-746
 				Y[n] = H[3] * q.x + H[4] * q.y + H[5];
 				Z[n] = H[6] * q.x + H[7] * q.y + H[8];
-				off[n] = j;
+				off[n] = i;
 			}
 			batch_rcp(Z, n, IZ);
 			for (int k = 0; k < n; ++k) {
-				const float ref_pix = tex_texel(ref_image, W, Hh, c.x + i, c.y + off[k]);
+				const float ref_pix = tex_texel(ref_image, W, Hh, c.x + off[k], c.y + j);
 				const float src_pix = tex_linear(src_image, W, Hh, X[k] * IZ[k], Y[k] * IZ[k], h.sampler);
-				const float weight = weight_of((float)i, (float)off[k], ref_pix);
+				const float weight = weight_of((float)off[k], (float)j, ref_pix);
 				const float wa = weight * ref_pix, wb = weight * src_pix;
 				r.ref += wa;
 				r.ref_ref += wa * ref_pix;
