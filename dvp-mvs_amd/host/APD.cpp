@@ -27,6 +27,10 @@ namespace {
 struct ImageEntry { Mat image; int orig_cols = 0, orig_rows = 0; uint64_t used = 0; };
 using ImageKey = std::tuple<std::string, int, int, int>;   // file, scale, pad width, pad height
 std::map<ImageKey, ImageEntry> g_img_cache;
+// decoded 8-bit images (one per file, all pyramid levels are made from it): a 25 Mpx JPEG takes ~0.3 s to decode and the
+// schedule visits every image once per level
+std::map<std::string, Mat> g_decoded;
+size_t g_decoded_bytes = 0;
 std::recursive_mutex g_img_cache_mutex;   // the driver's background worker (edge maps of the next view) shares the cache
 size_t g_img_cache_capacity = 96;
 uint64_t g_img_cache_clock = 0;
@@ -57,6 +61,8 @@ void APD::ReleasePooledContext() {
 	g_pool.ctx = nullptr;
 	std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
 	g_img_cache.clear();
+	g_decoded.clear();
+	g_decoded_bytes = 0;
 }
 
 
@@ -66,6 +72,17 @@ void APD::ReleasePooledContext() {
 static ImageKey image_key(const Problem& problem, int image_id, int pad_w, int pad_h) {
 	const path file = problem.dense_folder / path("images") / path(ToFormatIndex(image_id) + ".jpg");
 	return ImageKey{ file.string(), problem.scale_size, pad_w, pad_h };
+}
+Mat APD::DecodedGray(const path& file) {
+	std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
+	auto dit = g_decoded.find(file.string());
+	if (dit != g_decoded.end()) return dit->second;
+	Mat image_uint = ReadImageGray(file);
+	if (!image_uint.empty() && g_decoded_bytes + image_uint.step * image_uint.rows <= ((size_t)8 << 30)) {
+		g_decoded[file.string()] = image_uint;
+		g_decoded_bytes += image_uint.step * image_uint.rows;
+	}
+	return image_uint;
 }
 static ImageEntry load_image(const Problem& problem, int image_id, int pad_w, int pad_h, bool is_ref) {
 	std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
@@ -77,11 +94,12 @@ static ImageEntry load_image(const Problem& problem, int image_id, int pad_w, in
 		if (ir != g_img_cache.end() && ir->second.orig_cols == pad_w && ir->second.orig_rows == pad_h) { ir->second.used = ++g_img_cache_clock; return ir->second; }
 	}
 	make_room(problem.scale_size);
-	const Mat image_uint = ReadImageGray(std::get<0>(key));
+	const Mat image_uint = APD::DecodedGray(std::get<0>(key));
 	if (image_uint.empty()) DvpFatal(std::string("Can't read ") + (is_ref ? "reference" : "source") + " image " + std::to_string(image_id));
 	// uint8 -> float; a source image is zero-padded / cropped to the reference size (APD.cpp:1059, 1071-1079)
 	const int fw = is_ref ? image_uint.cols : pad_w, fh = is_ref ? image_uint.rows : pad_h;
 	Mat f = Mat::zeros(fh, fw, CV_32FC1);
+#pragma omp parallel for schedule(static) num_threads(8)
 	for (int r = 0; r < std::min(fh, image_uint.rows); ++r) {
 		const uint8_t* s = image_uint.ptr<uint8_t>(r);
 		float* d = f.ptr<float>(r);

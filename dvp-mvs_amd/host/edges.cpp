@@ -148,7 +148,7 @@ void GetProblemEdges(const Problem& problem, const std::vector<path>& outputs) {
 		if (need_edge) PublishResult(edge_path, Mat());
 	};
 	if (need_label) {   // from the full-size image (main.cpp:236)
-		Mat image_uint = ReadImageGray(problem.dense_folder / path("images") / path(ToFormatIndex(problem.ref_image_id) + ".jpg"));
+		const Mat image_uint = APD::DecodedGray(problem.dense_folder / path("images") / path(ToFormatIndex(problem.ref_image_id) + ".jpg"));
 		if (image_uint.empty()) { publish_empty(); return; }
 		PublishResult(label_path, EdgeSegment(scale, image_uint, 1));
 		need_label = false;

@@ -143,15 +143,19 @@ void RescaleMatToTargetSize(const Mat& src, Mat& dst, int tw, int th) {
 	if (src.cols == tw && src.rows == th) return;
 	const float scale_x = tw / static_cast<float>(src.cols);
 	const float scale_y = th / static_cast<float>(src.rows);
-	Mat src_clone = src.clone();
+	const Mat src_clone = src;   // shares the buffer: `out` is a fresh one, so src == dst is fine
 	Mat out = Mat::zeros(th, tw, src.type());
-	for (int r = 0; r < th; ++r)
+	// (the reference divides the row index by scale_x and the column index by scale_y, APD.cpp:1787-1788: kept)
+#pragma omp parallel for schedule(static) num_threads(8)
+	for (int r = 0; r < th; ++r) {
+		const int o_r = static_cast<int>(r / scale_x);
+		if (o_r < 0 || o_r >= src_clone.rows) continue;
 		for (int c = 0; c < tw; ++c) {
-			int o_r = static_cast<int>(r / scale_x);
-			int o_c = static_cast<int>(c / scale_y);
-			if (o_r < 0 || o_c < 0 || o_r >= src_clone.rows || o_c >= src_clone.cols) continue;
+			const int o_c = static_cast<int>(c / scale_y);
+			if (o_c < 0 || o_c >= src_clone.cols) continue;
 			out.at<TYPE>(r, c) = src_clone.at<TYPE>(o_r, o_c);
 		}
+	}
 	dst = out;
 }
 template void RescaleMatToTargetSize<float>(const Mat&, Mat&, int, int);
@@ -238,6 +242,7 @@ Mat ResizeLinear(const Mat& src, int new_cols, int new_rows) {
 		x0[dx] = ix;
 		ax[dx] = fx;
 	}
+#pragma omp parallel for schedule(static) num_threads(8)
 	for (int dy = 0; dy < new_rows; ++dy) {
 		float fy = (float)((dy + 0.5) * sy - 0.5);
 		int iy = (int)std::floor(fy);
