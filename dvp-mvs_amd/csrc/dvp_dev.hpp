@@ -316,7 +316,7 @@ DVP_HD void tap_weights(const TapW<0>& w, float* a, float* b) {
 }
 DVP_HD void tap_weights(const TapW<1>& w, float* a, float* b) { *a = w.a; *b = w.b; }
 
-DVP_HD unsigned tex_offset(int pitch, int i0, int j0) {
+DVP_HD unsigned tex_offset(int pitch, int i0, int j0, unsigned plane_off = 0) {
 	// i0 in [-1, W], j0 in [-1, H]: the footprint [i0, i0+1] x [j0, j0+1] lies inside the padded
 	// plane; (j0 + PAD) * pitch + (i0 + PAD) >= 0, the PAD terms are a wave-uniform constant
 	// |j0|, pitch < 2^23: 24-bit multiply (v_mad_i32_i24, full rate; a 32-bit multiply is quarter rate)
@@ -325,7 +325,7 @@ DVP_HD unsigned tex_offset(int pitch, int i0, int j0) {
 #else
 	const int e = j0 * pitch + i0;
 #endif
-	return ((unsigned)e << 3) + (unsigned)((kImgPad * pitch + kImgPad) * 8);
+	return ((unsigned)e << 3) + ((unsigned)((kImgPad * pitch + kImgPad) * 8) + plane_off);   // plane_off: byte offset of the lane's image plane when the base is the whole image set (probe)
 }
 // coordinate -> integer footprint origin (i0, j0) + the two interpolation weights.
 // CLAMP = false: the caller has PROVEN -1 <= x <= W and -1 <= y <= H (patch_stays_inside, dvp_ncc.hpp), for which the
@@ -351,10 +351,10 @@ DVP_HD void tex_origin(int W, int H, float x, float y, int* i0, int* j0, TapW<1>
 	*j0 = (int)fy;
 }
 template <int SMP, bool CLAMP = true>
-DVP_HD void tex_coord(int pitch, int W, int H, float x, float y, unsigned* off, TapW<SMP>* w) {
+DVP_HD void tex_coord(int pitch, int W, int H, float x, float y, unsigned* off, TapW<SMP>* w, unsigned plane_off = 0) {
 	int i0, j0;
 	tex_origin<CLAMP>(W, H, x, y, &i0, &j0, w);
-	*off = tex_offset(pitch, i0, j0);
+	*off = tex_offset(pitch, i0, j0, plane_off);
 }
 // the same for a plane of format FMT
 template <int FMT, int SMP>

@@ -419,6 +419,94 @@ extern "C" __global__ void __launch_bounds__(256) dvp_cost_all_pixels(const Dev 
 	out[center] = acc / S;
 }
 
+
+#ifdef DVP_PROBE
+// ---- mapping probe (experiment, not part of the product): K evaluations x S views per pixel with the planes of pixels
+// `stride` apart, (A) lane = pixel like the NCC kernels, (B) lane = (pixel, view): 64 / S x-adjacent pixels per wave, the
+// patch table of a pixel shared by its S lanes in LDS.
+#ifndef DVP_PROBE_LB
+#define DVP_PROBE_LB 2
+#endif
+extern "C" __global__ void __launch_bounds__(256, 2) dvp_probe_a(const Dev d, const LaunchArgs a, float* out, int K, int stride) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	int px, py;
+	if (!block_to_pixel(blockIdx.x, lane, wave, a.tiles_x, a.tiles, a.rows, 0, 0, d.width, d.height, &px, &py)) return;
+	const int center = px + py * d.width;
+	const int S = d.num_images - 1, L = d.width * d.height;
+	PatchCtx c;
+	__shared__ f2 lds_tab[kTaps * kTaps * 256];
+	int radius, inc;
+	patch_geometry(d, center, &radius, &inc);
+	build_patch_ctx(d, px, py, radius, inc, 0, PatchTab{&lds_tab[threadIdx.x], 256}, &c);
+	float acc = 0.0f;
+	for (int k = 0; k < K; ++k) {
+		int q = center + (k - K / 2) * stride;
+		q = q < 0 ? 0 : (q >= L ? L - 1 : q);
+		const f4 pl = d.planes[q];
+		for (int v = 0; v < S; ++v) acc += ncc_old<0>(d, c, px, py, v + 1, pl);
+	}
+	out[center] = acc;
+}
+extern "C" __global__ void __launch_bounds__(256, DVP_PROBE_LB) dvp_probe_b(const Dev d, float* out, int K, int stride) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int S = d.num_images - 1, L = d.width * d.height;
+	const int P = 64 / S;                                // pixels per wave
+	const int waves_x = (d.width + P - 1) / P;
+	const int gw = blockIdx.x * 4 + wave;
+	const int py = gw / waves_x, x0 = (gw - py * waves_x) * P;
+	if (py >= d.height) return;
+	__shared__ f2 tab[4][9 * 36];                         // [wave][pixel][tap] (P <= 9... here P * 36 <= 324 for S >= 7)
+	__shared__ float caa[4][9 * 36];
+	__shared__ float sums[4][9][3];
+	const int v = lane / P, pi = lane - v * P;           // lanes of one view are contiguous
+	const int px = x0 + pi;
+	const bool active = v < S && px < d.width;
+	const int radius = d.params.strong_radius, inc = d.params.strong_increment;
+	// table: entry e = pixel * 36 + tap, built by whichever lane
+	for (int e = lane; e < P * 36; e += 64) {
+		const int pe = e / 36, t = e - pe * 36, ty = t / 6, tx = t - ty * 6;
+		const int qx = x0 + pe < d.width ? x0 + pe : d.width - 1;
+		const float cpix = img_texel(d.images, d.org, d.pitch, d.width, d.height, qx, py);
+		const float av = img_texel(d.images, d.org, d.pitch, d.width, d.height, qx - radius + tx * inc, py - radius + ty * inc);
+		const float w = bilateral_weight((float)(-radius + tx * inc), (float)(-radius + ty * inc), av, cpix, d.params.sigma_spatial, d.params.sigma_color, 0);
+		tab[wave][e] = mk2(w, w * av);
+		caa[wave][e] = w * av * av;
+	}
+	__builtin_amdgcn_wave_barrier();
+	if (lane < P) {
+		float sr = 0.0f, srr = 0.0f, ws = 0.0f;
+		for (int ty = 0; ty < 6; ++ty) {
+			float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+			for (int tx = 0; tx < 6; ++tx) { const f2 t = tab[wave][lane * 36 + ty * 6 + tx]; a0 += t.y; a1 += caa[wave][lane * 36 + ty * 6 + tx]; a2 += t.x; }
+			sr += a0; srr += a1; ws += a2;
+		}
+		sums[wave][lane][0] = sr; sums[wave][lane][1] = srr; sums[wave][lane][2] = ws;
+	}
+	__builtin_amdgcn_wave_barrier();
+	if (!active) return;
+	PatchCtx c;
+	c.tab = PatchTab{&tab[wave][pi * 36], 1};
+	c.sum_ref = sums[wave][pi][0]; c.sum_ref_ref = sums[wave][pi][1]; c.wsum = sums[wave][pi][2];
+	c.radius = radius; c.inc = inc; c.fast = 1;
+	const ViewConst vc = d.views[v + 1];                  // per-lane record (vector loads)
+	const unsigned plane_off = (unsigned)((size_t)(v + 1) * d.plane_stride * 2 * sizeof(float));
+	const int center = px + py * d.width;
+	float acc = 0.0f;
+	for (int k = 0; k < K; ++k) {
+		int q = center + (k - K / 2) * stride;
+		q = q < 0 ? 0 : (q >= L ? L - 1 : q);
+		const f4 pl = d.planes[q];
+		float H[9];
+		homography(vc, pl, H);
+		const f2 pt = apply_homography(H, px, py);
+		if (pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f) { acc += 2.0f; continue; }
+		acc += ncc_patch_fast<0>(d, c, H, d.images, px, py, plane_off);
+	}
+	atomicAdd(&out[center], acc);
+}
+extern "C" int dvp_probe(dvp_ctx* c, int mode, int K, int stride, int repeat, float* mean_ms, float* checksum);
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
@@ -1203,5 +1291,37 @@ int dvp_bench_cost_kernel(dvp_ctx* c, int repeat, float* mean_kernel_ms, uint64_
 	if (evals_per_launch) *evals_per_launch = (uint64_t)c->L * (uint64_t)(c->NI - 1);
 	return 0;
 }
+
+#ifdef DVP_PROBE
+int dvp_probe(dvp_ctx* c, int mode, int K, int stride, int repeat, float* mean_ms, float* checksum) {
+	if (set_device(c)) return 1;
+	const LaunchGeom g = make_geom(c->W, c->H, false);
+	LaunchArgs a;
+	a.tiles_x = g.tiles_x; a.tiles = g.tiles; a.rows = g.rows; a.half = 0; a.colour = 0; a.iter = 0;
+	const int S = c->NI - 1, P = 64 / S;
+	const int waves = ((c->W + P - 1) / P) * c->H;
+	EventPairGuard ev;
+	HIP_TRY(c, hipEventCreate(&ev.a));
+	HIP_TRY(c, hipEventCreate(&ev.b));
+	for (int i = 0; i <= repeat; ++i) {
+		if (i == 1) HIP_TRY(c, hipEventRecord(ev.a, c->stream));
+		HIP_TRY(c, hipMemsetAsync(c->scratch_out, 0, c->L * 4, c->stream));
+		if (mode == 0) hipLaunchKernelGGL(dvp_probe_a, dim3(g.grid()), dim3(256), 0, c->stream, c->d, a, c->scratch_out, K, stride);
+		else hipLaunchKernelGGL(dvp_probe_b, dim3((waves + 3) / 4), dim3(256), 0, c->stream, c->d, c->scratch_out, K, stride);
+	}
+	HIP_TRY(c, hipEventRecord(ev.b, c->stream));
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	float ms = 0.0f;
+	HIP_TRY(c, hipEventElapsedTime(&ms, ev.a, ev.b));
+	*mean_ms = ms / repeat;
+	std::vector<float> h(c->L);
+	HIP_TRY(c, hipMemcpy(h.data(), c->scratch_out, c->L * 4, hipMemcpyDeviceToHost));
+	double sum = 0;
+	for (float v : h) sum += v;
+	*checksum = (float)(sum / (double)c->L);
+	return 0;
+}
+#endif
 
 }  // extern "C"

@@ -160,7 +160,7 @@ DVP_HD float ncc_patch_generic(const Dev& d, const float* H, const float* src, i
 // CLAMP = false: every tap's source coordinate is known to lie in [-1, W] x [-1, H] (patch_stays_inside) — the sampler's
 // clamp is then the identity and is left out; results are the same bits.
 template <int SMP, bool CLAMP = true>
-DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, const float* src, int px, int py) {
+DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, const float* src, int px, int py, unsigned plane_off = 0) {
 	const int W = d.width, Hh = d.height, P = d.pitch;
 	// H[k]*x and H[k]*y products for the 6 distinct tap columns / rows: same products the
 	// reference forms per tap (H[0]*p.x + H[1]*p.y + H[2], APD.cu:744-746), formed once.
@@ -196,7 +196,7 @@ DVP_HD float ncc_patch_fast(const Dev& d, const PatchCtx& c, const float* H, con
 		}                                                                                           \
 		batch_rcp(Z, kTaps, IZ);                                                                    \
 		_Pragma("unroll") for (int tx = 0; tx < kTaps; ++tx)                                        \
-			tex_coord<SMP, CLAMP>(P, W, Hh, X[tx] * IZ[tx], Y[tx] * IZ[tx], &off[BUF][tx], &tw[BUF][tx]); \
+			tex_coord<SMP, CLAMP>(P, W, Hh, X[tx] * IZ[tx], Y[tx] * IZ[tx], &off[BUF][tx], &tw[BUF][tx], plane_off); \
 	}
 #define DVP_ISSUE(BUF)                                                                              \
 	_Pragma("unroll") for (int k = 0; k < kTaps; ++k)                                               \

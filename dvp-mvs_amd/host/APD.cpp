@@ -99,7 +99,7 @@ static ImageEntry load_image(const Problem& problem, int image_id, int pad_w, in
 	// uint8 -> float; a source image is zero-padded / cropped to the reference size (APD.cpp:1059, 1071-1079)
 	const int fw = is_ref ? image_uint.cols : pad_w, fh = is_ref ? image_uint.rows : pad_h;
 	Mat f = Mat::zeros(fh, fw, CV_32FC1);
-#pragma omp parallel for schedule(static) num_threads(8)
+#pragma omp parallel for schedule(static) num_threads(HostThreads())
 	for (int r = 0; r < std::min(fh, image_uint.rows); ++r) {
 		const uint8_t* s = image_uint.ptr<uint8_t>(r);
 		float* d = f.ptr<float>(r);
@@ -245,7 +245,7 @@ void APD::InuputInitialization() {
 			std::cout << "Scale done\n";
 		}
 		long long wc = 0;
-#pragma omp parallel for reduction(+ : wc) schedule(static) num_threads(8)
+#pragma omp parallel for reduction(+ : wc) schedule(static) num_threads(HostThreads())
 		for (int r = 0; r < height; ++r) {
 			const uint8_t* row = weak_info_host.ptr<uint8_t>(r);
 			for (int c = 0; c < width; ++c) wc += row[c] == WEAK;
@@ -283,7 +283,7 @@ void APD::InuputInitialization() {
 			std::cerr << "Select view doesn't match the images' size!\n";
 			RescaleMatToTargetSize<unsigned int>(selected_views_host, selected_views_host, width, height);
 		}
-#pragma omp parallel for schedule(static) num_threads(8)
+#pragma omp parallel for schedule(static) num_threads(HostThreads())
 		for (int row = 0; row < height; ++row) {
 			const float* z = depth.ptr<float>(row);
 			const Vec3f* n = normal.ptr<Vec3f>(row);
@@ -337,7 +337,7 @@ void APD::SupportInitialization() {
 		const uint8_t* state = weak_info_host.ptr<uint8_t>(0);
 		int* rad = radius_host.ptr<int>(0);
 		const long long npx = (long long)width * height;
-#pragma omp parallel for schedule(static) num_threads(8)
+#pragma omp parallel for schedule(static) num_threads(HostThreads())
 		for (long long i = 0; i < npx; ++i)
 			if (state[i] == UNKNOWN) rad[i] = fallback;   // a pixel that lost its estimate restarts with the default patch
 	}

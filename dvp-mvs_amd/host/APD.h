@@ -46,6 +46,8 @@ Mat LabelSegment(const int scale, const Mat& src_image);   // EdgeSegment mode 1
 Mat ReadImageGray(const path& image_path_jpg);      // stands in for cv::imread(IMREAD_GRAYSCALE), APD.cpp:1057
 Mat ReadImageColor(const path& image_path_jpg);     // cv::imread(IMREAD_COLOR) (BGR), APD.cpp:1842
 Mat ResizeLinear(const Mat& src_f32, int new_cols, int new_rows);   // cv::resize(INTER_LINEAR), APD.cpp:1129
+// threads of the host-side pixel loops: min(32, hardware threads), DVP_HOST_THREADS overrides
+int HostThreads();
 // write-back cache of the per-view result files + background workers (host/store.cpp)
 void SetResultCache(bool enabled, size_t limit_bytes = 0);   // default: on, 32 GiB
 void PublishResult(const path& file, const Mat& m);          // keep in memory + write in the background (.part + rename); `m` must not be modified afterwards

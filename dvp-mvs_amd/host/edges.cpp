@@ -161,7 +161,7 @@ void GetProblemEdges(const Problem& problem, const std::vector<path>& outputs) {
 	if (scaled.empty()) { publish_empty(); return; }
 	const int new_cols = scaled.cols, new_rows = scaled.rows;
 	Mat u8(new_rows, new_cols, CV_8UC1);   // convertTo(CV_8UC1): round to nearest, saturate
-#pragma omp parallel for schedule(static) num_threads(8)
+#pragma omp parallel for schedule(static) num_threads(HostThreads())
 	for (int r = 0; r < new_rows; ++r)
 		for (int c = 0; c < new_cols; ++c) u8.at<uint8_t>(r, c) = (uint8_t)std::min(255L, std::max(0L, std::lrintf(scaled.at<float>(r, c))));
 	Mat edge = EdgeSegment(scale, u8, 0, true);

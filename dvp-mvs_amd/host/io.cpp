@@ -3,6 +3,7 @@
 // (APD.cpp:651-692), binary PLY (APD.cpp:842-882), PNM images, bilinear resize, nearest rescale.
 #include "APD.h"
 #include <cstring>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 
@@ -146,7 +147,7 @@ void RescaleMatToTargetSize(const Mat& src, Mat& dst, int tw, int th) {
 	const Mat src_clone = src;   // shares the buffer: `out` is a fresh one, so src == dst is fine
 	Mat out = Mat::zeros(th, tw, src.type());
 	// (the reference divides the row index by scale_x and the column index by scale_y, APD.cpp:1787-1788: kept)
-#pragma omp parallel for schedule(static) num_threads(8)
+#pragma omp parallel for schedule(static) num_threads(HostThreads())
 	for (int r = 0; r < th; ++r) {
 		const int o_r = static_cast<int>(r / scale_x);
 		if (o_r < 0 || o_r >= src_clone.rows) continue;
@@ -242,7 +243,7 @@ Mat ResizeLinear(const Mat& src, int new_cols, int new_rows) {
 		x0[dx] = ix;
 		ax[dx] = fx;
 	}
-#pragma omp parallel for schedule(static) num_threads(8)
+#pragma omp parallel for schedule(static) num_threads(HostThreads())
 	for (int dy = 0; dy < new_rows; ++dy) {
 		float fy = (float)((dy + 0.5) * sy - 0.5);
 		int iy = (int)std::floor(fy);
@@ -261,6 +262,15 @@ Mat ResizeLinear(const Mat& src, int new_cols, int new_rows) {
 		}
 	}
 	return dst;
+}
+
+int HostThreads() {
+	static const int n = [] {
+		if (const char* e = std::getenv("DVP_HOST_THREADS")) return std::max(1, std::atoi(e));
+		const unsigned hw = std::thread::hardware_concurrency();
+		return (int)std::min(32u, std::max(1u, hw));
+	}();
+	return n;
 }
 
 static void (*g_fatal_hook)(const char*) = nullptr;

@@ -142,7 +142,7 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	Mat radius = problem.params.use_radius ? APD.GetRadiusMap() : Mat();
 	// planes -> depth / normal maps; depths outside the admissible range are dropped and the pixel loses
 	// its state (main.cpp:300-309)
-#pragma omp parallel for schedule(static) num_threads(8)
+#pragma omp parallel for schedule(static) num_threads(HostThreads())
 	for (int r = 0; r < height; ++r) {
 		float* z = depth.ptr<float>(r);
 		Vec3f* n = normal.ptr<Vec3f>(r);
@@ -190,7 +190,7 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 				for (int c = 0; c < width; ++c) f[c] = (lab[c] != 0 && region_size[lab[c]] >= min_region) ? 0 : 1;
 			}
 		}
-#pragma omp parallel for schedule(static) num_threads(8)
+#pragma omp parallel for schedule(static) num_threads(HostThreads())
 		for (int r = 0; r < height; ++r) {
 			uint32_t* w = views.ptr<uint32_t>(r);
 			for (int c = 0; c < width; ++c) {
