@@ -16,7 +16,9 @@ def draw_config(rng):
     W = int(rng.integers(40, 120))
     H = int(rng.integers(34, 90))
     S = int(rng.integers(1, 6))
-    sc = synth.make_scene(W, H, S, seed=int(rng.integers(0, 1 << 30)))
+    # every draw has its own rotated rig (per-view R, K, centre); half of them with a skew K[1] != 0, which only
+    # ProjectonCamera_cu reads (geometric term, random normals) while ComputeHomography / Get3DPoint ignore it
+    sc = synth.make_scene(W, H, S, seed=int(rng.integers(0, 1 << 30)), skew=float(rng.choice([0.0, 0.4, 1.5])))
     state = int(rng.choice([synth.FIRST_INIT, synth.REFINE_INIT, synth.REFINE_ITER]))
     geom = int(state == synth.REFINE_ITER and rng.random() < 0.7)
     p = make_params(S + 1, max_iterations=int(rng.integers(1, 3)), state=state, use_APD=int(state != synth.FIRST_INIT),
