@@ -47,38 +47,31 @@ PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_r03.json")
 
 
 def csrc_sha256():
-    """Hash of the kernel sources the loaded library was built from (csrc/*.hip, *.hpp, *.inc, Makefile).  The PMC table
-    records the hash of the tree its counters were collected on; counters of another tree are refused."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "dvp-mvs_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.inc")) + [os.path.join(d, "Makefile")]):
-        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
-    return h.hexdigest()
+    """Hash of the kernel sources in the tree (tools/csrc_hash.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import csrc_hash
+    return csrc_hash.csrc_sha256()
 
 
 _PMC_CACHE = {}
+LOADED_BUILD_ID = None    # dvp_build_id() of the library the timed context runs on (set in main)
 
 
 def pmc_table():
-    """(table or None, note).  None when the file is absent, or was collected on other kernel sources than the ones in
-    the tree, or the built library is older than those sources (then nothing says what code ran)."""
+    """(table or None, note).  The counters are only used when the table was collected on exactly the kernel sources the
+    LOADED library was built from (the library embeds their hash); anything else — no table, another tree, a variant
+    build — gives None and the bench line says why."""
     if "t" in _PMC_CACHE:
         return _PMC_CACHE["t"]
     res = (None, "no PMC table (%s)" % os.path.relpath(PMC_TABLE, ROOT))
     try:
         t = json.load(open(PMC_TABLE))
-        sha = csrc_sha256()
-        lib = os.path.join(ROOT, "dvp-mvs_amd", "libdvp_mvs_hip.so")
-        import glob
-        newest = max(os.path.getmtime(f) for f in glob.glob(os.path.join(ROOT, "dvp-mvs_amd", "csrc", "*")))
-        if t.get("csrc_sha256") != sha:
-            res = (None, "PMC table refused: collected on csrc sha256 %s, tree is %s" % (str(t.get("csrc_sha256"))[:12], sha[:12]))
-        elif os.path.getmtime(lib) + 1.0 < newest:
-            res = (None, "PMC table refused: libdvp_mvs_hip.so is older than csrc/ (rebuild)")
+        if LOADED_BUILD_ID is None:
+            res = (None, "PMC table not consulted: library build id unknown")
+        elif t.get("csrc_sha256") != LOADED_BUILD_ID:
+            res = (None, "PMC table refused: collected on csrc sha256 %s, the loaded library was built from %s" % (str(t.get("csrc_sha256"))[:12], LOADED_BUILD_ID[:24]))
         else:
-            res = (t, "csrc sha256 %s" % sha[:12])
+            res = (t, "csrc sha256 %s" % LOADED_BUILD_ID[:12])
     except Exception as e:   # missing / unreadable table
         res = (None, "no usable PMC table: %s" % e)
     _PMC_CACHE["t"] = res
@@ -309,6 +302,8 @@ def main():
     del sids, flats, edge_t, label_t
 
     ctx = capi.Context(W, H, NI, device=local_rank)
+    global LOADED_BUILD_ID
+    LOADED_BUILD_ID = ctx.L.dvp_build_id().decode()
     ctx.set_images_device([imgs[i].data_ptr() for i in order], W)
     global IMAGE_FORMAT
     IMAGE_FORMAT = ctx.image_format()   # 1: 8-bit exact image set, the weak update reads the byte planes
@@ -412,6 +407,7 @@ def main():
             "ncc_evals_per_step": {k: int(v) for k, v in evals["ncc_evals"].items() if v > 0},
             "Gevals_per_s": {k: round(evals["ncc_evals"][k] / (tm["stage_ms"][k] / args.steps * 1e-3) / 1e9, 3)
                              for k in evals["ncc_evals"] if evals["ncc_evals"][k] > 0 and tm["stage_ms"][k] > 0},
+            "library_build_id": LOADED_BUILD_ID,
             "rank_busy_ms_per_step": [round(b / args.steps * 1e3, 1) for b in busy_all],
             "setup_s": round(t_setup, 1),
         }

@@ -32,7 +32,7 @@ EXPORTS = ["dvp_ctx_create", "dvp_ctx_destroy", "dvp_last_error", "dvp_upload_im
            "dvp_reset_state", "dvp_save_state", "dvp_restore_state", "dvp_set_params", "dvp_set_seed", "dvp_set_sampler", "dvp_set_profiling", "dvp_image_format", "dvp_run_patchmatch",
            "dvp_run_stage", "dvp_synchronize", "dvp_download_state", "dvp_buffer_bytes", "dvp_download_buffer",
            "dvp_upload_buffer", "dvp_weak_count", "dvp_get_timings", "dvp_reset_timings", "dvp_eval_cost_vectors",
-           "dvp_bench_cost_kernel"]
+           "dvp_bench_cost_kernel", "dvp_build_id"]
 
 
 class DvpTimings(ctypes.Structure):
@@ -84,6 +84,8 @@ def lib():
         L.dvp_get_timings.argtypes = [vp, ctypes.POINTER(DvpTimings)]
         L.dvp_reset_timings.argtypes = [vp]
         L.dvp_eval_cost_vectors.argtypes = [vp, vp, vp, ci, vp, ctypes.POINTER(ctypes.c_float)]
+        L.dvp_build_id.restype = ctypes.c_char_p
+        L.dvp_build_id.argtypes = []
         L.dvp_bench_cost_kernel.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64)]
         _LIB = L
     return _LIB

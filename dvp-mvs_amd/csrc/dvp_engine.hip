@@ -712,6 +712,11 @@ int dvp_ctx_destroy(dvp_ctx* c) {
 	return 0;
 }
 
+#ifndef DVP_BUILD_ID
+#define DVP_BUILD_ID "unknown"
+#endif
+const char* dvp_build_id(void) { return DVP_BUILD_ID; }
+
 const char* dvp_last_error(const dvp_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
 
 // `pairs` != nullptr: `dst` is the staging set and the row-pair planes are produced from it

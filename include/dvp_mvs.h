@@ -198,6 +198,8 @@ int dvp_eval_cost_vectors(dvp_ctx* ctx, const int32_t* px, const float* planes, 
                           float* kernel_ms);
 /* device-resident variant for benchmarking: same computation on every pixel of the image with
  * plane = current plane_hypotheses (camera frame), `repeat` launches; returns the mean kernel ms */
+/* sha256 of the kernel sources the library was built from (tools/csrc_hash.py), + the extra flags of a variant build */
+const char* dvp_build_id(void);
 int dvp_bench_cost_kernel(dvp_ctx* ctx, int repeat, float* mean_kernel_ms, uint64_t* evals_per_launch);
 
 #ifdef __cplusplus

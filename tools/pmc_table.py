@@ -46,6 +46,13 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     sha = bench.csrc_sha256()
+    ids = set()
+    for name in ("fetch", "write", "sq1", "sq2"):   # the library that produced the counters must be the tree's
+        js = os.path.join(out, name + ".json")
+        if os.path.exists(js):
+            ids.add(json.loads(open(js).read().strip().splitlines()[-1]).get("library_build_id"))
+    if ids and ids != {sha}:
+        raise SystemExit("PMC passes ran on library build(s) %s, the tree's kernel sources hash to %s: rebuild first" % (sorted(map(str, ids)), sha))
     table = {"notes": __doc__.split("Units and corrections")[1].strip(), "kernels": {}, "csrc_sha256": sha}
     if os.path.exists(table_path):
         old = json.load(open(table_path))
