@@ -54,6 +54,7 @@ def csrc_sha256():
 
 
 _PMC_CACHE = {}
+RIG = "rotated"
 LOADED_BUILD_ID = None    # dvp_build_id() of the library the timed context runs on (set in main)
 
 
@@ -170,6 +171,8 @@ def pmc_lookup(kernel, W, H, S):
     """PMC counters of `kernel` at exactly this problem size (profiles/pmc_r03.json, written by
     tools/pmc_table.py from separate rocprofv3 --pmc passes of this bench ON THE SAME KERNEL SOURCES) or None."""
     t, _ = pmc_table()
+    if RIG != "rotated":     # the table is collected on the default workload
+        return None
     return t["kernels"].get("%s|%dx%d|S%d" % (kernel, W, H, S)) if t else None
 
 
@@ -302,7 +305,8 @@ def main():
     del sids, flats, edge_t, label_t
 
     ctx = capi.Context(W, H, NI, device=local_rank)
-    global LOADED_BUILD_ID
+    global LOADED_BUILD_ID, RIG
+    RIG = args.rig
     LOADED_BUILD_ID = ctx.L.dvp_build_id().decode()
     ctx.set_images_device([imgs[i].data_ptr() for i in order], W)
     global IMAGE_FORMAT
@@ -392,7 +396,7 @@ def main():
             "metric": "Mpixels/sec/PatchMatch-iteration", "value": round(value, 3), "unit": "Mpx/s/iter",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (procedural texture quantised to 8-bit grey levels, as decoded image files are; image_format=%d)" % IMAGE_FORMAT,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (procedural texture quantised to 8-bit grey levels, as decoded image files are; image_format=%d; camera rig: %s)" % (IMAGE_FORMAT, "per-view rotations 5-30 deg, per-view K" if args.rig == "rotated" else "R = I, one K (round-1/2 rig)"),
             "config": {"workload": workload + ", one reference view per step per GPU", "baseline_config": args.config,
                        "width": W, "height": H, "src_views": S, "iterations": iters, "weak_fraction": round(weak_frac, 4),
                        "parallelism": "rank r takes view r mod %d of the scene as its reference view; %d rank(s), no data-path collective" % (NI, world)},
