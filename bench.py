@@ -83,8 +83,22 @@ def pmc_table():
 IMAGE_FORMAT = 0   # dvp_image_format of the timed context (1: the weak update reads byte planes)
 
 
+def decide_kernel(S):
+    return "dvp_strong_decide_v%d" % next(m for m in (4, 6, 8, 10, 12, 16) if S <= m)
+
+
+def extra_kernels(stage, S):
+    """the other kernels a launch site's timer covers (their counters are added to the first one's)"""
+    if stage == "gen_neighbours":
+        return ["dvp_gen_neighbours_fit"]       # (dvp_gen_candidates runs on the side stream, outside its launch site's timer)
+    if stage == "strong_update" and S <= 16 and os.environ.get("DVP_STRONG_SPLIT", "1") != "0":
+        return [decide_kernel(S), "dvp_strong_refine"]
+    return []
+
+
 def kernel_name(stage, S):
-    return {"strong_update": "dvp_strong_update_v8" if S <= 8 else ("dvp_strong_update_v16" if S <= 16 else "dvp_strong_update"),
+    split = S <= 16 and os.environ.get("DVP_STRONG_SPLIT", "1") != "0"
+    return {"strong_update": "dvp_strong_eval" if split else ("dvp_strong_update_v8" if S <= 8 else ("dvp_strong_update_v16" if S <= 16 else "dvp_strong_update")),
             "weak_update": "dvp_weak_update_wave_u8" if IMAGE_FORMAT else "dvp_weak_update_wave",
             "depth_to_weak": "dvp_depth_to_weak_refine",   # dvp_run_patchmatch: DepthToWeak + LocalRefine in one launch
             "gen_neighbours": "dvp_gen_neighbours_list",
@@ -193,14 +207,17 @@ def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
     sec = avg_ms * 1e-3
     alg = evals_per_launch * NCC_BYTES / sec / 1e9 if (sec > 0 and evals_per_launch) else None
     pmc = pmc_lookup(k, W, H, S)
-    second = {"gen_neighbours": "dvp_gen_neighbours_fit"}.get(stage)   # (dvp_gen_candidates runs on the side stream, outside its launch site's timer)
-    if pmc and second:   # a launch site with two kernels is timed as one: its counters are the sum of both
+    for second in (extra_kernels(stage, S) if pmc else []):   # a launch site with several kernels is timed as one: its counters are their sum
         p2 = pmc_lookup(second, W, H, S)
         if p2:
             pmc = dict(pmc)
-            for c in ("hbm_bytes_per_launch", "SQ_INSTS_VALU"):
+            for c in ("hbm_bytes_per_launch", "SQ_INSTS_VALU", "TCC_MISS", "TCC_HIT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"):
                 if c in pmc and c in p2:
                     pmc[c] = pmc[c] + p2[c]
+            if pmc.get("TCC_HIT") is not None and pmc.get("TCC_MISS"):
+                pmc["l2_hit_rate"] = round(pmc["TCC_HIT"] / (pmc["TCC_HIT"] + pmc["TCC_MISS"]), 4)
+            if pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAIT_ANY") is not None:
+                pmc["wait_any_frac"] = round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4)
             k = k + " + " + second
     r = {"kernel": k, "avg_launch_ms": round(avg_ms, 3), "evals_per_launch": int(evals_per_launch or 0),
          "work_rate": {"what": "SURVEY 8(d) algorithmic bytes: NCC evaluations x 724 B / launch time — a work rate, NOT a bound (caches/LDS serve it)",
@@ -406,8 +423,9 @@ def main():
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
             # every kernel of a launch site (the PMC tooling averages the last `n` dispatches of each)
             "launches_per_step": dict([(kernel_name(k, S), tm["stage_launches"][k] // args.steps) for k in stage_ms if k != "strong_prep"] +
+                                      [(extra, tm["stage_launches"][k] // args.steps) for k in stage_ms for extra in extra_kernels(k, S)] +
                                       [(extra, tm["stage_launches"][k] // args.steps) for k, extra in
-                                       (("gen_neighbours", "dvp_gen_neighbours_fit"), ("gen_edge_inform", "dvp_gen_candidates"), ("strong_prep", "dvp_strong_search")) if k in stage_ms]),
+                                       (("gen_edge_inform", "dvp_gen_candidates"), ("strong_prep", "dvp_strong_search")) if k in stage_ms]),
             "ncc_evals_per_step": {k: int(v) for k, v in evals["ncc_evals"].items() if v > 0},
             "Gevals_per_s": {k: round(evals["ncc_evals"][k] / (tm["stage_ms"][k] / args.steps * 1e-3) / 1e9, 3)
                              for k in evals["ncc_evals"] if evals["ncc_evals"][k] > 0 and tm["stage_ms"][k] > 0},

@@ -101,6 +101,11 @@ struct Dev {
 	s2* candidate;             // [view][pixel][8]: cand_ptr(); 64 x-adjacent pixels write/read 2 KB contiguous per view
 	const uint8_t* edge;
 	int* search_pos;           // [16][L]: sample positions of the strong update's 16 propagation slots (strong_search_px)
+	// split strong update (dvp_strong_eval / _decide / _refine): the cost vectors of the 16 propagation slots + the current plane,
+	// [slot][view][row * half_w + x / 2] (a red/black launch touches every second pixel of a row), or null
+	float* slot_costs;         // [17][S][half_w * H]
+	float* strong_rec;         // [SR_FIELDS][half_w * H]: hand-over from dvp_strong_decide to dvp_strong_refine
+	int half_w;
 	uint32_t* edge_bits;       // the edge map as 32x32-pixel bit tiles (128 B each), see edge_bit()
 	int edge_tiles_x;
 	uint32_t* strong_bits;     // same tiling, bit = (weak_info == STRONG); valid during FindNearestStrongPoint / GenNeighbours

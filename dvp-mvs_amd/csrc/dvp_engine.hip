@@ -111,6 +111,23 @@ DVP_KERNEL(dvp_random_init, DVP_ST_RANDOM_INIT, DVP_LB_HEAVY)
 DVP_KERNEL(dvp_strong_update, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY)
 DVP_KERNEL_MV(dvp_strong_update_v8, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY, kNarrowViews)
 DVP_KERNEL_MV(dvp_strong_update_v16, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY, 16)
+// split strong update (dvp_strong.hpp): evaluations of the 17 snapshot planes, decisions, refinement (S <= 16)
+DVP_KERNEL(dvp_strong_eval, kStageStrongEval, DVP_LB_HEAVY)
+DVP_KERNEL(dvp_strong_refine, kStageStrongRefine, DVP_LB_HEAVY)
+template <int MV>
+__device__ __forceinline__ void strong_decide_body(const Dev& d, const LaunchArgs& a) {
+	int px, py;
+	if (!block_to_pixel(blockIdx.x, threadIdx.x & 63, threadIdx.x >> 6, a.tiles_x, a.tiles, a.rows, a.half, a.colour, d.width, d.height, &px, &py)) return;
+	if (d.weak_info[px + py * d.width] != DVP_WEAK) strong_decide_px<MV>(d, px, py, a.iter);
+}
+// the cost vectors of the 8 directions live in registers: one instantiation per view-count bracket
+#define DVP_DECIDE_KERNEL(MV) extern "C" __global__ void __launch_bounds__(256) dvp_strong_decide_v##MV(const Dev d, const LaunchArgs a) { strong_decide_body<MV>(d, a); }
+DVP_DECIDE_KERNEL(4)
+DVP_DECIDE_KERNEL(6)
+DVP_DECIDE_KERNEL(8)
+DVP_DECIDE_KERNEL(10)
+DVP_DECIDE_KERNEL(12)
+DVP_DECIDE_KERNEL(16)
 DVP_KERNEL(dvp_get_depth_normal, DVP_ST_GET_DEPTH_NORMAL, 1)
 DVP_KERNEL(dvp_filter_strong, DVP_ST_FILTER_STRONG, 1)
 DVP_KERNEL(dvp_depth_to_weak, DVP_ST_DEPTH_TO_WEAK, DVP_LB_HEAVY)
@@ -539,6 +556,9 @@ struct dvp_ctx {
 	DvpCamera* cameras = nullptr; ViewConst* views = nullptr; int* sector_taps = nullptr; int* sector_start = nullptr;
 	f4* planes = nullptr; f4* planes_snap = nullptr; f4* fit_planes = nullptr;
 	int* search_pos = nullptr;   // [16][L]
+	float* slot_costs = nullptr; // [17][S][half_w * H]: split strong update (allocated at its first launch)
+	float* strong_rec = nullptr; // [SR_FIELDS][half_w * H]
+	bool strong_split = true;    // DVP_STRONG_SPLIT=0 in the environment: the monolithic kernel (A/B measurements)
 	float* costs = nullptr; float* costs_snap = nullptr; float* complex_ = nullptr;
 	uint32_t* selected_views = nullptr;
 	uint8_t* view_weight = nullptr; uint8_t* weak_info = nullptr; uint8_t* weak_reliable = nullptr; uint8_t* edge = nullptr;
@@ -603,6 +623,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.plane_stride = (size_t)c->pitch * (c->H + 2 * kImgPad);
 	d.images = c->images; d.images8 = c->images8_ok ? c->images8 : nullptr; d.img8_tiles_x = img8_tiles_x(c->W); d.img8_plane_bytes = (size_t)img8_tiles_x(c->W) * img8_tiles_y(c->H) * 128; d.depths = c->depths; d.cameras = c->cameras; d.views = c->views; d.sector_taps = c->sector_taps; d.sector_start = c->sector_start;
 	d.search_pos = c->search_pos;
+	d.slot_costs = c->slot_costs; d.strong_rec = c->strong_rec; d.half_w = (c->W + 1) / 2;
 	d.planes = c->planes; d.planes_snap = c->planes_snap; d.costs = c->costs; d.costs_snap = c->costs_snap;
 	d.selected_views = c->selected_views; d.view_weight = c->view_weight; d.weak_info = c->weak_info;
 	d.weak_reliable = c->weak_reliable; d.weak_nearest_strong = c->weak_nearest_strong;
@@ -637,6 +658,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	dvp_ctx* c = new dvp_ctx();
 	c->device = device; c->W = width; c->H = height; c->NI = num_images;
 	c->no_images8 = getenv("DVP_NO_IMAGES8") != nullptr;
+	if (const char* e = getenv("DVP_STRONG_SPLIT")) c->strong_split = atoi(e) != 0;
 	c->pitch = (width + 2 * kImgPad + 63) / 64 * 64;
 	c->L = (size_t)width * height;
 	auto fail = [&](int) { g_create_error = c->error; dvp_ctx_destroy(c); return 1; };
@@ -1049,7 +1071,23 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 		break;
 	case DVP_ST_RANDOM_INIT: hipLaunchKernelGGL(c->d.sampler ? dvp_random_init_exact : dvp_random_init, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_STRONG_UPDATE:
-		if (c->NI - 1 <= kNarrowViews) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v8_exact : dvp_strong_update_v8, grid, block, 0, c->stream, c->d, a);
+		if (c->strong_split && c->NI - 1 <= 16) {
+			if (!c->slot_costs) {
+				const size_t Lh = (size_t)((c->W + 1) / 2) * c->H;
+				if (dalloc(c, &c->slot_costs, (size_t)kSlotCount * (c->NI - 1) * Lh, false) || dalloc(c, &c->strong_rec, (size_t)SR_FIELDS * Lh, false)) return 1;
+				sync_dev_struct(c);
+			}
+			const int S = c->NI - 1;
+			hipLaunchKernelGGL(c->d.sampler ? dvp_strong_eval_exact : dvp_strong_eval, grid, block, 0, c->stream, c->d, a);
+			if (S <= 4) hipLaunchKernelGGL(dvp_strong_decide_v4, grid, block, 0, c->stream, c->d, a);
+			else if (S <= 6) hipLaunchKernelGGL(dvp_strong_decide_v6, grid, block, 0, c->stream, c->d, a);
+			else if (S <= 8) hipLaunchKernelGGL(dvp_strong_decide_v8, grid, block, 0, c->stream, c->d, a);
+			else if (S <= 10) hipLaunchKernelGGL(dvp_strong_decide_v10, grid, block, 0, c->stream, c->d, a);
+			else if (S <= 12) hipLaunchKernelGGL(dvp_strong_decide_v12, grid, block, 0, c->stream, c->d, a);
+			else hipLaunchKernelGGL(dvp_strong_decide_v16, grid, block, 0, c->stream, c->d, a);
+			hipLaunchKernelGGL(c->d.sampler ? dvp_strong_refine_exact : dvp_strong_refine, grid, block, 0, c->stream, c->d, a);
+		}
+		else if (c->NI - 1 <= kNarrowViews) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v8_exact : dvp_strong_update_v8, grid, block, 0, c->stream, c->d, a);
 		else if (c->NI - 1 <= 16) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v16_exact : dvp_strong_update_v16, grid, block, 0, c->stream, c->d, a);
 		else hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_exact : dvp_strong_update, grid, block, 0, c->stream, c->d, a);
 		break;

@@ -71,6 +71,8 @@ constexpr int kNarrowViews = 8;   // view capacity of the narrow strong-update i
 // internal launch site: DepthToWeak with LocalRefine done by the same thread (dvp_run_patchmatch issues the two
 // back to back; depth_to_weak_px<SMP, true>).  dvp_run_stage keeps the two separate launches.
 constexpr int kStageSweeps = 100;
+// internal launch sites of the split strong update (dvp_strong.hpp: strong_eval_px / strong_decide_px / strong_refine_px)
+constexpr int kStageStrongEval = 101, kStageStrongRefine = 102;
 template <int STAGE, int SMP, int MV = 32>
 DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long* nevals, PatchTab tab) {
 	const int center = px + py * d.width;
@@ -90,6 +92,8 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 	else if (STAGE == DVP_ST_NEIGHBOUR_UPDATE) neighbour_update_px(d, px, py);
 	else if (STAGE == DVP_ST_RANDOM_INIT) random_init_px<SMP>(d, px, py, tab, nevals);
 	else if (STAGE == DVP_ST_STRONG_UPDATE) { if (d.weak_info[center] != DVP_WEAK) strong_update_px<SMP, MV>(d, px, py, tab, iter, nevals); }
+	else if (STAGE == kStageStrongEval) { if (d.weak_info[center] != DVP_WEAK) strong_eval_px<SMP>(d, px, py, tab, nevals); }
+	else if (STAGE == kStageStrongRefine) { if (d.weak_info[center] != DVP_WEAK) strong_refine_px<SMP>(d, px, py, tab, nevals); }
 	else if (STAGE == DVP_ST_RANSAC_FIT) ransac_fit_plane_px(d, px, py, iter);
 	else if (STAGE == DVP_ST_WEAK_UPDATE) {
 		// device: own launch shape (one wave per WEAK pixel, dvp_weak_update_wave); this branch is the
@@ -110,10 +114,11 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 }
 // launch sites whose kernels need the per-lane patch table (LDS on the GPU)
 constexpr bool stage_uses_tab(int stage) {
-	return stage == DVP_ST_RANDOM_INIT || stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_DEPTH_TO_WEAK || stage == DVP_ST_LOCAL_REFINE || stage == kStageSweeps;
+	return stage == DVP_ST_RANDOM_INIT || stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_DEPTH_TO_WEAK || stage == DVP_ST_LOCAL_REFINE || stage == kStageSweeps ||
+	       stage == kStageStrongEval || stage == kStageStrongRefine;
 }
 constexpr bool stage_is_half_c(int stage) {
-	return stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_WEAK_UPDATE || stage == DVP_ST_FILTER_STRONG;
+	return stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_WEAK_UPDATE || stage == DVP_ST_FILTER_STRONG || stage == kStageStrongEval || stage == kStageStrongRefine;
 }
 inline bool stage_is_half(int stage) {
 	return stage == DVP_ST_STRONG_UPDATE || stage == DVP_ST_WEAK_UPDATE || stage == DVP_ST_FILTER_STRONG;

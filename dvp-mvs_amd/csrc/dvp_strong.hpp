@@ -457,6 +457,318 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, PatchTab tab, int ite
 	d.costs[center] = costs_center;
 }
 
+// ===== split form of the strong update (engine launches only; same evaluations, same operations, same bits) ==========
+// Measured on MI355X: the 36-tap evaluator alone runs at 32.7 G evaluations/s, inside the 23-slot loop of
+// strong_update_px at 20-22, and the loop's decision logic alone (scratch-resident cost arrays, view selection, random
+// normals at two waves per SIMD) costs 28 of the kernel's 109 ms.  The update is therefore issued as three launches:
+//   dvp_strong_eval    strong_eval_px    the 16 propagation slots + the current plane, all S views each: pure functions of
+//                                        the pre-launch snapshot; nothing live but the evaluator -> Dev::slot_costs
+//   dvp_strong_decide  strong_decide_px  slot bookkeeping, view selection, adoption, refinement hypotheses: no evaluator,
+//                                        no patch table, cost vectors in registers -> Dev::strong_rec (48 B per pixel)
+//   dvp_strong_refine  strong_refine_px  the five refinement hypotheses against the selected views, acceptance, write-back
+// strong_update_px stays the definition (host emulation, S > 16, dvp_run_stage A/B with DVP_STRONG_SPLIT=0).
+constexpr int kSlotCur = 16;                 // slot_costs slot of the pixel's current plane
+constexpr int kSlotCount = 17;
+enum { SR_PLANE = 0, SR_DEPTH = 4, SR_COST = 5, SR_CENTER = 6, SR_DRAND = 7, SR_DPERT = 8, SR_NRAND = 9, SR_FIELDS = 12 };
+DVP_HD size_t half_index(const Dev& d, int px, int py) { return (size_t)py * d.half_w + (size_t)(px >> 1); }
+DVP_HD size_t slot_cost_index(const Dev& d, int slot, int v, int px, int py) {
+	const size_t Lh = (size_t)d.half_w * (size_t)d.height;
+	return (size_t)(slot * (d.params.num_images - 1) + v) * Lh + half_index(d, px, py);
+}
+template <int SMP>
+DVP_HD void strong_eval_px(const Dev& d, int px, int py, PatchTab tab, unsigned long long* nevals) {
+	const int W = d.width;
+	const int center = py * W + px;
+	const int S = d.params.num_images - 1;
+	PatchCtx c;
+	{
+		int radius, inc;
+		patch_geometry(d, center, &radius, &inc);
+		build_patch_ctx(d, px, py, radius, inc, 0, tab, &c);
+	}
+	const size_t L = (size_t)W * d.height;
+	for (int slot = 0; slot < kSlotCount; ++slot) {
+		const int pos = slot < 16 ? d.search_pos[(size_t)slot * L + center] : center;
+		if (pos < 0) continue;
+		const f4 plane = d.planes_snap[pos];
+		for (int v = 0; v < S; ++v) d.slot_costs[slot_cost_index(d, slot, v, px, py)] = ncc_old<SMP>(d, c, px, py, v + 1, plane);
+		if (nevals) *nevals += (unsigned long long)S;
+	}
+}
+
+// Everything of strong_update_px between the propagation evaluations and the refinement evaluations, statement for
+// statement, with the cost vectors in registers (all loops over directions / views are unrolled; MV >= S).
+template <int MV>
+DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
+	const int W = d.width;
+	const int center = py * W + px;
+	const DvpParams& P = d.params;
+	const DvpCamera rc = load_camera(d, 0);
+	const int S = P.num_images - 1;
+	const size_t L = (size_t)W * d.height;
+	const size_t Lh = (size_t)d.half_w * (size_t)d.height, hi = half_index(d, px, py);
+	const float good_thr = 0.8f * dvp_expf((iter) * (iter) / (-90.0f));
+	float ca[8][MV];
+	uint32_t flag = 0;
+	int positions[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		positions[k] = 0;
+#pragma unroll
+		for (int v = 0; v < MV; ++v) ca[k][v] = 0.0f;
+	}
+	ca[0][0] = 2.0f;   // `= { 2.0f }` sets one element (APD.cu:2032)
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {      // slots 0-7 (APD.cu:2047-2090)
+		const int pos = d.search_pos[(size_t)k * L + center];
+		if (pos >= 0) {
+			flag |= 1u << k;
+			positions[k] = pos;
+#pragma unroll
+			for (int v = 0; v < MV; ++v)
+				if (v < S) ca[k][v] = d.slot_costs[(size_t)(k * S + v) * Lh + hi];
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {      // slots 8-15: the fixed-stride sample replaces the adaptive one if it is better (APD.cu:2104-2137)
+		const int pos = d.search_pos[(size_t)(8 + k) * L + center];
+		if (pos >= 0) {
+			const bool had = (flag >> k) & 1;
+			flag |= 1u << k;
+			float cb[MV];
+			int good0 = 0, good1 = 0, bad0 = 0, bad1 = 0;
+#pragma unroll
+			for (int j = 0; j < MV; ++j) {
+				cb[j] = 0.0f;
+				if (j < S) {
+					cb[j] = d.slot_costs[(size_t)((8 + k) * S + j) * Lh + hi];
+					const float a = ca[k][j], b = cb[j];
+					if (a < good_thr) good0++;
+					if (a > 1.2f) bad0++;
+					if (b < good_thr) good1++;
+					if (b > 1.2f) bad1++;
+				}
+			}
+			if (!had || good1 > good0 || (good1 == good0 && bad1 < bad0)) {
+				positions[k] = pos;
+#pragma unroll
+				for (int j = 0; j < MV; ++j)
+					if (j < S) ca[k][j] = cb[j];
+			}
+		}
+	}
+	// ---- view selection (APD.cu:2462-2530), joint_view_selection on the register arrays ----
+	float priors[MV];
+#pragma unroll
+	for (int i = 0; i < MV; ++i) priors[i] = 0.0f;
+	{
+		const int nb[4] = { center - W, center + W, center - 1, center + 1 };
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			if ((flag >> (2 * i)) & 1) {   // guards flag[0],[2],[4],[6] (APD.cu:2471)
+				const uint32_t sv = d.selected_views[nb[i]];
+#pragma unroll
+				for (int j = 0; j < MV; ++j)
+					if (j < S) priors[j] += is_set(sv, j) ? 0.9f : 0.1f;
+			}
+		}
+	}
+	float probs[MV];
+	const float thr = (float)(0.8 * dvp_expf((iter) * (iter) / (-90.0f)));
+#pragma unroll
+	for (int i = 0; i < MV; ++i) {
+		probs[i] = 0.0f;
+		if (i < S) {
+			float count = 0;
+			int count_false = 0;
+			float tmpw = 0;
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const float cst = ca[j][i];
+				if (cst < thr) { tmpw += dvp_expf(cst * cst / (-0.18f)); count++; }
+				if (cst > 1.2f) count_false++;
+			}
+			float pr = 0.0f;
+			if (count > 2 && count_false < 3) pr = tmpw / count;
+			else if (count_false < 3) pr = dvp_expf(thr * thr / (-0.32f));
+			probs[i] = pr * priors[i];
+		}
+	}
+	float psum = 0.0f;
+#pragma unroll
+	for (int i = 0; i < MV; ++i)
+		if (i < S) psum += probs[i];
+	const float inv = 1.0f / psum;
+	float cum = 0.0f;
+#pragma unroll
+	for (int i = 0; i < MV; ++i)
+		if (i < S) { cum += probs[i] * inv; probs[i] = cum; }
+	int vw[MV];
+#pragma unroll
+	for (int i = 0; i < MV; ++i) vw[i] = 0;
+	Rng rv(d.seed, (uint32_t)center, rng_site(PH_STRONG, iter, SUB_VIEW));
+	for (int s = 0; s < 15; ++s) {
+		const float rp = rv.uniform() - FLT_EPSILON;
+		bool done = false;
+#pragma unroll
+		for (int v = 0; v < MV; ++v)
+			if (v < S && !done && probs[v] > rp) { vw[v] += 1; done = true; }
+	}
+	uint32_t sel_mask = 0;
+	float weight_norm = 0;
+#pragma unroll
+	for (int i = 0; i < MV; ++i)
+		if (i < S && vw[i] > 0) { set_bit(&sel_mask, i); weight_norm += vw[i]; }
+	{
+		uint8_t* gvw = d.view_weight + (size_t)center * 32;
+		uint32_t words[8];
+#pragma unroll
+		for (int w8 = 0; w8 < 8; ++w8) {
+			uint32_t x = 0;
+#pragma unroll
+			for (int b = 0; b < 4; ++b)
+				if (w8 * 4 + b < MV) x |= ((uint32_t)vw[w8 * 4 + b] & 255u) << (8 * b);
+			words[w8] = x;
+		}
+		uint32_t* g32 = reinterpret_cast<uint32_t*>(gvw);   // 32-byte records: aligned
+#pragma unroll
+		for (int w8 = 0; w8 < 8; ++w8) g32[w8] = words[w8];
+	}
+	float final_costs[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		float fc = 0.0f;
+#pragma unroll
+		for (int j = 0; j < MV; ++j)
+			if (j < S && vw[j] > 0) fc += vw[j] * ca[k][j];
+		final_costs[k] = fc / weight_norm;
+	}
+	int min_cost_idx = 0;   // FindMinCostIndex (ties -> last, APD.cu:155-166)
+	{
+		float mc = final_costs[0];
+#pragma unroll
+		for (int k = 1; k < 8; ++k)
+			if (final_costs[k] <= mc) { mc = final_costs[k]; min_cost_idx = k; }
+	}
+	// ---- cost of the current plane under the new weights, adoption of the best neighbour (APD.cu:2546-2567) ----
+	float cn = 0.0f;
+#pragma unroll
+	for (int v = 0; v < MV; ++v)
+		if (v < S && vw[v] > 0) cn += vw[v] * d.slot_costs[(size_t)(kSlotCur * S + v) * Lh + hi];
+	float cost_now = cn / weight_norm;
+	const float costs_center = cost_now;
+	f4 plane_now = d.planes_snap[center];
+	float depth_now = depth_from_plane(rc, plane_now, px, py);
+	bool selected_views_written = false;
+	{
+		float fmin = final_costs[0];
+		int pmin = positions[0];
+#pragma unroll
+		for (int k = 1; k < 8; ++k)
+			if (k == min_cost_idx) { fmin = final_costs[k]; pmin = positions[k]; }
+		if ((flag >> min_cost_idx) & 1) {
+			const f4 cand = d.planes_snap[pmin];
+			const float db = depth_from_plane(rc, cand, px, py);
+			if (db >= P.depth_min && db <= P.depth_max && fmin < cost_now) {
+				depth_now = db;
+				plane_now = cand;
+				cost_now = fmin;
+				selected_views_written = true;
+			}
+		}
+	}
+	// ---- refinement hypotheses from the values at entry (APD.cu:1333-1360) ----
+	Rng rd(d.seed, (uint32_t)center, rng_site(PH_STRONG, iter, SUB_DEPTH_RAND));
+	Rng rn(d.seed, (uint32_t)center, rng_site(PH_STRONG, iter, SUB_NORMAL));
+	Rng rp(d.seed, (uint32_t)center, rng_site(PH_STRONG, iter, SUB_DEPTH_PERT));
+	const float depth_rand = rd.uniform() * (P.depth_max - P.depth_min) + P.depth_min;
+	if (selected_views_written) d.selected_views[center] = sel_mask;   // read by random_normal_yzl
+	const f4 n_rand = random_normal_yzl(d, px, py, rn, depth_now);
+	const float dmin_p = (1 - 0.02f) * depth_now, dmax_p = (1 + 0.02f) * depth_now;
+	const float depth_pert = rp.uniform() * (dmax_p - dmin_p) + dmin_p;
+	float* rec = d.strong_rec + hi;
+	rec[(SR_PLANE + 0) * Lh] = plane_now.x; rec[(SR_PLANE + 1) * Lh] = plane_now.y; rec[(SR_PLANE + 2) * Lh] = plane_now.z; rec[(SR_PLANE + 3) * Lh] = plane_now.w;
+	rec[SR_DEPTH * Lh] = depth_now; rec[SR_COST * Lh] = cost_now; rec[SR_CENTER * Lh] = costs_center;
+	rec[SR_DRAND * Lh] = depth_rand; rec[SR_DPERT * Lh] = depth_pert;
+	rec[(SR_NRAND + 0) * Lh] = n_rand.x; rec[(SR_NRAND + 1) * Lh] = n_rand.y; rec[(SR_NRAND + 2) * Lh] = n_rand.z;
+}
+
+// PlaneHypothesisRefinementStrong's evaluations and acceptance (APD.cu:1361-1383) + the write-back (APD.cu:2725-2737)
+template <int SMP>
+DVP_HD void strong_refine_px(const Dev& d, int px, int py, PatchTab tab, unsigned long long* nevals) {
+	const int W = d.width;
+	const int center = py * W + px;
+	const DvpParams& P = d.params;
+	const DvpCamera rc = load_camera(d, 0);
+	const int S = P.num_images - 1;
+	const size_t Lh = (size_t)d.half_w * (size_t)d.height, hi = half_index(d, px, py);
+	PatchCtx c;
+	{
+		int radius, inc;
+		patch_geometry(d, center, &radius, &inc);
+		build_patch_ctx(d, px, py, radius, inc, 0, tab, &c);
+	}
+	const float* rec = d.strong_rec + hi;
+	f4 plane_now = mk4(rec[(SR_PLANE + 0) * Lh], rec[(SR_PLANE + 1) * Lh], rec[(SR_PLANE + 2) * Lh], rec[(SR_PLANE + 3) * Lh]);
+	float depth_now = rec[SR_DEPTH * Lh], cost_now = rec[SR_COST * Lh], costs_center = rec[SR_CENTER * Lh];
+	const float depth_rand = rec[SR_DRAND * Lh], depth_pert = rec[SR_DPERT * Lh];
+	const f4 n_rand = mk4(rec[(SR_NRAND + 0) * Lh], rec[(SR_NRAND + 1) * Lh], rec[(SR_NRAND + 2) * Lh], 0.0f);
+	f4 n_pert = plane_now;   // GeneratePerturbedNormal returns the normalised input (APD.cu:617-661)
+	normalize3(&n_pert);
+	// view weights of this launch (strong_decide_px wrote them): two 16-byte loads
+	const uint32_t* g32 = reinterpret_cast<const uint32_t*>(d.view_weight + (size_t)center * 32);
+	uint32_t wq[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) wq[i] = g32[i];
+	float weight_norm = 0;
+	for (int i = 0; i < S; ++i) {
+		const int wv = (int)((wq[i >> 2] >> (8 * (i & 3))) & 255u);
+		if (wv > 0) weight_norm += wv;
+	}
+	// hypotheses 3 and 4 are the same plane (strong_update_px): the second one is not evaluated
+	const float hyp_depth[5] = { depth_rand, depth_now, depth_rand, depth_now, depth_pert };
+	const f4 hyp_normal[5] = { plane_now, n_rand, n_rand, n_pert, plane_now };
+	const float depth_entry = depth_now;
+	const f4 plane_entry = plane_now;
+	(void)depth_entry; (void)plane_entry;
+	for (int i = 0; i < 5; ++i) {
+		f4 plane = hyp_normal[i];
+		plane.w = distance_to_origin(rc, px, py, hyp_depth[i], plane);
+		// A hypothesis is adopted iff its depth is in range and its weighted cost is below the running best (strict).
+		// Two exact short cuts (the cost itself is only kept when adopted): (i) out of range -> not evaluated; (ii) the
+		// weighted sum only grows — every term is a weight > 0 times a cost in [0, 2], IEEE addition and division are
+		// monotone — so once the partial sum / weight_norm is not below cost_now the final one cannot be: the remaining
+		// views are not evaluated.  Random hypotheses are rejected after one or two views instead of all selected ones.
+		const float db = depth_from_plane(rc, plane, px, py);
+		if (!(db >= P.depth_min && db <= P.depth_max)) continue;
+		float tc = 0.0f;
+		bool alive = weight_norm > 0.0f;     // no selected view: 0 / 0 = NaN, never below cost_now
+		for (int j = 0; j < S && alive; ++j) {
+			const int wv = (int)((wq[j >> 2] >> (8 * (j & 3))) & 255u);
+			if (wv > 0) {
+				tc += wv * ncc_old<SMP>(d, c, px, py, j + 1, plane);
+				if (nevals) *nevals += 1;
+				alive = tc / weight_norm < cost_now;
+			}
+		}
+		if (alive) {      // == (tc / weight_norm < cost_now) of the complete sum
+			depth_now = db;
+			plane_now = plane;
+			cost_now = tc / weight_norm;
+		}
+	}
+	if (P.state == DVP_REFINE_INIT) {
+		if (cost_now < costs_center - 0.1) {   // double comparison (APD.cu:2728)
+			costs_center = cost_now;
+			d.planes[center] = plane_now;
+		}
+	} else {
+		costs_center = cost_now;
+		d.planes[center] = plane_now;
+	}
+	d.costs[center] = costs_center;
+}
+
 // GetDepthandNormal (APD.cu:3167-3182)
 DVP_HD void get_depth_normal_px(const Dev& d, int px, int py) {
 	const int center = py * d.width + px;
