@@ -555,7 +555,41 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 		wave_sync();
 
 		// ---- evaluate: view by view ----------------------------------------------------------------------
-		if (pmask && vmask) {
+		if (phase == 2 && pmask && vmask) {
+			// The five refinement hypotheses are adopted iff their depth is in range and their weighted cost is below the
+			// running best, which only ever decreases (APD.cu:1361-1383).  Two exact short cuts — the costs themselves are
+			// only kept on adoption: (i) out-of-range hypotheses are not evaluated; (ii) the weighted sum only grows (weights
+			// > 0, costs >= 0, IEEE addition and division are monotone), so a hypothesis whose FIRST selected view alone is
+			// not below the best cost at entry can never be adopted: it drops out before the remaining views are evaluated.
+			uint32_t keep = 0;
+			for (int i = 0; i < 5; ++i) {
+				const float db = depth_from_plane(rc, sh.pl[i], px, py);
+				if (db >= P.depth_min && db <= P.depth_max) keep |= 1u << i;
+			}
+			pmask = keep;
+			int first = 0;
+			while (!((vmask >> first) & 1)) ++first;
+			if (pmask) {
+				wave_ncc_new<SMP, FMT>(d, c, nbs, cpix, px, py, 1u << first, pmask, sh);
+				evals += (unsigned long long)__builtin_popcount(pmask);
+				if (P.geom_consistency) wave_geom_table(d, rc, px, py, pmask, sh);
+				uint32_t alive = 0;
+				const int w = sh.vw[first];
+				for (int i = 0; i < 5; ++i) {
+					if (!((pmask >> i) & 1)) continue;
+					float tc = 0.0f;
+					if (P.geom_consistency) tc += w * (sh.ev[i][first] + P.geom_factor * sh.gtab[i][first]);
+					else tc += w * sh.ev[i][first];
+					if (tc / weight_norm < cost_now) alive |= 1u << i;
+				}
+				pmask = alive;
+				const uint32_t rest = vmask & ~(1u << first);
+				if (pmask && rest) {
+					wave_ncc_new<SMP, FMT>(d, c, nbs, cpix, px, py, rest, pmask, sh);
+					evals += (unsigned long long)__builtin_popcount(pmask) * (unsigned long long)__builtin_popcount(rest);
+				}
+			}
+		} else if (pmask && vmask) {
 			wave_ncc_new<SMP, FMT>(d, c, nbs, cpix, px, py, vmask, pmask, sh);
 			evals += (unsigned long long)__builtin_popcount(pmask) * (unsigned long long)__builtin_popcount(vmask);
 		}
@@ -612,8 +646,9 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 				}
 			}
 		} else {
-			if (P.geom_consistency) wave_geom_table(d, rc, px, py, pmask, sh);
+			// (geometric table: filled in the evaluate step; pmask = the hypotheses that are still candidates)
 			for (int i = 0; i < 5; ++i) {
+				if (!((pmask >> i) & 1)) continue;
 				float tc = 0.0f;
 				for (int j = 0; j < S; ++j) {
 					const int w = sh.vw[j];
