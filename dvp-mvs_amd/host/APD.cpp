@@ -4,6 +4,12 @@
 // files read per pass.
 #include "APD.h"
 #include <mutex>
+#include <chrono>
+#include <memory>
+#include <thread>
+#include <atomic>
+#include <condition_variable>
+#include <set>
 #include <cstdlib>
 #include <map>
 #include <tuple>
@@ -55,8 +61,10 @@ struct PooledCtx {
 	// calls APD::ReleasePooledContext() before it returns
 } g_pool;
 }
+static std::atomic<int> g_prefetch_threads{0};
 void APD::ReserveImageCache(size_t views) { std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex); g_img_cache_capacity = std::max<size_t>(96, 2 * views + 8); }   // reference + padded source role
 void APD::ReleasePooledContext() {
+	while (g_prefetch_threads.load() > 0) std::this_thread::sleep_for(std::chrono::milliseconds(2));   // (they use the caches cleared below)
 	if (g_pool.ctx) dvp_ctx_destroy(g_pool.ctx);
 	g_pool.ctx = nullptr;
 	std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
@@ -73,27 +81,58 @@ static ImageKey image_key(const Problem& problem, int image_id, int pad_w, int p
 	const path file = problem.dense_folder / path("images") / path(ToFormatIndex(image_id) + ".jpg");
 	return ImageKey{ file.string(), problem.scale_size, pad_w, pad_h };
 }
+// decode outside the cache lock (a 25 Mpx JPEG takes ~0.3 s): a file being decoded by another thread is waited for
+namespace {
+std::set<std::string> g_decoding;
+std::condition_variable_any g_decoded_cv;
+}
 Mat APD::DecodedGray(const path& file) {
-	std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
-	auto dit = g_decoded.find(file.string());
-	if (dit != g_decoded.end()) return dit->second;
+	const std::string key = file.string();
+	std::unique_lock<std::recursive_mutex> lock(g_img_cache_mutex);
+	for (;;) {
+		auto dit = g_decoded.find(key);
+		if (dit != g_decoded.end()) return dit->second;
+		if (!g_decoding.count(key)) break;
+		g_decoded_cv.wait(lock);
+	}
+	g_decoding.insert(key);
+	lock.unlock();
 	Mat image_uint = ReadImageGray(file);
+	lock.lock();
+	g_decoding.erase(key);
 	if (!image_uint.empty() && g_decoded_bytes + image_uint.step * image_uint.rows <= ((size_t)8 << 30)) {
-		g_decoded[file.string()] = image_uint;
+		g_decoded[key] = image_uint;
 		g_decoded_bytes += image_uint.step * image_uint.rows;
 	}
+	g_decoded_cv.notify_all();
 	return image_uint;
 }
-static ImageEntry load_image(const Problem& problem, int image_id, int pad_w, int pad_h, bool is_ref) {
-	std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
-	const ImageKey key = image_key(problem, image_id, pad_w, pad_h);
-	auto it = g_img_cache.find(key);
-	if (it != g_img_cache.end()) { it->second.used = ++g_img_cache_clock; return it->second; }
-	if (!is_ref) {   // the same file cached in its reference role needs no padding when the sizes agree
-		auto ir = g_img_cache.find(image_key(problem, image_id, 0, 0));
-		if (ir != g_img_cache.end() && ir->second.orig_cols == pad_w && ir->second.orig_rows == pad_h) { ir->second.used = ++g_img_cache_clock; return ir->second; }
+// all images of the job decoded on a few threads while the first passes run (the coarse levels are decode-bound otherwise)
+void APD::PrefetchDecoded(const std::vector<path>& files) {
+	const int n = std::max(1, std::min(HostThreads() / 2, 8));
+	auto queue = std::make_shared<std::vector<path>>(files);
+	auto next = std::make_shared<std::atomic<size_t>>(0);
+	for (int t = 0; t < n; ++t) {
+		++g_prefetch_threads;
+		std::thread([queue, next]() {
+			for (size_t i = (*next)++; i < queue->size(); i = (*next)++) (void)APD::DecodedGray((*queue)[i]);
+			--g_prefetch_threads;
+		}).detach();
 	}
-	make_room(problem.scale_size);
+}
+static ImageEntry load_image(const Problem& problem, int image_id, int pad_w, int pad_h, bool is_ref) {
+	const ImageKey key = image_key(problem, image_id, pad_w, pad_h);
+	{
+		std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
+		auto it = g_img_cache.find(key);
+		if (it != g_img_cache.end()) { it->second.used = ++g_img_cache_clock; return it->second; }
+		if (!is_ref) {   // the same file cached in its reference role needs no padding when the sizes agree
+			auto ir = g_img_cache.find(image_key(problem, image_id, 0, 0));
+			if (ir != g_img_cache.end() && ir->second.orig_cols == pad_w && ir->second.orig_rows == pad_h) { ir->second.used = ++g_img_cache_clock; return ir->second; }
+		}
+	}
+	// decode / convert / resize WITHOUT the cache lock (the driver's background worker and the decode prefetch threads use
+	// the same caches); two threads may build the same entry at the same time: same bits, the second insert is dropped
 	const Mat image_uint = APD::DecodedGray(std::get<0>(key));
 	if (image_uint.empty()) DvpFatal(std::string("Can't read ") + (is_ref ? "reference" : "source") + " image " + std::to_string(image_id));
 	// uint8 -> float; a source image is zero-padded / cropped to the reference size (APD.cpp:1059, 1071-1079)
@@ -113,6 +152,8 @@ static ImageEntry load_image(const Problem& problem, int image_id, int pad_w, in
 		f = ResizeLinear(f, (int)std::round(f.cols * factor), (int)std::round(f.rows * factor));
 	}
 	ci.image = f;
+	std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
+	make_room(problem.scale_size);
 	ci.used = ++g_img_cache_clock;
 	return g_img_cache.emplace(key, ci).first->second;
 }

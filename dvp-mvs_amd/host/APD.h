@@ -98,6 +98,7 @@ public:
 	static Mat CachedImage(const Problem& problem, int image_id, int* orig_cols, int* orig_rows);
 	static void InsertCachedImage(const Problem& problem, int image_id, const Mat& image, int orig_cols, int orig_rows);
 	static Mat DecodedGray(const path& image_file);   // cv::imread(GRAYSCALE) through a per-file cache (read-only result)
+	static void PrefetchDecoded(const std::vector<path>& image_files);   // decode in the background (detached worker threads)
 	static void ReserveImageCache(size_t views);   // the cache holds at least this many images before it evicts
 	// Depth maps of the previous pass resident on this process' device (row-major, pitch = width).  When
 	// the maps of a view and all its sources are registered, a geometric-consistency pass takes them from

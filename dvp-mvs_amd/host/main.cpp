@@ -68,7 +68,7 @@ std::vector<Problem> ReadViewGraph(const path& dense_folder, int max_src) {
 
 int PyramidLevels(const std::vector<Problem>& problems) {   // main.cpp:248-264
 	if (problems.empty()) return 0;
-	const Mat first = ReadImageGray(problems[0].dense_folder / "images" / (ToFormatIndex(problems[0].ref_image_id) + ".jpg"));
+	const Mat first = APD::DecodedGray(problems[0].dense_folder / "images" / (ToFormatIndex(problems[0].ref_image_id) + ".jpg"));
 	if (first.empty()) return 0;
 	int levels = 1;
 	for (int side = std::max(first.cols, first.rows); side > 800; side /= 2) ++levels;
@@ -364,6 +364,15 @@ int main(int argc, char** argv) {
 
 	std::vector<Problem> problems = ReadViewGraph(opt.dense_folder, opt.max_src);
 	std::cout << "There are " << problems.size() << " problems needed to be processed!" << std::endl;
+	{   // this rank's images are decoded in the background from now on (every pyramid level is made from the decoded file)
+		std::vector<path> mine;
+		for (const Problem& p : problems)
+			if (p.index % opt.world == opt.rank) mine.push_back(opt.dense_folder / "images" / (ToFormatIndex(p.ref_image_id) + ".jpg"));
+		if (opt.world == 1)   // a single rank also reads every source image itself
+			for (const Problem& p : problems)
+				for (int id : p.src_image_ids) mine.push_back(opt.dense_folder / "images" / (ToFormatIndex(id) + ".jpg"));
+		APD::PrefetchDecoded(mine);
+	}
 	const int round_num = PyramidLevels(problems);
 	std::cout << "Round nums: " << round_num << std::endl;
 

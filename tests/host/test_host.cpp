@@ -1,5 +1,7 @@
 // host-layer checks that need no GPU: on-disk formats, camera parser, connected components,
 // rescale helpers.  Exit code 0 = all passed.
+#include <thread>
+#include <chrono>
 #include "../../dvp-mvs_amd/host/APD.h"
 #include <cassert>
 #include <cstdio>
@@ -156,6 +158,63 @@ int main(int argc, char** argv) {
 		CHECK(!ReadBinMat(tmp / "does_not_exist.dmb", e));
 		CHECK(writeDepthDmb(tmp / "t_acmm.dmb", d) == 0);
 		CHECK(std::filesystem::file_size(tmp / "t_acmm.dmb") == 16 + 3 * 5 * 4);
+	}
+	// write-back result cache + background worker (host/store.cpp): a published map is served from memory while its file is
+	// still being written, a map the reader will modify is never shared with the writer, an announced path makes the reader
+	// wait for its job, the files end up on disk byte-identical, eviction keeps working under a tiny limit
+	{
+		const path dir = tmp / "store_test";
+		std::filesystem::create_directories(dir);
+		SetResultCache(true, (size_t)1 << 20);
+		Mat a(64, 64, CV_32FC1);
+		for (int i = 0; i < 64 * 64; ++i) a.ptr<float>(0)[i] = (float)i;
+		PublishResult(dir / "a.dmb", a);
+		Mat b;
+		CHECK(LoadResult(dir / "a.dmb", b));                       // from memory (the write may still be queued)
+		CHECK(b.data == a.data || std::memcmp(b.data, a.data, 64 * 64 * 4) == 0);
+		Mat c;
+		CHECK(LoadResult(dir / "a.dmb", c, true));                 // will_modify: own buffer unless the write is done
+		c.ptr<float>(0)[0] = -1.0f;
+		FlushResults();
+		Mat d;
+		CHECK(ReadBinMat(dir / "a.dmb", d) && d.ptr<float>(0)[0] == 0.0f && d.ptr<float>(0)[4095] == 4095.0f);   // the file never saw the modification
+		CHECK(!std::filesystem::exists(dir / "a.dmb.part"));
+		// announced result: the loader blocks until the background job publishes it
+		ExpectResult(dir / "late.dmb");
+		RunInBackground([dir]() {
+			std::this_thread::sleep_for(std::chrono::milliseconds(150));
+			Mat m = Mat::zeros(8, 8, CV_8UC1);
+			m.data[5] = 77;
+			PublishResult(dir / "late.dmb", m);
+		});
+		const auto t0 = std::chrono::steady_clock::now();
+		Mat late;
+		CHECK(LoadResult(dir / "late.dmb", late) && late.data[5] == 77);
+		CHECK(std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(100));
+		CHECK(ResultExists(dir / "late.dmb") && !ResultExists(dir / "never.dmb"));
+		// eviction under a 1 MiB limit: 40 maps of 64 KiB; everything is still loadable (memory or file) and intact
+		for (int k = 0; k < 40; ++k) {
+			Mat m(128, 128, CV_32SC1);
+			for (int i = 0; i < 128 * 128; ++i) m.ptr<int>(0)[i] = k * 100000 + i;
+			PublishResult(dir / ("m" + std::to_string(k) + ".dmb"), m);
+		}
+		FlushResults();
+		for (int k = 0; k < 40; ++k) {
+			Mat m;
+			CHECK(LoadResult(dir / ("m" + std::to_string(k) + ".dmb"), m) && m.ptr<int>(0)[777] == k * 100000 + 777);
+		}
+		// a newer version of a path replaces the older one, in memory and on disk
+		Mat v1 = Mat::zeros(4, 4, CV_8UC1), v2 = Mat::zeros(4, 4, CV_8UC1);
+		v1.data[0] = 1; v2.data[0] = 2;
+		PublishResult(dir / "v.dmb", v1);
+		PublishResult(dir / "v.dmb", v2);
+		Mat v;
+		CHECK(LoadResult(dir / "v.dmb", v) && v.data[0] == 2);
+		FlushResults(true);
+		CHECK(ReadBinMat(dir / "v.dmb", v) && v.data[0] == 2);
+		ShutdownResultStore();
+		SetResultCache(true, (size_t)32 << 30);
+		std::filesystem::remove_all(dir);
 	}
 	// camera text (APD.cpp:651-692): c = -R^T t, depth_min interval depth_num depth_max
 	{
