@@ -863,7 +863,30 @@ DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, PatchTab tab, unsigne
 	float p_costs[61];
 	float lr_costs[11];            // LocalRefine's total of sweep slot pd = -5..5
 	unsigned lr_live = 0;          // ... bit pd+5: the slot is inside the depth range
-	for (int pd = -30; pd <= 30; ++pd) {
+	// Sweep order: the central window first.  A pixel is WEAK whenever there is no cost peak <= 0.5 within
+	// weak_peak_radius of the current depth — either there is no peak at all (min_peak = 0), or the lowest peak lies outside
+	// the window, or it lies inside with a cost above 0.5 (APD.cu:4018-4023) — and that is decided by the window and its two
+	// neighbours alone: such pixels skip the other ~46 planes (exact: their costs cannot change the state, and LocalRefine
+	// only reads the slots -5..5).  Textureless regions, i.e. most WEAK pixels, leave here.  One loop, one call site of the
+	// evaluator: k walks the window (-cw..cw), then the planes left of it, then those right of it.
+	int cw = P.weak_peak_radius + 1;
+	if (cw < 5) cw = 5;
+	if (cw > 30) cw = 30;
+	bool central_peak = false;
+	auto window_has_peak = [&]() {
+		bool any = false;
+		for (int i = 30 - P.weak_peak_radius; i <= 30 + P.weak_peak_radius; ++i) {
+			if (i < 2 || i > 58) continue;
+			if (p_costs[i - 1] > p_costs[i] && p_costs[i + 1] > p_costs[i] && !(p_costs[i] > 0.5f)) any = true;
+		}
+		return any;
+	};
+	for (int k = 0; k < 61; ++k) {
+		if (k == 2 * cw + 1) {
+			central_peak = window_has_peak();
+			if (!central_peak) break;
+		}
+		const int pd = k <= 2 * cw ? k - cw : (k - (2 * cw + 1) < 30 - cw ? k - (2 * cw + 1) - 30 : k - 30);
 		const float p_depth = rc.K[0] * base_line / (disp + pd);
 		if (p_depth < P.depth_min || p_depth > P.depth_max) { p_costs[pd + 30] = 2.0f; continue; }
 		f4 pl = origin;
@@ -892,10 +915,11 @@ DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, PatchTab tab, unsigne
 		p_costs[pd + 30] = DVP_MIN(2.0f, pc);
 		if (both) { lr_costs[pd + 5] = lr / weight_normal; lr_live |= 1u << (pd + 5); }
 	}
+	if (cw == 30) central_peak = window_has_peak();
 	uint64_t is_peak = 0;
 	int peak_count = 0, min_peak = 0;
 	float min_cost = 2.0f;
-	for (int i = 2; i < 59; ++i) {
+	for (int i = 2; central_peak && i < 59; ++i) {
 		if (p_costs[i - 1] > p_costs[i] && p_costs[i + 1] > p_costs[i]) {
 			is_peak |= (uint64_t)1 << i;
 			peak_count++;
@@ -904,7 +928,8 @@ DVP_HD void depth_to_weak_px(const Dev& d, int px, int py, PatchTab tab, unsigne
 	}
 	const int dpk = min_peak - 30;
 	uint8_t state;
-	if ((dpk < 0 ? -dpk : dpk) > P.weak_peak_radius || p_costs[min_peak] > 0.5f) state = DVP_WEAK;
+	if (!central_peak) state = DVP_WEAK;
+	else if ((dpk < 0 ? -dpk : dpk) > P.weak_peak_radius || p_costs[min_peak] > 0.5f) state = DVP_WEAK;
 	else if (peak_count == 1) state = (p_costs[min_peak] <= 0.15f) ? DVP_STRONG : DVP_WEAK;
 	else {
 		float var = 0.0f;
