@@ -8,6 +8,7 @@
 #include "../../dvp-mvs_amd/csrc/dvp_stages.hpp"
 #include <cstring>
 #include <vector>
+#include <cstdlib>
 
 using namespace dvp;
 
@@ -23,6 +24,7 @@ struct Emu {
 	std::vector<int> sector_taps, sector_start;
 	std::vector<f4> planes, planes_snap, fit_planes;
 	std::vector<int> search_pos;
+	std::vector<float> slot_costs, strong_rec;   // the split strong update's hand-over buffers (dvp_strong.hpp)
 	std::vector<float> costs, costs_snap, complex_;
 	std::vector<uint32_t> selected_views;
 	std::vector<uint8_t> view_weight, weak_info, weak_reliable, edge;
@@ -55,6 +57,7 @@ void refresh(Emu& e) {
 	d.sector_taps = e.sector_taps.data();
 	d.sector_start = e.sector_start.data();
 	d.search_pos = e.search_pos.data();
+	d.slot_costs = e.slot_costs.data(); d.strong_rec = e.strong_rec.data(); d.half_w = (e.W + 1) / 2;
 	d.planes = e.planes.data(); d.planes_snap = e.planes_snap.data();
 	d.costs = e.costs.data(); d.costs_snap = e.costs_snap.data();
 	d.selected_views = e.selected_views.data();
@@ -125,6 +128,8 @@ void* emu_create(int W, int H, int NI) {
 	e->planes.assign(L, mk4(0, 0, 0, 0));
 	e->planes_snap = e->planes;
 	e->search_pos.assign(L * 16, -1);
+	e->slot_costs.assign((size_t)kSlotCount * (S > 0 ? S : 1) * ((W + 1) / 2) * H, 0.0f);
+	e->strong_rec.assign((size_t)SR_FIELDS * ((W + 1) / 2) * H, 0.0f);
 	e->fit_planes = e->planes;
 	e->costs.assign(L, 0.0f);
 	e->costs_snap = e->costs;
@@ -363,7 +368,40 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 					int px, py;
 					if (block_to_pixel(b, lane, wave, g.tiles_x, g.tiles, g.rows, 1, colour, e.W, e.H, &px, &py)) strong_search_px(e.d, px, py);
 				}
-		launch<DVP_ST_STRONG_UPDATE>(e, iter, colour);
+		// the engine issues the update as three launches for S <= 16 (dvp_strong_eval / _decide / _refine) unless
+		// DVP_STRONG_SPLIT=0; the emulation follows the same switch, so both forms are checked against the oracle
+		const char* sp = getenv("DVP_STRONG_SPLIT");
+		const int S = e.NI - 1;
+		if (S <= 16 && !(sp && atoi(sp) == 0)) {
+			unsigned long long total = 0;
+			for (int part = 0; part < 3; ++part) {
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+				for (int b = 0; b < g.grid(); ++b)
+					for (int wave = 0; wave < 4; ++wave)
+						for (int lane = 0; lane < 64; ++lane) {
+							int px, py;
+							if (!block_to_pixel(b, lane, wave, g.tiles_x, g.tiles, g.rows, 1, colour, e.W, e.H, &px, &py)) continue;
+							if (e.d.weak_info[px + py * e.W] == DVP_WEAK) continue;
+							unsigned long long n = 0;
+							f2 tab_mem[kTaps * kTaps];
+							const PatchTab tab{tab_mem, 1};
+							if (part == 0) { if (e.d.sampler) strong_eval_px<1>(e.d, px, py, tab, e.count ? &n : nullptr); else strong_eval_px<0>(e.d, px, py, tab, e.count ? &n : nullptr); }
+							else if (part == 1) {
+								if (S <= 4) strong_decide_px<4>(e.d, px, py, iter);
+								else if (S <= 6) strong_decide_px<6>(e.d, px, py, iter);
+								else if (S <= 8) strong_decide_px<8>(e.d, px, py, iter);
+								else if (S <= 10) strong_decide_px<10>(e.d, px, py, iter);
+								else if (S <= 12) strong_decide_px<12>(e.d, px, py, iter);
+								else strong_decide_px<16>(e.d, px, py, iter);
+							}
+							else { if (e.d.sampler) strong_refine_px<1>(e.d, px, py, tab, e.count ? &n : nullptr); else strong_refine_px<0>(e.d, px, py, tab, e.count ? &n : nullptr); }
+							total += n;
+						}
+			}
+			e.evals += total;
+		} else {
+			launch<DVP_ST_STRONG_UPDATE>(e, iter, colour);
+		}
 		break;
 	}
 	case DVP_ST_RANSAC_FIT: pack_edge(e); launch<DVP_ST_RANSAC_FIT>(e, iter, colour); break;

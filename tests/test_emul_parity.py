@@ -182,3 +182,28 @@ def test_launch_geometry_covers_every_pixel_once():
         assert L.emu_tile_map_check(w, h, 0, 0) == 0, (w, h, "full")
         for colour in (0, 1):
             assert L.emu_tile_map_check(w, h, 1, colour) == 0, (w, h, "half", colour)
+
+
+@pytest.mark.parametrize("form", ["split", "monolithic"])
+@pytest.mark.parametrize("S", [3, 5, 9, 12])
+def test_strong_update_forms_equal_the_oracle(form, S, monkeypatch):
+    """The engine issues the strong update as three launches (dvp_strong_eval / _decide_vN / _refine: evaluator-only kernel,
+    register-resident decisions, refinement with the exact early exits) or, with DVP_STRONG_SPLIT=0, as the one monolithic
+    kernel; the emulation follows the same switch.  Both forms, every view-count bracket of the decision kernel, REFINE_INIT's
+    write-back rule included: bit-identical to the oracle after every launch."""
+    monkeypatch.setenv("DVP_STRONG_SPLIT", "1" if form == "split" else "0")
+    W, H = 72, 56
+    sc = synth.make_scene(W, H, S)
+    for state in (synth.FIRST_INIT, synth.REFINE_INIT):
+        p = make_params(S + 1, max_iterations=2, state=state, use_APD=0)
+        st = first_pass_state(sc)
+        if state == synth.REFINE_INIT:
+            rng = np.random.default_rng(S)
+            L = W * H
+            n = np.tile(sc["normal_gt"], (L, 1)) + rng.normal(0, 0.05, (L, 3)).astype(np.float32)
+            n /= np.linalg.norm(n, axis=1, keepdims=True)
+            depth = (sc["depth_gt"][0].reshape(-1) * (1 + rng.normal(0, 0.02, L))).astype(np.float32)
+            st["planes"] = np.concatenate([n, depth[:, None]], 1).astype(np.float32)
+            st["views"] = rng.integers(1, 1 << S, L).astype(np.uint32)
+        a, b = _pair(sc, p, st)
+        _run_and_compare(a, b, 2, names=("planes", "costs", "selected_views", "view_weight"))
