@@ -263,3 +263,30 @@ def test_apd_source_image_smaller_than_the_reference(tmp_path):
     d2 = g.get("planes")[:, 3].reshape(H, W).copy()
     d2[(d2 < p["depth_min"]) | (d2 > p["depth_max"])] = 0
     assert count_diff(dep, d2) == 0
+
+
+def test_apd_result_cache_and_background_worker_leave_the_same_files(tmp_path):
+    """The driver's write-back result cache, background finisher (visibility clean-up + writes behind the next view),
+    resident depth maps and decode prefetch (host/store.cpp, main.cpp) against the synchronous file flow of the reference
+    (--sync-io: every pass re-reads its inputs from the files the previous one wrote): every result file byte-identical."""
+    import filecmp
+    W, H, NV = 160, 120, 4
+    outs = {}
+    for tag, extra in (("async", []), ("sync", ["--sync-io"])):
+        d = str(tmp_path / tag)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), "3", "--jpg"])
+        out = subprocess.run([os.path.join(ROOT, "dvp-mvs_amd", "apd"), d, "0", "--iters", "2", "--passes", "2", "--min-scale", "1", "--seed", "11", "--labels"],
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        outs[tag] = d
+    n = 0
+    for v in range(NV):
+        ra, rs = (os.path.join(outs[t], "APD", "%08d" % v) for t in ("async", "sync"))
+        names = sorted(os.listdir(rs))
+        assert names == sorted(os.listdir(ra)), (names, sorted(os.listdir(ra)))
+        for fn in names:
+            assert not fn.endswith(".part")
+            assert filecmp.cmp(os.path.join(ra, fn), os.path.join(rs, fn), shallow=False), (v, fn)
+            n += 1
+    assert n >= NV * 6
+    assert filecmp.cmp(os.path.join(outs["async"], "APD", "APD.ply"), os.path.join(outs["sync"], "APD", "APD.ply"), shallow=False)
