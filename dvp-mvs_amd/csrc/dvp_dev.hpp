@@ -95,8 +95,8 @@ struct Dev {
 	s2* weak_nearest_strong;
 	const int* neighbours_map;
 	s2* neighbours;            // 12 per WEAK pixel
-	s2* gn_points;             // GenNeighbours hand-over: 160 candidate points per WEAK pixel (holes = (-1,-1))
-	int* gn_count;             // ... and how many list entries are in use (0: fewer than 4 candidates, pixel not reliable)
+	s2* gn_points;             // GenNeighbours hand-over: the 32 directional slots per WEAK pixel (holes = (-1,-1))
+	int* gn_count;             // ... and how many of them are filled
 	f4* fit_planes;
 	s2* candidate;             // [view][pixel][8]: cand_ptr(); 64 x-adjacent pixels write/read 2 KB contiguous per view
 	const uint8_t* edge;

@@ -136,7 +136,15 @@ DVP_KERNEL(dvp_depth_to_weak_refine, kStageSweeps, DVP_LB_HEAVY)   // the two sw
 
 // the weak-path launch sites: one lane per entry of the WEAK-pixel list
 DVP_KERNEL_LIST(dvp_find_nearest_strong_list, DVP_ST_FIND_NEAREST_STRONG, 1)
-DVP_KERNEL_LIST(dvp_gen_neighbours_list, DVP_ST_GEN_NEIGHBOURS, 1)
+// GenNeighbours' directional search: one lane per WEAK pixel, the list of found points in LDS (one column per lane)
+extern "C" __global__ void __launch_bounds__(256) dvp_gen_neighbours_list(const Dev d, const ListArgs a) {
+	__shared__ s2 pts[kGnDirSlots * 256];
+	const int t = list_block(blockIdx.x, gridDim.x, kListRun) * 256 + threadIdx.x;
+	if (t >= a.count) return;
+	const int center = d.weak_list[a.base + t];
+	const int py = center / d.width, px = center - py * d.width;
+	gen_neighbours_px(d, px, py, pts + threadIdx.x, 256);
+}
 DVP_KERNEL_LIST(dvp_neighbour_update_list, DVP_ST_NEIGHBOUR_UPDATE, 1)
 DVP_KERNEL_LIST(dvp_ransac_fit_plane_list, DVP_ST_RANSAC_FIT, 1)
 
@@ -156,8 +164,24 @@ __device__ __forceinline__ void weak_wave_body(const Dev& d, const ListArgs& a) 
 	weak_update_wave<SMP, FMT>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, sh[wave]);
 	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
 }
+// first half of GenNeighbours (directional anchor search + label extension): one wave per WEAK pixel, the tries of a
+// direction over the lanes (dvp_weak_wave.hpp: gen_neighbours_search_wave)
+#ifndef DVP_LB_GN
+#define DVP_LB_GN 8   // waves per SIMD (64 VGPRs + 164 B scratch; measured 86 ms per cfg3 pass, 4 waves without scratch: 105 ms)
+#endif
+extern "C" __global__ void __launch_bounds__(256, DVP_LB_GN) dvp_gen_neighbours_search(const Dev d, const ListArgs a) {
+	__shared__ GnShared sh[4];
+	const int wave = threadIdx.x >> 6;
+	const int t = list_block(blockIdx.x, gridDim.x, kListRun * 64) * 4 + wave;
+	if (t >= a.count) return;
+	const int center = d.weak_list[a.base + t];
+	if (d.weak_info[center] != DVP_WEAK) return;
+	const int py = center / d.width, px = center - py * d.width;
+	gen_neighbours_search_wave(d, px, py, sh[wave]);
+}
 // second half of GenNeighbours (RANSAC plane + ranking): one wave per WEAK pixel, point tables in LDS
-extern "C" __global__ void __launch_bounds__(256) dvp_gen_neighbours_fit(const Dev d, const ListArgs a) {
+// (3 workgroups per CU is what the 12.6 KB of LDS per wave allow; stated, the compiler fits the kernel in 108 VGPRs, left alone it takes 179: 2 waves per SIMD)
+extern "C" __global__ void __launch_bounds__(256, 3) dvp_gen_neighbours_fit(const Dev d, const ListArgs a) {
 	__shared__ FitShared sh[4];
 	const int wave = threadIdx.x >> 6;
 	const int t = list_block(blockIdx.x, gridDim.x, kListRun * 64) * 4 + wave;
@@ -559,6 +583,7 @@ struct dvp_ctx {
 	float* slot_costs = nullptr; // [17][S][half_w * H]: split strong update (allocated at its first launch)
 	float* strong_rec = nullptr; // [SR_FIELDS][half_w * H]
 	bool strong_split = true;    // DVP_STRONG_SPLIT=0 in the environment: the monolithic kernel (A/B measurements)
+	bool gn_wave = false;        // DVP_GN_WAVE=1: GenNeighbours' search as one wave per WEAK pixel (dvp_gen_neighbours_search; measured slower)
 	float* costs = nullptr; float* costs_snap = nullptr; float* complex_ = nullptr;
 	uint32_t* selected_views = nullptr;
 	uint8_t* view_weight = nullptr; uint8_t* weak_info = nullptr; uint8_t* weak_reliable = nullptr; uint8_t* edge = nullptr;
@@ -659,6 +684,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	c->device = device; c->W = width; c->H = height; c->NI = num_images;
 	c->no_images8 = getenv("DVP_NO_IMAGES8") != nullptr;
 	if (const char* e = getenv("DVP_STRONG_SPLIT")) c->strong_split = atoi(e) != 0;
+	if (const char* e = getenv("DVP_GN_WAVE")) c->gn_wave = atoi(e) != 0;
 	c->pitch = (width + 2 * kImgPad + 63) / 64 * 64;
 	c->L = (size_t)width * height;
 	auto fail = [&](int) { g_create_error = c->error; dvp_ctx_destroy(c); return 1; };
@@ -814,13 +840,13 @@ static int ensure_weak_buffers(dvp_ctx* c, size_t weak_count) {
 	const size_t need = weak_count ? weak_count : 1;
 	if (need > c->weak_alloc) {
 		// The host driver recycles one context over all views and passes (APD.cpp pool): grow geometrically and give the
-		// superseded blocks back (at 160 * 4 B of gn_points per WEAK pixel they are gigabytes at full resolution).
+		// superseded blocks back.
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
 		if (c->side) HIP_TRY(c, hipStreamSynchronize(c->side));
 		dfree(c, &c->neighbours); dfree(c, &c->gn_points); dfree(c, &c->gn_count); dfree(c, &c->complex_); dfree(c, &c->label_boundary);
 		const size_t cap = std::min<size_t>(c->L, std::max(need, c->weak_alloc + c->weak_alloc / 2));
 		if (dalloc(c, &c->neighbours, cap * DVP_NEIGHBOUR_NUM, false)) return 1;
-		if (dalloc(c, &c->gn_points, cap * kGnMaxPoints, false) || dalloc(c, &c->gn_count, cap)) return 1;
+		if (dalloc(c, &c->gn_points, cap * kGnDirSlots, false) || dalloc(c, &c->gn_count, cap)) return 1;
 		if (dalloc(c, &c->complex_, cap)) return 1;
 		if (dalloc(c, &c->label_boundary, cap * 8, false)) return 1;
 		c->weak_alloc = cap;
@@ -1039,7 +1065,8 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 			switch (stage) {
 			case DVP_ST_FIND_NEAREST_STRONG: hipLaunchKernelGGL(ex ? dvp_find_nearest_strong_list_exact : dvp_find_nearest_strong_list, lg, block, 0, c->stream, c->d, la); break;
 			case DVP_ST_GEN_NEIGHBOURS:
-				hipLaunchKernelGGL(ex ? dvp_gen_neighbours_list_exact : dvp_gen_neighbours_list, lg, block, 0, c->stream, c->d, la);
+				if (c->gn_wave) hipLaunchKernelGGL(dvp_gen_neighbours_search, dim3((la.count + 3) / 4), block, 0, c->stream, c->d, la);
+				else hipLaunchKernelGGL(dvp_gen_neighbours_list, lg, block, 0, c->stream, c->d, la);
 				hipLaunchKernelGGL(dvp_gen_neighbours_fit, dim3((la.count + 3) / 4), block, 0, c->stream, c->d, la);
 				break;
 			case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(ex ? dvp_neighbour_update_list_exact : dvp_neighbour_update_list, lg, block, 0, c->stream, c->d, la); break;

@@ -84,9 +84,17 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 	}
 	else if (STAGE == DVP_ST_FIND_NEAREST_STRONG) find_nearest_strong_px(d, px, py);
 	else if (STAGE == DVP_ST_GEN_NEIGHBOURS) {
-		gen_neighbours_px(d, px, py);
-#if !defined(__HIPCC__)   // device: second half in its own launch shape, one wave per WEAK pixel (dvp_gen_neighbours_fit)
-		if (d.weak_info[center] == DVP_WEAK) { FitShared sh; gen_neighbours_fit_wave(d, px, py, sh); }
+		// device: the directional search one lane per WEAK pixel (dvp_gen_neighbours_list) or, DVP_GN_WAVE=1, one wave per
+		// WEAK pixel (dvp_gen_neighbours_search); label extension + fit one wave per WEAK pixel (dvp_gen_neighbours_fit).
+		// Host emulation: the same choice.
+#if !defined(__HIPCC__)
+		if (d.weak_info[center] == DVP_WEAK) {
+			const char* gw_env = getenv("DVP_GN_WAVE");
+			if (gw_env && atoi(gw_env) != 0) { GnShared gs; gen_neighbours_search_wave(d, px, py, gs); }
+			else { s2 pts[kGnDirSlots]; gen_neighbours_px(d, px, py, pts, 1); }
+			FitShared sh;
+			gen_neighbours_fit_wave(d, px, py, sh);
+		}
 #endif
 	}
 	else if (STAGE == DVP_ST_NEIGHBOUR_UPDATE) neighbour_update_px(d, px, py);

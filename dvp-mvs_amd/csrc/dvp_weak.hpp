@@ -310,29 +310,31 @@ DVP_HD bool bresenham_hits_edge(const Dev& d, int Ax, int Ay, int Bx, int By) {
 }
 
 // ---- GenNeighbours (APD.cu:3330-3711) -----------------------------------------------------------
-// First half, one lane per WEAK pixel: the anchor candidates (directional search APD.cu:3382-3452, label
-// extension :3455-3560).  The search of a direction depends on the points found for the directions
-// before it and on how many random tries those consumed, so a pixel is sequential here.  The second half
-// (RANSAC plane + ranking, :3562-3711) is gen_neighbours_fit_wave.
+// First third, one lane per WEAK pixel: the directional search (APD.cu:3382-3452).  The search of a direction depends on
+// the points found for the directions before it and on how many random tries those consumed, so a pixel is sequential
+// here, and the lanes of a wave — neighbouring WEAK pixels — walk the SAME direction at the same time: their tries land
+// near each other (measured: letting every lane run through its directions at its own pace costs 50 ms of 80, a wave per
+// pixel with the tries over the lanes 6-25 ms).  The list of found points lives in LDS (`pts`, one
+// column per lane): as a private array it is scratch memory, re-read for every try's duplicate test — 100 GB of HBM
+// fetch per cfg3 launch (FETCH_SIZE, profiles/pmc_r03.json) for 0.2 GB of state.  The label extension (:3455-3560)
+// and the plane fit (:3562-3711) are one wave per pixel: gen_neighbours_extend_wave / gen_neighbours_fit_wave.
 constexpr int kGnMaxPoints = 160;   // max_pt_num (APD.cu:3338)
-DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
+constexpr int kGnDirSlots = 32;     // 8 octants x 4 rotations: the directional slots at the head of the list
+DVP_HD void gen_neighbours_px(const Dev& d, int px, int py, s2* pts, int stride) {
 	const int W = d.width, H = d.height;
 	const int center = px + py * W;
 	if (d.weak_info[center] != DVP_WEAK) return;
 	const DvpParams& P = d.params;
-	const DvpCamera cam = load_camera(d, 0);
-	const int max_pt_num = kGnMaxPoints;
 	const int min_margin = 6;
-	s2* neighbours = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
+	const int wi = d.neighbours_map[center];
+	s2* neighbours = d.neighbours + (size_t)wi * DVP_NEIGHBOUR_NUM;
 	Rng r_limit(d.seed, (uint32_t)center, rng_site(PH_NEIGHBOURS, 0, SUB_LIMIT));
 	Rng r_search(d.seed, (uint32_t)center, rng_site(PH_NEIGHBOURS, 0, SUB_SEARCH));
 
 	for (int i = 0; i < DVP_NEIGHBOUR_NUM; ++i) neighbours[i] = mks2(-1, -1);
 	neighbours[0] = mks2(px, py);
-	s2 strong_points[max_pt_num];   // (-1,-1) == not valid (the reference's dir_valid[])
-	// only the 32 directional slots can stay empty; label-extension points are appended behind them
-	// and every later loop stops at the last appended one (the reference clears all 160 entries)
-	for (int i = 0; i < 32; ++i) strong_points[i] = mks2(-1, -1);
+	// (-1,-1) == not valid (the reference's dir_valid[])
+	for (int i = 0; i < kGnDirSlots; ++i) pts[i * stride] = mks2(-1, -1);
 	int strong_point_size = 0;
 	const int rotate_time = P.rotate_time;
 
@@ -340,7 +342,7 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 	if (P.use_limit) {
 		edge_limit = true;
 		if (P.use_edge) {
-			const float complex_val = d.complex_[d.neighbours_map[center]];
+			const float complex_val = d.complex_[wi];
 			const float rp = r_limit.uniform() - FLT_EPSILON;
 			if (rp < complex_val) edge_limit = false;
 		}
@@ -390,20 +392,24 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 							if (np.x == -1 || np.y == -1) continue;
 							npc = np.x + np.y * W;
 						}
-						bool same = false;   // (no early exit: the loads are independent and pipeline)
-						for (int k = 0; k < dir_index; k++)
-							same |= (strong_points[k].x == np.x) & (strong_points[k].y == np.y);
-						if (same) continue;
+						// the angle test before the duplicate test (the reference has them the other way round, APD.cu:3425-3440;
+						// both only skip the try): the cheap one first
 						f2 td = mk2((float)(np.x - px), (float)(np.y - py));
 						normalize2(&td);
 						const float cos_a = td.x * od.x + td.y * od.y;
 						if (!(cos_a > d.nb_thresh)) continue;
+						bool same = false;   // (no early exit: the loads are independent and pipeline)
+						for (int k = 0; k < dir_index; k++) {
+							const s2 q = pts[k * stride];
+							same |= (q.x == np.x) & (q.y == np.y);
+						}
+						if (same) continue;
 						cand = true;
 						break;
 					}
 					if (!cand) break;
 					if (!edge_limit || !bresenham_hits_edge(d, px, py, np.x, np.y)) {
-						strong_points[dir_index] = np;
+						pts[dir_index * stride] = np;
 						strong_point_size++;
 						found_dir = true;
 					}
@@ -417,63 +423,10 @@ DVP_HD void gen_neighbours_px(const Dev& d, int px, int py) {
 		}
 	}
 
-	int extend_index = 31;
-	if (P.use_label && d.label[center] > 0) {
-		const int ldx[16] = { 0, 0, -1, 1, -1, 1, -1, 1, 1, 0, 0, -1, -1, 0, 0, 1 };   // APD.cu:3462 (0.5 -> 0)
-		const int ldy[16] = { -1, 1, 0, 0, -1, 1, 1, -1, 0, 1, 1, 0, 0, -1, -1, 0 };
-		const s2* lb = d.label_boundary + (size_t)d.neighbours_map[center] * 8;
-		float bound_dist[16];
-		int dir_step[16];
-		for (int i = 0; i < 16; ++i) { bound_dist[i] = 0.0f; dir_step[i] = 0; }
-		for (int i = 0; i < 8; ++i) {
-			const s2 bp = lb[i];
-			float dist = 0.0f;
-			if (bp.x != -1 && bp.y != -1) {
-				const double ex = (double)(px - bp.x), ey = (double)(py - bp.y);
-				dist = (float)sqrt(ex * ex + ey * ey);
-				if (i >= 4) dist = (float)((double)dist / sqrt(2.0));
-			}
-			bound_dist[i] = dist;
-			if (i % 2 == 1) { dir_step[i - 1] = 4 * rotate_time - 1; dir_step[i] = 1; }   // APD.cu:3477: step == 1
-		}
-		const int ca[8] = { 3, 1, 1, 2, 2, 4, 7, 7 };
-		const int cb[8] = { 5, 5, 6, 6, 4, 0, 0, 3 };
-		for (int q = 0; q < 8; ++q) {
-			dir_step[8 + q] = (dir_step[ca[q]] + dir_step[cb[q]]) / 2;
-			bound_dist[8 + q] = (bound_dist[ca[q]] + bound_dist[cb[q]]) / 2;
-		}
-		for (int i = 0; i < 16; ++i) {
-			const float dist = bound_dist[i];
-			const int gap_num = dir_step[i] + 1;
-			const int step_len = DVP_MAX(1, (int)floor(1.0 * dist / gap_num));
-			for (int step = 1; step <= dir_step[i]; ++step) {
-				s2 np = mks2(px + step * step_len * ldx[i], py + step * step_len * ldy[i]);
-				if (np.x < min_margin || np.y < min_margin || np.x >= W - min_margin || np.y >= H - min_margin) continue;
-				int npc = np.x + np.y * W;
-				if (!strong_bit(d, np.x, np.y)) {
-					np = d.weak_nearest_strong[npc];
-					if (np.x == -1 || np.y == -1) continue;
-					npc = np.x + np.y * W;
-				}
-				bool same = false;
-				for (int k = 0; k <= extend_index; k++)
-					if (strong_points[k].x == np.x && strong_points[k].y == np.y) { same = true; break; }
-				if (same) continue;
-				if (extend_index + 1 >= max_pt_num) continue;
-				extend_index++;
-				strong_points[extend_index] = np;
-				strong_point_size++;
-			}
-		}
-	}
-
-	// hand-over to the plane-fit half (gen_neighbours_fit_wave, dvp_weak_wave.hpp): the candidate list as it
-	// stands — the 32 directional slots with their holes, then the label-extension points
-	const int wi = d.neighbours_map[center];
-	if (strong_point_size <= 3) { d.weak_reliable[center] = 0; d.gn_count[wi] = 0; return; }
-	s2* out = d.gn_points + (size_t)wi * kGnMaxPoints;
-	for (int i = 0; i <= extend_index; ++i) out[i] = strong_points[i];
-	d.gn_count[wi] = extend_index + 1;
+	// hand-over to the wave-per-pixel rest (dvp_weak_wave.hpp): the 32 directional slots with their holes, and how many are filled
+	s2* out = d.gn_points + (size_t)wi * kGnDirSlots;
+	for (int i = 0; i < kGnDirSlots; ++i) out[i] = pts[i * stride];
+	d.gn_count[wi] = strong_point_size;
 }
 
 // NeigbourUpdate (APD.cu:3713-3729)

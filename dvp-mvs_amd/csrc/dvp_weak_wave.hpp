@@ -23,6 +23,9 @@
 
 #include "dvp_weak.hpp"
 
+#if defined(DVP_GN_STATS) && !defined(__HIPCC__)
+#include <cstdio>
+#endif
 namespace dvp {
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -741,6 +744,277 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 	wave_sync();
 }
 
+// ---- GenNeighbours, first half (APD.cu:3330-3505): the anchor search, ONE WAVE PER WEAK PIXEL ------------------------
+// gen_neighbours_px (dvp_weak.hpp) walks, per lane, 32 directions x a sequence of tries with two to four dependent loads
+// each (and a line walk per surviving try): 80 ms per cfg3 pass at 7 % VALU activity, the slowest lane of 64 unrelated
+// pixels setting the pace of every direction.  What is sequential in it is only (i) the shared random stream — but a try
+// always consumes exactly four draws, so try t of a direction that starts at counter k0 uses k0 + 4 t .. + 3 — and (ii)
+// "this point was already found by an earlier direction".  Within ONE direction the tries are therefore independent
+// functions of (k0, t): the lanes evaluate tries t0 .. t0 + kGnTries - 1 at once (RNG, candidate point, STRONG test,
+// nearest-strong fall-back, duplicate test against the earlier directions, angle test), the edge-limited line walks of
+// the surviving tries run eight tries at a time, and the direction takes the FIRST try that passes, exactly like the
+// sequential loop; the stream advances by 4 x (tries the sequential loop would have made).  The label-extension points
+// are found the same way ((direction, step) items over the lanes) and appended in item order.  Same points, same order,
+// same random numbers: the per-lane function stays in the tree as the definition and the tests compare the two.
+#ifndef DVP_GN_TRIES
+#define DVP_GN_TRIES 64
+#endif
+constexpr int kGnTries = DVP_GN_TRIES;   // tries of one direction evaluated per round (<= 64)
+struct GnShared {
+	s2 pts[kGnDirSlots];    // the directional slots (holes = (-1,-1))
+	s2 cnp[64];             // the candidate of this lane's try
+	uint8_t flag[64];       // 0 = try failed, 1 = try accepted, 2 = the try does not exist, 4 = candidate, line walk pending
+};
+// first lane < limit whose flag has one of the bits in `mask` (64 = none)
+DVP_HD int wave_first_flag(const uint8_t* flag, int mask, int limit) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	const int l = (int)(threadIdx.x & 63u);
+	const unsigned long long m = __ballot(l < limit && (flag[l] & mask) != 0);
+	return m ? (int)__builtin_ctzll(m) : 64;
+#else
+	for (int l = 0; l < limit; ++l) if (flag[l] & mask) return l;
+	return 64;
+#endif
+}
+#if defined(DVP_GN_STATS) && !defined(__HIPCC__)
+// test instrumentation (tests/emul, -DDVP_GN_STATS): histogram of the try index a direction ends at
+struct GnStats { long hist[8] = {0}, found = 0, out = 0; ~GnStats() { fprintf(stderr, "gn tries <1 <4 <8 <16 <32 <64 <128 more: %ld %ld %ld %ld %ld %ld %ld %ld found %ld out %ld\n", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], found, out); } };
+inline void gn_stats_note(int t, bool found) {
+	static GnStats g;
+	const int lim[7] = { 1, 4, 8, 16, 32, 64, 128 };
+	int b = 7;
+	for (int i = 6; i >= 0; --i) if (t < lim[i]) b = i;
+#pragma omp critical
+	{ g.hist[b]++; if (found) g.found++; else g.out++; }
+}
+#endif
+DVP_HD int gn_radius_of_group(int g) { return g <= 4 ? (2 << g) : 32 + 25 * (g - 4); }   // 2, 4, 8, 16, 32, 57, 82, ... (APD.cu:3449: min(2r, r + 25))
+
+DVP_HD void gen_neighbours_search_wave(const Dev& d, int px, int py, GnShared& sh) {
+	const int W = d.width, H = d.height;
+	const int center = px + py * W;
+	const DvpParams& P = d.params;
+	const int min_margin = 6;
+	const int wi = d.neighbours_map[center];
+	s2* neighbours = d.neighbours + (size_t)wi * DVP_NEIGHBOUR_NUM;
+	const uint32_t site_search = rng_site(PH_NEIGHBOURS, 0, SUB_SEARCH);
+	DVP_LANES(l) {
+		if (l < DVP_NEIGHBOUR_NUM) neighbours[l] = l == 0 ? mks2(px, py) : mks2(-1, -1);
+		if (l < 32) sh.pts[l] = mks2(-1, -1);
+	}
+	wave_sync();
+	int strong_point_size = 0;
+	const int rotate_time = P.rotate_time;
+	bool edge_limit = false;
+	if (P.use_limit) {
+		edge_limit = true;
+		if (P.use_edge) {
+			Rng r_limit(d.seed, (uint32_t)center, rng_site(PH_NEIGHBOURS, 0, SUB_LIMIT));
+			const float rp = r_limit.uniform() - FLT_EPSILON;
+			if (rp < d.complex_[wi]) edge_limit = false;
+		}
+	}
+	uint32_t k0 = 0;   // r_search's counter at the start of the current direction
+	int odi = -1;
+	for (int odx = -1; odx <= 1; ++odx) {
+		for (int ody = -1; ody <= 1; ++ody) {
+			if (odx == 0 && ody == 0) continue;
+			f2 od = mk2((float)odx, (float)ody);
+			normalize2(&od);
+			odi++;
+			for (int rot = 0; rot < rotate_time; ++rot) {
+				const int dir_index = odi * 4 + rot;
+				bool resolved = false;
+				for (int t0 = 0; !resolved; t0 += kGnTries) {
+					DVP_LANES(l) {
+						const int t = t0 + l;
+						const int cur_radius = gn_radius_of_group(t >> 2);
+						uint8_t f = 0;
+						s2 np = mks2(-1, -1);
+						// the try exists iff its radius group was entered: radius <= 4096 and the ray still inside the image
+						const float tx = px + od.x * cur_radius, ty = py + od.y * cur_radius;
+						if (l >= kGnTries) f = 0;
+						else if (cur_radius > 4096 || tx < 0 || ty < 0 || tx >= W || ty >= H) f = 2;
+						else {
+							const uint32_t kk = k0 + 4u * (uint32_t)t;
+							const uint32_t sgx = (rand_u32(d.seed, (uint32_t)center, site_search, kk) % 2 == 0) ? 1u : 0xFFFFFFFFu;
+							const int xs = (int)((sgx * rand_u32(d.seed, (uint32_t)center, site_search, kk + 1)) % (uint32_t)d.nb_shift_range);
+							const uint32_t sgy = (rand_u32(d.seed, (uint32_t)center, site_search, kk + 2) % 2 == 0) ? 1u : 0xFFFFFFFFu;
+							const int ys = (int)((sgy * rand_u32(d.seed, (uint32_t)center, site_search, kk + 3)) % (uint32_t)d.nb_shift_range);
+							f2 dir = mk2(od.x * 20 + xs, od.y * 20 + ys);
+							normalize2(&dir);
+							np = mks2((int)(px + dir.x * cur_radius), (int)(py + dir.y * cur_radius));
+							bool ok = !(np.x < min_margin || np.y < min_margin || np.x >= W - min_margin || np.y >= H - min_margin);
+							if (ok && !strong_bit(d, np.x, np.y)) {
+								np = d.weak_nearest_strong[np.x + np.y * W];
+								ok = !(np.x == -1 || np.y == -1);
+							}
+							if (ok) {
+								bool same = false;
+								for (int k = 0; k < dir_index; k++) same |= (sh.pts[k].x == np.x) & (sh.pts[k].y == np.y);
+								f2 td = mk2((float)(np.x - px), (float)(np.y - py));
+								normalize2(&td);
+								const float cos_a = td.x * od.x + td.y * od.y;
+								if (!same && cos_a > d.nb_thresh) f = edge_limit ? 4 : 1;
+							}
+						}
+						sh.cnp[l] = np;
+						sh.flag[l] = f;
+					}
+					wave_sync();
+					// the sequential loop's outcome: the first try that is accepted (1) or does not exist (2); a pending try (4)
+					// in front of it has to be walked first — eight tries per round, most directions end in the first
+					int first = 64;
+					for (int r0 = 0; r0 < kGnTries; r0 += 8) {
+						if (edge_limit) {
+							DVP_LANES(l) {
+								if (l >= r0 && l < r0 + 8 && sh.flag[l] == 4) {
+									const s2 np = sh.cnp[l];
+									sh.flag[l] = bresenham_hits_edge(d, px, py, np.x, np.y) ? 0 : 1;
+								}
+							}
+							wave_sync();
+						}
+						first = wave_first_flag(sh.flag, 3, r0 + 8);
+						if (first < 64) break;
+					}
+#if defined(DVP_GN_STATS) && !defined(__HIPCC__)
+					if (first < 64) gn_stats_note(t0 + first, sh.flag[first] == 1);
+#endif
+					if (first < 64) {
+						resolved = true;
+						if (sh.flag[first] == 1) {
+							const s2 np = sh.cnp[first];
+							wave_sync();
+							if (DVP_LANE0) sh.pts[dir_index] = np;
+							strong_point_size++;
+							k0 += 4u * (uint32_t)(t0 + first + 1);
+						} else {
+							k0 += 4u * (uint32_t)(t0 + first);
+						}
+					}
+					wave_sync();
+				}
+				f2 rd;
+				rd.x = od.x * d.nb_cos - od.y * d.nb_sin;
+				rd.y = od.x * d.nb_sin + od.y * d.nb_cos;
+				normalize2(&rd);
+				od = rd;
+			}
+		}
+	}
+
+	// hand-over: the 32 directional slots with their holes, and how many are filled (the same as gen_neighbours_px)
+	s2* out = d.gn_points + (size_t)wi * kGnDirSlots;
+	DVP_LANES(l) { if (l < kGnDirSlots) out[l] = sh.pts[l]; }
+	if (DVP_LANE0) d.gn_count[wi] = strong_point_size;
+}
+
+// ---- GenNeighbours, the label extension (APD.cu:3455-3560): one wave per WEAK pixel --------------------------------
+// Points on 16 rays through the pixel's label region, every one mapped to a STRONG pixel and appended to the list unless
+// it is in the list already.  The (ray, step) items are independent but for that duplicate test: 64 items per round over
+// the lanes, each tested against the list as it stood before the round and against the EARLIER items of the round, then
+// appended in item order — the list the reference's sequential loop builds.  `pts` is the list (LDS, kGnMaxPoints
+// entries, the first 32 filled by the directional search); returns the index of the last entry, *n_appended how many
+// were added.  cnp / flag / keep: 64 entries of shared scratch each.
+DVP_HD int gen_neighbours_extend_wave(const Dev& d, int px, int py, int wi, s2* pts, s2* cnp, uint8_t* flag, uint8_t* keep, int* n_appended) {
+	const int W = d.width, H = d.height;
+	const int center = px + py * W;
+	const DvpParams& P = d.params;
+	const int min_margin = 6;
+	const int rotate_time = P.rotate_time;
+	int extend_index = kGnDirSlots - 1;
+	int total_appended = 0;
+	if (P.use_label && d.label[center] > 0) {
+		const int ldx[16] = { 0, 0, -1, 1, -1, 1, -1, 1, 1, 0, 0, -1, -1, 0, 0, 1 };   // APD.cu:3462 (0.5 -> 0)
+		const int ldy[16] = { -1, 1, 0, 0, -1, 1, 1, -1, 0, 1, 1, 0, 0, -1, -1, 0 };
+		const s2* lb = d.label_boundary + (size_t)wi * 8;
+		float bound_dist[16];
+		int dir_step[16];
+#pragma unroll
+		for (int i = 0; i < 16; ++i) { bound_dist[i] = 0.0f; dir_step[i] = 0; }
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const s2 bp = lb[i];
+			float dist = 0.0f;
+			if (bp.x != -1 && bp.y != -1) {
+				const double ex = (double)(px - bp.x), ey = (double)(py - bp.y);
+				dist = (float)sqrt(ex * ex + ey * ey);
+				if (i >= 4) dist = (float)((double)dist / sqrt(2.0));
+			}
+			bound_dist[i] = dist;
+			if (i % 2 == 1) { dir_step[i - 1] = 4 * rotate_time - 1; dir_step[i] = 1; }   // APD.cu:3477: step == 1
+		}
+		const int ca[8] = { 3, 1, 1, 2, 2, 4, 7, 7 };
+		const int cb[8] = { 5, 5, 6, 6, 4, 0, 0, 3 };
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			dir_step[8 + q] = (dir_step[ca[q]] + dir_step[cb[q]]) / 2;
+			bound_dist[8 + q] = (bound_dist[ca[q]] + bound_dist[cb[q]]) / 2;
+		}
+		int n_items = 0;     // items = (direction i, step 1 .. dir_step[i]) in the reference's loop order
+#pragma unroll
+		for (int i = 0; i < 16; ++i) n_items += dir_step[i] > 0 ? dir_step[i] : 0;
+		for (int c0 = 0; c0 < n_items; c0 += 64) {
+			DVP_LANES(l) {
+				const int c = c0 + l;
+				uint8_t f = 0;
+				s2 np = mks2(-1, -1);
+				if (c < n_items) {
+					int first = 0, step = 0, step_len = 1, ddx = 0, ddy = 0;   // (a select chain: the tables stay in registers)
+#pragma unroll
+					for (int i = 0; i < 16; ++i) {
+						const int n = dir_step[i] > 0 ? dir_step[i] : 0;
+						if (c >= first && c < first + n) {
+							step = c - first + 1;
+							step_len = DVP_MAX(1, (int)floor(1.0 * bound_dist[i] / (dir_step[i] + 1)));
+							ddx = ldx[i];
+							ddy = ldy[i];
+						}
+						first += n;
+					}
+					np = mks2(px + step * step_len * ddx, py + step * step_len * ddy);
+					bool ok = !(np.x < min_margin || np.y < min_margin || np.x >= W - min_margin || np.y >= H - min_margin);
+					if (ok && !strong_bit(d, np.x, np.y)) {
+						np = d.weak_nearest_strong[np.x + np.y * W];
+						ok = !(np.x == -1 || np.y == -1);
+					}
+					if (ok) {
+						bool same = false;      // against everything accepted before this batch ...
+						for (int k = 0; k <= extend_index; k++) same |= (pts[k].x == np.x) & (pts[k].y == np.y);
+						if (!same) f = 1;
+					}
+				}
+				cnp[l] = np;
+				flag[l] = f;
+			}
+			wave_sync();
+			DVP_LANES(l) {
+				// ... and against the earlier items of the batch: the first occurrence of a point is the one the sequential
+				// loop appends (an earlier equal item that was itself dropped had an even earlier equal one)
+				const s2 np = cnp[l];
+				bool kp = flag[l] == 1;
+				for (int q = 0; q < l; ++q) kp &= !((flag[q] == 1) & (cnp[q].x == np.x) & (cnp[q].y == np.y));
+				keep[l] = kp ? 1 : 0;
+			}
+			wave_sync();
+			int appended = 0;
+			DVP_LANES(l) {
+				int before = 0, total = 0;    // kept items in front of this one / in the batch
+				for (int k = 0; k < 64; ++k) { total += keep[k]; before += k < l ? keep[k] : 0; }
+				const int pos = extend_index + 1 + before;
+				if (keep[l] && pos < kGnMaxPoints) pts[pos] = cnp[l];
+				appended = DVP_MIN(total, kGnMaxPoints - 1 - extend_index);
+			}
+			wave_sync();
+			extend_index += appended;
+			total_appended += appended;
+		}
+	}
+	*n_appended = total_appended;
+	return extend_index;
+}
+
 // ---- GenNeighbours, second half (APD.cu:3562-3711): RANSAC plane through the candidate anchors, then the
 // anchors ranked by their distance to that plane — ONE WAVE per WEAK pixel.
 //
@@ -840,8 +1114,15 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 	const int center = px + py * W;
 	const DvpParams& P = d.params;
 	const int wi = d.neighbours_map[center];
-	const int listed = d.gn_count[wi];
-	if (listed <= 0) return;   // fewer than four candidates: the first half already marked the pixel unreliable
+	// ---- the list: the directional slots from the search kernel, then the label extension -------------------------
+	DVP_LANES(l) { if (l < kGnDirSlots) sh.raw[l] = d.gn_points[(size_t)wi * kGnDirSlots + l]; }
+	wave_sync();
+	int n_extended = 0;
+	const int listed = 1 + gen_neighbours_extend_wave(d, px, py, wi, sh.raw, sh.spv, sh.req_from, sh.req_to, &n_extended);
+	if (d.gn_count[wi] + n_extended <= 3) {   // fewer than four candidates (APD.cu:3562): not reliable, no plane
+		if (DVP_LANE0) d.weak_reliable[center] = 0;
+		return;
+	}
 	const DvpCamera cam = load_camera(d, 0);
 	const float depth_diff = P.depth_max - P.depth_min;
 	s2* neighbours = d.neighbours + (size_t)wi * DVP_NEIGHBOUR_NUM;
@@ -861,7 +1142,7 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 	for (int i0 = 0; i0 < listed; i0 += 64) {
 		DVP_LANES(l) {
 			s2 r = mks2(-1, -1);
-			if (i0 + l < listed) { r = d.gn_points[(size_t)wi * kGnMaxPoints + i0 + l]; sh.raw[i0 + l] = r; }
+			if (i0 + l < listed) r = sh.raw[i0 + l];
 			const bool valid = r.x != -1;
 			const int slot = wave_ordered_slot(valid, &sh.n_valid);   // the list without its holes, order kept
 			if (valid) sh.slot_of[slot] = (uint8_t)(i0 + l);

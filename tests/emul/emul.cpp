@@ -140,7 +140,7 @@ void* emu_create(int W, int H, int NI) {
 	e->weak_nearest_strong.assign(L, mks2(-1, -1));
 	e->neighbours_map.assign(L, 0);
 	e->neighbours.assign(DVP_NEIGHBOUR_NUM, mks2(-1, -1));
-	e->gn_points.assign(kGnMaxPoints, mks2(-1, -1));
+	e->gn_points.assign(kGnDirSlots, mks2(-1, -1));
 	e->gn_count.assign(1, 0);
 	e->candidate.assign(L * (size_t)(S > 0 ? S : 1) * 8, mks2(0, 0));
 	e->edge.assign(L, 0);
@@ -236,7 +236,7 @@ void emu_upload_state(void* c, const f4* planes, const uint32_t* views, const ui
 	e.d.weak_count = wc;
 	const size_t n = (size_t)(wc > 0 ? wc : 1);
 	e.neighbours.assign(n * DVP_NEIGHBOUR_NUM, mks2(-1, -1));
-	e.gn_points.assign(n * kGnMaxPoints, mks2(-1, -1));
+	e.gn_points.assign(n * kGnDirSlots, mks2(-1, -1));
 	e.gn_count.assign(n, 0);
 	e.complex_.assign(n, 0.0f);
 	e.label_boundary.assign(n * 8, mks2(-1, -1));

@@ -123,6 +123,67 @@ def test_find_nearest_strong_ring_order(seed):
     find_nearest_strong_case(seed, _pair)
 
 
+def gen_neighbours_case(seed, pair):
+    """GenNeighbours alone (APD.cu:3330-3711) where the directional search has work to do: large WEAK areas with few
+    STRONG pixels (a direction runs through many tries — more than one 64-try round of the wave kernel — before it
+    finds a new point or leaves the image), random edge segments (the edge-limited line walk rejects tries), label
+    regions with boundaries (label extension: up to ~100 items, duplicates among them and against the directional
+    points), rotate_time 4 (32 directions).  The oracle walks tries and items one at a time."""
+    rng = np.random.default_rng(100 + seed)
+    W, H, S = [420, 420, 640][seed], 260, 1
+    side = [300, 300, 470][seed]   # a textured side; seed 2: rays from the far left need more than 64 tries to reach it
+    sc = synth.make_scene(W, H, S)
+    p = make_params(S + 1, max_iterations=1, state=synth.REFINE_ITER, use_APD=1, rotate_time=4,
+                    use_limit=[1, 1, 0][seed], use_edge=[1, 0, 1][seed])
+    st = first_pass_state(sc)
+    L = W * H
+    n = np.tile(sc["normal_gt"], (L, 1)) + rng.normal(0, 0.03, (L, 3)).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    depth = (sc["depth_gt"][0].reshape(-1) * (1 + rng.normal(0, 0.01, L))).astype(np.float32)
+    st["planes"] = np.concatenate([n, depth[:, None]], 1).astype(np.float32)
+    st["views"] = np.ones(L, np.uint32)
+    weak = np.full((H, W), synth.WEAK, np.uint8)
+    weak.reshape(-1)[rng.choice(L, [60, 900, 9][seed], replace=False)] = synth.STRONG
+    weak[rng.random((H, W)) < 0.03] = synth.UNKNOWN
+    weak[:, side:] = np.where(rng.random((H, W - side)) < 0.4, synth.STRONG, weak[:, side:])
+    st["weak"] = weak.reshape(-1)
+    edge = np.zeros((H, W), np.uint8)
+    for _ in range(25):      # random segments
+        x0, y0 = rng.integers(0, W), rng.integers(0, H)
+        ang, ln = rng.uniform(0, np.pi), rng.integers(10, 120)
+        t = np.arange(ln)
+        xs = np.clip((x0 + t * np.cos(ang)).astype(int), 0, W - 1)
+        ys = np.clip((y0 + t * np.sin(ang)).astype(int), 0, H - 1)
+        edge[ys, xs] = 1
+    st["edge"] = edge.reshape(-1)
+    yy, xx = np.mgrid[0:H, 0:W]
+    label = (1 + xx // 70 + 10 * (yy // 65)).astype(np.int32)
+    label[(xx % 70 == 0) | (yy % 65 == 0) | (edge == 1)] = -1
+    label[100:140, 150:230] = 0
+    st["label"] = label.reshape(-1)
+    a, b = pair(sc, p, st)
+    for x in (a, b):
+        for stage in ("gen_edge_inform", "find_nearest_strong", "gen_neighbours"):
+            x.run_stage(stage, 0, 0)
+    for name in ("complex", "label_boundary", "weak_nearest_strong", "neighbours", "weak_reliable", "fit_planes"):
+        assert count_diff(a.get(name), b.get(name)) == 0, name
+    rel = b.get("weak_reliable").reshape(H, W)
+    assert (rel[weak == synth.WEAK] == 1).sum() > 1000
+    nb = b.get("neighbours").reshape(-1, 12, 2)
+    assert (nb[:, 1:, 0] >= 0).any()
+
+
+@pytest.mark.parametrize("form", ["wave", "per_lane"])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_gen_neighbours_search_forms_equal_the_oracle(form, seed, monkeypatch):
+    """The per-lane search (dvp_gen_neighbours_list: angle test first, signature-filtered duplicate test) and the
+    wave-per-pixel search (DVP_GN_WAVE=1, dvp_gen_neighbours_search: the tries of a direction over the lanes; measured
+    slower on the GPU, kept as the record of that measurement): the same anchors, in the same order, from the same
+    random numbers."""
+    monkeypatch.setenv("DVP_GN_WAVE", "1" if form == "wave" else "0")
+    gen_neighbours_case(seed, _pair)
+
+
 def many_views_case(S, pair, make_engine):
     W, H = 88, 64
     sc = synth.make_scene(W, H, S)

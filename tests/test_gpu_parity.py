@@ -160,6 +160,17 @@ def test_find_nearest_strong_ring_order(seed):
     find_nearest_strong_case(seed, _pair)
 
 
+@pytest.mark.parametrize("form", ["per_lane", "wave"])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_gen_neighbours_search_forms_equal_the_oracle(form, seed, monkeypatch):
+    """GenNeighbours on the GPU — dvp_gen_neighbours_list (directional search, one lane per WEAK pixel, list in LDS) or
+    dvp_gen_neighbours_search (DVP_GN_WAVE=1: one wave per pixel), then label extension + plane fit in
+    dvp_gen_neighbours_fit — on maps where directions need tens of tries and the extension meets duplicates."""
+    from test_emul_parity import gen_neighbours_case
+    monkeypatch.setenv("DVP_GN_WAVE", "1" if form == "wave" else "0")
+    gen_neighbours_case(seed, _pair)
+
+
 @pytest.mark.parametrize("S", [12, 18])
 def test_many_views_weak_path(S):
     """More than 9 and more than 16 source views: the 16- and 32-view instantiations of the strong update, several
