@@ -134,7 +134,7 @@ def gen_neighbours_case(seed, pair):
     side = [300, 300, 470][seed]   # a textured side; seed 2: rays from the far left need more than 64 tries to reach it
     sc = synth.make_scene(W, H, S)
     p = make_params(S + 1, max_iterations=1, state=synth.REFINE_ITER, use_APD=1, rotate_time=4,
-                    use_limit=[1, 1, 0][seed], use_edge=[1, 0, 1][seed])
+                    use_limit=[1, 1, 0][seed])   # (use_edge stays on: the engine rejects use_edge = 0, dvp_set_params)
     st = first_pass_state(sc)
     L = W * H
     n = np.tile(sc["normal_gt"], (L, 1)) + rng.normal(0, 0.03, (L, 3)).astype(np.float32)
