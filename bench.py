@@ -101,7 +101,7 @@ def kernel_name(stage, S):
     return {"strong_update": "dvp_strong_eval" if split else ("dvp_strong_update_v8" if S <= 8 else ("dvp_strong_update_v16" if S <= 16 else "dvp_strong_update")),
             "weak_update": "dvp_weak_update_wave_u8" if IMAGE_FORMAT else "dvp_weak_update_wave",
             "depth_to_weak": "dvp_depth_to_weak_refine",   # dvp_run_patchmatch: DepthToWeak + LocalRefine in one launch
-            "gen_neighbours": "dvp_gen_neighbours_list",
+            "gen_neighbours": "dvp_gen_neighbours_search" if os.environ.get("DVP_GN_WAVE", "0") not in ("", "0") else "dvp_gen_neighbours_list",
             "ransac_fit": "dvp_ransac_fit_plane_list", "find_nearest_strong": "dvp_find_nearest_strong_list",
             "neighbour_update": "dvp_neighbour_update_list"}.get(stage, "dvp_" + stage)
 
