@@ -117,6 +117,7 @@ def parse():
     ap.add_argument("--src", type=int, default=0)
     ap.add_argument("--iters", type=int, default=0)
     ap.add_argument("--weak-frac", type=float, default=0.05, help="share of 32x32 tiles handed over as WEAK (refine configs)")
+    ap.add_argument("--weak-layout", default="tiles", choices=["tiles", "regions"], help="shape of the pixels handed over as WEAK: 32x32 tiles (default) or a few large connected regions (workloads.weak_regions)")
     ap.add_argument("--rig", default="rotated", choices=["rotated", "axis"], help="camera rig of the synthetic scene: per-view rotations and intrinsics (default) or the round-1/2 rig (R = I, one K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=str, default="auto", help="WxH of the CPU-baseline view (auto: scaled to the core count)")
@@ -162,7 +163,7 @@ def cpu_baseline(pkg, args, cfg, S, iters, device=0):
     if cfg["refine"]:
         p2 = wl.refine_iter_params(S, iters)
         st = wl.hand_over(o.get("planes"), o.get("selected_views"), o.get("weak_info"), o.get("radius"), p1, w, h,
-                          extra_weak=wl.weak_tiles(w, h, args.weak_frac, sc["flat"]))
+                          extra_weak=wl.weak_mask(args.weak_layout, w, h, args.weak_frac, sc["flat"]))
         for e in (o, g):
             e.set_params(p2)
             e.set_depths(sc["depth_gt"])
@@ -340,7 +341,7 @@ def main():
         # untimed FIRST_INIT pass -> hand-over -> the REFINE_ITER pass that is timed
         ctx.run_patchmatch()
         planes, views, weak, radius = ctx.download_state()
-        st = wl.hand_over(planes, views, weak, radius, p1, W, H, extra_weak=wl.weak_tiles(W, H, args.weak_frac, flat))
+        st = wl.hand_over(planes, views, weak, radius, p1, W, H, extra_weak=wl.weak_mask(args.weak_layout, W, H, args.weak_frac, flat))
         del planes, views, weak, radius
         ctx.set_params(wl.refine_iter_params(S, iters))
         ctx.set_depths_device([deps[i].data_ptr() for i in order], W)
@@ -407,7 +408,7 @@ def main():
         dom = ranked[0]
         workload = "BASELINE %s stand-in: %dx%d, S=%d source views, %d PatchMatch iterations, %s" % (
             args.config if (W, H, S) == (cfg["W"], cfg["H"], cfg["S"]) else "custom(%s-like)" % args.config, W, H, S, iters,
-            ("REFINE_ITER pass, geom_consistency on, use_APD on (%.1f %% WEAK pixels), edge/label/radius priors on, inputs from an untimed FIRST_INIT pass" % (100 * weak_frac))
+            ("REFINE_ITER pass, geom_consistency on, use_APD on (%.1f %% WEAK pixels%s), edge/label/radius priors on, inputs from an untimed FIRST_INIT pass" % (100 * weak_frac, ", a few large connected regions" if args.weak_layout == "regions" else ""))
             if cfg["refine"] else "FIRST_INIT, geom off")
         out = {
             "metric": "Mpixels/sec/PatchMatch-iteration", "value": round(value, 3), "unit": "Mpx/s/iter",
@@ -415,7 +416,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (procedural texture quantised to 8-bit grey levels, as decoded image files are; image_format=%d; camera rig: %s)" % (IMAGE_FORMAT, "per-view rotations 5-30 deg, per-view K" if args.rig == "rotated" else "R = I, one K (round-1/2 rig)"),
             "config": {"workload": workload + ", one reference view per step per GPU", "baseline_config": args.config,
-                       "width": W, "height": H, "src_views": S, "iterations": iters, "weak_fraction": round(weak_frac, 4),
+                       "width": W, "height": H, "src_views": S, "iterations": iters, "weak_fraction": round(weak_frac, 4), "weak_layout": args.weak_layout,
                        "parallelism": "rank r takes view r mod %d of the scene as its reference view; %d rank(s), no data-path collective" % (NI, world)},
             "roofline": dict(roofs[dom], launch_site=dom, share_of_step=round(stage_ms[dom] / (dt * 1e3), 3)),
             "rooflines_top_kernels": roofs,

@@ -55,6 +55,33 @@ def hand_over(planes, views, weak, radius, params, W, H, extra_weak=None):
     return planes, views, weak, radius
 
 
+def weak_regions(W, H, frac, flat=None, seed=0, border=8, cells=12):
+    """bool [H,W]: a few LARGE connected regions covering ~frac of the image (+ the scene's low-albedo window) — the shape
+    textureless walls and skies have in real scenes, where FindNearestStrongPoint walks many rings and GenNeighbours'
+    directions run through tens of tries before they reach a STRONG pixel (32 x 32 tiles never ask for that).  A smooth
+    random field (`cells` control points across the width, bilinear) thresholded at its (1 - frac) quantile."""
+    rng = np.random.default_rng(seed)
+    gy = max(2, int(round(cells * H / float(W))) + 1)
+    g = rng.random((gy, cells + 1))
+    xs, ys = np.linspace(0, cells, W), np.linspace(0, gy - 1, H)
+    rows = np.stack([np.interp(xs, np.arange(cells + 1), g[j]) for j in range(gy)])            # [gy, W]
+    y0 = np.minimum(ys.astype(np.int64), gy - 2)
+    t = (ys - y0)[:, None]
+    field = rows[y0] * (1.0 - t) + rows[y0 + 1] * t                                              # [H, W]
+    mask = field > np.quantile(field[::8, ::8], 1.0 - frac)
+    if flat is not None:
+        mask = mask | flat
+    mask[:border] = False
+    mask[-border:] = False
+    mask[:, :border] = False
+    mask[:, -border:] = False
+    return mask
+
+
+def weak_mask(layout, W, H, frac, flat=None, seed=0):
+    return weak_regions(W, H, frac, flat, seed) if layout == "regions" else weak_tiles(W, H, frac, flat, seed)
+
+
 def weak_tiles(W, H, frac, flat=None, seed=0, tile=32, border=8):
     """bool [H,W]: `tile` x `tile` blocks drawn at random until ~frac of the image (+ the scene's
     low-albedo window), away from the border."""
