@@ -82,7 +82,7 @@ def test_cfg1_engine_equals_cpu_path():
 
 
 # ---- cfg3-shaped parity ---------------------------------------------------------------------------
-def _two_pass(make, sc, S, iters, weak_frac):
+def _two_pass(make, sc, S, iters, weak_frac, layout="tiles"):
     """FIRST_INIT pass -> hand-over (+ forced WEAK tiles) -> a FRESH engine (the reference constructs
     one APD per view per pass, main.cpp:273) ready for the REFINE_ITER pass"""
     W, H = sc["width"], sc["height"]
@@ -91,7 +91,7 @@ def _two_pass(make, sc, S, iters, weak_frac):
     e.upload_state(**_first_state(sc))
     e.run_patchmatch()
     st = wl.hand_over(e.get("planes"), e.get("selected_views"), e.get("weak_info"), e.get("radius"), p1, W, H,
-                      extra_weak=wl.weak_tiles(W, H, weak_frac, sc["flat"]))
+                      extra_weak=wl.weak_mask(layout, W, H, weak_frac, sc["flat"]))
     e.close()
     e = make(sc, wl.refine_iter_params(S, iters))
     e.set_depths(sc["depth_gt"])
@@ -124,6 +124,32 @@ def test_cfg3_shaped_parity_stage_by_stage():
     assert (b.get("weak_reliable") == 1).sum() > 0.5 * b.weak_count()
     assert (b.get("radius") > 5).sum() > 0          # adaptive radius in use
     assert (b.get("label_boundary")[:, 0] >= 0).any()
+
+
+@pytest.mark.gpu
+def test_large_weak_regions_parity_stage_by_stage():
+    """The WEAK pixels as a few large connected regions (workloads.weak_regions: what textureless walls look like; the
+    32 x 32 tiles of the other tests never make FindNearestStrongPoint walk tens of rings or GenNeighbours' directions
+    run through tens of tries): every launch site of a REFINE_ITER pass bit for bit, S = 4, 30 % WEAK."""
+    ncores = len(os.sched_getaffinity(0))
+    W, H = (720, 540) if ncores >= 64 else (240, 180)
+    S, iters = 4, 2
+    sc = synth.make_scene(W, H, S)
+    capi = pkg("capi")
+    a = _two_pass(lambda s, p: O.from_scene(s, p), sc, S, iters, 0.30, layout="regions")
+    b = _two_pass(lambda s, p: capi.from_scene(s, p), sc, S, iters, 0.30, layout="regions")
+    assert a.weak_count() == b.weak_count() >= 0.2 * W * H
+    for st, it, col in stage_sequence(iters):
+        a.run_stage(st, it, col)
+        b.run_stage(st, it, col)
+        for n in CHECKED:
+            nd = count_diff(a.get(n), b.get(n))
+            assert nd == 0, "%s differs in %d entries after %s(it=%d, colour=%d)" % (n, nd, st, it, col)
+    far = b.get("weak_nearest_strong").reshape(H, W, 2)
+    yy, xx = np.mgrid[0:H, 0:W]
+    dist = np.maximum(np.abs(far[..., 0] - xx), np.abs(far[..., 1] - yy))[far[..., 0] >= 0]
+    assert dist.max() >= 20          # the regions are deep: some WEAK pixel's nearest STRONG pixel is >= 20 rings away
+    assert (b.get("weak_reliable") == 1).sum() > 0
 
 
 # ---- full-size property tests (cfg3, cfg5) ----------------------------------------------------------
