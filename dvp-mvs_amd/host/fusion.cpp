@@ -117,10 +117,16 @@ void RunFusion(const path& dense_folder, const std::vector<Problem>& problems) {
 	std::vector<int> slot_of_id(max_id + 1, -1);   // image id -> position in `views`
 	for (int i = 0; i < n_views; ++i) {
 		std::cout << "Reading image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
-		if (!load_view(dense_folder, problems[i], &views[i])) std::cerr << "RunFusion: no depth/normal maps for view " << problems[i].ref_image_id << std::endl;
-		if (use_block) blocks[i] = load_block_mask(dense_folder, problems[i].ref_image_id);
 		slot_of_id[problems[i].ref_image_id] = i;
 	}
+	std::vector<char> loaded(n_views, 0);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::min(HostThreads(), 8))   // (maps from the result cache or the files, one colour JPEG per view)
+	for (int i = 0; i < n_views; ++i) {
+		loaded[i] = load_view(dense_folder, problems[i], &views[i]) ? 1 : 0;
+		if (use_block) blocks[i] = load_block_mask(dense_folder, problems[i].ref_image_id);
+	}
+	for (int i = 0; i < n_views; ++i)
+		if (!loaded[i]) std::cerr << "RunFusion: no depth/normal maps for view " << problems[i].ref_image_id << std::endl;
 
 	// The scan as two alternating steps over blocks of rows.  (1) For every pixel of the block, in parallel: the sources
 	// whose pixel under X passes the three geometric tests, with their votes — nothing here depends on what has been claimed
@@ -141,7 +147,10 @@ void RunFusion(const path& dense_folder, const std::vector<Problem>& problems) {
 		for (const FusionView& v : views) pixels_with_depth += v.depth.empty() ? 0 : (size_t)v.rows() * v.cols();
 		cloud.reserve(pixels_with_depth / 4);
 	}
-	std::vector<Witness> witnesses;
+	std::vector<uint8_t*> flags_of(n_views, nullptr);   // claimed map of a view (CV_8UC1, rows contiguous: Mat::zeros)
+	for (int v = 0; v < n_views; ++v) flags_of[v] = views[v].claimed.data;
+	std::vector<uint8_t*> claim_list(4096);
+	int n_claims = 0;
 	Block buffers[2];
 	for (int i = 0; i < n_views; ++i) {
 		std::cout << "Fusing image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
@@ -158,7 +167,7 @@ void RunFusion(const path& dense_folder, const std::vector<Problem>& problems) {
 		auto gather = [&](Block& bl, int y0, int y1) {
 			bl.y0 = y0;
 			bl.y1 = y1;
-#pragma omp parallel for schedule(dynamic, 4) num_threads(HostThreads())
+#pragma omp parallel for schedule(dynamic, 4) num_threads(std::max(1, HostThreads() - 1))   // (one core stays with step 2)
 			for (int y = y0; y < y1; ++y) {
 				for (int x = 0; x < W; ++x) {
 					const size_t p = (size_t)(y - y0) * W + x;
@@ -196,29 +205,35 @@ void RunFusion(const path& dense_folder, const std::vector<Problem>& problems) {
 		};
 		// step 2 for the rows of `bl`, in the reference's order
 		auto resolve = [&](const Block& bl) {
+			const uint8_t* weak_rows = R.weak.data;
 			for (int y = bl.y0; y < bl.y1; ++y) {
+				const short* counts = bl.count.data() + (size_t)(y - bl.y0) * W;
 				for (int x = 0; x < W; ++x) {
-					const size_t p = (size_t)(y - bl.y0) * W + x;
-					if (bl.count[p] <= 0) continue;   // not a reference pixel, or no witness
-					const Candidate* in = bl.cand.data() + p * NS;
-					const uint8_t* c0 = R.bgr(x, y);
-					float sum[3] = { (float)c0[0], (float)c0[1], (float)c0[2] };
-					witnesses.clear();
-					float votes = 0.0f;
-					for (int k = 0; k < bl.count[p]; ++k) {
-						uint8_t* flags = views[in[k].view].claimed.data;   // (CV_8UC1, rows contiguous: Mat::zeros)
-						if (flags[in[k].pixel] == 1) continue;
-						witnesses.push_back(Witness{ in[k].view, in[k].pixel, 0 });
+					const int nc = counts[x];
+					if (nc <= 0) continue;   // not a reference pixel, or no witness
+					const Candidate* in = bl.cand.data() + ((size_t)(y - bl.y0) * W + x) * NS;
+					float votes = 0.0f, sb = 0.0f, sg = 0.0f, sr = 0.0f;
+					int n = 0;
+					uint64_t live = 0;   // bit k: candidate k is a witness (NS <= 64 sources; more fall back to the byte flags below)
+					for (int k = 0; k < nc; ++k) {
+						if (flags_of[in[k].view][in[k].pixel] == 1) continue;
+						if (k < 64) live |= (uint64_t)1 << k;
 						votes += in[k].vote;
-						sum[0] += in[k].bgr[0]; sum[1] += in[k].bgr[1]; sum[2] += in[k].bgr[2];
+						sb += in[k].bgr[0]; sg += in[k].bgr[1]; sr += in[k].bgr[2];
+						++n;
 					}
-					const int n = (int)witnesses.size();
-					const float needed = R.weak.at<uint8_t>(y, x) == WEAK ? 0.45f : 0.3f;
+					const float needed = weak_rows[(size_t)y * R.weak.step + x] == WEAK ? 0.45f : 0.3f;
 					if (n < 1 || !(votes > needed * n)) continue;
-					for (const Witness& w : witnesses) views[w.view].claimed.data[w.x] = 1;
+					for (int k = 0; k < nc; ++k)   // the witnesses are claimed (k >= 64: whatever was unclaimed a moment ago)
+						if (k < 64 ? ((live >> k) & 1) != 0 : flags_of[in[k].view][in[k].pixel] != 1) claim_list[n_claims++] = flags_of[in[k].view] + in[k].pixel;
+					for (int c = 0; c < n_claims; ++c) *claim_list[c] = 1;
+					n_claims = 0;
+					const uint8_t* c0 = R.bgr(x, y);
+					// the reference adds the pixel's own colour first, then the witnesses' in source order (APD.cpp:1935-1946):
+					// small integers in binary32, every partial sum exact, so the order of these additions cannot matter
 					PointList pt;
 					pt.coord = R.lift(x, y, R.depth.at<float>(y, x));
-					pt.color = float3{ sum[0] / (n + 1), sum[1] / (n + 1), sum[2] / (n + 1) };
+					pt.color = float3{ ((float)c0[0] + sb) / (n + 1), ((float)c0[1] + sg) / (n + 1), ((float)c0[2] + sr) / (n + 1) };
 					cloud.push_back(pt);
 				}
 			}

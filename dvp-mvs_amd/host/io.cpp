@@ -119,14 +119,16 @@ bool ExportPointCloud(const path& point_cloud_path, std::vector<PointList>& poin
 	out << "end_header\n";
 	constexpr size_t kRecord = 3 * sizeof(float) + 3;
 	std::vector<char> records(pointcloud.size() * kRecord);
-	char* w = records.data();
-	for (const PointList& pt : pointcloud) {
+	const long long n_points = (long long)pointcloud.size();
+#pragma omp parallel for schedule(static) num_threads(HostThreads())
+	for (long long i = 0; i < n_points; ++i) {
+		const PointList& pt = pointcloud[(size_t)i];
+		char* w = records.data() + (size_t)i * kRecord;
 		const float xyz[3] = { pt.coord.x, pt.coord.y, pt.coord.z };
 		memcpy(w, xyz, sizeof(xyz));
-		w += sizeof(xyz);
-		*w++ = (char)(unsigned char)pt.color.x;
-		*w++ = (char)(unsigned char)pt.color.y;
-		*w++ = (char)(unsigned char)pt.color.z;
+		w[12] = (char)(unsigned char)pt.color.x;
+		w[13] = (char)(unsigned char)pt.color.y;
+		w[14] = (char)(unsigned char)pt.color.z;
 	}
 	out.write(records.data(), (std::streamsize)records.size());
 	return out.good();
