@@ -8,6 +8,7 @@
 // resolve to libstdc++'s overload set (float in -> float out; pow(float, int) -> double, as C++11 specifies), which is
 // what a g++ build that sees <math.h> through the OpenCV / CUDA headers gets.
 #include "ora_common.h"
+#include <cfloat>
 #include <cmath>
 #include <vector>
 
@@ -130,6 +131,111 @@ int ora_run_fusion(int num_images, int rows, int cols, const Camera* cameras, co
 						out_bgr[3 * n_points + 2] = consistent_Color[2];
 					}
 					n_points++;
+				}
+			}
+		}
+	}
+	return n_points;
+}
+
+// RunFusion_TAT_Intermediate / RunFusion_TAT_advanced (APD.cpp:1962-2130 / 2132-2279) on in-memory maps; arguments as
+// ora_run_fusion (no weak maps: these variants do not read them).  Differences to RunFusion that the restatement keeps: a
+// reference pixel is NOT skipped for being claimed; the per-source residuals `diff[]` are one array per VIEW, only
+// overwritten when a source yields a comparison (a source that drops out keeps the residuals of the last pixel it was
+// compared for); a pixel is kept for the first k = 2..num_ngb with at least k sources inside k-scaled thresholds; a
+// kept pixel claims ITSELF; the intermediate variant also tests the normals and averages the colours, the advanced one
+// keeps the pixel's colour.
+int ora_run_fusion_tat(int advanced, int num_images, int rows, int cols, const Camera* cameras, const float* const* depths, const float* const* normals,
+                       const uint8_t* const* images, const uint8_t* const* blocks, const int* src_index, int max_src,
+                       float* out_xyz, float* out_bgr, int cap) {
+	const float dist_base = 0.25f;
+	const float depth_base = advanced ? 1.0f / 3000.0f : 1.0f / 3500.0f;
+	const float angle_base = 0.06981317007977318f;   // 4 degree
+	const float angle_grad = 0.05235987755982988f;   // 3 degree
+	struct CostData {
+		float dist, depth, angle;
+		int src_r, src_c;
+		bool use;
+		CostData() { dist = FLT_MAX; depth = FLT_MAX; angle = FLT_MAX; src_r = 0; src_c = 0; use = false; }
+	};
+	std::vector<std::vector<uint8_t>> masks(num_images, std::vector<uint8_t>((size_t)rows * cols, 0));
+	int n_points = 0;
+	for (int i = 0; i < num_images; ++i) {
+		const int ref_index = i;
+		int num_ngb = 0;
+		while (num_ngb < max_src && src_index[i * max_src + num_ngb] >= 0) ++num_ngb;
+		std::vector<CostData> diff(num_ngb, CostData());
+		for (int r = 0; r < rows; ++r) {
+			for (int c = 0; c < cols; ++c) {
+				if (blocks && blocks[ref_index] && blocks[ref_index][(size_t)r * cols + c] < 128) continue;
+				float ref_depth = depths[ref_index][(size_t)r * cols + c];
+				if (ref_depth <= 0.0) continue;
+				const float* ref_normal = &normals[ref_index][((size_t)r * cols + c) * 3];
+				float3 PointX = Get3DPointonWorld(c, r, ref_depth, cameras[ref_index]);
+				float3 consistent_Point = PointX;
+				const uint8_t* px = &images[ref_index][((size_t)r * cols + c) * 3];
+				for (int j = 0; j < num_ngb; ++j) {
+					int src = src_index[i * max_src + j];
+					float2 point;
+					float proj_depth;
+					ProjectCamera(PointX, cameras[src], point, proj_depth);
+					int src_r = int(point.y + 0.5f);
+					int src_c = int(point.x + 0.5f);
+					if (src_c >= 0 && src_c < cols && src_r >= 0 && src_r < rows) {
+						if (masks[src][(size_t)src_r * cols + src_c] == 1) continue;
+						float src_depth = depths[src][(size_t)src_r * cols + src_c];
+						if (src_depth <= 0.0) continue;
+						const float* src_normal = &normals[src][((size_t)src_r * cols + src_c) * 3];
+						float3 tmp_X = Get3DPointonWorld(src_c, src_r, src_depth, cameras[src]);
+						float2 tmp_pt;
+						ProjectCamera(tmp_X, cameras[ref_index], tmp_pt, proj_depth);
+						float reproj_error = (float)std::sqrt(std::pow(c - tmp_pt.x, 2) + std::pow(r - tmp_pt.y, 2));
+						float relative_depth_diff = std::fabs(proj_depth - ref_depth) / ref_depth;
+						float angle = GetAngle(ref_normal, src_normal);
+						diff[j].dist = reproj_error;
+						diff[j].depth = relative_depth_diff;
+						diff[j].angle = angle;
+						diff[j].src_r = src_r;
+						diff[j].src_c = src_c;
+					}
+				}
+				for (int k = 2; k <= num_ngb; ++k) {
+					int count = 0;
+					for (int j = 0; j < num_ngb; ++j) {
+						diff[j].use = false;
+						if (diff[j].dist < k * dist_base && diff[j].depth < k * depth_base && (advanced || diff[j].angle < (k * angle_grad + angle_base))) {
+							count++;
+							diff[j].use = true;
+						}
+					}
+					if (count >= k) {
+						float consistent_Color[3] = { (float)px[0], (float)px[1], (float)px[2] };
+						if (!advanced) {
+							for (int j = 0; j < num_ngb; ++j) {
+								if (diff[j].use) {
+									int src = src_index[i * max_src + j];
+									const uint8_t* color = &images[src][((size_t)diff[j].src_r * cols + diff[j].src_c) * 3];
+									consistent_Color[0] += (float)color[0];
+									consistent_Color[1] += (float)color[1];
+									consistent_Color[2] += (float)color[2];
+								}
+							}
+							consistent_Color[0] /= (count + 1.0f);
+							consistent_Color[1] /= (count + 1.0f);
+							consistent_Color[2] /= (count + 1.0f);
+						}
+						if (n_points < cap) {
+							out_xyz[3 * n_points + 0] = consistent_Point.x;
+							out_xyz[3 * n_points + 1] = consistent_Point.y;
+							out_xyz[3 * n_points + 2] = consistent_Point.z;
+							out_bgr[3 * n_points + 0] = consistent_Color[0];
+							out_bgr[3 * n_points + 1] = consistent_Color[1];
+							out_bgr[3 * n_points + 2] = consistent_Color[2];
+						}
+						n_points++;
+						masks[ref_index][(size_t)r * cols + c] = 1;
+						break;
+					}
 				}
 			}
 		}

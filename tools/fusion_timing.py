@@ -35,7 +35,8 @@ def main():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "dvp-mvs_amd", "host")])
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "host")])
     t0 = time.time()
-    out = subprocess.run([os.path.join(ROOT, "tests", "host", "test_host"), "--fuse", d] + ([kind] if kind else []), capture_output=True, text=True)
+    out = subprocess.run([os.path.join(ROOT, "tests", "host", "test_host"), "--fuse", d], capture_output=True, text=True,
+                         env=dict(os.environ, DVP_FUSION_KIND=kind or "eth"))
     dt = time.time() - t0
     tail = [l for l in out.stdout.split("\n") if "Fusion" in l or "[fusion]" in l]
     print("RunFusion %dx%d, %d views x %d sources: %.2f s   %s" % (W, H, NV, NSRC, dt, " | ".join(tail)))
