@@ -286,69 +286,125 @@ void RunFusionGraded(const path& dense_folder, const std::vector<Problem>& probl
 		if (use_block) blocks[i] = load_block_mask(dense_folder, problems[i].ref_image_id);
 		slot_of_id[problems[i].ref_image_id] = i;
 	}
+	// Two steps per block of rows, as in RunFusion.  Here a pixel claims ITSELF and the claimed flags a pixel reads belong to
+	// its source views, which do not change during this view's scan: the comparison of a (pixel, source) pair is a pure
+	// function of the inputs (step 1, parallel).  What is ordered is the stale-residual quirk — `res[j]` keeps the values of
+	// the last pixel source j was compared for — and the output order (step 2, one thread: copy the fresh residuals in,
+	// the k = 2 .. n loop, emit).
 	struct Residual { float err = FLT_MAX, rel = FLT_MAX, ang = FLT_MAX; int x = 0, y = 0; };
+	struct Fresh { float err, rel, ang; int pixel; };   // pixel = y * cols + x in the source view, -1 = no comparison for this source
+	struct Block { std::vector<Fresh> fresh; std::vector<uint8_t> is_ref; int y0 = 0, y1 = 0; };
 	std::vector<PointList> cloud;
+	{
+		size_t pixels_with_depth = 0;
+		for (const FusionView& v : views) pixels_with_depth += v.depth.empty() ? 0 : (size_t)v.rows() * v.cols();
+		cloud.reserve(pixels_with_depth / 4);
+	}
+	Block buffers[2];
 	for (int i = 0; i < n_views; ++i) {
 		std::cout << "Fusing image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
 		FusionView& R = views[i];
 		if (R.depth.empty()) continue;
 		const std::vector<int>& src_ids = problems[i].src_image_ids;
 		const int n_src = (int)src_ids.size();
+		std::vector<int> slot(n_src, -1);   // view slot of source j, -1 = not part of the job / no maps
+		for (int j = 0; j < n_src; ++j) {
+			const int sv = (src_ids[j] >= 0 && src_ids[j] <= max_id) ? slot_of_id[src_ids[j]] : -1;
+			slot[j] = (sv >= 0 && !views[sv].depth.empty()) ? sv : -1;
+		}
 		std::vector<Residual> res(n_src);   // NOT reset per pixel (see above)
 		std::vector<char> agrees(n_src);
-		for (int y = 0; y < R.rows(); ++y)
-			for (int x = 0; x < R.cols(); ++x) {
-				if (use_block && !blocks[i].empty() && blocks[i].at<uint8_t>(y, x) < 128) continue;
-				const float z = R.depth.at<float>(y, x);
-				if (z <= 0.0) continue;
-				const float3 X = R.lift(x, y, z);
-				const Vec3f n_ref = R.normal.at<Vec3f>(y, x);
-				for (int j = 0; j < n_src; ++j) {
-					const int s = (src_ids[j] >= 0 && src_ids[j] <= max_id) ? slot_of_id[src_ids[j]] : -1;
-					if (s < 0 || views[s].depth.empty()) continue;
-					const FusionView& S = views[s];
-					float2 q;
-					float zq;
-					ProjectCamera(X, S.cam, q, zq);
-					const int sx = int(q.x + 0.5f), sy = int(q.y + 0.5f);
-					if (sx < 0 || sx >= S.cols() || sy < 0 || sy >= S.rows()) continue;
-					const float zs = S.depth.at<float>(sy, sx);
-					if (S.claimed.at<uint8_t>(sy, sx) == 1 || zs <= 0.0) continue;
-					float2 back;
-					float z_seen;
-					ProjectCamera(S.lift(sx, sy, zs), R.cam, back, z_seen);
-					res[j].err = (float)std::sqrt(std::pow(x - back.x, 2) + std::pow(y - back.y, 2));
-					res[j].rel = std::fabs(z_seen - z) / z;
-					res[j].ang = normal_angle(n_ref, S.normal.at<Vec3f>(sy, sx));
-					res[j].x = sx;
-					res[j].y = sy;
-				}
-				for (int k = 2; k <= n_src; ++k) {
-					int count = 0;
+		const int W = R.cols(), H = R.rows();
+		const int block_rows = std::max(1, std::min(H, (int)((size_t)(64u << 20) / ((size_t)std::max(1, n_src) * W * sizeof(Fresh)) + 1)));
+		for (Block& bl : buffers) { bl.fresh.resize((size_t)block_rows * W * std::max(1, n_src)); bl.is_ref.resize((size_t)block_rows * W); }
+		auto gather = [&](Block& bl, int y0, int y1) {
+			bl.y0 = y0;
+			bl.y1 = y1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(std::max(1, HostThreads() - 1))   // (one core stays with step 2)
+			for (int y = y0; y < y1; ++y) {
+				for (int x = 0; x < W; ++x) {
+					const size_t p = (size_t)(y - y0) * W + x;
+					bl.is_ref[p] = 0;
+					if (use_block && !blocks[i].empty() && blocks[i].at<uint8_t>(y, x) < 128) continue;
+					const float z = R.depth.at<float>(y, x);
+					if (z <= 0.0) continue;
+					bl.is_ref[p] = 1;
+					const float3 X = R.lift(x, y, z);
+					const Vec3f n_ref = R.normal.at<Vec3f>(y, x);
+					Fresh* out = bl.fresh.data() + p * n_src;
 					for (int j = 0; j < n_src; ++j) {
-						agrees[j] = res[j].err < k * dist_base && res[j].rel < k * depth_base && (advanced || res[j].ang < (k * angle_grad + angle_base));
-						count += agrees[j];
+						out[j].pixel = -1;
+						if (slot[j] < 0) continue;
+						const FusionView& S = views[slot[j]];
+						float2 q;
+						float zq;
+						ProjectCamera(X, S.cam, q, zq);
+						const int sx = int(q.x + 0.5f), sy = int(q.y + 0.5f);
+						if (sx < 0 || sx >= S.cols() || sy < 0 || sy >= S.rows()) continue;
+						const float zs = S.depth.at<float>(sy, sx);
+						if (S.claimed.at<uint8_t>(sy, sx) == 1 || zs <= 0.0) continue;   // (S's flags are final or still untouched: S is not the view being scanned)
+						float2 back;
+						float z_seen;
+						ProjectCamera(S.lift(sx, sy, zs), R.cam, back, z_seen);
+						out[j].err = (float)std::sqrt(std::pow(x - back.x, 2) + std::pow(y - back.y, 2));
+						out[j].rel = std::fabs(z_seen - z) / z;
+						out[j].ang = normal_angle(n_ref, S.normal.at<Vec3f>(sy, sx));
+						out[j].pixel = sy * S.cols() + sx;
 					}
-					if (count < k) continue;
-					const uint8_t* c0 = R.bgr(x, y);
-					float sum[3] = { (float)c0[0], (float)c0[1], (float)c0[2] };
-					if (!advanced) {
-						for (int j = 0; j < n_src; ++j) {
-							if (!agrees[j]) continue;
-							const FusionView& S = views[slot_of_id[src_ids[j]]];
-							const uint8_t* cw = S.bgr(std::min(res[j].x, S.cols() - 1), std::min(res[j].y, S.rows() - 1));
-							sum[0] += cw[0]; sum[1] += cw[1]; sum[2] += cw[2];
-						}
-						sum[0] /= (count + 1.0f); sum[1] /= (count + 1.0f); sum[2] /= (count + 1.0f);
-					}
-					PointList pt;
-					pt.coord = X;
-					pt.color = float3{ sum[0], sum[1], sum[2] };
-					cloud.push_back(pt);
-					R.claimed.at<uint8_t>(y, x) = 1;
-					break;
 				}
 			}
+		};
+		auto resolve = [&](const Block& bl) {
+			for (int y = bl.y0; y < bl.y1; ++y) {
+				for (int x = 0; x < W; ++x) {
+					const size_t p = (size_t)(y - bl.y0) * W + x;
+					if (!bl.is_ref[p]) continue;
+					const Fresh* in = bl.fresh.data() + p * n_src;
+					for (int j = 0; j < n_src; ++j) {
+						if (in[j].pixel < 0) continue;
+						const int sc = views[slot[j]].cols();
+						res[j].err = in[j].err; res[j].rel = in[j].rel; res[j].ang = in[j].ang;
+						res[j].x = in[j].pixel % sc;
+						res[j].y = in[j].pixel / sc;
+					}
+					for (int k = 2; k <= n_src; ++k) {
+						int count = 0;
+						for (int j = 0; j < n_src; ++j) {
+							agrees[j] = res[j].err < k * dist_base && res[j].rel < k * depth_base && (advanced || res[j].ang < (k * angle_grad + angle_base));
+							count += agrees[j];
+						}
+						if (count < k) continue;
+						const uint8_t* c0 = R.bgr(x, y);
+						float sum[3] = { (float)c0[0], (float)c0[1], (float)c0[2] };
+						if (!advanced) {
+							for (int j = 0; j < n_src; ++j) {
+								if (!agrees[j]) continue;
+								const FusionView& S = views[slot_of_id[src_ids[j]]];
+								const uint8_t* cw = S.bgr(std::min(res[j].x, S.cols() - 1), std::min(res[j].y, S.rows() - 1));
+								sum[0] += cw[0]; sum[1] += cw[1]; sum[2] += cw[2];
+							}
+							sum[0] /= (count + 1.0f); sum[1] /= (count + 1.0f); sum[2] /= (count + 1.0f);
+						}
+						PointList pt;
+						pt.coord = R.lift(x, y, R.depth.at<float>(y, x));
+						pt.color = float3{ sum[0], sum[1], sum[2] };
+						cloud.push_back(pt);
+						R.claimed.at<uint8_t>(y, x) = 1;
+						break;
+					}
+				}
+			}
+		};
+		int cur = 0;
+		gather(buffers[cur], 0, std::min(H, block_rows));
+		for (int y0 = 0; y0 < H; y0 += block_rows) {
+			const int n0 = y0 + block_rows, n1 = std::min(H, n0 + block_rows);
+			std::future<void> next;
+			if (n0 < H) next = std::async(std::launch::async, [&, n0, n1, cur] { gather(buffers[cur ^ 1], n0, n1); });
+			resolve(buffers[cur]);
+			if (next.valid()) next.get();
+			cur ^= 1;
+		}
 	}
 	const path ply_path = dense_folder / "APD" / "APD.ply";
 	ExportPointCloud(ply_path, cloud);
