@@ -43,7 +43,17 @@ struct ListArgs { int base, count, iter, covered_rows; };
 // (instead of every 8th block) keeps the workgroups that share anchors — and the source-image lines
 // their anchor sub-patches gather — behind one L2.  Bijection on [0, nblocks): whole groups of
 // 8 * kListRun blocks are permuted, the ragged tail keeps its order.
-constexpr int kListRun = 16;
+#ifndef DVP_LIST_RUN
+#define DVP_LIST_RUN 16
+#endif
+constexpr int kListRun = DVP_LIST_RUN;
+// The wave-per-pixel kernels (workgroup = 4 WEAK pixels) use shorter runs: 1 .. 64 blocks measure the same (weak update 400-402 ms
+// per cfg3 pass), 256 blocks 405, the 1 024 of round 2 (the lane kernels' run in pixels) 419 — a run longer than what an XCD has
+// in flight only delays the neighbours.
+#ifndef DVP_WAVE_RUN
+#define DVP_WAVE_RUN 16
+#endif
+constexpr int kWaveRun = DVP_WAVE_RUN;
 __device__ __forceinline__ int list_block(int b, int nblocks, int run) {
 	const int group = 8 * run;
 	if (b >= nblocks / group * group) return b;
@@ -156,7 +166,7 @@ template <int SMP, int FMT>
 __device__ __forceinline__ void weak_wave_body(const Dev& d, const ListArgs& a) {
 	__shared__ WeakShared sh[4];
 	const int wave = threadIdx.x >> 6;
-	const int t = list_block(blockIdx.x, gridDim.x, kListRun * 64) * 4 + wave;
+	const int t = list_block(blockIdx.x, gridDim.x, kWaveRun) * 4 + wave;
 	if (t >= a.count) return;
 	const int center = d.weak_list[a.base + t];
 	const int py = center / d.width, px = center - py * d.width;
@@ -174,7 +184,7 @@ __device__ __forceinline__ void weak_wave_body(const Dev& d, const ListArgs& a) 
 extern "C" __global__ void __launch_bounds__(256, DVP_LB_GN) dvp_gen_neighbours_search(const Dev d, const ListArgs a) {
 	__shared__ GnShared sh[4];
 	const int wave = threadIdx.x >> 6;
-	const int t = list_block(blockIdx.x, gridDim.x, kListRun * 64) * 4 + wave;
+	const int t = list_block(blockIdx.x, gridDim.x, kWaveRun) * 4 + wave;
 	if (t >= a.count) return;
 	const int center = d.weak_list[a.base + t];
 	if (d.weak_info[center] != DVP_WEAK) return;
@@ -186,7 +196,7 @@ extern "C" __global__ void __launch_bounds__(256, DVP_LB_GN) dvp_gen_neighbours_
 extern "C" __global__ void __launch_bounds__(256, 3) dvp_gen_neighbours_fit(const Dev d, const ListArgs a) {
 	__shared__ FitShared sh[4];
 	const int wave = threadIdx.x >> 6;
-	const int t = list_block(blockIdx.x, gridDim.x, kListRun * 64) * 4 + wave;
+	const int t = list_block(blockIdx.x, gridDim.x, kWaveRun) * 4 + wave;
 	if (t >= a.count) return;
 	const int center = d.weak_list[a.base + t];
 	if (d.weak_info[center] != DVP_WEAK) return;
