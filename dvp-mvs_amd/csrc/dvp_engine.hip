@@ -76,6 +76,30 @@ __device__ __forceinline__ void stage_body_list(const Dev& d, const ListArgs& a)
 	}
 	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
 }
+// The same launch sites with ONE wave per workgroup (18 KB of LDS each): tile t = the workgroups b with
+// (b >> 5) * 8 + (b & 7) == t, its row (b >> 3) & 3 — the four rows of a tile stay on the XCD block_to_pixel's map gives the tile.
+// No wave waits for the slowest of its workgroup before the LDS is given back: the strong update's evaluation and refinement
+// kernels gain 11 ms per cfg3 pass (DepthToWeak nothing: stays on 256-lane workgroups).
+template <int STAGE, int SMP, int MV = 32>
+__device__ __forceinline__ void stage_body64(const Dev& d, const LaunchArgs& a) {
+	const int lane = threadIdx.x;
+	const int b = blockIdx.x;
+	const int tile = (b >> 5) * 8 + (b & 7), wave = (b >> 3) & 3;
+	int px, py;
+	unsigned long long n = 0;
+	__shared__ f2 lds_tab[kTaps * kTaps * 64];
+	const PatchTab tab{&lds_tab[lane], 64};
+	if (block_to_pixel(tile, lane, wave, a.tiles_x, a.tiles, a.rows, a.half, a.colour, d.width, d.height, &px, &py))
+		run_pixel<STAGE, SMP, MV>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, tab);
+	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
+}
+#define DVP_KERNEL64(NAME, STAGE, MINW)                                                                    \
+	extern "C" __global__ void __launch_bounds__(64, MINW) NAME(const Dev d, const LaunchArgs a) {          \
+		stage_body64<STAGE, 0>(d, a);                                                                       \
+	}                                                                                                       \
+	extern "C" __global__ void __launch_bounds__(64, MINW) NAME##_exact(const Dev d, const LaunchArgs a) {  \
+		stage_body64<STAGE, 1>(d, a);                                                                       \
+	}
 #define DVP_KERNEL_LIST_MV(NAME, STAGE, MINW, MV)                                                         \
 	extern "C" __global__ void __launch_bounds__(256, MINW) NAME(const Dev d, const ListArgs a) {         \
 		stage_body_list<STAGE, 0, MV>(d, a);                                                               \
@@ -122,8 +146,8 @@ DVP_KERNEL(dvp_strong_update, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY)
 DVP_KERNEL_MV(dvp_strong_update_v8, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY, kNarrowViews)
 DVP_KERNEL_MV(dvp_strong_update_v16, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY, 16)
 // split strong update (dvp_strong.hpp): evaluations of the 17 snapshot planes, decisions, refinement (S <= 16)
-DVP_KERNEL(dvp_strong_eval, kStageStrongEval, DVP_LB_HEAVY)
-DVP_KERNEL(dvp_strong_refine, kStageStrongRefine, DVP_LB_HEAVY)
+DVP_KERNEL64(dvp_strong_eval, kStageStrongEval, DVP_LB_HEAVY)
+DVP_KERNEL64(dvp_strong_refine, kStageStrongRefine, DVP_LB_HEAVY)
 template <int MV>
 __device__ __forceinline__ void strong_decide_body(const Dev& d, const LaunchArgs& a) {
 	int px, py;
@@ -1038,6 +1062,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 	if (c->profiling) HIP_TRY(c, hipMemsetAsync(c->eval_counter, 0, 8, c->stream));
 	HIP_TRY(c, hipEventRecord(ep.a, c->stream));
 	const dim3 grid(g.grid()), block(256);
+	const dim3 wave_grid((unsigned)((g.grid() + 7) / 8 * 32)), wave_block(64);   // DVP_KERNEL64 launch sites: four one-wave workgroups per tile
 	const bool list_stage = stage == DVP_ST_FIND_NEAREST_STRONG || stage == DVP_ST_GEN_NEIGHBOURS || stage == DVP_ST_NEIGHBOUR_UPDATE ||
 	                        stage == DVP_ST_RANSAC_FIT || stage == DVP_ST_WEAK_UPDATE;
 	if (stage == DVP_ST_FIND_NEAREST_STRONG && c->d.weak_black + c->d.weak_red > 0) {   // its ring search reads row and column segments of the STRONG map
@@ -1117,14 +1142,14 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 				sync_dev_struct(c);
 			}
 			const int S = c->NI - 1;
-			hipLaunchKernelGGL(c->d.sampler ? dvp_strong_eval_exact : dvp_strong_eval, grid, block, 0, c->stream, c->d, a);
+			hipLaunchKernelGGL(c->d.sampler ? dvp_strong_eval_exact : dvp_strong_eval, wave_grid, wave_block, 0, c->stream, c->d, a);
 			if (S <= 4) hipLaunchKernelGGL(dvp_strong_decide_v4, grid, block, 0, c->stream, c->d, a);
 			else if (S <= 6) hipLaunchKernelGGL(dvp_strong_decide_v6, grid, block, 0, c->stream, c->d, a);
 			else if (S <= 8) hipLaunchKernelGGL(dvp_strong_decide_v8, grid, block, 0, c->stream, c->d, a);
 			else if (S <= 10) hipLaunchKernelGGL(dvp_strong_decide_v10, grid, block, 0, c->stream, c->d, a);
 			else if (S <= 12) hipLaunchKernelGGL(dvp_strong_decide_v12, grid, block, 0, c->stream, c->d, a);
 			else hipLaunchKernelGGL(dvp_strong_decide_v16, grid, block, 0, c->stream, c->d, a);
-			hipLaunchKernelGGL(c->d.sampler ? dvp_strong_refine_exact : dvp_strong_refine, grid, block, 0, c->stream, c->d, a);
+			hipLaunchKernelGGL(c->d.sampler ? dvp_strong_refine_exact : dvp_strong_refine, wave_grid, wave_block, 0, c->stream, c->d, a);
 		}
 		else if (c->NI - 1 <= kNarrowViews) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v8_exact : dvp_strong_update_v8, grid, block, 0, c->stream, c->d, a);
 		else if (c->NI - 1 <= 16) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v16_exact : dvp_strong_update_v16, grid, block, 0, c->stream, c->d, a);
