@@ -184,13 +184,15 @@ extern "C" __global__ void __launch_bounds__(256) dvp_gen_neighbours_list(const 
 DVP_KERNEL_LIST(dvp_neighbour_update_list, DVP_ST_NEIGHBOUR_UPDATE, 1)
 DVP_KERNEL_LIST(dvp_ransac_fit_plane_list, DVP_ST_RANSAC_FIT, 1)
 
-// Black/RedPixelUpdateWeak (APD.cu:4487-4489): one WAVE per WEAK pixel of the list segment, four
-// pixels per workgroup, per-pixel state in LDS (dvp_weak_wave.hpp)
+// Black/RedPixelUpdateWeak (APD.cu:4487-4489): one WAVE per WEAK pixel of the list segment, per-pixel state in LDS
+// (dvp_weak_wave.hpp)
 template <int SMP, int FMT>
 __device__ __forceinline__ void weak_wave_body(const Dev& d, const ListArgs& a) {
-	__shared__ WeakShared sh[4];
-	const int wave = threadIdx.x >> 6;
-	const int t = list_block(blockIdx.x, gridDim.x, kWaveRun) * 4 + wave;
+	// one wave = one WEAK pixel = one workgroup (10 KB of LDS): with four pixels per workgroup the LDS of a finished pixel waited
+	// for the slowest of the four (weak update 400 -> 376 ms per cfg3 pass); the XCD runs keep their length in pixels
+	__shared__ WeakShared sh[1];
+	const int wave = 0;
+	const int t = list_block(blockIdx.x, gridDim.x, kWaveRun * 4);
 	if (t >= a.count) return;
 	const int center = d.weak_list[a.base + t];
 	const int py = center / d.width, px = center - py * d.width;
@@ -217,10 +219,10 @@ extern "C" __global__ void __launch_bounds__(256, DVP_LB_GN) dvp_gen_neighbours_
 }
 // second half of GenNeighbours (RANSAC plane + ranking): one wave per WEAK pixel, point tables in LDS
 // (3 workgroups per CU is what the 12.6 KB of LDS per wave allow; stated, the compiler fits the kernel in 108 VGPRs, left alone it takes 179: 2 waves per SIMD)
-extern "C" __global__ void __launch_bounds__(256, 3) dvp_gen_neighbours_fit(const Dev d, const ListArgs a) {
-	__shared__ FitShared sh[4];
-	const int wave = threadIdx.x >> 6;
-	const int t = list_block(blockIdx.x, gridDim.x, kWaveRun) * 4 + wave;
+extern "C" __global__ void __launch_bounds__(64, 3) dvp_gen_neighbours_fit(const Dev d, const ListArgs a) {
+	__shared__ FitShared sh[1];   // (one wave per workgroup, as the weak update: 65 -> 59 ms per cfg3 launch)
+	const int wave = 0;
+	const int t = list_block(blockIdx.x, gridDim.x, kWaveRun * 4);
 	if (t >= a.count) return;
 	const int center = d.weak_list[a.base + t];
 	if (d.weak_info[center] != DVP_WEAK) return;
@@ -231,11 +233,11 @@ extern "C" __global__ void __launch_bounds__(256, 3) dvp_gen_neighbours_fit(cons
 #ifndef DVP_LB_WEAK
 #define DVP_LB_WEAK 4   // waves per SIMD the wave kernel is compiled for (LDS: 34 KB per workgroup -> 4 workgroups per CU; 128 VGPRs)
 #endif
-extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK) dvp_weak_update_wave(const Dev d, const ListArgs a) { weak_wave_body<0, 0>(d, a); }
-extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK) dvp_weak_update_wave_exact(const Dev d, const ListArgs a) { weak_wave_body<1, 0>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave(const Dev d, const ListArgs a) { weak_wave_body<0, 0>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_exact(const Dev d, const ListArgs a) { weak_wave_body<1, 0>(d, a); }
 // the same launch site reading the byte planes (Dev::images8: all images 8-bit exact)
-extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK) dvp_weak_update_wave_u8(const Dev d, const ListArgs a) { weak_wave_body<0, 1>(d, a); }
-extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK) dvp_weak_update_wave_exact_u8(const Dev d, const ListArgs a) { weak_wave_body<1, 1>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_u8(const Dev d, const ListArgs a) { weak_wave_body<0, 1>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_exact_u8(const Dev d, const ListArgs a) { weak_wave_body<1, 1>(d, a); }
 
 // replicate the image border into the kImgPad-wide frame of a padded plane set
 extern "C" __global__ void dvp_pad_replicate(float* planes, int W, int H, int pitch, size_t plane_stride, int n_planes) {
@@ -1104,13 +1106,13 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 			case DVP_ST_GEN_NEIGHBOURS:
 				if (c->gn_wave) hipLaunchKernelGGL(dvp_gen_neighbours_search, dim3((la.count + 3) / 4), block, 0, c->stream, c->d, la);
 				else hipLaunchKernelGGL(dvp_gen_neighbours_list, lg, block, 0, c->stream, c->d, la);
-				hipLaunchKernelGGL(dvp_gen_neighbours_fit, dim3((la.count + 3) / 4), block, 0, c->stream, c->d, la);
+				hipLaunchKernelGGL(dvp_gen_neighbours_fit, dim3(la.count), dim3(64), 0, c->stream, c->d, la);
 				break;
 			case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(ex ? dvp_neighbour_update_list_exact : dvp_neighbour_update_list, lg, block, 0, c->stream, c->d, la); break;
 			case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(ex ? dvp_ransac_fit_plane_list_exact : dvp_ransac_fit_plane_list, lg, block, 0, c->stream, c->d, la); break;
 			case DVP_ST_WEAK_UPDATE:
-				if (c->images8_ok) hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact_u8 : dvp_weak_update_wave_u8, dim3((la.count + 3) / 4), block, 0, c->stream, c->d, la);
-				else hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact : dvp_weak_update_wave, dim3((la.count + 3) / 4), block, 0, c->stream, c->d, la);
+				if (c->images8_ok) hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact_u8 : dvp_weak_update_wave_u8, dim3(la.count), dim3(64), 0, c->stream, c->d, la);
+				else hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact : dvp_weak_update_wave, dim3(la.count), dim3(64), 0, c->stream, c->d, la);
 				break;
 			}
 			HIP_TRY(c, hipGetLastError());
