@@ -120,6 +120,8 @@ def parse():
     ap.add_argument("--weak-layout", default="tiles", choices=["tiles", "regions"], help="shape of the pixels handed over as WEAK: 32x32 tiles (default) or a few large connected regions (workloads.weak_regions)")
     ap.add_argument("--rig", default="rotated", choices=["rotated", "axis"], help="camera rig of the synthetic scene: per-view rotations and intrinsics (default) or the round-1/2 rig (R = I, one K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-launch", action="store_true", help="launcher check without a GPU: start the ranks, rendezvous over gloo, print one line with each rank's environment")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself (0: pick a free one)")
     ap.add_argument("--cpu-size", type=str, default="auto", help="WxH of the CPU-baseline view (auto: scaled to the core count)")
     return ap.parse_args()
 
@@ -259,8 +261,60 @@ def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
     return r
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this very command line, one per GPU, under
+    torch.distributed.run (the same form the driver uses when it launches the ranks itself) and pass rank 0's JSON
+    line through on stdout.  The reference has nothing to mirror here: /root/reference/main.cpp:430-434 picks ONE
+    device per process."""
+    import subprocess
+    if not args.dry_launch:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s) (torch.cuda.device_count()); refusing to measure fewer ranks than asked for" % (args.gpus, have))
+    port = args.master_port or free_port()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_launch(args, json_fd, rank, local_rank, world):
+    """Launcher check that needs no GPU: every rank joins a gloo group and reports the environment it was started
+    with; rank 0 prints the line (tests/test_sharding.py::test_bench_gpus_flag_starts_the_ranks)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    mine = {"rank": rank, "local_rank": local_rank, "world_size": world, "pid": os.getpid(),
+            "device": "cuda:%d" % local_rank, "master": "%s:%s" % (os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"])}
+    seen = [mine]
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+    if rank == 0:
+        os.write(json_fd, (json.dumps({"metric": "Mpixels/sec/PatchMatch-iteration", "value": None, "dry_launch": True,
+                                       "n_gpus": world, "gpus_flag": args.gpus, "ranks": seen}) + "\n").encode())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args)       # does not return
     # stdout carries ONE JSON line (rank 0).  Libraries write there too (RCCL prints its NCCL_DEBUG=VERSION banner and
     # its warnings on stdout): from here on file descriptor 1 is stderr, the JSON line goes to the saved descriptor.
     sys.stdout.flush()
@@ -269,6 +323,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; n_gpus must be what was asked for" % (args.gpus, world))
+    if args.dry_launch:
+        return dry_launch(args, json_fd, rank, local_rank, world)
     import torch   # device plumbing + torch.distributed (RCCL); loaded first so one HIP runtime is shared
     import torch.distributed as dist
     if not torch.cuda.is_available():

@@ -1139,10 +1139,23 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 	case DVP_ST_STRONG_UPDATE:
 		if (c->strong_split && c->NI - 1 <= 16) {
 			if (!c->slot_costs) {
+				// 17 x S floats per pixel of one colour (7.8 GB at 6208x4128, S = 9): a part that cannot spare them runs the
+				// monolithic kernel below instead, which gives the same bits (test_strong_update_forms_equal_the_oracle)
 				const size_t Lh = (size_t)((c->W + 1) / 2) * c->H;
-				if (dalloc(c, &c->slot_costs, (size_t)kSlotCount * (c->NI - 1) * Lh, false) || dalloc(c, &c->strong_rec, (size_t)SR_FIELDS * Lh, false)) return 1;
-				sync_dev_struct(c);
+				void *sc = nullptr, *sr = nullptr;
+				if (getenv("DVP_TEST_SPLIT_ALLOC_FAIL") /* test hook: take the fallback */ || hipMalloc(&sc, (size_t)kSlotCount * (c->NI - 1) * Lh * sizeof(*c->slot_costs)) != hipSuccess || hipMalloc(&sr, (size_t)SR_FIELDS * Lh * sizeof(*c->strong_rec)) != hipSuccess) {
+					(void)hipGetLastError();   // clear the sticky out-of-memory status
+					if (sc) (void)hipFree(sc);
+					c->strong_split = false;
+					fprintf(stderr, "dvp: no room for the split strong update's cost buffer (%.1f GB); using the monolithic kernel\n", (double)kSlotCount * (c->NI - 1) * Lh * 4 / 1e9);
+				} else {
+					c->allocs.push_back(sc); c->allocs.push_back(sr);
+					c->slot_costs = (decltype(c->slot_costs))sc; c->strong_rec = (decltype(c->strong_rec))sr;
+					sync_dev_struct(c);
+				}
 			}
+		}
+		if (c->strong_split && c->NI - 1 <= 16) {
 			const int S = c->NI - 1;
 			hipLaunchKernelGGL(c->d.sampler ? dvp_strong_eval_exact : dvp_strong_eval, wave_grid, wave_block, 0, c->stream, c->d, a);
 			if (S <= 4) hipLaunchKernelGGL(dvp_strong_decide_v4, grid, block, 0, c->stream, c->d, a);

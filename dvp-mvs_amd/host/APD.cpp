@@ -37,17 +37,29 @@ std::map<ImageKey, ImageEntry> g_img_cache;
 // schedule visits every image once per level
 std::map<std::string, Mat> g_decoded;
 size_t g_decoded_bytes = 0;
+constexpr size_t kDecodedLimit = (size_t)8 << 30;   // decoded 8-bit images kept across pyramid levels
+bool g_decoded_full = false;                        // an image has been refused: prefetching more would decode them twice
 std::recursive_mutex g_img_cache_mutex;   // the driver's background worker (edge maps of the next view) shares the cache
 size_t g_img_cache_capacity = 96;
 uint64_t g_img_cache_clock = 0;
 // Room for one more entry: images of other pyramid levels go first (a level never comes back), then the least
 // recently used one — never the whole cache (a scene with more views than the capacity would otherwise re-read
 // every file for every view).
-void make_room(int scale) {
-	if (g_img_cache.size() < g_img_cache_capacity) return;
+size_t g_img_cache_byte_limit = [] {   // float images are ~100 MB each at full resolution: the cache is bounded by bytes as well as by entries
+	const char* e = std::getenv("DVP_IMAGE_CACHE_GB");
+	return (size_t)(e ? std::max(1, std::atoi(e)) : 48) << 30;
+}();
+size_t cache_bytes_locked() {
+	size_t b = 0;
+	for (const auto& kv : g_img_cache) b += kv.second.image.step * (size_t)kv.second.image.rows;
+	return b;
+}
+void make_room(int scale, size_t incoming_bytes) {
+	auto full = [&] { return g_img_cache.size() >= g_img_cache_capacity || (!g_img_cache.empty() && cache_bytes_locked() + incoming_bytes > g_img_cache_byte_limit); };
+	if (!full()) return;
 	for (auto it = g_img_cache.begin(); it != g_img_cache.end();)
 		it = (std::get<1>(it->first) != scale) ? g_img_cache.erase(it) : std::next(it);
-	while (g_img_cache.size() >= g_img_cache_capacity) {
+	while (full()) {
 		auto lru = g_img_cache.begin();
 		for (auto it = g_img_cache.begin(); it != g_img_cache.end(); ++it)
 			if (it->second.used < lru->second.used) lru = it;
@@ -71,6 +83,7 @@ void APD::ReleasePooledContext() {
 	g_img_cache.clear();
 	g_decoded.clear();
 	g_decoded_bytes = 0;
+	g_decoded_full = false;
 }
 
 
@@ -100,22 +113,33 @@ Mat APD::DecodedGray(const path& file) {
 	Mat image_uint = ReadImageGray(file);
 	lock.lock();
 	g_decoding.erase(key);
-	if (!image_uint.empty() && g_decoded_bytes + image_uint.step * image_uint.rows <= ((size_t)8 << 30)) {
+	if (!image_uint.empty() && g_decoded_bytes + image_uint.step * image_uint.rows <= kDecodedLimit) {
 		g_decoded[key] = image_uint;
 		g_decoded_bytes += image_uint.step * image_uint.rows;
-	}
+	} else if (!image_uint.empty()) g_decoded_full = true;
 	g_decoded_cv.notify_all();
 	return image_uint;
 }
 // all images of the job decoded on a few threads while the first passes run (the coarse levels are decode-bound otherwise)
 void APD::PrefetchDecoded(const std::vector<path>& files) {
 	const int n = std::max(1, std::min(HostThreads() / 2, 8));
-	auto queue = std::make_shared<std::vector<path>>(files);
+	// every file once (a source image appears in the list of every view that uses it), and nothing once the decoded cache
+	// is full: an image that cannot be kept would be decoded here, dropped, and decoded again by load_image
+	auto queue = std::make_shared<std::vector<path>>();
+	std::set<std::string> listed;
+	for (const path& f : files)
+		if (listed.insert(f.string()).second) queue->push_back(f);
 	auto next = std::make_shared<std::atomic<size_t>>(0);
 	for (int t = 0; t < n; ++t) {
 		++g_prefetch_threads;
 		std::thread([queue, next]() {
-			for (size_t i = (*next)++; i < queue->size(); i = (*next)++) (void)APD::DecodedGray((*queue)[i]);
+			for (size_t i = (*next)++; i < queue->size(); i = (*next)++) {
+				{
+					std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
+					if (g_decoded_full) break;
+				}
+				(void)APD::DecodedGray((*queue)[i]);
+			}
 			--g_prefetch_threads;
 		}).detach();
 	}
@@ -153,7 +177,7 @@ static ImageEntry load_image(const Problem& problem, int image_id, int pad_w, in
 	}
 	ci.image = f;
 	std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
-	make_room(problem.scale_size);
+	make_room(problem.scale_size, f.step * (size_t)f.rows);
 	ci.used = ++g_img_cache_clock;
 	return g_img_cache.emplace(key, ci).first->second;
 }
@@ -170,7 +194,7 @@ void APD::InsertCachedImage(const Problem& problem, int image_id, const Mat& ima
 	ci.orig_cols = orig_cols;
 	ci.orig_rows = orig_rows;
 	ci.used = ++g_img_cache_clock;
-	make_room(problem.scale_size);
+	make_room(problem.scale_size, image.step * (size_t)image.rows);
 	g_img_cache[image_key(problem, image_id, 0, 0)] = ci;
 }
 
@@ -216,14 +240,14 @@ void APD::InuputInitialization() {
 	}
 	{
 		Camera cam;
-		ReadCamera(cam_folder / path(ToFormatIndex(problem.ref_image_id) + "_cam.txt"), cam);
+		ReadCameraOrDie(cam_folder / path(ToFormatIndex(problem.ref_image_id) + "_cam.txt"), cam);
 		cam.width = width;
 		cam.height = height;
 		cameras.push_back(cam);
 	}
 	for (const auto& src_idx : problem.src_image_ids) {
 		Camera cam;
-		ReadCamera(cam_folder / path(ToFormatIndex(src_idx) + "_cam.txt"), cam);
+		ReadCameraOrDie(cam_folder / path(ToFormatIndex(src_idx) + "_cam.txt"), cam);
 		cam.width = width;
 		cam.height = height;
 		cameras.push_back(cam);

@@ -21,6 +21,7 @@ bool WriteBinMat(const path& mat_path, const Mat& mat);                         
 int writeDepthDmb(const path& mat_path, const Mat& depth);                             // APD.cpp:575-600
 int writeNormalDmb(const path& mat_path, const Mat& normal);                           // APD.cpp:603-628
 bool ReadCamera(const path& cam_path, Camera& cam);                                    // APD.cpp:651-692
+void ReadCameraOrDie(const path& cam_path, Camera& cam);                                // ReadCamera + DvpFatal when the file is unusable (no caller may go on with an uninitialised camera)
 bool ExportPointCloud(const path& point_cloud_path, std::vector<PointList>& pointcloud);   // APD.cpp:842-882
 std::string ToFormatIndex(int index);                                                  // APD.cpp:978-982
 template <typename TYPE>

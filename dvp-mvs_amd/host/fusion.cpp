@@ -86,7 +86,7 @@ Mat load_block_mask(const path& dense_folder, int image_id) {
 bool load_view(const path& dense_folder, const Problem& problem, FusionView* v) {
 	const std::string id = ToFormatIndex(problem.ref_image_id);
 	v->image_id = problem.ref_image_id;
-	ReadCamera(dense_folder / "cams" / (id + "_cam.txt"), v->cam);
+	ReadCameraOrDie(dense_folder / "cams" / (id + "_cam.txt"), v->cam);
 	v->set_centre();
 	if (!LoadResult(problem.result_folder / "depths.dmb", v->depth) || !LoadResult(problem.result_folder / "APD_normals.dmb", v->normal)) return false;
 	Mat weak;

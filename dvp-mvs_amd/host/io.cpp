@@ -79,23 +79,25 @@ int writeNormalDmb(const path& mat_path, const Mat& normal) { return write_dmb(m
 bool ReadCamera(const path& cam_path, Camera& cam) {
 	std::ifstream in(cam_path);
 	if (!in.good()) return false;
-	auto block = [&in](const char* keyword, double* dst, int n) {
+	// values are extracted straight into float, as the reference's `in >> cam.R[...]` does (APD.cpp:662-671): going
+	// through double and narrowing can round a decimal twice and differ by one ulp
+	auto block = [&in](const char* keyword, float* dst, int n) {
 		std::string word;
 		if (!(in >> word) || word != keyword) return false;
 		for (int i = 0; i < n; ++i)
 			if (!(in >> dst[i])) return false;
 		return true;
 	};
-	double E[16], K[9], range[4];
+	float E[16], K[9], range[4];
 	if (!block("extrinsic", E, 16) || !block("intrinsic", K, 9)) return false;
-	for (double& v : range)
+	for (float& v : range)
 		if (!(in >> v)) return false;
 	for (int r = 0; r < 3; ++r) {
 		for (int c = 0; c < 3; ++c) {
-			cam.R[3 * r + c] = (float)E[4 * r + c];
-			cam.K[3 * r + c] = (float)K[3 * r + c];
+			cam.R[3 * r + c] = E[4 * r + c];
+			cam.K[3 * r + c] = K[3 * r + c];
 		}
-		cam.t[r] = (float)E[4 * r + 3];
+		cam.t[r] = E[4 * r + 3];
 	}
 	// camera centre C = -R^T t from the float32 R and t, accumulated in double (APD.cpp:673-677)
 	for (int c = 0; c < 3; ++c) {
@@ -103,9 +105,15 @@ bool ReadCamera(const path& cam_path, Camera& cam) {
 		for (int r = 0; r < 3; ++r) acc += (double)cam.R[3 * r + c] * (double)cam.t[r];
 		cam.c[c] = -(float)acc;
 	}
-	cam.depth_min = (float)range[0];   // TAT & ETH layout (APD.cpp:680-682); interval and depth_num are not used
-	cam.depth_max = (float)range[3];
+	cam.depth_min = range[0];   // TAT & ETH layout (APD.cpp:680-682); interval and depth_num are not used
+	cam.depth_max = range[3];
 	return true;
+}
+
+// A camera file that cannot be read in full leaves no usable camera: every caller stops the job (through DvpFatal, i.e.
+// through the multi-rank abort) instead of going on with an uninitialised one.
+void ReadCameraOrDie(const path& cam_path, Camera& cam) {
+	if (!ReadCamera(cam_path, cam)) DvpFatal("ReadCamera: " + cam_path.string() + " is missing, short or mislabelled (expected `extrinsic` 4x4, `intrinsic` 3x3, `depth_min interval depth_num depth_max`)");
 }
 
 // binary little-endian PLY: x y z float + diffuse_blue/green/red uchar per vertex (APD.cpp:842-882); PointList::color

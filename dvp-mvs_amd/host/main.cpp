@@ -419,6 +419,11 @@ int main(int argc, char** argv) {
 			if (exchange) mine[problem.index] = r.depth;
 			if (inplace) inplace->Update(problem.ref_image_id, r.depth);
 		}
+		// With peers, a view whose size differs from a source's takes that source's depth map from APD/<id>/depths.dmb
+		// (APD.cpp fallback from the resident maps to LoadResult): the owner's background writer must have put this
+		// pass' files on disk BEFORE the barrier lets anyone into the next pass, or the reader sees the previous pass'
+		// map (or none) depending on timing.  One rank has no other reader: its cache serves its own next pass.
+		if (opt.world > 1) FlushResults();
 		if (exchange) exchange->Publish(mine);   // collective: also the barrier between passes
 		else comm.Barrier();
 		if (pass.geom_index == opt.geom_passes - 1 || (opt.geom_passes == 0 && pass.geom_index < 0)) std::cout << "Round: " << pass.level << " done\n";

@@ -11,8 +11,9 @@
 //     another process wrote it);
 //   * RunInBackground(job) runs a view's post-processing (visibility-mask clean-up, publishing) while the GPU is
 //     already on the next view; a path announced with ExpectResult() makes LoadResult wait for its job.
-// The files on disk end up byte-identical to the synchronous pipeline's; FlushResults() joins everything (before
-// the fusion, at exit, before another rank may read the folder).
+// The files on disk end up byte-identical to the synchronous pipeline's; FlushResults() joins everything: before
+// the fusion, at exit, and — with more than one rank — before every inter-pass barrier (host/main.cpp), because
+// another rank may read this rank's depths.dmb in the next pass.
 #include "APD.h"
 #include <condition_variable>
 #include <deque>
@@ -116,7 +117,9 @@ void PublishResult(const path& file, const Mat& m) {
 		path tmp = file;
 		tmp += ".part";
 		if (!WriteBinMat(tmp, m)) DvpFatal("cannot write " + tmp.string());
-		std::filesystem::rename(tmp, file);
+		std::error_code ec;
+		std::filesystem::rename(tmp, file, ec);   // (the throwing overload would end in std::terminate, past the agreed multi-rank abort)
+		if (ec) DvpFatal("cannot rename " + tmp.string() + " to " + file.string() + ": " + ec.message());
 		lk.lock();
 		g.expected.erase(key);
 		g.cv.notify_all();
@@ -161,6 +164,8 @@ bool LoadResult(const path& file, Mat& m, bool will_modify) {
 			return true;
 		}
 		g.cv.wait(lk, [&] { return !g.writing.count(key); });   // evicted while queued cannot happen; defensive
+		// a failed background write means the file on disk is stale or missing: never compute from it
+		if (!g.write_error.empty()) { const std::string e = g.write_error; lk.unlock(); DvpFatal(e + " (noticed by LoadResult of " + key + ")"); }
 	}
 	if (!std::filesystem::exists(file)) return false;
 	return ReadBinMat(file, m);

@@ -12,6 +12,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "hostbox: needs no GPU (host / numpy / literal-mode oracles); on a box WITH a GPU these also carry the gpu marker, "
+                                       "so the driver's `pytest -m gpu` record includes them (VERDICT r03 #4); without a GPU they run under -m 'not gpu'")
     if os.path.exists("/dev/kfd"):
         # tests that render full-size scenes on the GPU use torch: its HIP runtime must be initialised
         # before libdvp_mvs_hip.so pulls in /opt/rocm's copy (the order bench.py uses), or torch finds no device
@@ -20,6 +22,15 @@ def pytest_configure(config):
             torch.cuda.init()
         except Exception:
             pass
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_collection_modifyitems(config, items):
+    # before the -m expression is applied: on the GPU box the host-side oracle comparisons join the gpu run
+    if os.path.exists("/dev/kfd"):
+        for item in items:
+            if item.get_closest_marker("hostbox") is not None and item.get_closest_marker("gpu") is None:
+                item.add_marker(pytest.mark.gpu)
 
 
 def pkg(name=""):

@@ -1,3 +1,4 @@
+import pytest
 """The drop-in boundary without a GPU: the C-ABI library loads and exports every symbol
 include/dvp_mvs.h declares; POD layouts match the reference's; the C++ host mirror builds and its
 format / parser / connected-component code passes its own checks; nothing in the product path
@@ -55,6 +56,7 @@ def test_product_does_not_reference_the_oracle():
                 assert "import oracle" not in src and "from oracle" not in src, (base, f)
 
 
+@pytest.mark.hostbox
 def test_host_layer_cpp():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "dvp-mvs_amd", "host")])
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "host")])
@@ -65,6 +67,7 @@ def test_host_layer_cpp():
     assert "host tests ok" in out.stdout
 
 
+@pytest.mark.hostbox
 def test_fusion_cpu(tmp_path):
     """RunFusion (host/fusion.cpp) without a GPU: three views of the synthetic scene with their TRUE depth /
     normal maps as APD/<id>/ results.  Every interior pixel of view 0 has consistent witnesses, is fused
@@ -122,6 +125,7 @@ def _host_tool(*args):
     return subprocess.run([os.path.join(ROOT, "tests", "host", "test_host")] + [str(a) for a in args], capture_output=True, text=True)
 
 
+@pytest.mark.hostbox
 def test_jpeg_decoder_equals_libjpeg(tmp_path):
     """host/jpeg.cpp against this image's libjpeg (through PIL): the grey output — what
     cv::imread(IMREAD_GRAYSCALE) hands the reference (APD.cpp:1057) — must be bit-identical to libjpeg's
@@ -163,6 +167,7 @@ def test_jpeg_decoder_equals_libjpeg(tmp_path):
     assert _host_tool("--jpeg", f, str(tmp_path / "o.bin"), 1).returncode == 2
 
 
+@pytest.mark.hostbox
 def test_label_segmentation(tmp_path):
     """EdgeSegment mode 1 (host/labels.cpp; APD.cpp:348-401, 437-499): two flat regions separated by a
     textured band get two different positive labels, texture is 0, and the map has the size of the

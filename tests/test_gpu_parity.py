@@ -291,3 +291,20 @@ def test_golden_weak_pass_engine():
     """the committed REFINE_ITER / weak-path fixture through the C ABI"""
     from test_oracle_kat import _golden_weak_pass
     _golden_weak_pass(lambda sc, p, seed, dep: capi().from_scene(sc, p, seed=seed, depths=dep))
+
+
+def test_split_strong_update_falls_back_when_its_buffer_does_not_fit(monkeypatch):
+    """The split strong update keeps 17 x S floats per pixel of one colour (7.8 GB at 6208x4128, S = 9).  When that block
+    cannot be allocated the launch site must carry on with the monolithic kernel — same bits — instead of failing the
+    pass.  DVP_TEST_SPLIT_ALLOC_FAIL makes the allocation report failure."""
+    monkeypatch.setenv("DVP_TEST_SPLIT_ALLOC_FAIL", "1")
+    W, H, S = 80, 56, 5
+    sc = synth.make_scene(W, H, S)
+    p = make_params(S + 1, max_iterations=2, state=synth.FIRST_INIT, use_APD=0)
+    a, b = _pair(sc, p, first_pass_state(sc))
+    a.run_patchmatch()
+    b.run_patchmatch()
+    for n in ("planes", "costs", "selected_views", "view_weight", "weak_info"):
+        assert count_diff(a.get(n), b.get(n)) == 0, n
+    launches = b.timings()["stage_launches"]
+    assert launches["strong_update"] == 4

@@ -17,6 +17,8 @@ from conftest import ROOT, synth
 from oracle import oracle as O
 
 
+pytestmark = pytest.mark.hostbox   # no GPU needed; joins the `-m gpu` run on a GPU box (conftest.py)
+
 def _write_binmat(path, a, typ):
     with open(path, "wb") as f:
         f.write(np.array([1, a.shape[0], a.shape[1], typ], np.int32).tobytes())

@@ -24,6 +24,8 @@ from oracle import oracle as O
 wl = pkg("workloads")
 
 
+pytestmark = pytest.mark.hostbox   # no GPU needed; joins the `-m gpu` run on a GPU box (conftest.py)
+
 def _pipeline(sc, S, numerics, seed):
     W, H = sc["width"], sc["height"]
     L = W * H

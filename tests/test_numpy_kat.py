@@ -14,6 +14,8 @@ import np_model as M
 wl = pkg("workloads")
 
 
+pytestmark = pytest.mark.hostbox   # no GPU needed; joins the `-m gpu` run on a GPU box (conftest.py)
+
 def _scene(W=128, H=96, S=4, **kw):
     sc = synth.make_scene(W, H, S, **kw)
     cams = [M.cam64(c) for c in sc["cameras"]]

@@ -71,9 +71,9 @@ def test_random_configs_emulated_kernels(case):
     run_pair(lambda sc, p, seed, smp, dep: O.from_scene(sc, p, seed=seed, sampler=smp, depths=dep, cls=E.Emul), rng)
 
 
-# DVP_RANDOM_CASES=N widens the sweep for soak runs (default 10 cases)
+# DVP_RANDOM_CASES=N widens the sweep for soak runs (default: 50 cases on a GPU box — the driver's run —, 10 elsewhere)
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", range(int(os.environ.get("DVP_RANDOM_CASES", "10"))))
+@pytest.mark.parametrize("case", range(int(os.environ.get("DVP_RANDOM_CASES", "50" if os.path.exists("/dev/kfd") else "10"))))
 def test_random_configs_gpu(case):
     rng = np.random.default_rng(5000 + case)
     capi = pkg("capi")

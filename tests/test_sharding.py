@@ -123,3 +123,37 @@ def test_pipeline_depth_exchange_two_ranks_equal_one():
     """FIRST_INIT pass + one geom pass over 4 views: the all-gathered depth maps feed the geom pass;
     2 ranks (gloo) must reproduce the 1-rank result bit for bit (Jacobi order across views)."""
     assert _run_worker(PIPE_WORKER, 2) == _run_worker(PIPE_WORKER, 1)
+
+
+def test_bench_gpus_flag_starts_the_ranks():
+    """`python bench.py --gpus 2` (no launcher around it) must start two ranks — one per GPU, LOCAL_RANK = device —
+    and report n_gpus = 2; the reference picks one device per process (main.cpp:430-434).  --dry-launch keeps the GPU out."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                      # ONE JSON line on stdout, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["gpus_flag"] == 2
+    ranks = sorted(line["ranks"], key=lambda r: r["rank"])
+    assert [(r["rank"], r["local_rank"], r["world_size"], r["device"]) for r in ranks] == [(0, 0, 2, "cuda:0"), (1, 1, 2, "cuda:1")]
+    assert len({r["pid"] for r in ranks}) == 2              # one process per GPU
+    assert all(r["master"].startswith("127.0.0.1:") for r in ranks)
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    """Under a launcher that started another number of ranks than --gpus says, the line would lie about n_gpus: refuse."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-launch"], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"))
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
+
+
+def test_bench_gpus_flag_without_the_gpus_fails_loudly():
+    if os.path.exists("/dev/kfd"):
+        import torch
+        if torch.cuda.device_count() >= 64:
+            return
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "refusing" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
