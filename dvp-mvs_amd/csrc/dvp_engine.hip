@@ -186,7 +186,7 @@ DVP_KERNEL_LIST(dvp_ransac_fit_plane_list, DVP_ST_RANSAC_FIT, 1)
 
 // Black/RedPixelUpdateWeak (APD.cu:4487-4489): one WAVE per WEAK pixel of the list segment, per-pixel state in LDS
 // (dvp_weak_wave.hpp)
-template <int SMP, int FMT>
+template <int SMP, int FMT, int TAB>
 __device__ __forceinline__ void weak_wave_body(const Dev& d, const ListArgs& a) {
 	// one wave = one WEAK pixel = one workgroup (10 KB of LDS): with four pixels per workgroup the LDS of a finished pixel waited
 	// for the slowest of the four (weak update 400 -> 376 ms per cfg3 pass); the XCD runs keep their length in pixels
@@ -199,7 +199,7 @@ __device__ __forceinline__ void weak_wave_body(const Dev& d, const ListArgs& a) 
 	if (py >= a.covered_rows) return;   // rows beyond the reference's half grid (APD.cu:4421-4424)
 	if (d.weak_info[center] != DVP_WEAK) return;   // NeigbourUpdate turned it UNKNOWN since the list was built (APD.cu:3119-3123)
 	unsigned long long n = 0;
-	weak_update_wave<SMP, FMT>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, sh[wave]);
+	weak_update_wave<SMP, FMT, TAB>(d, px, py, a.iter, d.eval_counter ? &n : nullptr, sh[wave]);
 	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
 }
 // first half of GenNeighbours (directional anchor search + label extension): one wave per WEAK pixel, the tries of a
@@ -233,11 +233,29 @@ extern "C" __global__ void __launch_bounds__(64, 3) dvp_gen_neighbours_fit(const
 #ifndef DVP_LB_WEAK
 #define DVP_LB_WEAK 4   // waves per SIMD the wave kernel is compiled for (LDS: 34 KB per workgroup -> 4 workgroups per CU; 128 VGPRs)
 #endif
-extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave(const Dev d, const ListArgs a) { weak_wave_body<0, 0>(d, a); }
-extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_exact(const Dev d, const ListArgs a) { weak_wave_body<1, 0>(d, a); }
+// (no suffix: the anchor sub-patches' reference side comes from the pass' table, Dev::anchor_tab; _notab: formed per item —
+// the definition, used when the table does not fit or DVP_WEAK_ANCHOR_TAB=0)
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave(const Dev d, const ListArgs a) { weak_wave_body<0, 0, 1>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_exact(const Dev d, const ListArgs a) { weak_wave_body<1, 0, 1>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_notab(const Dev d, const ListArgs a) { weak_wave_body<0, 0, 0>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_exact_notab(const Dev d, const ListArgs a) { weak_wave_body<1, 0, 0>(d, a); }
 // the same launch site reading the byte planes (Dev::images8: all images 8-bit exact)
-extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_u8(const Dev d, const ListArgs a) { weak_wave_body<0, 1>(d, a); }
-extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_exact_u8(const Dev d, const ListArgs a) { weak_wave_body<1, 1>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_u8(const Dev d, const ListArgs a) { weak_wave_body<0, 1, 1>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_exact_u8(const Dev d, const ListArgs a) { weak_wave_body<1, 1, 1>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_u8_notab(const Dev d, const ListArgs a) { weak_wave_body<0, 1, 0>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_exact_u8_notab(const Dev d, const ListArgs a) { weak_wave_body<1, 1, 0>(d, a); }
+// the pass' table of anchor reference sides: thread = (WEAK list entry, view, anchor), anchor fastest (neighbouring lanes write
+// neighbouring 128-byte records)
+extern "C" __global__ void __launch_bounds__(256) dvp_weak_anchor_table(const Dev d, const ListArgs a) {
+	const int S = d.params.num_images - 1;
+	const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+	if (i >= (long long)a.count * S * kAnchors) return;
+	const int k = (int)(i % kAnchors);
+	const long long r = i / kAnchors;
+	const int v0 = (int)(r % S);
+	const int t = (int)(r / S);
+	build_anchor_record(d, d.weak_list[a.base + t], v0, k);
+}
 
 // replicate the image border into the kImgPad-wide frame of a padded plane set
 extern "C" __global__ void dvp_pad_replicate(float* planes, int W, int H, int pitch, size_t plane_stride, int n_planes) {
@@ -630,6 +648,10 @@ struct dvp_ctx {
 	unsigned long long* eval_counter = nullptr;
 	float* scratch_out = nullptr;
 	size_t weak_alloc = 0;       // capacity (in WEAK pixels) of the per-WEAK buffers
+	AnchorRec* anchor_tab = nullptr;   // [WEAK][S][11] reference sides of the anchor sub-patches (dvp_weak_wave.hpp), allocated at the first weak update
+	size_t anchor_tab_alloc = 0;       // capacity in records
+	bool anchor_tab_valid = false;     // built for the current anchors / offsets / images (any launch or upload that can change them clears it)
+	bool anchor_tab_off = false;       // DVP_WEAK_ANCHOR_TAB=0, or the table did not fit: the weak update forms the reference side per item
 	int* weak_list = nullptr;    // compacted WEAK pixel indices (black first, then red)
 	size_t weak_list_alloc = 0;
 	int* weak_counts = nullptr;  // scratch of the device-side compaction: per-slot black / red counts, per-chunk counts, then 3 totals
@@ -690,7 +712,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.planes = c->planes; d.planes_snap = c->planes_snap; d.costs = c->costs; d.costs_snap = c->costs_snap;
 	d.selected_views = c->selected_views; d.view_weight = c->view_weight; d.weak_info = c->weak_info;
 	d.weak_reliable = c->weak_reliable; d.weak_nearest_strong = c->weak_nearest_strong;
-	d.neighbours_map = c->neighbours_map; d.neighbours = c->neighbours; d.gn_points = c->gn_points; d.gn_count = c->gn_count; d.fit_planes = c->fit_planes;
+	d.anchor_tab = (c->anchor_tab_off || !c->anchor_tab_valid) ? nullptr : c->anchor_tab; d.neighbours_map = c->neighbours_map; d.neighbours = c->neighbours; d.gn_points = c->gn_points; d.gn_count = c->gn_count; d.fit_planes = c->fit_planes;
 	d.candidate = c->candidate; d.edge = c->edge; d.edge_bits = c->edge_bits; d.strong_bits = c->strong_bits; d.strong_bits_t = c->strong_bits_t; d.edge_sat = c->edge_sat; d.sat_cells_x = sat_cells(c->W); d.sat_cells_y = sat_cells(c->H); d.edge_tiles_x = edge_tiles_x(c->W); d.edge_neigh = c->edge_neigh; d.label = c->label;
 	d.label_boundary = c->label_boundary; d.label_stop = c->label_stop; d.complex_ = c->complex_; d.radius = c->radius;
 	d.weak_list = c->weak_list;
@@ -722,6 +744,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	c->device = device; c->W = width; c->H = height; c->NI = num_images;
 	c->no_images8 = getenv("DVP_NO_IMAGES8") != nullptr;
 	if (const char* e = getenv("DVP_STRONG_SPLIT")) c->strong_split = atoi(e) != 0;
+	if (const char* e = getenv("DVP_WEAK_ANCHOR_TAB")) c->anchor_tab_off = atoi(e) == 0;   // A/B measurements and the tests of the per-item form
 	if (const char* e = getenv("DVP_GN_WAVE")) c->gn_wave = atoi(e) != 0;
 	c->pitch = (width + 2 * kImgPad + 63) / 64 * 64;
 	c->L = (size_t)width * height;
@@ -842,9 +865,11 @@ static int upload_planes(dvp_ctx* c, float* dst, const float* const* src, int pi
 	return 0;
 }
 int dvp_upload_images(dvp_ctx* c, const float* const* images, int pitch_floats) {
+	c->anchor_tab_valid = false;
 	return upload_planes(c, c->image_stage, images, pitch_floats, hipMemcpyHostToDevice, c->images);
 }
 int dvp_upload_images_device(dvp_ctx* c, const float* const* images, int pitch_floats) {
+	c->anchor_tab_valid = false;
 	return upload_planes(c, c->image_stage, images, pitch_floats, hipMemcpyDeviceToDevice, c->images);
 }
 static int ensure_depths(dvp_ctx* c) {
@@ -897,6 +922,7 @@ static int ensure_weak_buffers(dvp_ctx* c, size_t weak_count) {
 
 int dvp_upload_state(dvp_ctx* c, const float* planes, const uint32_t* views, const uint8_t* weak,
                      const uint8_t* edge, const int32_t* label, const int32_t* radius) {
+	c->anchor_tab_valid = false;
 	if (set_device(c)) return 1;
 	const size_t L = c->L;
 	if (planes) HIP_TRY(c, hipMemcpyAsync(c->planes, planes, L * 16, hipMemcpyHostToDevice, c->stream));
@@ -949,6 +975,7 @@ int dvp_upload_state(dvp_ctx* c, const float* planes, const uint32_t* views, con
 }
 
 int dvp_reset_state(dvp_ctx* c) {
+	c->anchor_tab_valid = false;
 	if (set_device(c)) return 1;
 	const size_t L = c->L;
 	HIP_TRY(c, hipMemsetAsync(c->planes, 0, L * 16, c->stream));
@@ -989,6 +1016,7 @@ int dvp_save_state(dvp_ctx* c) {
 	return 0;
 }
 int dvp_restore_state(dvp_ctx* c) {
+	c->anchor_tab_valid = false;
 	if (set_device(c)) return 1;
 	if (!c->have_saved) { c->error = "dvp_restore_state: no saved state"; return 1; }
 	const size_t L = c->L;
@@ -1005,6 +1033,7 @@ int dvp_restore_state(dvp_ctx* c) {
 }
 
 int dvp_set_params(dvp_ctx* c, const DvpParams* p) {
+	c->anchor_tab_valid = false;
 	if (set_device(c)) return 1;
 	if (p->num_images != c->NI) { c->error = "dvp_set_params: params.num_images != context num_images"; return 1; }
 	if (p->use_edge == 0) { c->error = "dvp_set_params: use_edge=false is rejected: the reference's legacy ACMH branch (APD.cu:2142-2460) adopts planes through positions[], which only the use_edge branch assigns (APD.cu:2036, 2084, 2133 vs 2559-2563) - it has no defined result to reproduce"; return 1; }
@@ -1031,6 +1060,50 @@ int dvp_set_profiling(dvp_ctx* c, int on) { c->profiling = on != 0; sync_dev_str
 // `fused` (dvp_run_patchmatch only): DepthToWeak does LocalRefine too; GenEdgeInform leaves the visibility-prior
 // candidates to dvp_run_patchmatch (side stream; not computed at all when the pass has no WEAK pixel: their only
 // reader is the weak update's anchor_cost)
+// The pass' table of anchor reference sides (dvp_weak_wave.hpp: build_anchor_record) — built at the first weak update after
+// anything that can change the anchors (GenNeighbours, NeigbourUpdate), the offsets (GenEdgeInform), the images or the WEAK
+// list; the iterations of a pass then share it.  A table that does not fit is not an error: the kernels that form the
+// reference side per item give the same bits.
+static int ensure_anchor_table(dvp_ctx* c, int covered_rows) {
+	if (c->anchor_tab_off) return 0;
+	if (c->anchor_tab_valid) return 0;
+	const int wc = c->d.weak_black + c->d.weak_red;
+	const size_t need = (size_t)wc * (size_t)(c->NI - 1) * kAnchors;
+	if (need > c->anchor_tab_alloc) {
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		dfree(c, &c->anchor_tab);
+		c->anchor_tab_alloc = 0;
+		const size_t cap = need + need / 4;
+		void* q = nullptr;
+		size_t got = cap;
+		if (hipMalloc(&q, cap * sizeof(AnchorRec)) != hipSuccess) {
+			(void)hipGetLastError();
+			got = need;
+			if (hipMalloc(&q, need * sizeof(AnchorRec)) != hipSuccess) q = nullptr;
+		}
+		if (!q) {
+			(void)hipGetLastError();
+			c->anchor_tab_off = true;
+			sync_dev_struct(c);
+			fprintf(stderr, "dvp: no room for the weak update's anchor table (%.1f GB); forming the reference side per item\n", (double)need * sizeof(AnchorRec) / 1e9);
+			return 0;
+		}
+		c->allocs.push_back(q);
+		c->anchor_tab = (AnchorRec*)q;
+		c->anchor_tab_alloc = got;
+	}
+	c->anchor_tab_valid = true;
+	sync_dev_struct(c);
+	ListArgs la;
+	la.base = 0; la.count = wc; la.iter = 0; la.covered_rows = covered_rows;
+	const long long n = (long long)need;
+	if (n > 0) {
+		hipLaunchKernelGGL(dvp_weak_anchor_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d, la);
+		HIP_TRY(c, hipGetLastError());
+	}
+	return 0;
+}
+
 static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused = false) {
 	if (stage < 0 || stage >= DVP_ST_LAUNCHABLE) { c->error = "bad stage id"; return 1; }
 	if (!c->sector_taps) { c->error = "dvp_set_params must be called before running kernels"; return 1; }
@@ -1040,6 +1113,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 	a.tiles_x = g.tiles_x; a.tiles = g.tiles; a.rows = g.rows; a.half = g.half ? 1 : 0;
 	a.colour = colour; a.iter = iter;
 	if (c->events.size() >= 2048 && dvp_get_timings(c, nullptr)) return 1;   // fold pending timings: bounds the event pool
+	if (stage != DVP_ST_STRONG_UPDATE && stage != DVP_ST_RANSAC_FIT && stage != DVP_ST_WEAK_UPDATE) c->anchor_tab_valid = false;   // anchors / offsets / WEAK states may change: the next weak update rebuilds its table
 	if (stage == DVP_ST_STRONG_UPDATE) {
 		// pre-launch snapshot: the direction-4 samples of the strong update are same-colour pixels
 		// (APD.cu:2071-2074); every neighbour read of that kernel sees the state before the launch.
@@ -1111,8 +1185,14 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 			case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(ex ? dvp_neighbour_update_list_exact : dvp_neighbour_update_list, lg, block, 0, c->stream, c->d, la); break;
 			case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(ex ? dvp_ransac_fit_plane_list_exact : dvp_ransac_fit_plane_list, lg, block, 0, c->stream, c->d, la); break;
 			case DVP_ST_WEAK_UPDATE:
-				if (c->images8_ok) hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact_u8 : dvp_weak_update_wave_u8, dim3(la.count), dim3(64), 0, c->stream, c->d, la);
-				else hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact : dvp_weak_update_wave, dim3(la.count), dim3(64), 0, c->stream, c->d, la);
+				if (ensure_anchor_table(c, la.covered_rows)) return 1;
+				if (c->d.anchor_tab) {
+					if (c->images8_ok) hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact_u8 : dvp_weak_update_wave_u8, dim3(la.count), dim3(64), 0, c->stream, c->d, la);
+					else hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact : dvp_weak_update_wave, dim3(la.count), dim3(64), 0, c->stream, c->d, la);
+				} else {
+					if (c->images8_ok) hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact_u8_notab : dvp_weak_update_wave_u8_notab, dim3(la.count), dim3(64), 0, c->stream, c->d, la);
+					else hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact_notab : dvp_weak_update_wave_notab, dim3(la.count), dim3(64), 0, c->stream, c->d, la);
+				}
 				break;
 			}
 			HIP_TRY(c, hipGetLastError());
@@ -1204,6 +1284,7 @@ int dvp_synchronize(dvp_ctx* c) {
 
 // APD::RunPatchMatch (APD.cu:4406-4532): same launch order; no host sync between launches.
 int dvp_run_patchmatch(dvp_ctx* c) {
+	c->anchor_tab_valid = false;
 	if (set_device(c)) return 1;
 	EventPair tot, itl;
 	tot.stage = EV_TOTAL; itl.stage = EV_ITER_LOOP;
@@ -1317,6 +1398,7 @@ int dvp_download_buffer(dvp_ctx* c, int id, void* dst) {
 	return 0;
 }
 int dvp_upload_buffer(dvp_ctx* c, int id, const void* src) {
+	c->anchor_tab_valid = false;
 	if (set_device(c)) return 1;
 	size_t b; void* p = buffer_ptr(c, id, &b);
 	if (!p) { c->error = "bad or unallocated buffer id"; return 1; }

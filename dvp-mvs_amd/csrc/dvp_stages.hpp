@@ -109,8 +109,13 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 #if !defined(__HIPCC__)
 		if (d.weak_info[center] == DVP_WEAK) {
 			WeakShared sh;
-			if (d.images8) weak_update_wave<SMP, 1>(d, px, py, iter, nevals, sh);
-			else weak_update_wave<SMP, 0>(d, px, py, iter, nevals, sh);
+			if (d.anchor_tab) {
+				if (d.images8) weak_update_wave<SMP, 1, 1>(d, px, py, iter, nevals, sh);
+				else weak_update_wave<SMP, 0, 1>(d, px, py, iter, nevals, sh);
+			} else {
+				if (d.images8) weak_update_wave<SMP, 1, 0>(d, px, py, iter, nevals, sh);
+				else weak_update_wave<SMP, 0, 0>(d, px, py, iter, nevals, sh);
+			}
 		}
 #endif
 	}

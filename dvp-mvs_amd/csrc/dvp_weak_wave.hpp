@@ -248,6 +248,101 @@ DVP_HD float anchor_cost(const Dev& d, const float* H, const void* src, s2 nb, i
 	return ncc_from_sums(a_sr, a_srr, s_s, s_ss, s_rs, a_sw);
 }
 
+// ---- the anchor sub-patches' reference side, once per pass -------------------------------------------------------------
+// Of an anchor sub-patch (APD.cu:936-1006) only the nine gathers in the source image and the three source-side sums
+// depend on the plane hypothesis.  The nine tap positions (anchor + the visibility-prior offsets of (anchor, view)), the
+// colour weights w = exp(-|I(tap) - I(pixel)| / 2 sigma_c^2), the products w * I(tap) and the three reference sums depend
+// on (WEAK pixel, view, anchor) only — and anchors (GenNeighbours / NeigbourUpdate) and offsets (GenEdgeInform) are fixed
+// before the first iteration.  anchor_cost() recomputes them for every (view, anchor, PLANE) item of all three phases of
+// every weak-update launch: 9 reference texel loads, 9 exp and 27 multiply-adds per item.  build_anchor_record() forms
+// them ONCE per pass — same operations, same order, hence the same bits — into one 128-byte record per (WEAK pixel, view,
+// anchor) (Dev::anchor_tab: 12.4 KB per WEAK pixel at S = 9; 22 GB at 6208x4128 with 7 % WEAK — it is a 288 GB part), and
+// anchor_cost_tab() reads the record with eight 16-byte loads that the eight plane lanes of a pair share.
+struct alignas(16) AnchorRec {
+	f2 wt[9];            // (w, w * ref) per tap
+	uint32_t pos[9];     // tap position: (x & 0xffff) | (y << 16), signed 16-bit halves
+	float a_sr, a_srr, a_sw;
+	uint32_t pad[2];
+};
+static_assert(sizeof(AnchorRec) == 128, "one cache line per (WEAK pixel, view, anchor)");
+DVP_HD size_t anchor_rec_index(const Dev& d, int weak_index, int v0, int k) {
+	return ((size_t)weak_index * (size_t)(d.params.num_images - 1) + (size_t)v0) * kAnchors + (size_t)k;
+}
+// record of anchor k (0-based: neighbours[k + 1]) of the WEAK pixel `center` for source view v0 (0-based)
+DVP_HD void build_anchor_record(const Dev& d, int center, int v0, int k) {
+	const int W = d.width;
+	const int py = center / W, px = center - py * W;
+	const int wi = d.neighbours_map[center];
+	const s2 nb = d.neighbours[(size_t)wi * DVP_NEIGHBOUR_NUM + k + 1];
+	if (nb.x == -1 || nb.y == -1) return;   // no anchor: the record is never read (state 0)
+	const float cpix = ref_texel_t<0>(d, px, py);
+	const s2* cand = d.candidate + cand_index(d, nb.x + nb.y * W, v0);
+	AnchorRec r;
+	float a_sr = 0.0f, a_srr = 0.0f, a_sw = 0.0f;
+#pragma unroll
+	for (int t = 0; t < 9; ++t) {
+		int i = 0, j = 0;
+		if (t < 8) {
+			i = cand[t].x;
+			j = cand[t].y;
+			if (i == 0 && j == 0) {   // default +-5 ring (APD.cu:943-952): {-5,0,5}^2 without its centre, x-major
+				const int u = t + (t >= 4 ? 1 : 0);
+				i = (u / 3 - 1) * 5;
+				j = (u % 3 - 1) * 5;
+			}
+		}
+		const int tx = nb.x + i, ty = nb.y + j;
+		const float av = ref_texel_t<0>(d, tx, ty);
+		const float w = bilateral_weight((float)i, (float)j, av, cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
+		const float wa = w * av;
+		a_sr += wa;
+		a_srr += wa * av;
+		a_sw += w;
+		r.wt[t] = mk2(w, wa);
+		r.pos[t] = ((uint32_t)tx & 0xffffu) | ((uint32_t)ty << 16);
+	}
+	r.a_sr = a_sr;
+	r.a_srr = a_srr;
+	r.a_sw = a_sw;
+	r.pad[0] = r.pad[1] = 0u;
+	d.anchor_tab[anchor_rec_index(d, wi, v0, k)] = r;
+}
+
+// anchor_cost() with the reference side taken from the pass' table
+template <int SMP, int FMT>
+DVP_HD float anchor_cost_tab(const Dev& d, const float* H, const void* src, s2 nb, int state, const AnchorRec* recp) {
+	const int W = d.width, Hh = d.height, Pt = d.pitch;
+	if (state == 0) return -1.0f;
+	const bool visible = state == 2;
+	const f2 nsp = apply_homography(H, nb.x, nb.y);
+	const bool outside = nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh;
+	if (outside) return visible ? 2.0f : -1.0f;
+	if (!visible) return 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
+	const AnchorRec r = *recp;
+	unsigned off[9];
+	TapW<SMP> tw[9];
+	float qd[9][4];
+#pragma unroll
+	for (int t = 0; t < 9; ++t) {
+		const f2 sp = apply_homography(H, (int)(int16_t)(r.pos[t] & 0xffffu), (int)(int16_t)(r.pos[t] >> 16));
+		tex_coord_t<FMT>(d, sp.x, sp.y, &off[t], &tw[t]);
+	}
+#pragma unroll
+	for (int t = 0; t < 9; ++t) load_quad_t<FMT>(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
+	float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+#pragma unroll
+	for (int t = 0; t < 9; ++t) {
+		float fa, fb;
+		tap_weights(tw[t], &fa, &fb);
+		const float b = tex_lerp(fa, fb, qd[t][0], qd[t][1], qd[t][2], qd[t][3]);
+		const float wb = r.wt[t].x * b;
+		s_s += wb;
+		s_ss = fmaf(wb, b, s_ss);
+		s_rs = fmaf(r.wt[t].y, b, s_rs);
+	}
+	return ncc_from_sums(r.a_sr, r.a_srr, s_s, s_ss, s_rs, r.a_sw);
+}
+
 // ComputeBilateralNCCNew (APD.cu:835-1021) for the live planes sh.pl[q] (q in pmask) and the source views
 // in vmask: sh.ev[q][view] = cost.  c = centre-patch context (colour-only weights) built by wave_patch_ctx.
 // Views are taken kWeakPairs / np at a time with ONE shared-memory hand-over per batch:
@@ -259,8 +354,9 @@ DVP_HD float anchor_cost(const Dev& d, const float* H, const void* src, s2 nb, i
 //              The anchor pixel and its view mask do not depend on the view and are fetched once.
 //              Then lane (plane q, row r): one row of the 36-tap centre patch.
 //   section 2  lane (view slot, plane q): rows and anchors summed in the reference's order -> ev.
-template <int SMP, int FMT>
+template <int SMP, int FMT, int TAB>
 DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float cpix, int px, int py, uint32_t vmask, uint32_t pmask, WeakShared& sh) {
+	const int weak_index = TAB ? d.neighbours_map[px + py * d.width] : 0;
 	const int W = d.width, Hh = d.height, Pt = d.pitch;
 	const int np = 32 - __builtin_clz(pmask | 1u);   // plane slots in use (8 candidates, then 2 and 5)
 	uint32_t rest = vmask;
@@ -290,7 +386,7 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 					const int nbc = nb.x + nb.y * W;
 					const int v0 = nth_set_bit(batch, slot);   // 0-based view
 					state = is_set(d.selected_views[nbc], v0) ? 2 : 1;
-					if (state == 2) {
+					if (!TAB && state == 2) {   // (with the pass' table the offsets are already inside the records)
 						const s2* cand = d.candidate + cand_index(d, nbc, v0);
 #pragma unroll
 						for (int t = 0; t < 4; ++t) {
@@ -320,7 +416,8 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 				const bool inside = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f);
 				if (k == 0) sh.inq[slot * np + q] = inside ? 1 : 0;
 				if (!inside) continue;
-				sh.acost[slot * np + q][k] = anchor_cost<SMP, FMT>(d, H, img_plane<FMT>(d, v), nbs[k + 1], sh.astate[slot * kAnchors + k], sh.aoff[slot * kAnchors + k], cpix);
+				if (TAB) sh.acost[slot * np + q][k] = anchor_cost_tab<SMP, FMT>(d, H, img_plane<FMT>(d, v), nbs[k + 1], sh.astate[slot * kAnchors + k], d.anchor_tab + anchor_rec_index(d, weak_index, v - 1, k));
+				else sh.acost[slot * np + q][k] = anchor_cost<SMP, FMT>(d, H, img_plane<FMT>(d, v), nbs[k + 1], sh.astate[slot * kAnchors + k], sh.aoff[slot * kAnchors + k], cpix);
 			}
 			const int n_centre = nv * np * rows_per;
 			for (int it0 = 0; it0 < n_centre; it0 += 64) {
@@ -398,7 +495,7 @@ DVP_HD void wave_geom_table(const Dev& d, const DvpCamera& rc, int px, int py, u
 	wave_sync();
 }
 
-template <int SMP, int FMT>
+template <int SMP, int FMT, int TAB>
 DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned long long* nevals, WeakShared& sh) {
 	const int W = d.width, Hh = d.height;
 	const int center = py * W + px;
@@ -573,7 +670,7 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 			int first = 0;
 			while (!((vmask >> first) & 1)) ++first;
 			if (pmask) {
-				wave_ncc_new<SMP, FMT>(d, c, nbs, cpix, px, py, 1u << first, pmask, sh);
+				wave_ncc_new<SMP, FMT, TAB>(d, c, nbs, cpix, px, py, 1u << first, pmask, sh);
 				evals += (unsigned long long)__builtin_popcount(pmask);
 				if (P.geom_consistency) wave_geom_table(d, rc, px, py, pmask, sh);
 				uint32_t alive = 0;
@@ -588,12 +685,12 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 				pmask = alive;
 				const uint32_t rest = vmask & ~(1u << first);
 				if (pmask && rest) {
-					wave_ncc_new<SMP, FMT>(d, c, nbs, cpix, px, py, rest, pmask, sh);
+					wave_ncc_new<SMP, FMT, TAB>(d, c, nbs, cpix, px, py, rest, pmask, sh);
 					evals += (unsigned long long)__builtin_popcount(pmask) * (unsigned long long)__builtin_popcount(rest);
 				}
 			}
 		} else if (pmask && vmask) {
-			wave_ncc_new<SMP, FMT>(d, c, nbs, cpix, px, py, vmask, pmask, sh);
+			wave_ncc_new<SMP, FMT, TAB>(d, c, nbs, cpix, px, py, vmask, pmask, sh);
 			evals += (unsigned long long)__builtin_popcount(pmask) * (unsigned long long)__builtin_popcount(vmask);
 		}
 

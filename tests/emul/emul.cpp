@@ -32,6 +32,8 @@ struct Emu {
 	std::vector<int> edge_sat;
 	std::vector<s2> weak_nearest_strong, neighbours, candidate, edge_neigh, label_boundary, label_stop, gn_points;
 	std::vector<int> gn_count;
+	std::vector<AnchorRec> anchor_tab;   // the weak update's per-pass table (dvp_weak_wave.hpp), same validity rule as the engine's
+	bool anchor_tab_valid = false, anchor_tab_off = false;
 	std::vector<int> neighbours_map, label, radius;
 	unsigned long long evals = 0;
 	bool count = false;
@@ -71,6 +73,7 @@ void refresh(Emu& e) {
 	d.gn_count = e.gn_count.data();
 	d.fit_planes = e.fit_planes.data();
 	d.candidate = e.candidate.data();
+	d.anchor_tab = (e.anchor_tab_off || !e.anchor_tab_valid) ? nullptr : e.anchor_tab.data();
 	d.edge = e.edge.data();
 	d.edge_bits = e.edge_bits.data();
 	d.edge_sat = e.edge_sat.data();
@@ -168,6 +171,7 @@ static void fill_plane(Emu& e, float* plane, const float* data) {
 }
 void emu_set_image(void* c, int idx, const float* data) {
 	Emu& e = *(Emu*)c;
+	e.anchor_tab_valid = false;
 	std::vector<float> plain(e.d.plane_stride, 0.0f);
 	fill_plane(e, plain.data(), data);
 	const int PH = e.H + 2 * kImgPad;
@@ -208,6 +212,7 @@ void emu_set_cameras(void* c, const DvpCamera* cams, int n) {
 }
 void emu_set_params(void* c, const DvpParams* p) {
 	Emu& e = *(Emu*)c;
+	e.anchor_tab_valid = false;
 	e.d.params = *p;
 	set_neighbour_consts(&e.d);
 	make_sector_taps(p->weak_radius, &e.sector_taps, &e.sector_start);
@@ -221,6 +226,7 @@ long long emu_get_evals(void* c) { return (long long)((Emu*)c)->evals; }
 void emu_upload_state(void* c, const f4* planes, const uint32_t* views, const uint8_t* weak,
 	const uint8_t* edge, const int* label, const int* radius) {
 	Emu& e = *(Emu*)c;
+	e.anchor_tab_valid = false;
 	const size_t L = (size_t)e.W * e.H;
 	if (planes) std::memcpy(e.planes.data(), planes, L * sizeof(f4));
 	if (views) std::memcpy(e.selected_views.data(), views, L * 4);
@@ -281,6 +287,7 @@ int emu_get_buffer(void* c, int id, void* dst) {
 	return 0;
 }
 int emu_set_buffer(void* c, int id, const void* src) {
+	((Emu*)c)->anchor_tab_valid = false;
 	size_t b; void* p = buf_ptr(*(Emu*)c, id, &b); if (!p) return -1;
 	if (id == DVP_BUF_CANDIDATE) cand_transpose(*(Emu*)c, (const s2*)src, (s2*)p, true); else std::memcpy(p, src, b);
 	return 0;
@@ -327,6 +334,25 @@ static void pack_edge(Emu& e) {
 
 int emu_run_stage(void* c, int stage, int iter, int colour) {
 	Emu& e = *(Emu*)c;
+	// the engine's rule (dvp_engine.hip: launch_stage / ensure_anchor_table): any launch other than the three of the iteration
+	// loop may change anchors, offsets or WEAK states; the first weak update after it rebuilds the table
+	if (stage != DVP_ST_STRONG_UPDATE && stage != DVP_ST_RANSAC_FIT && stage != DVP_ST_WEAK_UPDATE) e.anchor_tab_valid = false;
+	if (stage == DVP_ST_WEAK_UPDATE) {
+		const char* off = getenv("DVP_WEAK_ANCHOR_TAB");
+		e.anchor_tab_off = off && atoi(off) == 0;
+		if (!e.anchor_tab_off && !e.anchor_tab_valid) {
+			const int S = e.NI - 1;
+			e.anchor_tab.assign((size_t)std::max(e.d.weak_count, 1) * S * kAnchors, AnchorRec{});
+			e.anchor_tab_valid = true;
+			refresh(e);
+			const long long L = (long long)e.W * e.H;
+#pragma omp parallel for schedule(dynamic, 64)
+			for (long long center = 0; center < L; ++center)
+				if (e.weak_info[(size_t)center] == DVP_WEAK)
+					for (int v0 = 0; v0 < S; ++v0)
+						for (int k = 0; k < kAnchors; ++k) build_anchor_record(e.d, (int)center, v0, k);
+		} else refresh(e);
+	}
 	switch (stage) {
 	case DVP_ST_GEN_EDGE_INFORM:
 		if (e.d.params.use_edge) {

@@ -35,11 +35,15 @@ def test_first_pass_strong_path(W, H, S, sampler):
     _run_and_compare(a, b, 2)
 
 
+@pytest.mark.parametrize("anchors", ["table", "per_item"])
 @pytest.mark.parametrize("images", ["8bit", "float"])
-def test_two_pass_weak_path_with_geom(images):
-    """pass 1 (FIRST_INIT) on the oracle, then a REFINE_ITER pass with WEAK pixels, labels, adaptive
+def test_two_pass_weak_path_with_geom(images, anchors, monkeypatch):
+    """`anchors`: the reference side of the anchor sub-patches from the pass' table (built once, before the first weak
+    update of the pass) or formed per (view, anchor, plane) item as the source text does (DVP_WEAK_ANCHOR_TAB=0).
+    pass 1 (FIRST_INIT) on the oracle, then a REFINE_ITER pass with WEAK pixels, labels, adaptive
     radius and geometric consistency on both.  `images`: integer grey levels (the weak update reads the
     byte planes) or non-integers (float planes)."""
+    monkeypatch.setenv("DVP_WEAK_ANCHOR_TAB", "1" if anchors == "table" else "0")
     W, H, S = 112, 80, 3
     sc = synth.make_scene(W, H, S)
     if images == "float":

@@ -100,10 +100,14 @@ def test_full_run_matches_and_converges():
     assert np.median(rel[m.reshape(-1)]) < 2e-3
 
 
+@pytest.mark.parametrize("anchors", ["table", "per_item"])
 @pytest.mark.parametrize("images", ["8bit", "float"])
-def test_two_pass_weak_path_with_geom(images):
-    """`images`: the synthetic grey levels are integers (8-bit files) -> the weak update reads the byte planes
+def test_two_pass_weak_path_with_geom(images, anchors, monkeypatch):
+    """`anchors`: the reference side of the anchor sub-patches from the pass' table (built once, before the first weak
+    update of the pass) or formed per (view, anchor, plane) item as the source text does (DVP_WEAK_ANCHOR_TAB=0).
+    `images`: the synthetic grey levels are integers (8-bit files) -> the weak update reads the byte planes
     (Dev::images8); scaled to non-integers it reads the float planes.  Both against the oracle."""
+    monkeypatch.setenv("DVP_WEAK_ANCHOR_TAB", "1" if anchors == "table" else "0")
     W, H, S = 112, 80, 3
     sc = synth.make_scene(W, H, S)
     if images == "float":
