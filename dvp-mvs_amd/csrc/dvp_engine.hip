@@ -190,7 +190,7 @@ template <int SMP, int FMT, int TAB>
 __device__ __forceinline__ void weak_wave_body(const Dev& d, const ListArgs& a) {
 	// one wave = one WEAK pixel = one workgroup (10 KB of LDS): with four pixels per workgroup the LDS of a finished pixel waited
 	// for the slowest of the four (weak update 400 -> 376 ms per cfg3 pass); the XCD runs keep their length in pixels
-	__shared__ WeakShared sh[1];
+	__shared__ WeakSharedT<TAB> sh[1];
 	const int wave = 0;
 	const int t = list_block(blockIdx.x, gridDim.x, kWaveRun * 4);
 	if (t >= a.count) return;

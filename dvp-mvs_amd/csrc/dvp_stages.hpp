@@ -108,11 +108,12 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 		// host emulation of that wave (tests/emul): DVP_LANES loops over the 64 lanes
 #if !defined(__HIPCC__)
 		if (d.weak_info[center] == DVP_WEAK) {
-			WeakShared sh;
 			if (d.anchor_tab) {
+				WeakSharedT<1> sh;
 				if (d.images8) weak_update_wave<SMP, 1, 1>(d, px, py, iter, nevals, sh);
 				else weak_update_wave<SMP, 0, 1>(d, px, py, iter, nevals, sh);
 			} else {
+				WeakSharedT<0> sh;
 				if (d.images8) weak_update_wave<SMP, 1, 0>(d, px, py, iter, nevals, sh);
 				else weak_update_wave<SMP, 0, 0>(d, px, py, iter, nevals, sh);
 			}

@@ -53,8 +53,11 @@ constexpr int kAnchorTaps = kAnchors * 9;         // 99
 constexpr int kWeakPairs = DVP_WEAK_PAIRS;
 constexpr int kWeakViews = 7;   // ... and at most this many views (size of the (view, anchor) prefetch table)
 
-// per-wave shared state (LDS on the device), ~8.6 KB
-struct WeakShared {
+// per-wave shared state (LDS on the device).  TAB = 1 (the anchor reference sides come from the pass' table): no offset
+// table, and the homographies of the batch's (view, plane) pairs instead — in the bytes of cost_array, which is dead
+// while a batch is evaluated (written by the epilogue of the propagation phase, read by the view selection).
+template <int TAB>
+struct WeakSharedT {
 	f2 ctab[kTaps * kTaps];        // centre patch: (w, w*ref) per tap, row-major
 	float caa[kTaps * kTaps];      // w*ref*ref per tap (reference moments only)
 	float rows[kWeakPairs][kTaps][3];    // centre-patch row sums (s_s, s_ss, s_rs) per pair (view slot * np + plane) and row; the final-cost section uses pairs 0..7 for 8 views
@@ -62,9 +65,12 @@ struct WeakShared {
 	int inq[kWeakPairs];                 // pair: the centre projects inside the source image
 	// (view slot, anchor) of the batch, fetched once before the items run: the anchor's 8 visibility-prior offsets
 	// for that view as signed bytes (x, y) and what anchor_cost has to do with the pair
-	uint32_t aoff[kWeakViews * kAnchors][4];
+	uint32_t aoff[TAB ? 1 : kWeakViews * kAnchors][4];
 	uint8_t astate[kWeakViews * kAnchors];   // 0: no anchor; 1: the anchor did not select the view; 2: sub-patch
-	float cost_array[8][32];
+	union {
+		float cost_array[8][32];
+		float Hq[TAB ? kWeakPairs : 1][9];   // homography of the batch's pair (view slot * np + live-plane index)
+	};
 	float ev[8][32];
 	float gtab[8][32];             // geometric-consistency cost per (plane, view)
 	float probs[32];
@@ -74,6 +80,7 @@ struct WeakShared {
 	uint8_t vw[32];
 	f4 pl[8];
 };
+using WeakShared = WeakSharedT<0>;
 
 // ComputeGeomConsistencyCost (APD.cu:1218-1256) with both cameras given (lane-varying view index)
 DVP_HD float geom_cost_cams(const Dev& d, const DvpCamera& rc, const DvpCamera& sc, int v, int px, int py, const f4 plane) {
@@ -97,8 +104,8 @@ DVP_HD float geom_cost_cams(const Dev& d, const DvpCamera& rc, const DvpCamera& 
 
 // build_patch_ctx (dvp_ncc.hpp) by the wave: lane t < 36 owns tap t; the reference moments are then
 // summed in the row-then-total order by every lane.
-template <int FMT>
-DVP_HD void wave_patch_ctx(const Dev& d, int px, int py, int radius, int inc, int colour_only, WeakShared& sh, PatchCtx* c) {
+template <int FMT, class SH>
+DVP_HD void wave_patch_ctx(const Dev& d, int px, int py, int radius, int inc, int colour_only, SH& sh, PatchCtx* c) {
 	c->radius = radius;
 	c->inc = inc;
 	c->fast = (inc > 0 && (2 * radius) / inc + 1 == kTaps) ? 1 : 0;
@@ -137,8 +144,8 @@ DVP_HD void wave_patch_ctx(const Dev& d, int px, int py, int radius, int inc, in
 
 // one row (6 taps) of the 36-tap patch for homography H: the row's three source-side sums
 // (ncc_patch_fast, dvp_ncc.hpp: same products, same shared division per row, same order)
-template <int SMP, int FMT>
-DVP_HD void patch_row_sums(const Dev& d, const WeakShared& sh, const float* H, const void* src, int px, int py, int radius, int inc, int row, float* out /*[3]*/) {
+template <int SMP, int FMT, class SH>
+DVP_HD void patch_row_sums(const Dev& d, const SH& sh, const float* H, const void* src, int px, int py, int radius, int inc, int row, float* out /*[3]*/) {
 	const int W = d.width, Hh = d.height, P = d.pitch;
 	const float fy = (float)(py - radius + row * inc);
 	const float hy1 = H[1] * fy, hy4 = H[4] * fy, hy7 = H[7] * fy;
@@ -318,7 +325,21 @@ DVP_HD float anchor_cost_tab(const Dev& d, const float* H, const void* src, s2 n
 	const bool outside = nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= Hh;
 	if (outside) return visible ? 2.0f : -1.0f;
 	if (!visible) return 2.0f;   // anchor not visible in this view: the reference's 0/0 path yields exactly 2
-	const AnchorRec r = *recp;
+#if defined(DVP_ABL_NO_ANCHOR)   // timing ablation (wrong results): what the launch costs without the anchor sub-patches
+	return 1.0f;
+#endif
+	AnchorRec r;
+#if defined(__HIP_DEVICE_COMPILE__)
+	{   // eight 16-byte loads (a plain struct copy is split into 30 dword loads)
+		typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+		const u4* src4 = reinterpret_cast<const u4*>(recp);
+		u4* dst4 = reinterpret_cast<u4*>(&r);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) dst4[i] = src4[i];
+	}
+#else
+	r = *recp;
+#endif
 	unsigned off[9];
 	TapW<SMP> tw[9];
 	float qd[9][4];
@@ -326,6 +347,9 @@ DVP_HD float anchor_cost_tab(const Dev& d, const float* H, const void* src, s2 n
 	for (int t = 0; t < 9; ++t) {
 		const f2 sp = apply_homography(H, (int)(int16_t)(r.pos[t] & 0xffffu), (int)(int16_t)(r.pos[t] >> 16));
 		tex_coord_t<FMT>(d, sp.x, sp.y, &off[t], &tw[t]);
+#if defined(DVP_ABL_ANCHOR_NOGATHER)   // timing ablation (wrong results): every gather hits one line
+		off[t] = (unsigned)t * 4u;
+#endif
 	}
 #pragma unroll
 	for (int t = 0; t < 9; ++t) load_quad_t<FMT>(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
@@ -354,9 +378,8 @@ DVP_HD float anchor_cost_tab(const Dev& d, const float* H, const void* src, s2 n
 //              The anchor pixel and its view mask do not depend on the view and are fetched once.
 //              Then lane (plane q, row r): one row of the 36-tap centre patch.
 //   section 2  lane (view slot, plane q): rows and anchors summed in the reference's order -> ev.
-template <int SMP, int FMT, int TAB>
+template <int SMP, int FMT>
 DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float cpix, int px, int py, uint32_t vmask, uint32_t pmask, WeakShared& sh) {
-	const int weak_index = TAB ? d.neighbours_map[px + py * d.width] : 0;
 	const int W = d.width, Hh = d.height, Pt = d.pitch;
 	const int np = 32 - __builtin_clz(pmask | 1u);   // plane slots in use (8 candidates, then 2 and 5)
 	uint32_t rest = vmask;
@@ -386,7 +409,7 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 					const int nbc = nb.x + nb.y * W;
 					const int v0 = nth_set_bit(batch, slot);   // 0-based view
 					state = is_set(d.selected_views[nbc], v0) ? 2 : 1;
-					if (!TAB && state == 2) {   // (with the pass' table the offsets are already inside the records)
+					if (state == 2) {
 						const s2* cand = d.candidate + cand_index(d, nbc, v0);
 #pragma unroll
 						for (int t = 0; t < 4; ++t) {
@@ -416,8 +439,7 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 				const bool inside = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f);
 				if (k == 0) sh.inq[slot * np + q] = inside ? 1 : 0;
 				if (!inside) continue;
-				if (TAB) sh.acost[slot * np + q][k] = anchor_cost_tab<SMP, FMT>(d, H, img_plane<FMT>(d, v), nbs[k + 1], sh.astate[slot * kAnchors + k], d.anchor_tab + anchor_rec_index(d, weak_index, v - 1, k));
-				else sh.acost[slot * np + q][k] = anchor_cost<SMP, FMT>(d, H, img_plane<FMT>(d, v), nbs[k + 1], sh.astate[slot * kAnchors + k], sh.aoff[slot * kAnchors + k], cpix);
+				sh.acost[slot * np + q][k] = anchor_cost<SMP, FMT>(d, H, img_plane<FMT>(d, v), nbs[k + 1], sh.astate[slot * kAnchors + k], sh.aoff[slot * kAnchors + k], cpix);
 			}
 			const int n_centre = nv * np * rows_per;
 			for (int it0 = 0; it0 < n_centre; it0 += 64) {
@@ -432,6 +454,9 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 				homography(vc, sh.pl[cq], Hc);
 				const f2 pt = apply_homography(Hc, px, py);
 				if (pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f) continue;
+#if defined(DVP_ABL_NO_CENTRE)   // timing ablation (wrong results): what the launch costs without the centre patches
+				continue;
+#endif
 				if (c.fast) {
 					float o[3];
 					patch_row_sums<SMP, FMT>(d, sh, Hc, img_plane<FMT>(d, v), px, py, c.radius, c.inc, r, o);
@@ -482,8 +507,140 @@ DVP_HD void wave_ncc_new(const Dev& d, const PatchCtx& c, const s2* nbs, float c
 	}
 }
 
+// it / n for 0 <= it < 65536, 1 <= n <= 64 through one float multiplication (exact: (it + 0.5) / n is at least 1 / 2n away from
+// an integer, the rounding error of the product is below 2^-7); the generic 32-bit division is ~25 instructions
+DVP_HD int small_div(int it, float inv_n) { return (int)(((float)it + 0.5f) * inv_n); }
+
+// wave_ncc_new with the anchor reference sides from the pass' table (TAB = 1).  Same evaluations, same bits; what changes
+// is the bookkeeping around them:
+//   * the homography of a (view, plane) pair is formed ONCE per batch into sh.Hq (section 0) instead of by each of the
+//     pair's 17 items — 11 anchor sub-patches and 6 centre rows — (a quarter of an anchor round's instructions);
+//   * the live planes are compacted: pair = view slot * np + (index among the set bits of pmask), np = popcount(pmask),
+//     so the refinement phase's survivors (e.g. hypotheses 1 and 4 of 5) fill whole rounds;
+//   * items decode with small_div.
+template <int SMP, int FMT>
+DVP_HD void wave_ncc_new_tab(const Dev& d, const PatchCtx& c, const s2* nbs, int px, int py, uint32_t vmask, uint32_t pmask, WeakSharedT<1>& sh) {
+	const int W = d.width;
+	const int np = __builtin_popcount(pmask);
+	if (np == 0) return;
+	const float inv_np = 1.0f / (float)np;
+	const int weak_index = d.neighbours_map[px + py * W];
+	uint32_t rest = vmask;
+	while (rest) {
+		uint32_t batch = 0;
+		for (int n = 0; n < kWeakPairs / np && n < kWeakViews && rest; ++n) { const uint32_t low = rest & (0u - rest); batch |= low; rest ^= low; }
+		const int nv = __builtin_popcount(batch);
+		const int rows_per = c.fast ? kTaps : 1;
+		// section 0: (view slot, anchor) states and the homographies of the (view slot, plane) pairs
+		for (int i0 = 0; i0 < nv * kAnchors; i0 += 64) {
+			DVP_LANES(l) {
+				const int i = i0 + l;
+				if (i >= nv * kAnchors) continue;
+				const int slot = i / kAnchors, k = i - slot * kAnchors;
+				const s2 nb = nbs[k + 1];
+				int state = 0;
+				if (!(nb.x == -1 || nb.y == -1)) state = is_set(d.selected_views[nb.x + nb.y * W], nth_set_bit(batch, slot)) ? 2 : 1;
+				sh.astate[i] = (uint8_t)state;
+			}
+		}
+		DVP_LANES(l) {
+			if (l >= nv * np) continue;
+			const int slot = small_div(l, inv_np), qi = l - slot * np;
+			const int v = nth_set_bit(batch, slot) + 1;   // 1-based image index of the source view
+			const ViewConst vc = d.views[v];
+			float H[9];
+			homography(vc, sh.pl[nth_set_bit(pmask, qi)], H);
+			const f2 pt = apply_homography(H, px, py);
+			sh.inq[l] = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f) ? 1 : 0;
+#pragma unroll
+			for (int i = 0; i < 9; ++i) sh.Hq[l][i] = H[i];
+		}
+		wave_sync();
+		// section 1: anchor items (view slot, anchor k, live plane qi), qi fastest — the np planes of one (view, anchor) sit in
+		// adjacent lanes, so a load instruction's lanes share lines —, then centre items (pair, patch row)
+		DVP_LANES(l) {
+			const int n_anchor = nv * kAnchors * np;
+			for (int it0 = 0; it0 < n_anchor; it0 += 64) {
+				const int it = it0 + l;
+				if (it >= n_anchor) continue;
+				const int t2 = small_div(it, inv_np), qi = it - t2 * np;
+				const int slot = t2 / kAnchors, k = t2 - slot * kAnchors;
+				const int pair = slot * np + qi;
+				if (!sh.inq[pair]) continue;
+				const int v = nth_set_bit(batch, slot) + 1;
+				float H[9];
+#pragma unroll
+				for (int i = 0; i < 9; ++i) H[i] = sh.Hq[pair][i];
+				sh.acost[pair][k] = anchor_cost_tab<SMP, FMT>(d, H, img_plane<FMT>(d, v), nbs[k + 1], sh.astate[slot * kAnchors + k], d.anchor_tab + anchor_rec_index(d, weak_index, v - 1, k));
+			}
+			const int n_centre = nv * np * rows_per;
+			for (int it0 = 0; it0 < n_centre; it0 += 64) {
+				const int it = it0 + l;
+				if (it >= n_centre) continue;
+				const int pair = it / rows_per, r = it - pair * rows_per;
+				if (!sh.inq[pair]) continue;
+#if defined(DVP_ABL_NO_CENTRE)   // timing ablation (wrong results)
+				continue;
+#endif
+				const int slot = small_div(pair, inv_np);
+				const int v = nth_set_bit(batch, slot) + 1;
+				float Hc[9];
+#pragma unroll
+				for (int i = 0; i < 9; ++i) Hc[i] = sh.Hq[pair][i];
+				if (c.fast) {
+					float o[3];
+					patch_row_sums<SMP, FMT>(d, sh, Hc, img_plane<FMT>(d, v), px, py, c.radius, c.inc, r, o);
+					sh.rows[pair][r][0] = o[0];
+					sh.rows[pair][r][1] = o[1];
+					sh.rows[pair][r][2] = o[2];
+				} else {   // generic (non-6-tap) patches sample the float planes
+					sh.rows[pair][0][0] = ncc_patch_generic(d, Hc, d.images + (size_t)v * d.plane_stride * 2, px, py, c.radius, c.inc, 1);
+				}
+			}
+		}
+		wave_sync();
+		// section 2: lane = pair: rows and anchors summed in the reference's order -> ev
+		DVP_LANES(l) {
+			for (int it0 = 0; it0 < nv * np; it0 += 64) {
+				const int pair = it0 + l;
+				if (pair >= nv * np) continue;
+				const int slot = small_div(pair, inv_np), qi = pair - slot * np;
+				const int q = nth_set_bit(pmask, qi);
+				const int v = nth_set_bit(batch, slot);   // 0-based view index
+				if (!sh.inq[pair]) { sh.ev[q][v] = 2.0f; continue; }
+				float cc;
+				if (c.fast) {
+					float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+					for (int r = 0; r < kTaps; ++r) {
+						s_s += sh.rows[pair][r][0];
+						s_ss += sh.rows[pair][r][1];
+						s_rs += sh.rows[pair][r][2];
+					}
+					cc = ncc_from_sums(c.sum_ref, c.sum_ref_ref, s_s, s_ss, s_rs, c.wsum);
+				} else {
+					cc = sh.rows[pair][0][0];
+				}
+				float scost = 0.0f, scnt = 0.0f;
+				for (int k = 0; k < kAnchors; ++k) {
+					const float ac = sh.acost[pair][k];
+					if (ac >= 0.0f) { scost += ac; scnt += 1.0f; }
+				}
+				float out = cc;
+				if (scnt > 0.0f) {
+					float sc2 = scost / scnt;   // strong_cost /= strong_count (int -> float, exact)
+					sc2 = DVP_MIN(sc2, 2.0f);
+					out = (float)(0.25 * cc + 0.75 * sc2);
+				}
+				sh.ev[q][v] = out;
+			}
+		}
+		wave_sync();
+	}
+}
+
 // gtab[q][j] = ComputeGeomConsistencyCost(pixel, view j+1, sh.pl[q]) for q in pmask, views with weight > 0
-DVP_HD void wave_geom_table(const Dev& d, const DvpCamera& rc, int px, int py, uint32_t pmask, WeakShared& sh) {
+template <class SH>
+DVP_HD void wave_geom_table(const Dev& d, const DvpCamera& rc, int px, int py, uint32_t pmask, SH& sh) {
 	const int S = d.params.num_images - 1;
 	for (int j0 = 0; j0 < S; j0 += 8) {
 		DVP_LANES(l) {
@@ -495,8 +652,17 @@ DVP_HD void wave_geom_table(const Dev& d, const DvpCamera& rc, int px, int py, u
 	wave_sync();
 }
 
+template <int SMP, int FMT>
+DVP_HD void weak_eval(const Dev& d, const PatchCtx& c, const s2* nbs, float cpix, int px, int py, uint32_t vmask, uint32_t pmask, WeakSharedT<0>& sh) {
+	wave_ncc_new<SMP, FMT>(d, c, nbs, cpix, px, py, vmask, pmask, sh);
+}
+template <int SMP, int FMT>
+DVP_HD void weak_eval(const Dev& d, const PatchCtx& c, const s2* nbs, float cpix, int px, int py, uint32_t vmask, uint32_t pmask, WeakSharedT<1>& sh) {
+	wave_ncc_new_tab<SMP, FMT>(d, c, nbs, px, py, vmask, pmask, sh);
+}
+
 template <int SMP, int FMT, int TAB>
-DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned long long* nevals, WeakShared& sh) {
+DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned long long* nevals, WeakSharedT<TAB>& sh) {
 	const int W = d.width, Hh = d.height;
 	const int center = py * W + px;
 	const DvpParams& P = d.params;
@@ -515,12 +681,12 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 		wave_patch_ctx<FMT>(d, px, py, radius, inc, 1, sh, &c);
 	}
 	DVP_LANES(l) {
-		for (int i = l; i < 8 * 32; i += 64) (&sh.cost_array[0][0])[i] = 0.0f;
 		if (l < 32) sh.vw[l] = 0;
 		if (l < 8) sh.positions[l] = 0;
 	}
 	wave_sync();
-	if (DVP_LANE0) sh.cost_array[0][0] = 2.0f;   // `= { 2.0f }` sets one element (APD.cu:2769)
+	// (cost_array: `= { 2.0f }` sets one element, the rest is 0 (APD.cu:2769) — written whole by the epilogue of the propagation
+	// phase below; until then its bytes hold the batch homographies of the TAB form)
 	uint32_t flag = 0;
 	uint32_t sel_mask = 0;
 	uint32_t sel_now = d.selected_views[center];   // what random_normal_yzl reads (updated on adoption)
@@ -670,7 +836,7 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 			int first = 0;
 			while (!((vmask >> first) & 1)) ++first;
 			if (pmask) {
-				wave_ncc_new<SMP, FMT, TAB>(d, c, nbs, cpix, px, py, 1u << first, pmask, sh);
+				weak_eval<SMP, FMT>(d, c, nbs, cpix, px, py, 1u << first, pmask, sh);
 				evals += (unsigned long long)__builtin_popcount(pmask);
 				if (P.geom_consistency) wave_geom_table(d, rc, px, py, pmask, sh);
 				uint32_t alive = 0;
@@ -685,12 +851,12 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 				pmask = alive;
 				const uint32_t rest = vmask & ~(1u << first);
 				if (pmask && rest) {
-					wave_ncc_new<SMP, FMT, TAB>(d, c, nbs, cpix, px, py, rest, pmask, sh);
+					weak_eval<SMP, FMT>(d, c, nbs, cpix, px, py, rest, pmask, sh);
 					evals += (unsigned long long)__builtin_popcount(pmask) * (unsigned long long)__builtin_popcount(rest);
 				}
 			}
 		} else if (pmask && vmask) {
-			wave_ncc_new<SMP, FMT, TAB>(d, c, nbs, cpix, px, py, vmask, pmask, sh);
+			weak_eval<SMP, FMT>(d, c, nbs, cpix, px, py, vmask, pmask, sh);
 			evals += (unsigned long long)__builtin_popcount(pmask) * (unsigned long long)__builtin_popcount(vmask);
 		}
 
@@ -699,7 +865,7 @@ DVP_HD void weak_update_wave(const Dev& d, int px, int py, int iter, unsigned lo
 			DVP_LANES(l) {
 				for (int i = l; i < 8 * 32; i += 64) {
 					const int k = i >> 5, v = i & 31;
-					if (((flag >> k) & 1) && v < S) sh.cost_array[k][v] = sh.ev[k][v];
+					sh.cost_array[k][v] = (((flag >> k) & 1) && v < S) ? sh.ev[k][v] : (i == 0 ? 2.0f : 0.0f);
 				}
 			}
 			wave_sync();
