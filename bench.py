@@ -87,20 +87,33 @@ def decide_kernel(S):
     return "dvp_strong_decide_v%d" % next(m for m in (4, 6, 8, 10, 12, 16) if S <= m)
 
 
+def sweep_split():
+    return os.environ.get("DVP_SWEEP_SPLIT", "1") != "0"
+
+
 def extra_kernels(stage, S):
-    """the other kernels a launch site's timer covers (their counters are added to the first one's)"""
+    """the other kernels a launch site's timer covers: [(kernel, launches per launch of the site)]; their counters are added to
+    the first one's"""
     if stage == "gen_neighbours":
-        return ["dvp_gen_neighbours_fit"]       # (dvp_gen_candidates runs on the side stream, outside its launch site's timer)
+        return [("dvp_gen_neighbours_fit", 1)]       # (dvp_gen_candidates runs on the side stream, outside its launch site's timer)
     if stage == "strong_update" and S <= 16 and os.environ.get("DVP_STRONG_SPLIT", "1") != "0":
-        return [decide_kernel(S), "dvp_strong_refine"]
+        return [(decide_kernel(S), 1), ("dvp_strong_refine", 1)]
+    if stage == "depth_to_weak" and sweep_split():   # DepthToWeak + LocalRefine as view-compacted passes (DESIGN.md §4)
+        return [("dvp_sweep_prepare", 1), ("dvp_sweep_decide1", 1), ("dvp_sweep_decide2", 1), ("dvp_depth_to_weak_refine", 1)] + \
+               ([("dvp_sweep_geom", 2)] if os.environ.get("DVP_SWEEP_GEOM_KERNEL", "1") != "0" else [])
     return []
+
+
+def primary_launches(stage):
+    """launches of the site's first kernel per launch of the site"""
+    return 2 if (stage == "depth_to_weak" and sweep_split()) else 1
 
 
 def kernel_name(stage, S):
     split = S <= 16 and os.environ.get("DVP_STRONG_SPLIT", "1") != "0"
     return {"strong_update": "dvp_strong_eval" if split else ("dvp_strong_update_v8" if S <= 8 else ("dvp_strong_update_v16" if S <= 16 else "dvp_strong_update")),
-            "weak_update": "dvp_weak_update_wave_u8" if IMAGE_FORMAT else "dvp_weak_update_wave",
-            "depth_to_weak": "dvp_depth_to_weak_refine",   # dvp_run_patchmatch: DepthToWeak + LocalRefine in one launch
+            "weak_update": ("dvp_weak_update_wave_u8" if IMAGE_FORMAT else "dvp_weak_update_wave") + ("" if os.environ.get("DVP_WEAK_ANCHOR_TAB", "1") != "0" else "_notab"),
+            "depth_to_weak": "dvp_sweep_eval" if sweep_split() else "dvp_depth_to_weak_refine",   # dvp_run_patchmatch: DepthToWeak + LocalRefine as one launch site
             "gen_neighbours": "dvp_gen_neighbours_search" if os.environ.get("DVP_GN_WAVE", "0") not in ("", "0") else "dvp_gen_neighbours_list",
             "ransac_fit": "dvp_ransac_fit_plane_list", "find_nearest_strong": "dvp_find_nearest_strong_list",
             "neighbour_update": "dvp_neighbour_update_list"}.get(stage, "dvp_" + stage)
@@ -210,18 +223,25 @@ def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
     sec = avg_ms * 1e-3
     alg = evals_per_launch * NCC_BYTES / sec / 1e9 if (sec > 0 and evals_per_launch) else None
     pmc = pmc_lookup(k, W, H, S)
-    for second in (extra_kernels(stage, S) if pmc else []):   # a launch site with several kernels is timed as one: its counters are their sum
+    SUMMED = ("hbm_bytes_per_launch", "SQ_INSTS_VALU", "TCC_MISS", "TCC_HIT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU")
+    if pmc and primary_launches(stage) != 1:   # the table holds per-launch averages: a site that launches a kernel twice has twice of each
+        pmc = dict(pmc)
+        for c in SUMMED:
+            if c in pmc:
+                pmc[c] = pmc[c] * primary_launches(stage)
+    for second, mult in (extra_kernels(stage, S) if pmc else []):   # a launch site with several kernels is timed as one: its counters are their sum
         p2 = pmc_lookup(second, W, H, S)
         if p2:
             pmc = dict(pmc)
-            for c in ("hbm_bytes_per_launch", "SQ_INSTS_VALU", "TCC_MISS", "TCC_HIT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"):
+            for c in SUMMED:
                 if c in pmc and c in p2:
-                    pmc[c] = pmc[c] + p2[c]
-            if pmc.get("TCC_HIT") is not None and pmc.get("TCC_MISS"):
-                pmc["l2_hit_rate"] = round(pmc["TCC_HIT"] / (pmc["TCC_HIT"] + pmc["TCC_MISS"]), 4)
-            if pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAIT_ANY") is not None:
-                pmc["wait_any_frac"] = round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4)
+                    pmc[c] = pmc[c] + mult * p2[c]
             k = k + " + " + second
+    if pmc:
+        if pmc.get("TCC_HIT") is not None and pmc.get("TCC_MISS"):
+            pmc["l2_hit_rate"] = round(pmc["TCC_HIT"] / (pmc["TCC_HIT"] + pmc["TCC_MISS"]), 4)
+        if pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAIT_ANY") is not None:
+            pmc["wait_any_frac"] = round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4)
     r = {"kernel": k, "avg_launch_ms": round(avg_ms, 3), "evals_per_launch": int(evals_per_launch or 0),
          "work_rate": {"what": "SURVEY 8(d) algorithmic bytes: NCC evaluations x 724 B / launch time — a work rate, NOT a bound (caches/LDS serve it)",
                        "bytes_per_eval": NCC_BYTES, "gbs": round(alg, 1) if alg else None,
@@ -481,8 +501,8 @@ def main():
             "iter_loop_value": round(float(W) * H * iters * args.steps / (tm["iter_loop_ms"] * 1e-3) / 1e6, 3) if tm["iter_loop_ms"] > 0 else None,
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
             # every kernel of a launch site (the PMC tooling averages the last `n` dispatches of each)
-            "launches_per_step": dict([(kernel_name(k, S), tm["stage_launches"][k] // args.steps) for k in stage_ms if k != "strong_prep"] +
-                                      [(extra, tm["stage_launches"][k] // args.steps) for k in stage_ms for extra in extra_kernels(k, S)] +
+            "launches_per_step": dict([(kernel_name(k, S), primary_launches(k) * tm["stage_launches"][k] // args.steps) for k in stage_ms if k != "strong_prep"] +
+                                      [(extra, mult * tm["stage_launches"][k] // args.steps) for k in stage_ms for extra, mult in extra_kernels(k, S)] +
                                       [(extra, tm["stage_launches"][k] // args.steps) for k, extra in
                                        (("gen_edge_inform", "dvp_gen_candidates"), ("strong_prep", "dvp_strong_search")) if k in stage_ms]),
             "ncc_evals_per_step": {k: int(v) for k, v in evals["ncc_evals"].items() if v > 0},

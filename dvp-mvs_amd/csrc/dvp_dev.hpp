@@ -107,6 +107,10 @@ struct Dev {
 	// [slot][view][row * half_w + x / 2] (a red/black launch touches every second pixel of a row), or null
 	float* slot_costs;         // [17][S][half_w * H]
 	float* strong_rec;         // [SR_FIELDS][half_w * H]: hand-over from dvp_strong_decide to dvp_strong_refine
+	// DepthToWeak + LocalRefine as view-compacted passes (dvp_strong.hpp: sweep_*), or null (the fused per-pixel kernel)
+	f4* sweep_rec;             // [2][L]: (camera-frame normal, depth) and (mean baseline, disparity, weight sum, flags) per pixel
+	float* sweep_cost;         // [S][kSweepFields][L]: per (view, sweep slot, pixel) costs written by dvp_sweep_eval
+	float* sweep_pc;           // [61][L]: the folded cost line of the central window, handed from the first decision pass to the second
 	int half_w;
 	uint32_t* edge_bits;       // the edge map as 32x32-pixel bit tiles (128 B each), see edge_bit()
 	int edge_tiles_x;

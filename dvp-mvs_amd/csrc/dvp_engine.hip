@@ -169,6 +169,72 @@ DVP_KERNEL(dvp_filter_strong, DVP_ST_FILTER_STRONG, 1)
 DVP_KERNEL(dvp_depth_to_weak, DVP_ST_DEPTH_TO_WEAK, DVP_LB_HEAVY)
 DVP_KERNEL(dvp_local_refine, DVP_ST_LOCAL_REFINE, DVP_LB_HEAVY)
 DVP_KERNEL(dvp_depth_to_weak_refine, kStageSweeps, DVP_LB_HEAVY)   // the two sweeps in one launch (dvp_run_patchmatch)
+// ... and the same launch site as view-compacted passes (dvp_strong.hpp: sweep_*)
+template <int WHAT>
+__device__ __forceinline__ void sweep_light_body(const Dev& d, const LaunchArgs& a) {
+	int px, py;
+	if (!block_to_pixel(blockIdx.x, threadIdx.x & 63, threadIdx.x >> 6, a.tiles_x, a.tiles, a.rows, 0, 0, d.width, d.height, &px, &py)) return;
+	if (WHAT == 0) sweep_prepare_px(d, px, py);
+	else if (WHAT == 1) sweep_decide1_px(d, px, py);
+	else sweep_decide2_px(d, px, py);
+}
+extern "C" __global__ void __launch_bounds__(256) dvp_sweep_prepare(const Dev d, const LaunchArgs a) { sweep_light_body<0>(d, a); }
+extern "C" __global__ void __launch_bounds__(256) dvp_sweep_decide1(const Dev d, const LaunchArgs a) { sweep_light_body<1>(d, a); }
+extern "C" __global__ void __launch_bounds__(256) dvp_sweep_decide2(const Dev d, const LaunchArgs a) { sweep_light_body<2>(d, a); }
+// Evaluation pass: workgroup = one wave = one 64 x 4 tile of the launch map, grid.y = source view (dispatched view after view:
+// the workgroups in flight gather from ONE image).  The tile's pixels that take part — they selected the view with a weight
+// > 0 — are compacted into a list in LDS (ballot ranks, row after row) and taken 64 per round, so that every lane of a round
+// evaluates (71 % of the pixels select a given view at cfg3: 2.8 rounds of 64 instead of 4 rows with 29 % of the lanes idle).
+// a.iter = stage (0: central window + LocalRefine's extra slot, 1: the rest of the line for pixels with a central peak).
+#ifndef DVP_SWEEP_ROWS
+#define DVP_SWEEP_ROWS 14
+#endif
+constexpr int kSweepRows = DVP_SWEEP_ROWS;   // rows of a dvp_sweep_eval tile (64 x kSweepRows pixels; 14: patch table 18 KB + list 1.75 KB + two cameras = 20 KB, 8 workgroups per CU)
+template <int SMP>
+__device__ __forceinline__ void sweep_eval_body(const Dev& d, const LaunchArgs& a) {
+	const int lane = threadIdx.x;
+	const int v = blockIdx.y;
+	__shared__ f2 lds_tab[kTaps * kTaps * 64];
+	__shared__ uint16_t list[64 * kSweepRows];   // tile-local pixel index (row * 64 + x): 18 KB + 2 KB = 8 workgroups per CU
+	__shared__ DvpCamera cams[2];                // reference camera, camera of the launch's view
+	const PatchTab tab{&lds_tab[lane], 64};
+	static_assert(sizeof(DvpCamera) == 112, "28 dwords");
+	if (lane < 56) {
+		const int which = lane >= 28 ? 1 : 0;
+		reinterpret_cast<uint32_t*>(&cams[which])[lane - 28 * which] = reinterpret_cast<const uint32_t*>(d.cameras + (which ? v + 1 : 0))[lane - 28 * which];
+	}
+	// tile of this workgroup: the strip map of block_to_pixel (XCD b % 8 owns a column of a strip of 8 tile columns) over
+	// tiles of kSweepRows rows; a.tiles_x / a.tiles = that grid
+	const int tiles_y = a.tiles / a.tiles_x;
+	int tx, ty;
+	{
+		const int per_strip = 8 * tiles_y;
+		const int st = (int)blockIdx.x / per_strip, rem = (int)blockIdx.x - st * per_strip;
+		const int w_last = a.tiles_x - st * 8;
+		if (w_last >= 8) { ty = rem >> 3; tx = st * 8 + (rem & 7); }
+		else { ty = rem / w_last; tx = st * 8 + (rem - ty * w_last); }
+	}
+	const int x = tx * 64 + lane;
+	int n = 0;
+	for (int r = 0; r < kSweepRows; ++r) {
+		const int y = ty * kSweepRows + r;
+		const bool go = x < d.width && y < d.height && sweep_go(d, x + y * d.width, v, a.iter);
+		const unsigned long long m = __ballot(go);
+		if (go) list[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(r * 64 + lane);
+		n += __popcll(m);
+	}
+	__syncthreads();
+	unsigned long long cnt = 0;
+	for (int i0 = 0; i0 < n; i0 += 64) {
+		if (i0 + lane < n) {
+			const int e = list[i0 + lane];
+			sweep_eval_px<SMP>(d, tx * 64 + (e & 63), ty * kSweepRows + (e >> 6), v, a.iter, tab, d.eval_counter ? &cnt : nullptr, cams);
+		}
+	}
+	if (d.eval_counter && cnt) atomicAdd(d.eval_counter, cnt);
+}
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_HEAVY) dvp_sweep_eval(const Dev d, const LaunchArgs a) { sweep_eval_body<0>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_HEAVY) dvp_sweep_eval_exact(const Dev d, const LaunchArgs a) { sweep_eval_body<1>(d, a); }
 
 // the weak-path launch sites: one lane per entry of the WEAK-pixel list
 DVP_KERNEL_LIST(dvp_find_nearest_strong_list, DVP_ST_FIND_NEAREST_STRONG, 1)
@@ -639,6 +705,8 @@ struct dvp_ctx {
 	float* slot_costs = nullptr; // [17][S][half_w * H]: split strong update (allocated at its first launch)
 	float* strong_rec = nullptr; // [SR_FIELDS][half_w * H]
 	bool strong_split = true;    // DVP_STRONG_SPLIT=0 in the environment: the monolithic kernel (A/B measurements)
+	f4* sweep_rec = nullptr; float* sweep_cost = nullptr; float* sweep_pc = nullptr;   // DepthToWeak + LocalRefine as view-compacted passes (allocated at the first fused launch)
+	bool sweep_split = true;     // DVP_SWEEP_SPLIT=0, or the buffers did not fit: the fused per-pixel kernel
 	bool gn_wave = false;        // DVP_GN_WAVE=1: GenNeighbours' search as one wave per WEAK pixel (dvp_gen_neighbours_search; measured slower)
 	float* costs = nullptr; float* costs_snap = nullptr; float* complex_ = nullptr;
 	uint32_t* selected_views = nullptr;
@@ -708,7 +776,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.plane_stride = (size_t)c->pitch * (c->H + 2 * kImgPad);
 	d.images = c->images; d.images8 = c->images8_ok ? c->images8 : nullptr; d.img8_tiles_x = img8_tiles_x(c->W); d.img8_plane_bytes = (size_t)img8_tiles_x(c->W) * img8_tiles_y(c->H) * 128; d.depths = c->depths; d.cameras = c->cameras; d.views = c->views; d.sector_taps = c->sector_taps; d.sector_start = c->sector_start;
 	d.search_pos = c->search_pos;
-	d.slot_costs = c->slot_costs; d.strong_rec = c->strong_rec; d.half_w = (c->W + 1) / 2;
+	d.sweep_rec = c->sweep_rec; d.sweep_cost = c->sweep_cost; d.sweep_pc = c->sweep_pc; d.slot_costs = c->slot_costs; d.strong_rec = c->strong_rec; d.half_w = (c->W + 1) / 2;
 	d.planes = c->planes; d.planes_snap = c->planes_snap; d.costs = c->costs; d.costs_snap = c->costs_snap;
 	d.selected_views = c->selected_views; d.view_weight = c->view_weight; d.weak_info = c->weak_info;
 	d.weak_reliable = c->weak_reliable; d.weak_nearest_strong = c->weak_nearest_strong;
@@ -744,6 +812,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	c->device = device; c->W = width; c->H = height; c->NI = num_images;
 	c->no_images8 = getenv("DVP_NO_IMAGES8") != nullptr;
 	if (const char* e = getenv("DVP_STRONG_SPLIT")) c->strong_split = atoi(e) != 0;
+	if (const char* e = getenv("DVP_SWEEP_SPLIT")) c->sweep_split = atoi(e) != 0;
 	if (const char* e = getenv("DVP_WEAK_ANCHOR_TAB")) c->anchor_tab_off = atoi(e) == 0;   // A/B measurements and the tests of the per-item form
 	if (const char* e = getenv("DVP_GN_WAVE")) c->gn_wave = atoi(e) != 0;
 	c->pitch = (width + 2 * kImgPad + 63) / 64 * 64;
@@ -1253,7 +1322,40 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 	case DVP_ST_GET_DEPTH_NORMAL: hipLaunchKernelGGL(c->d.sampler ? dvp_get_depth_normal_exact : dvp_get_depth_normal, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_FILTER_STRONG: hipLaunchKernelGGL(c->d.sampler ? dvp_filter_strong_exact : dvp_filter_strong, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_DEPTH_TO_WEAK:
-		if (fused) hipLaunchKernelGGL(c->d.sampler ? dvp_depth_to_weak_refine_exact : dvp_depth_to_weak_refine, grid, block, 0, c->stream, c->d, a);
+		if (fused && c->sweep_split && !c->sweep_cost) {
+			// 73 floats per (pixel, view) + 61 + 8 per pixel (67 GB at 6208x4128, S = 9): a context that cannot have them keeps the fused kernel
+			const size_t L = c->L;
+			void *r = nullptr, *sc = nullptr, *pc = nullptr;
+			if (getenv("DVP_TEST_SWEEP_ALLOC_FAIL") || hipMalloc(&r, 2 * L * sizeof(f4)) != hipSuccess || hipMalloc(&pc, 61 * L * sizeof(float)) != hipSuccess ||
+			    hipMalloc(&sc, (size_t)(c->NI - 1) * kSweepFields * L * sizeof(float)) != hipSuccess) {
+				(void)hipGetLastError();
+				if (r) (void)hipFree(r);
+				if (pc) (void)hipFree(pc);
+				c->sweep_split = false;
+				fprintf(stderr, "dvp: no room for the view-compacted DepthToWeak's cost buffer (%.1f GB); using the fused kernel\n", (double)(c->NI - 1) * kSweepFields * L * 4 / 1e9);
+			} else {
+				c->allocs.push_back(r); c->allocs.push_back(sc); c->allocs.push_back(pc);
+				c->sweep_rec = (f4*)r; c->sweep_cost = (float*)sc; c->sweep_pc = (float*)pc;
+				sync_dev_struct(c);
+			}
+		}
+		if (fused && c->sweep_split) {
+			const bool ex = c->d.sampler != 0;
+			LaunchArgs s0 = a, s1 = a, sb = a;
+			s0.iter = 0; s1.iter = 1; sb.iter = kSweepBorderOnly;
+			const int etx = (c->W + 63) / 64, ety = (c->H + kSweepRows - 1) / kSweepRows;
+			s0.tiles_x = s1.tiles_x = etx; s0.tiles = s1.tiles = etx * ety;
+			const dim3 egrid((unsigned)(etx * ety), (unsigned)(c->NI - 1));
+			hipLaunchKernelGGL(dvp_sweep_prepare, grid, block, 0, c->stream, c->d, a);
+			hipLaunchKernelGGL(ex ? dvp_sweep_eval_exact : dvp_sweep_eval, egrid, dim3(64), 0, c->stream, c->d, s0);
+			hipLaunchKernelGGL(dvp_sweep_decide1, grid, block, 0, c->stream, c->d, a);
+			if (sweep_window(c->d.params) < 30) {
+				hipLaunchKernelGGL(ex ? dvp_sweep_eval_exact : dvp_sweep_eval, egrid, dim3(64), 0, c->stream, c->d, s1);
+			}
+			hipLaunchKernelGGL(dvp_sweep_decide2, grid, block, 0, c->stream, c->d, a);
+			hipLaunchKernelGGL(ex ? dvp_depth_to_weak_refine_exact : dvp_depth_to_weak_refine, grid, block, 0, c->stream, c->d, sb);
+		}
+		else if (fused) hipLaunchKernelGGL(c->d.sampler ? dvp_depth_to_weak_refine_exact : dvp_depth_to_weak_refine, grid, block, 0, c->stream, c->d, a);
 		else hipLaunchKernelGGL(c->d.sampler ? dvp_depth_to_weak_exact : dvp_depth_to_weak, grid, block, 0, c->stream, c->d, a);
 		break;
 	case DVP_ST_LOCAL_REFINE: hipLaunchKernelGGL(c->d.sampler ? dvp_local_refine_exact : dvp_local_refine, grid, block, 0, c->stream, c->d, a); break;

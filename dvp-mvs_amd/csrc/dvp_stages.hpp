@@ -71,6 +71,7 @@ constexpr int kNarrowViews = 8;   // view capacity of the narrow strong-update i
 // internal launch site: DepthToWeak with LocalRefine done by the same thread (dvp_run_patchmatch issues the two
 // back to back; depth_to_weak_px<SMP, true>).  dvp_run_stage keeps the two separate launches.
 constexpr int kStageSweeps = 100;
+constexpr int kSweepBorderOnly = -1;
 // internal launch sites of the split strong update (dvp_strong.hpp: strong_eval_px / strong_decide_px / strong_refine_px)
 constexpr int kStageStrongEval = 101, kStageStrongRefine = 102;
 template <int STAGE, int SMP, int MV = 32>
@@ -123,7 +124,12 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 	else if (STAGE == DVP_ST_GET_DEPTH_NORMAL) get_depth_normal_px(d, px, py);
 	else if (STAGE == DVP_ST_FILTER_STRONG) { if (d.weak_info[center] != DVP_WEAK) filter_strong_px(d, px, py); }
 	else if (STAGE == DVP_ST_DEPTH_TO_WEAK) depth_to_weak_px<SMP, false>(d, px, py, tab, nevals);
-	else if (STAGE == kStageSweeps) depth_to_weak_px<SMP, true>(d, px, py, tab, nevals);
+	else if (STAGE == kStageSweeps) {
+		// iter == kSweepBorderOnly: the border launch of the view-compacted form (sweep_* in dvp_strong.hpp), which leaves the
+		// 6-pixel frame — UNKNOWN for DepthToWeak, a full LocalRefine — to this kernel
+		if (iter == kSweepBorderOnly && !sweep_is_border(d, px, py)) return;
+		depth_to_weak_px<SMP, true>(d, px, py, tab, nevals);
+	}
 	else if (STAGE == DVP_ST_LOCAL_REFINE) local_refine_px<SMP>(d, px, py, tab, nevals);
 }
 // launch sites whose kernels need the per-lane patch table (LDS on the GPU)

@@ -1037,5 +1037,270 @@ DVP_HD void local_refine_px(const Dev& d, int px, int py, PatchTab tab, unsigned
 	if (cost_now - min_cost > 0.1) d.planes[center].w = best_depth;
 }
 
+// ---- DepthToWeak + LocalRefine as view-compacted evaluation passes --------------------------------------------------------
+// depth_to_weak_px<SMP, true> above is the definition: one lane per pixel walks 61 (+1) planes x its selected views.  A wave
+// of 64 pixels executes a view as soon as ONE lane selected it (6.4 views per pixel, 8.0 per wave at cfg3), every plane makes
+// the workgroup cycle through all source images (125 B of HBM traffic per evaluation against 10.8 in dvp_strong_eval), and the
+// cost line, the weights and the peak logic sit in the evaluator's register budget.  Same evaluations, same bits, as passes:
+//   sweep_prepare_px   per pixel: validity, (camera-frame normal, depth), mean baseline, disparity, weight sum -> sweep_rec
+//   sweep_eval_px      per (pixel, source view): the planes of one stage against ONE view — launched view by view over the
+//                      pixels that selected the view with a weight > 0 (compacted tile by tile: dvp_sweep_eval), nothing live
+//                      but the evaluator -> sweep_cost.  Stage 0: the central window (-cw..cw) and LocalRefine's extra slot
+//                      (the current depth); stage 1: the rest of the line, only for pixels whose window holds a cost peak
+//                      (the others are WEAK whatever the rest says: exact, see depth_to_weak_px)
+//   sweep_decide1_px   per pixel: folds the window in the reference's view order, decides `central peak`, does LocalRefine
+//                      (its slots -5..5 and the current depth are all stage 0)
+//   sweep_decide2_px   per pixel with a central peak: folds the rest of the line, peak statistics -> weak_info
+// Border pixels (DepthToWeak marks them UNKNOWN, LocalRefine has no border rule) go through the fused kernel.
+constexpr int kSweepExtra = 72;     // sweep_cost field of the current depth: ncc + factor * geom (APD.cu:4085-4089)
+constexpr int kSweepFields = 73;    // [0, 61): slot pd + 30 — ncc for |pd| <= 5, ncc + factor * geom otherwise; [61, 72): geom of slot |pd| <= 5
+enum { SWF_VALID = 1, SWF_REFINE = 2, SWF_PEAK = 4 };
+DVP_HD int sweep_window(const DvpParams& P) { int cw = P.weak_peak_radius + 1; if (cw < 5) cw = 5; if (cw > 30) cw = 30; return cw; }
+DVP_HD size_t sweep_cost_index(const Dev& d, int v, int f, int center) {
+	const size_t L = (size_t)d.width * (size_t)d.height;
+	return ((size_t)v * kSweepFields + (size_t)f) * L + (size_t)center;
+}
+DVP_HD bool sweep_is_border(const Dev& d, int px, int py) { return px < 6 || py < 6 || px >= d.width - 6 || py >= d.height - 6; }
+
+DVP_HD void sweep_prepare_px(const Dev& d, int px, int py) {
+	const int W = d.width;
+	const int center = px + py * W;
+	const size_t L = (size_t)W * (size_t)d.height;
+	const DvpParams& P = d.params;
+	const DvpCamera rc = load_camera(d, 0);
+	const int S = P.num_images - 1;
+	if (P.use_radius && d.radius[center] == 0) d.radius[center] = P.strong_radius;
+	f4 info = mk4(0.0f, 0.0f, 0.0f, 0.0f);   // .w: flags (as an integer value)
+	d.sweep_rec[L + center] = info;
+	if (sweep_is_border(d, px, py)) { d.weak_info[center] = DVP_UNKNOWN; return; }   // (+ LocalRefine: the fused kernel's border launch)
+	const f4 origin = normal_world_to_cam(rc, d.planes[center]);
+	if (origin.w == 0) { d.weak_info[center] = DVP_UNKNOWN; return; }
+	const uint32_t sel = d.selected_views[center];
+	const uint8_t* vw = d.view_weight + (size_t)center * 32;
+	float base_line = 0, weight_normal = 0.0f;
+	int valid = 0;
+	for (int v = 0; v < S; ++v) {
+		if (!is_set(sel, v)) continue;
+		weight_normal += vw[v];
+		const float c0 = rc.c[0] - d.cameras[v + 1].c[0];
+		const float c1 = rc.c[1] - d.cameras[v + 1].c[1];
+		const float c2 = rc.c[2] - d.cameras[v + 1].c[2];
+		base_line += sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+		valid++;
+	}
+	if (valid == 0) { d.weak_info[center] = DVP_UNKNOWN; return; }
+	base_line /= valid;
+	const float disp = rc.K[0] * base_line / origin.w;
+	d.sweep_rec[center] = origin;
+	d.sweep_rec[L + center] = mk4(base_line, disp, weight_normal, (float)(SWF_VALID | (weight_normal != 0 ? SWF_REFINE : 0)));
+}
+
+// does (pixel, view v (0-based)) take part in stage `stage`?
+DVP_HD bool sweep_go(const Dev& d, int center, int v, int stage) {
+	const size_t L = (size_t)d.width * (size_t)d.height;
+	const int flags = (int)d.sweep_rec[L + center].w;
+	if (!(flags & (stage == 0 ? SWF_VALID : SWF_PEAK))) return false;
+	return is_set(d.selected_views[center], v) && d.view_weight[(size_t)center * 32 + v] != 0;
+}
+
+// `cams`: the reference camera and the camera of view v + 1 ([0], [1]) where the caller keeps them (LDS), or null
+template <int SMP>
+DVP_HD void sweep_eval_px(const Dev& d, int px, int py, int v, int stage, PatchTab tab, unsigned long long* nevals, const DvpCamera* cams = nullptr) {
+	const int W = d.width;
+	const int center = px + py * W;
+	const size_t L = (size_t)W * (size_t)d.height;
+	const DvpParams& P = d.params;
+	const DvpCamera rc_own = load_camera(d, 0);
+	const DvpCamera& rc = cams ? cams[0] : rc_own;
+	const f4 origin = d.sweep_rec[center];
+	const f4 info = d.sweep_rec[L + center];
+	const float base_line = info.x, disp = info.y;
+	const bool refine = ((int)info.w & SWF_REFINE) != 0;
+	PatchCtx c;
+	{
+		int radius, inc;
+		patch_geometry(d, center, &radius, &inc);
+		build_patch_ctx(d, px, py, radius, inc, 0, tab, &c);
+	}
+	const int cw = sweep_window(P);
+	float* out = d.sweep_cost + sweep_cost_index(d, v, 0, center);
+	const int k0 = stage == 0 ? 0 : 2 * cw + 1, k1 = stage == 0 ? 2 * cw + 1 + (refine ? 1 : 0) : 61;
+	for (int k = k0; k < k1; ++k) {
+		const bool extra = stage == 0 && k == 2 * cw + 1;   // LocalRefine's current-depth slot
+		const int pd = k <= 2 * cw ? k - cw : (k - (2 * cw + 1) < 30 - cw ? k - (2 * cw + 1) - 30 : k - 30);
+		float p_depth = origin.w;
+		if (!extra) {
+			p_depth = rc.K[0] * base_line / (disp + pd);
+			if (p_depth < P.depth_min || p_depth > P.depth_max) continue;
+		}
+		f4 pl = origin;
+		pl.w = distance_to_origin(rc, px, py, p_depth, pl);
+		const float ncc = ncc_old<SMP>(d, c, px, py, v + 1, pl);
+		if (nevals) *nevals += 1;
+#if defined(DVP_ABL_SWEEP_NO_GEOM)   // timing ablation (wrong results)
+		const float gc = 0.0f;
+#else
+		const float gc = !P.geom_consistency ? 0.0f : (cams ? geom_cost_cams(d, cams[0], cams[1], v + 1, px, py, pl) : geom_cost(d, px, py, v + 1, pl));
+#endif
+		if (extra) {
+			float t = ncc;
+			if (P.geom_consistency) t += P.geom_factor * gc;
+			out[(size_t)kSweepExtra * L] = t;
+		} else if (pd >= -5 && pd <= 5) {
+			out[(size_t)(pd + 30) * L] = ncc;
+			if (P.geom_consistency) out[(size_t)(61 + pd + 5) * L] = gc;
+		} else {
+			float cst = ncc;
+			if (P.geom_consistency) cst += P.geom_factor * gc;
+			out[(size_t)(pd + 30) * L] = cst;
+		}
+	}
+}
+
+// fold of sweep slot pd over the views in the reference's order (APD.cu:3965-4005, 4110-4130): *pc = the DepthToWeak cost
+// (not yet divided), *lr = LocalRefine's total of the same slot
+DVP_HD void sweep_fold(const Dev& d, int center, int pd, uint32_t sel, const uint8_t* vw, bool both, float* pc_out, float* lr_out) {
+	const DvpParams& P = d.params;
+	const int S = P.num_images - 1;
+	const size_t L = (size_t)d.width * (size_t)d.height;
+	float pc = 0.0f, lr = 0.0f;
+	for (int v = 0; v < S; ++v) {
+		if (!is_set(sel, v)) continue;
+		if (vw[v] == 0) continue;
+		const float* in = d.sweep_cost + sweep_cost_index(d, v, 0, center);
+		float ncc = 0.0f, gc = 0.0f, cst;
+		if (pd >= -5 && pd <= 5) {
+			ncc = in[(size_t)(pd + 30) * L];
+			cst = ncc;
+			if (P.geom_consistency) { gc = in[(size_t)(61 + pd + 5) * L]; cst += P.geom_factor * gc; }
+		} else {
+			cst = in[(size_t)(pd + 30) * L];
+		}
+		const float tc = 0.0f + cst;
+		pc += tc * vw[v];
+		if (both) {   // ncc*w and (factor*geom)*w added separately, APD.cu:4124-4126
+			lr += ncc * vw[v];
+			if (P.geom_consistency) lr += (P.geom_factor * gc * vw[v]);
+		}
+	}
+	*pc_out = pc;
+	*lr_out = lr;
+}
+
+DVP_HD void sweep_decide1_px(const Dev& d, int px, int py) {
+	const int W = d.width;
+	const int center = px + py * W;
+	const size_t L = (size_t)W * (size_t)d.height;
+	const DvpParams& P = d.params;
+	const DvpCamera rc = load_camera(d, 0);
+	const int S = P.num_images - 1;
+	const f4 info = d.sweep_rec[L + center];
+	const int flags = (int)info.w;
+	if (!(flags & SWF_VALID)) return;
+	const f4 origin = d.sweep_rec[center];
+	const float base_line = info.x, disp = info.y, weight_normal = info.z;
+	const bool refine = (flags & SWF_REFINE) != 0;
+	const uint32_t sel = d.selected_views[center];
+	const uint8_t* vw = d.view_weight + (size_t)center * 32;
+	const int cw = sweep_window(P);
+	float lr_costs[11];
+	unsigned lr_live = 0;
+	for (int pd = -cw; pd <= cw; ++pd) {
+		const float p_depth = rc.K[0] * base_line / (disp + pd);
+		float pcv = 2.0f;
+		if (!(p_depth < P.depth_min || p_depth > P.depth_max)) {
+			const bool both = refine && pd >= -5 && pd <= 5;
+			float pc, lr;
+			sweep_fold(d, center, pd, sel, vw, both, &pc, &lr);
+			pc /= weight_normal;
+			pcv = DVP_MIN(2.0f, pc);
+			if (both) { lr_costs[pd + 5] = lr / weight_normal; lr_live |= 1u << (pd + 5); }
+		}
+		d.sweep_pc[(size_t)(pd + 30) * L + center] = pcv;
+	}
+	bool central_peak = false;
+	for (int i = 30 - P.weak_peak_radius; i <= 30 + P.weak_peak_radius; ++i) {
+		if (i < 2 || i > 58) continue;
+		const float a = d.sweep_pc[(size_t)(i - 1) * L + center], b = d.sweep_pc[(size_t)i * L + center], e = d.sweep_pc[(size_t)(i + 1) * L + center];
+		if (a > b && e > b && !(b > 0.5f)) central_peak = true;
+	}
+	if (!central_peak) d.weak_info[center] = DVP_WEAK;
+	else d.sweep_rec[L + center].w = (float)(flags | SWF_PEAK);
+	if (!refine) return;
+	// ---- LocalRefine: the current depth (cost_now, APD.cu:4080-4090), then the minimum over the sweep slots ----
+	float cost_now = 0.0f;
+	for (int v = 0; v < S; ++v) {
+		if (!is_set(sel, v)) continue;
+		if (vw[v] == 0) continue;
+		cost_now += d.sweep_cost[sweep_cost_index(d, v, kSweepExtra, center)] * vw[v];
+	}
+	cost_now /= weight_normal;
+	float lr_min = 2.0f;
+	int best_pd = -6;
+	for (int pd = -5; pd <= 5; ++pd) {
+		if (!((lr_live >> (pd + 5)) & 1)) continue;
+		if (lr_costs[pd + 5] < lr_min) { lr_min = lr_costs[pd + 5]; best_pd = pd; }
+	}
+	const float best_depth = (best_pd == -6) ? origin.w : rc.K[0] * base_line / (disp + best_pd);
+	if (cost_now - lr_min > 0.1) d.planes[center].w = best_depth;
+}
+
+DVP_HD void sweep_decide2_px(const Dev& d, int px, int py) {
+	const int W = d.width;
+	const int center = px + py * W;
+	const size_t L = (size_t)W * (size_t)d.height;
+	const DvpParams& P = d.params;
+	const DvpCamera rc = load_camera(d, 0);
+	const f4 info = d.sweep_rec[L + center];
+	if (!((int)info.w & SWF_PEAK)) return;
+	const float base_line = info.x, disp = info.y, weight_normal = info.z;
+	const uint32_t sel = d.selected_views[center];
+	const uint8_t* vw = d.view_weight + (size_t)center * 32;
+	const int cw = sweep_window(P);
+	float p_costs[61];
+#pragma unroll
+	for (int i = 0; i < 61; ++i) {
+		const int pd = i - 30;
+		if (pd >= -cw && pd <= cw) { p_costs[i] = d.sweep_pc[(size_t)i * L + center]; continue; }
+		const float p_depth = rc.K[0] * base_line / (disp + pd);
+		if (p_depth < P.depth_min || p_depth > P.depth_max) { p_costs[i] = 2.0f; continue; }
+		float pc, lr;
+		sweep_fold(d, center, pd, sel, vw, false, &pc, &lr);
+		pc /= weight_normal;
+		p_costs[i] = DVP_MIN(2.0f, pc);
+	}
+	uint64_t is_peak = 0;
+	int peak_count = 0, min_peak = 0;
+	float min_cost = 2.0f;
+#pragma unroll
+	for (int i = 2; i < 59; ++i) {
+		if (p_costs[i - 1] > p_costs[i] && p_costs[i + 1] > p_costs[i]) {
+			is_peak |= (uint64_t)1 << i;
+			peak_count++;
+			if (p_costs[i] < min_cost) { min_peak = i; min_cost = p_costs[i]; }
+		}
+	}
+	// p_costs[min_peak] == min_cost whenever a peak below 2 exists; otherwise min_peak = 0 and the line's first entry is read
+	const float at_min = (min_peak == 0) ? p_costs[0] : min_cost;
+	const int dpk = min_peak - 30;
+	uint8_t state;
+	if ((dpk < 0 ? -dpk : dpk) > P.weak_peak_radius || at_min > 0.5f) state = DVP_WEAK;
+	else if (peak_count == 1) state = (at_min <= 0.15f) ? DVP_STRONG : DVP_WEAK;
+	else {
+		float var = 0.0f;
+#pragma unroll
+		for (int i = 2; i < 59; ++i) {
+			if (((is_peak >> i) & 1) && i != min_peak) {
+				const float dist = p_costs[i] - min_cost;
+				var += dist * dist;
+			}
+		}
+		var = sqrtf(var);
+		var /= (peak_count - 1);
+		state = (var > 0.2f) ? DVP_STRONG : DVP_WEAK;
+	}
+	d.weak_info[center] = state;
+}
+
 }  // namespace dvp
 #endif

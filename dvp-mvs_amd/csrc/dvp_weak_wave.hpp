@@ -82,26 +82,6 @@ struct WeakSharedT {
 };
 using WeakShared = WeakSharedT<0>;
 
-// ComputeGeomConsistencyCost (APD.cu:1218-1256) with both cameras given (lane-varying view index)
-DVP_HD float geom_cost_cams(const Dev& d, const DvpCamera& rc, const DvpCamera& sc, int v, int px, int py, const f4 plane) {
-	const float* dimg = d.depths + (size_t)v * d.plane_stride;
-	const float depth = depth_from_plane(rc, plane, px, py);
-	const f3 fwd = point_on_world((float)px, (float)py, depth, rc);
-	f2 sp;
-	float sd;
-	project_on_camera(fwd, sc, &sp, &sd);
-	const float cx = fminf(fmaxf(sp.x, -1.0f), (float)d.width);
-	const float cy = fminf(fmaxf(sp.y, -1.0f), (float)d.height);
-	const float src_depth = tex_texel(dimg, d.org, d.pitch, d.width, d.height, (int)cx, (int)cy);
-	if (src_depth == 0.0f) return 3.0f;
-	const f3 back = point_on_world(sp.x, sp.y, src_depth, sc);
-	f2 bp;
-	float rd;
-	project_on_camera(back, rc, &bp, &rd);
-	const float dc = px - bp.x, dr = py - bp.y;
-	return fminf(3.0f, sqrtf(dc * dc + dr * dr));
-}
-
 // build_patch_ctx (dvp_ncc.hpp) by the wave: lane t < 36 owns tap t; the reference moments are then
 // summed in the row-then-total order by every lane.
 template <int FMT, class SH>

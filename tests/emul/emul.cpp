@@ -25,6 +25,8 @@ struct Emu {
 	std::vector<f4> planes, planes_snap, fit_planes;
 	std::vector<int> search_pos;
 	std::vector<float> slot_costs, strong_rec;   // the split strong update's hand-over buffers (dvp_strong.hpp)
+	std::vector<f4> sweep_rec;                   // DepthToWeak + LocalRefine as view-compacted passes (dvp_strong.hpp: sweep_*)
+	std::vector<float> sweep_cost, sweep_pc;
 	std::vector<float> costs, costs_snap, complex_;
 	std::vector<uint32_t> selected_views;
 	std::vector<uint8_t> view_weight, weak_info, weak_reliable, edge;
@@ -60,6 +62,7 @@ void refresh(Emu& e) {
 	d.sector_start = e.sector_start.data();
 	d.search_pos = e.search_pos.data();
 	d.slot_costs = e.slot_costs.data(); d.strong_rec = e.strong_rec.data(); d.half_w = (e.W + 1) / 2;
+	d.sweep_rec = e.sweep_rec.data(); d.sweep_cost = e.sweep_cost.data(); d.sweep_pc = e.sweep_pc.data();
 	d.planes = e.planes.data(); d.planes_snap = e.planes_snap.data();
 	d.costs = e.costs.data(); d.costs_snap = e.costs_snap.data();
 	d.selected_views = e.selected_views.data();
@@ -436,7 +439,43 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 	case DVP_ST_FILTER_STRONG: launch<DVP_ST_FILTER_STRONG>(e, iter, colour); break;
 	case DVP_ST_DEPTH_TO_WEAK: launch<DVP_ST_DEPTH_TO_WEAK>(e, iter, colour); break;
 	case DVP_ST_LOCAL_REFINE: launch<DVP_ST_LOCAL_REFINE>(e, iter, colour); break;
-	case kStageSweeps: launch<kStageSweeps>(e, iter, colour); break;
+	case kStageSweeps: {
+		// the engine issues the fused launch site as view-compacted passes unless DVP_SWEEP_SPLIT=0; the emulation follows the switch
+		const char* sp = getenv("DVP_SWEEP_SPLIT");
+		if (sp && atoi(sp) == 0) { launch<kStageSweeps>(e, iter, colour); break; }
+		const size_t L = (size_t)e.W * e.H;
+		const int S = e.NI - 1;
+		e.sweep_rec.assign(2 * L, mk4(0, 0, 0, 0));
+		e.sweep_cost.assign((size_t)S * kSweepFields * L, -7.0f);   // (a value no decision may ever read)
+		e.sweep_pc.assign(61 * L, -7.0f);
+		refresh(e);
+		const long long n = (long long)L;
+		auto each_pixel = [&](auto&& f) {
+#pragma omp parallel for schedule(dynamic, 256)
+			for (long long c = 0; c < n; ++c) f((int)(c % e.W), (int)(c / e.W));
+		};
+		each_pixel([&](int px, int py) { sweep_prepare_px(e.d, px, py); });
+		for (int stage = 0; stage < 2; ++stage) {
+			if (stage == 1 && sweep_window(e.d.params) >= 30) break;
+			unsigned long long total = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : total)
+			for (long long c = 0; c < n; ++c)
+				for (int v = 0; v < S; ++v) {
+					if (!sweep_go(e.d, (int)c, v, stage)) continue;
+					unsigned long long k = 0;
+					f2 tab_mem[kTaps * kTaps];
+					const PatchTab tab{tab_mem, 1};
+					if (e.d.sampler) sweep_eval_px<1>(e.d, (int)(c % e.W), (int)(c / e.W), v, stage, tab, e.count ? &k : nullptr);
+					else sweep_eval_px<0>(e.d, (int)(c % e.W), (int)(c / e.W), v, stage, tab, e.count ? &k : nullptr);
+					total += k;
+				}
+			e.evals += total;
+			if (stage == 0) each_pixel([&](int px, int py) { sweep_decide1_px(e.d, px, py); });
+		}
+		each_pixel([&](int px, int py) { sweep_decide2_px(e.d, px, py); });
+		launch<kStageSweeps>(e, kSweepBorderOnly, colour);
+		break;
+	}
 	default: return -1;
 	}
 	return 0;

@@ -130,14 +130,21 @@ def test_two_pass_weak_path_with_geom(images, anchors, monkeypatch):
     assert (b.get("weak_reliable") == 1).sum() > 0
 
 
+@pytest.mark.parametrize("form,wpr", [("passes", None), ("fused", None), ("passes", 9), ("passes", 40)])
 @pytest.mark.parametrize("geom", [0, 1])
-def test_fused_sweeps_equal_the_two_launches(geom):
-    """dvp_run_patchmatch issues DepthToWeak + LocalRefine (APD.cu:4502-4505) as ONE launch; dvp_run_stage keeps
+def test_fused_sweeps_equal_the_two_launches(geom, form, wpr, monkeypatch):
+    """`form`: the fused launch site as view-compacted passes (prepare / evaluate per view over the pixels that selected it /
+    decide, dvp_strong.hpp: sweep_*) or as the one per-pixel kernel (DVP_SWEEP_SPLIT=0); `wpr`: weak_peak_radius — the
+    central window that is evaluated first grows with it (9 -> 21 slots, 40 -> the whole line, no second stage).
+    dvp_run_patchmatch issues DepthToWeak + LocalRefine (APD.cu:4502-4505) as ONE launch; dvp_run_stage keeps
     them separate.  Both must leave the same bits (and both equal the oracle's two functions, checked by the
     full-run tests): border pixels, out-of-range sweep slots and the geometric term included."""
     W, H, S = 150, 97, 4
+    monkeypatch.setenv("DVP_SWEEP_SPLIT", "1" if form == "passes" else "0")
     sc = synth.make_scene(W, H, S)
     p = make_params(S + 1, max_iterations=2, state=synth.FIRST_INIT, use_APD=0, geom_consistency=geom)
+    if wpr is not None:
+        p["weak_peak_radius"] = wpr
     p["depth_min"] = np.float32(3.2)   # part of the +-30 disparity sweep leaves the depth range
     st = first_pass_state(sc)
     dm = sc["depth_gt"] if geom else None
