@@ -1157,6 +1157,10 @@ DVP_HD void sweep_eval_px(const Dev& d, int px, int py, int v, int stage, PatchT
 	}
 }
 
+// The decision passes fold the per-view costs of a slot in the reference's view order (APD.cu:3965-4005, 4110-4130):
+// pc = sum over the selected views of (0 + cost) * weight.  View outside, slots inside (unrolled): the ~50 loads of one
+// view are in flight together, and every slot's sum still receives its terms in view order — a slot-outside loop is one
+// dependent round trip per (slot, view) (35 ms per cfg3 launch for 33 GB).
 // fold of sweep slot pd over the views in the reference's order (APD.cu:3965-4005, 4110-4130): *pc = the DepthToWeak cost
 // (not yet divided), *lr = LocalRefine's total of the same slot
 DVP_HD void sweep_fold(const Dev& d, int center, int pd, uint32_t sel, const uint8_t* vw, bool both, float* pc_out, float* lr_out) {
@@ -1245,29 +1249,53 @@ DVP_HD void sweep_decide1_px(const Dev& d, int px, int py) {
 	if (cost_now - lr_min > 0.1) d.planes[center].w = best_depth;
 }
 
+// (the window is 11 slots at the default radius: the slot-outside fold of sweep_fold measures 8 ms per cfg3 launch, the unrolled
+// view-outside form used below for the rest of the line 13 — 168 registers and a predicate per slot)
 DVP_HD void sweep_decide2_px(const Dev& d, int px, int py) {
 	const int W = d.width;
 	const int center = px + py * W;
 	const size_t L = (size_t)W * (size_t)d.height;
 	const DvpParams& P = d.params;
 	const DvpCamera rc = load_camera(d, 0);
+	const int S = P.num_images - 1;
 	const f4 info = d.sweep_rec[L + center];
 	if (!((int)info.w & SWF_PEAK)) return;
 	const float base_line = info.x, disp = info.y, weight_normal = info.z;
 	const uint32_t sel = d.selected_views[center];
 	const uint8_t* vw = d.view_weight + (size_t)center * 32;
 	const int cw = sweep_window(P);
+	uint64_t live = 0;   // slots outside the window that are inside the depth range
+	for (int pd = -30; pd <= 30; ++pd) {
+		if (pd >= -cw && pd <= cw) continue;
+		const float p_depth = rc.K[0] * base_line / (disp + pd);
+		if (!(p_depth < P.depth_min || p_depth > P.depth_max)) live |= (uint64_t)1 << (pd + 30);
+	}
 	float p_costs[61];
+#pragma unroll
+	for (int i = 0; i < 61; ++i) p_costs[i] = 0.0f;
+	for (int v = 0; v < S; ++v) {
+		if (!is_set(sel, v)) continue;
+		if (vw[v] == 0) continue;
+		const float* in = d.sweep_cost + sweep_cost_index(d, v, 0, center);
+		const float w = vw[v];
+#pragma unroll
+		for (int i = 0; i < 61; ++i) {
+			const int pd = i - 30;
+			if (pd >= -cw && pd <= cw) continue;          // (uniform; cw >= 5: the slots with separate ncc / geom fields are all inside)
+			const float cst = in[(size_t)i * L];
+			if ((live >> i) & 1) {
+				const float tc = 0.0f + cst;
+				p_costs[i] += tc * w;
+			}
+		}
+	}
 #pragma unroll
 	for (int i = 0; i < 61; ++i) {
 		const int pd = i - 30;
 		if (pd >= -cw && pd <= cw) { p_costs[i] = d.sweep_pc[(size_t)i * L + center]; continue; }
-		const float p_depth = rc.K[0] * base_line / (disp + pd);
-		if (p_depth < P.depth_min || p_depth > P.depth_max) { p_costs[i] = 2.0f; continue; }
-		float pc, lr;
-		sweep_fold(d, center, pd, sel, vw, false, &pc, &lr);
-		pc /= weight_normal;
-		p_costs[i] = DVP_MIN(2.0f, pc);
+		float q = p_costs[i] / weight_normal;
+		q = DVP_MIN(2.0f, q);
+		p_costs[i] = ((live >> i) & 1) ? q : 2.0f;
 	}
 	uint64_t is_peak = 0;
 	int peak_count = 0, min_peak = 0;
