@@ -43,7 +43,8 @@ VALU_MEASURED_PEAK_GINST = 977.5
 VALU_CEILING_BY_WAVES = {1: 501.6, 2: 761.6, 3: 852.3, 4: 896.1, 6: 943.3, 8: 977.5}
 GATHER_ROOF_GLINES = 51.4   # tools/gather_peak.hip on MI355X (profiles/r02_gather_peak.txt): 128-byte line requests per second of 16-byte gathers = 6.6 TB/s
 WAVES_PER_SIMD = {"strong_update": 2, "depth_to_weak": 2, "local_refine": 2, "random_init": 2, "weak_update": 4}
-PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_r03.json")
+PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_r04.json")
+EVALUATOR_PEAK_GEVALS = 32.7   # the 36-tap evaluator alone at 2 waves per SIMD (tools/pv_probe.py, profiles/r03_pv_probe.txt): what a launch site of NCC evaluations can reach at best
 
 
 def csrc_sha256():
@@ -198,7 +199,7 @@ def cpu_baseline(pkg, args, cfg, S, iters, device=0):
 
 
 def pmc_lookup(kernel, W, H, S):
-    """PMC counters of `kernel` at exactly this problem size (profiles/pmc_r03.json, written by
+    """PMC counters of `kernel` at exactly this problem size (profiles/pmc_r04.json, written by
     tools/pmc_table.py from separate rocprofv3 --pmc passes of this bench ON THE SAME KERNEL SOURCES) or None."""
     t, _ = pmc_table()
     if RIG != "rotated":     # the table is collected on the default workload
@@ -208,7 +209,7 @@ def pmc_lookup(kernel, W, H, S):
 
 def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
     """Roofline entry of one launch site; a reader can recompute every fraction from profiles/ alone:
-      frac (bound "valu")  = SQ_INSTS_VALU per launch (profiles/pmc_r03.json) / live launch time / 1228.8 G/s
+      frac (bound "valu")  = SQ_INSTS_VALU per launch (profiles/pmc_r04.json) / live launch time / 1228.8 G/s
                              (guide peak: 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 v_fma_f32);
       valu_frac_of_measured_issue_peak = same rate / 977.5 G/s (tools/valu_peak.hip, 8 waves per SIMD);
       valu_frac_of_occupancy_ceiling   = same rate / the measured ceiling at the kernel's own waves per SIMD;
@@ -238,11 +239,21 @@ def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
                     pmc[c] = pmc[c] + mult * p2[c]
             k = k + " + " + second
     if pmc:
+        # lane utilisation of the site = active-lane cycles / VALU-busy cycles x 64, summed over its kernels
+        parts = [(pmc_lookup(kernel_name(stage, S), W, H, S), primary_launches(stage))] + [(pmc_lookup(e, W, H, S), m) for e, m in extra_kernels(stage, S)]
+        tc = sum(m * q["SQ_THREAD_CYCLES_VALU"] for q, m in parts if q and q.get("lane_utilisation"))
+        act = sum(m * q["SQ_THREAD_CYCLES_VALU"] / q["lane_utilisation"] for q, m in parts if q and q.get("lane_utilisation"))
+        pmc["lane_utilisation"] = round(tc / act, 4) if act else None
         if pmc.get("TCC_HIT") is not None and pmc.get("TCC_MISS"):
             pmc["l2_hit_rate"] = round(pmc["TCC_HIT"] / (pmc["TCC_HIT"] + pmc["TCC_MISS"]), 4)
         if pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAIT_ANY") is not None:
             pmc["wait_any_frac"] = round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4)
+    gev = evals_per_launch / sec / 1e9 if (sec > 0 and evals_per_launch) else None
     r = {"kernel": k, "avg_launch_ms": round(avg_ms, 3), "evals_per_launch": int(evals_per_launch or 0),
+         # what the lanes did: evaluations per second against the evaluator running alone (36-tap evaluations; the weak
+         # update's are 135-tap evaluations of another evaluator, its figure is not comparable and left out)
+         "Gevals_per_s": round(gev, 2) if gev else None,
+         "useful_eval_rate_frac": round(gev / EVALUATOR_PEAK_GEVALS, 3) if (gev and stage != "weak_update") else None,
          "work_rate": {"what": "SURVEY 8(d) algorithmic bytes: NCC evaluations x 724 B / launch time — a work rate, NOT a bound (caches/LDS serve it)",
                        "bytes_per_eval": NCC_BYTES, "gbs": round(alg, 1) if alg else None,
                        "over_hbm_peak": round(alg / HBM_PEAK_GBS, 4) if alg else None}}
@@ -269,9 +280,11 @@ def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
                  valu_instr_per_launch=insts,
                  valu_instr_per_wave_eval=round(insts * 64.0 / evals_per_launch, 1) if (insts and evals_per_launch) else None,
                  pmc_source="profiles/%s[%s|%dx%d|S%d], %s" % (os.path.basename(PMC_TABLE), k, W, H, S, pmc_table()[1]))
-        for c in ("l2_hit_rate", "wait_any_frac"):
+        for c in ("l2_hit_rate", "wait_any_frac", "lane_utilisation"):
             if c in pmc:
                 r[c] = pmc[c]
+        if traffic and evals_per_launch:
+            r["hbm_bytes_per_eval"] = round(traffic / evals_per_launch, 1)
         if pmc.get("TCC_MISS"):   # L2 line misses per second against the measured gather roof
             r["l2_miss_glines_s"] = round(pmc["TCC_MISS"] / sec / 1e9, 2)
             r["gather_roof_frac"] = round(pmc["TCC_MISS"] / sec / 1e9 / GATHER_ROOF_GLINES, 4)

@@ -43,7 +43,9 @@ bool BuildPlanePrior(const Problem& problem, const Camera& scaled_ref_camera, in
 // image I/O without OpenCV: images/<id>.jpg through the built-in baseline decoder (host/jpeg.cpp), else
 // <id>.pgm|.ppm (binary P5/P6); returns an empty Mat if nothing readable is found.
 Mat DecodeJpeg(const path& file, int channels);     // 1: luma plane (libjpeg JCS_GRAYSCALE), 3: BGR
-Mat LabelSegment(const int scale, const Mat& src_image);   // EdgeSegment mode 1 (APD.cpp:348-401, 437-499), host/labels.cpp
+// intermediate maps of LabelSegment for the stage-by-stage comparison with an independent reading (tests/test_host_oracles.py)
+struct LabelStages { Mat quarter, texture, texture_lines, resized, cleaned; int weak_tex_num = 0; };
+Mat LabelSegment(const int scale, const Mat& src_image, LabelStages* stages = nullptr);   // EdgeSegment mode 1 (APD.cpp:348-401, 437-499), host/labels.cpp
 Mat ReadImageGray(const path& image_path_jpg);      // stands in for cv::imread(IMREAD_GRAYSCALE), APD.cpp:1057
 Mat ReadImageColor(const path& image_path_jpg);     // cv::imread(IMREAD_COLOR) (BGR), APD.cpp:1842
 Mat ResizeLinear(const Mat& src_f32, int new_cols, int new_rows);   // cv::resize(INTER_LINEAR), APD.cpp:1129

@@ -170,7 +170,7 @@ std::vector<Segment> HoughSegments(const Mat& image, int threshold, int min_leng
 }  // namespace
 
 // EdgeSegment(scale, src_image, mode = 1, use_canny = false): CV_32SC1 label map at src size / 2^scale
-Mat LabelSegment(const int scale, const Mat& src_image) {
+Mat LabelSegment(const int scale, const Mat& src_image, LabelStages* stages) {
 	const int robthr = 4;
 	const int weak_tex_num = (int)(1.0 * src_image.rows * src_image.cols / (1024 << scale << scale));
 	Mat quarter = resize_u8(src_image, src_image.cols / 2, src_image.rows / 2);
@@ -178,6 +178,7 @@ Mat LabelSegment(const int scale, const Mat& src_image) {
 	const int unit = (int)(std::min(quarter.cols, quarter.rows) / 30.0);   // Hough threshold, minimum length and maximum gap
 	Mat texture = RobertsCross(quarter);
 	binarise(texture, robthr);
+	if (stages) { stages->quarter = quarter.clone(); stages->texture = texture.clone(); stages->weak_tex_num = weak_tex_num; }
 	{
 		Mat region(texture.rows, texture.cols, CV_32S);
 		std::vector<int> region_size;
@@ -200,9 +201,11 @@ Mat LabelSegment(const int scale, const Mat& src_image) {
 			for (const Segment& s : HoughSegments(outline, unit, unit, unit)) draw_line(texture, s.x0, s.y0, s.x1, s.y1, 255);
 		}
 	}
+	if (stages) stages->texture_lines = texture.clone();
 	const float factor = 1.0f / (float)(1 << scale);
 	Mat map = resize_u8(texture, (int)std::round(src_image.cols * factor), (int)std::round(src_image.rows * factor));
 	binarise(map, robthr);
+	if (stages) stages->resized = map.clone();
 	const int rows = map.rows, cols = map.cols;
 	uint8_t* D = map.data;   // frame clean-up (APD.cpp:452-463)
 	for (int y = 0; y < rows; y++) {
@@ -213,6 +216,7 @@ Mat LabelSegment(const int scale, const Mat& src_image) {
 		if (D[1 * cols + x] == 0) D[0 * cols + x] = 0;
 		if (D[(rows - 2) * cols + x] == 0) D[(rows - 1) * cols + x] = 0;
 	}
+	if (stages) stages->cleaned = map.clone();
 	Mat label(rows, cols, CV_32S);
 	std::vector<int> label_size;
 	Connect(map, label, label_size);

@@ -108,6 +108,19 @@ static int dump_labels(const path& in, int scale, const path& out) {
 	return WriteBinMat(out, EdgeSegment(scale, img, 1)) ? 0 : 3;
 }
 
+// `test_host --label-stages image.pgm scale prefix`: LabelSegment with its intermediate maps as BinMat files
+// prefix_{quarter,texture,lines,resized,cleaned,labels}.dmb + prefix_n.txt (weak_tex_num)
+static int dump_label_stages(const path& in, int scale, const std::string& prefix) {
+	const Mat img = ReadImageGray(in);
+	if (img.empty()) return 2;
+	LabelStages st;
+	const Mat lab = LabelSegment(scale, img, &st);
+	bool ok = WriteBinMat(prefix + "_quarter.dmb", st.quarter) && WriteBinMat(prefix + "_texture.dmb", st.texture) && WriteBinMat(prefix + "_lines.dmb", st.texture_lines) &&
+	          WriteBinMat(prefix + "_resized.dmb", st.resized) && WriteBinMat(prefix + "_cleaned.dmb", st.cleaned) && WriteBinMat(prefix + "_labels.dmb", lab);
+	std::ofstream(prefix + "_n.txt") << st.weak_tex_num << "\n";
+	return ok ? 0 : 3;
+}
+
 // `test_host --edges image.pgm scale out.dmb`: EdgeSegment(scale, image, mode 0, Canny) -> BinMat (CV_8UC1)
 static int dump_edges(const path& in, int scale, const path& out) {
 	const Mat img = ReadImageGray(in);
@@ -137,6 +150,7 @@ int main(int argc, char** argv) {
 	if (argc > 6 && std::string(argv[1]) == "--prior") return dump_prior(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), argv[6]);
 	if (argc > 4 && std::string(argv[1]) == "--jpeg") return dump_jpeg(argv[2], argv[3], std::atoi(argv[4]));
 	if (argc > 4 && std::string(argv[1]) == "--labels") return dump_labels(argv[2], std::atoi(argv[3]), argv[4]);
+	if (argc > 4 && std::string(argv[1]) == "--label-stages") return dump_label_stages(argv[2], std::atoi(argv[3]), argv[4]);
 	path tmp = argc > 1 ? path(argv[1]) : std::filesystem::temp_directory_path();
 	// BinMat round trips (APD.cpp:548-573, 630-649): header = version 1, rows, cols, cv type
 	{

@@ -201,6 +201,89 @@ def test_canny_edge_map_vs_independent_canny(tmp_path):
         assert diff == 0, (k, diff, int(w2.sum()))
 
 
+def _read_binmat(fn):
+    raw = open(fn, "rb").read()
+    ver, rows, cols, typ = np.frombuffer(raw[:16], np.int32)
+    dt = {0: np.uint8, 4: np.int32, 5: np.float32}[int(typ)]
+    return np.frombuffer(raw[16:], dt).reshape(rows, cols)
+
+
+def test_label_stages_vs_independent_reading(tmp_path):
+    """The label half of the priors (host/labels.cpp = EdgeSegment mode 1, APD.cpp:348-401, 437-499), stage by stage against
+    an array-based numpy / scipy reading written from the source text.  Deterministic integer work, compared exactly:
+      * Roberts cross (APD.cpp:120-136: (uchar)sqrt(t1^2 + t2^2) on the interior, 50 / 50 on the frame) + threshold 4;
+      * the frame clean-up (:452-463, sequential: columns first, then rows);
+      * 4-connected regions of the zero pixels (Connect + Label_Update, :192-346): the PARTITION must be scipy.ndimage.label's,
+        label 0 = textured, a region of at most weak_tex_num = rows * cols / (1024 << 2 scale) pixels becomes -1, the others
+        keep distinct positive labels numbered in raster order of their first pixel's provisional label.
+    Third-party arithmetic in between — cv::resize (bilinear on 8-bit), cv::HoughLinesP, cv::line — stays property-tested
+    (test_boundary.py::test_label_segmentation): the Hough stage may only ADD white pixels, the resized map is fed to the
+    independent reading as it comes."""
+    from scipy import ndimage
+    rng = np.random.default_rng(11)
+    H, W = 360, 480
+    img = np.full((H, W), 90, np.uint8)
+    img[:, 250:] = 170
+    img[:, 238:262] = rng.integers(0, 255, (H, 24))
+    img[120:170, 60:120] = rng.integers(0, 255, (50, 60))
+    img[200:206, 300:420] = rng.integers(0, 255, (6, 120))          # a thin textured bar inside the right wall
+    img[128:140, 80:92] = 128                                         # a flat island inside the textured block: a region below weak_tex_num
+    img[148:160, 100:112] = 40
+    img += rng.integers(0, 2, (H, W)).astype(np.uint8)                # grain below the Roberts threshold
+    img[300:340, 20:200] = (np.arange(180)[None, :] * 1.4).astype(np.uint8) + 20   # a ramp: gradient 1.4 per pixel at full size
+    pgm = str(tmp_path / "i.pgm")
+    with open(pgm, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (W, H))
+        f.write(img.tobytes())
+    for scale in (0, 1):
+        pre = str(tmp_path / ("s%d" % scale))
+        r = _host_tool("--label-stages", pgm, scale, pre)
+        assert r.returncode == 0, r.stderr
+        quarter, texture, lines, resized, cleaned, labels = [_read_binmat("%s_%s.dmb" % (pre, n)) for n in ("quarter", "texture", "lines", "resized", "cleaned", "labels")]
+        weak_tex_num = int(open(pre + "_n.txt").read())
+        assert weak_tex_num == int(1.0 * H * W / (1024 << scale << scale))
+        assert quarter.shape == (H // 2 // 2, W // 2 // 2)
+        # --- Roberts cross + threshold on the quarter-size image
+        q = quarter.astype(np.int64)
+        t1 = np.full(q.shape, 50, np.int64)
+        t2 = np.full(q.shape, 50, np.int64)
+        t1[1:-1, 1:-1] = q[1:-1, 1:-1] - q[2:, 2:]
+        t2[1:-1, 1:-1] = q[2:, 1:-1] - q[1:-1, 2:]
+        rob = np.floor(np.sqrt((t1 * t1 + t2 * t2).astype(np.float64))).astype(np.int64)
+        rob = np.where(rob > 255, rob & 255, rob)                     # (uchar) of a value above 255 wraps (|t| <= 255: sqrt <= 360)
+        want_tex = np.where(rob > 4, 255, 0).astype(np.uint8)
+        assert np.array_equal(texture, want_tex), int((texture != want_tex).sum())
+        assert 0.02 < (want_tex > 0).mean() < 0.6
+        # --- the Hough stage only draws white lines
+        assert np.all(lines[texture > 0] == 255) and set(np.unique(lines)) <= {0, 255}
+        # --- frame clean-up of the resized, re-thresholded map
+        rows, cols = resized.shape
+        assert (rows, cols) == (int(round(H / (1 << scale))), int(round(W / (1 << scale)))) and set(np.unique(resized)) <= {0, 255}
+        c = resized.copy()
+        for y in range(rows):
+            if c[y, 1] == 0:
+                c[y, 0] = 0
+            if c[y, cols - 2] == 0:
+                c[y, cols - 1] = 0
+        for x in range(cols):
+            if c[1, x] == 0:
+                c[0, x] = 0
+            if c[rows - 2, x] == 0:
+                c[rows - 1, x] = 0
+        assert np.array_equal(c, cleaned)
+        # --- regions of zero pixels: partition, sizes, the small-region rule
+        lab, n = ndimage.label(cleaned == 0, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+        sizes = np.bincount(lab.ravel(), minlength=n + 1)
+        small = (lab > 0) & (sizes[lab] <= weak_tex_num)
+        assert np.array_equal(labels == 0, cleaned == 255)
+        assert np.array_equal(labels == -1, small)
+        big = (lab > 0) & ~small
+        assert big.any() and small.any()
+        pairs = np.unique(np.stack([lab[big], labels[big]], 1), axis=0)   # (scipy region, engine label): must be a bijection
+        assert len(pairs) == len(np.unique(pairs[:, 0])) == len(np.unique(pairs[:, 1])) and np.all(pairs[:, 1] > 0)
+        print("labels scale %d: %d regions, %d kept, %d pixels marked -1, weak_tex_num %d" % (scale, n, len(pairs), int(small.sum()), weak_tex_num))
+
+
 def test_prior_ratio_map_on_a_hand_built_point_file(tmp_path):
     """The Depth-Anything prior (APD.cpp:1210-1424, host/prior.cpp) on a hand-built sfm/ file of 5 points: the metric depth
     inside the triangulated hull must be (255 - raw) / (barycentric interpolation of the per-point ratio

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Fold the PMC passes of tools/pmc_collect.sh into profiles/pmc_r03.json.
-usage: pmc_table.py OUTDIR [TABLE=profiles/pmc_r03.json]
+"""Fold the PMC passes of tools/pmc_collect.sh into profiles/pmc_r04.json.
+usage: pmc_table.py OUTDIR [TABLE=profiles/pmc_r04.json]
 
 Per kernel only the launches of the bench's LAST step are averaged (the untimed FIRST_INIT pass and
 the counting warm-up step launch the same kernels earlier): the last `launches_per_step[kernel]`
@@ -11,7 +11,8 @@ Units and corrections (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE / WRITE_SIZE are 
 L2's fabric-side request counters (Infinity-Cache hits included).  On gfx950 FETCH_SIZE tallies the
 128-byte requests of 16 B/lane reads at 64 bytes: the fetch part is doubled; WRITE_SIZE is
 uncalibrated and reported raw.  SQ_INSTS_* count wave-level instructions; SQ_WAVE_CYCLES / SQ_WAIT_* /
-SQ_ACTIVE_INST_* count quad-cycles."""
+SQ_ACTIVE_INST_* count quad-cycles.  lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) of one pass: the share of the
+lanes that were switched on while the VALU worked (0.96 for dvp_strong_eval, 0.47 for dvp_strong_refine)."""
 import collections
 import csv
 import glob
@@ -42,12 +43,12 @@ def per_kernel_last(path, launches_per_step):
 
 def main():
     out = sys.argv[1]
-    table_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_r03.json")
+    table_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_r04.json")
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     sha = bench.csrc_sha256()
     ids = set()
-    for name in ("fetch", "write", "sq1", "sq2"):   # the library that produced the counters must be the tree's
+    for name in ("fetch", "write", "sq1", "sq2", "sq3"):   # the library that produced the counters must be the tree's
         js = os.path.join(out, name + ".json")
         if os.path.exists(js):
             ids.add(json.loads(open(js).read().strip().splitlines()[-1]).get("library_build_id"))
@@ -60,7 +61,7 @@ def main():
             table = old
     merged = collections.defaultdict(dict)
     cfg = None
-    for name in ("fetch", "write", "sq1", "sq2"):
+    for name in ("fetch", "write", "sq1", "sq2", "sq3"):
         js = os.path.join(out, name + ".json")
         cs = glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True)
         if not (os.path.exists(js) and cs):
@@ -69,6 +70,10 @@ def main():
         bench = json.loads(open(js).read().strip().splitlines()[-1])
         cfg = bench["config"]
         for k, v in per_kernel_last(cs[0], bench["launches_per_step"]).items():
+            if name == "sq3":   # its own pair of counters -> one ratio (SQ_ACTIVE_INST_VALU of pass sq1 stays the table's figure)
+                act = v.get("SQ_ACTIVE_INST_VALU", 0.0)
+                v = {"SQ_THREAD_CYCLES_VALU": v.get("SQ_THREAD_CYCLES_VALU", 0.0),
+                     "lane_utilisation": round(v.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * act), 4) if act else None}
             merged[k].update(v)
     if cfg is None:
         raise SystemExit("no PMC pass found under " + out)
