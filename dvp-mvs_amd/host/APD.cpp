@@ -204,6 +204,8 @@ std::map<int, ResidentDepth> g_resident_depths;
 }
 void APD::SetResidentDepth(int image_id, const float* device_ptr, int width, int height) { g_resident_depths[image_id] = ResidentDepth{ device_ptr, width, height }; }
 void APD::ClearResidentDepths() { g_resident_depths.clear(); }
+namespace { void (*g_resident_download)(float*, const float*, size_t) = nullptr; }
+void APD::SetResidentDownloader(void (*copy)(float*, const float*, size_t)) { g_resident_download = copy; }
 
 APD::~APD() {                        // APD.cpp:989-1043
 	delete[] plane_hypotheses_host;
@@ -291,6 +293,14 @@ void APD::InuputInitialization() {
 		} else {
 			for (int id : ids) {
 				Mat depth;
+				// A map of another size (views of unequal size).  With a depth exchange (--jacobi / several ranks) the resident
+				// copy IS the previous pass' map, on every rank alike: it is fetched and rescaled.  The owner's file would be the
+				// previous pass' or this pass' map depending on how far the owner has come — never read it then.
+				auto it = g_resident_depths.find(id);
+				if (it != g_resident_depths.end() && g_resident_download) {
+					depth = Mat(it->second.h, it->second.w, CV_32FC1);
+					g_resident_download(depth.ptr<float>(0), it->second.ptr, (size_t)it->second.w * it->second.h);
+				} else
 				LoadResult(problem.dense_folder / path("APD") / path(ToFormatIndex(id)) / path("depths.dmb"), depth);
 				if (depth.empty()) depth = Mat::zeros(height, width, CV_32FC1);
 				if (depth.cols != width || depth.rows != height) RescaleMatToTargetSize<float>(depth, depth, width, height);

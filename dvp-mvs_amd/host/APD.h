@@ -51,6 +51,7 @@ Mat ReadImageColor(const path& image_path_jpg);     // cv::imread(IMREAD_COLOR) 
 Mat ResizeLinear(const Mat& src_f32, int new_cols, int new_rows);   // cv::resize(INTER_LINEAR), APD.cpp:1129
 // threads of the host-side pixel loops: min(32, hardware threads), DVP_HOST_THREADS overrides
 int HostThreads();
+void SetHostThreadShare(int world);   // caps HostThreads() at cores / world (one rank per GPU shares the host with its peers)
 // write-back cache of the per-view result files + background workers (host/store.cpp)
 void SetResultCache(bool enabled, size_t limit_bytes = 0);   // default: on, 32 GiB
 void PublishResult(const path& file, const Mat& m);          // keep in memory + write in the background (.part + rename); `m` must not be modified afterwards
@@ -108,6 +109,7 @@ public:
 	// there (dvp_upload_depths_device) instead of reading APD/<id>/depths.dmb (APD.cpp:1147-1166).
 	static void SetResidentDepth(int image_id, const float* device_ptr, int width, int height);
 	static void ClearResidentDepths();
+	static void SetResidentDownloader(void (*copy)(float* host, const float* device, size_t count));   // device -> host copy used when a resident map of another size has to be rescaled on the host
 	const DvpTimings& GetTimings() const { return timings; }
 
 private:

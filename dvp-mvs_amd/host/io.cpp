@@ -2,6 +2,7 @@
 // BinMat (APD.cpp:548-573, 630-649), ACMM dmb (APD.cpp:575-628), MVSNet camera text
 // (APD.cpp:651-692), binary PLY (APD.cpp:842-882), PNM images, bilinear resize, nearest rescale.
 #include "APD.h"
+#include <atomic>
 #include <cstring>
 #include <thread>
 #include <cstdio>
@@ -274,12 +275,21 @@ Mat ResizeLinear(const Mat& src, int new_cols, int new_rows) {
 	return dst;
 }
 
+// Host-thread budget of this process.  One rank per GPU means `world` processes share the node's cores: the driver caps
+// every rank at cores / world (SetHostThreadShare) so that eight ranks on a 256-core host run 8 x 32 threads, not 8 x 32
+// on top of each other's background workers.  DVP_HOST_THREADS overrides both.
+static std::atomic<int> g_thread_share{0};
+void SetHostThreadShare(int world) {
+	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+	g_thread_share = world > 1 ? (int)std::max(1u, hw / (unsigned)world) : 0;
+}
 int HostThreads() {
-	static const int n = [] {
-		if (const char* e = std::getenv("DVP_HOST_THREADS")) return std::max(1, std::atoi(e));
-		const unsigned hw = std::thread::hardware_concurrency();
-		return (int)std::min(32u, std::max(1u, hw));
-	}();
+	static const int env = [] { const char* e = std::getenv("DVP_HOST_THREADS"); return e ? std::max(1, std::atoi(e)) : 0; }();
+	if (env) return env;
+	const unsigned hw = std::thread::hardware_concurrency();
+	int n = (int)std::min(32u, std::max(1u, hw));
+	const int share = g_thread_share.load();
+	if (share > 0) n = std::min(n, share);
 	return n;
 }
 

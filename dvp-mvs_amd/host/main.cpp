@@ -21,6 +21,7 @@
 // number of ranks.  Result files are always written to a temporary name and renamed, so a reader never
 // sees a torn file.
 #include "APD.h"
+#include <thread>
 #include "comm.h"
 #include <cstdlib>
 #include <map>
@@ -353,6 +354,8 @@ int main(int argc, char** argv) {
 	}
 	const Options opt = ParseOptions(argc, argv);
 	std::filesystem::create_directories(opt.dense_folder / "APD");
+	SetHostThreadShare(opt.world);
+	if (opt.world > 1) std::cout << "rank " << opt.rank << " of " << opt.world << ": " << HostThreads() << " host threads (of " << std::thread::hardware_concurrency() << " cores)" << std::endl;
 	APD::SetDevice(opt.gpu);
 	APD::SetSeed(opt.seed);
 	APD::SetUseLabelFiles(opt.label_files);
@@ -388,7 +391,7 @@ int main(int argc, char** argv) {
 
 	std::unique_ptr<DepthExchange> exchange;
 	std::unique_ptr<InPlaceDepths> inplace;
-	if (opt.jacobi) exchange.reset(new DepthExchange(comm, problems));
+	if (opt.jacobi) { exchange.reset(new DepthExchange(comm, problems)); APD::SetResidentDownloader(&RankComm::DeviceToHost); }
 	else if (!opt.sync_io) inplace.reset(new InPlaceDepths());
 	int shared_scale = -1;
 	for (size_t it = 0; it < plan.size(); ++it) {

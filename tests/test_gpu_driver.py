@@ -209,6 +209,51 @@ def test_apd_two_ranks_equal_single_rank_jacobi(tmp_path):
         assert np.array_equal(outs["single"][v], outs["world2"][v]), v
 
 
+def test_apd_eight_ranks_host_transport(tmp_path):
+    """world = 8 — the rank count of an MI355X node — without the node: eight `apd` processes on the one GPU of the box over
+    the host transport, 17 views of unequal size (three image files are cropped: per-view dimensions in the depth exchange,
+    and views whose sources have another size rescale the exchanged previous-pass map — reading the owner's depths.dmb instead
+    gave the previous or the current pass' map depending on timing, which this test caught — ADVICE r03).  Every depth map bit-identical to the single-rank --jacobi run;
+    every rank reports its host-thread budget = cores / 8 (SetHostThreadShare), not 32 each.  The RCCL calls stay
+    "unmeasured on hardware"."""
+    import re
+    import time
+    W, H, NV = 96, 72, 17
+    outs, wall = {}, {}
+    for tag in ("single", "world8"):
+        d = str(tmp_path / tag)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), "4"], stdout=subprocess.DEVNULL)
+        sc = synth.make_scene(W, H, NV - 1)
+        for v, (w, h) in ((2, (80, 72)), (9, (96, 56)), (14, (88, 64))):
+            with open(os.path.join(d, "images", "%08d.pgm" % v), "wb") as f:
+                f.write(b"P5\n%d %d\n255\n" % (w, h))
+                f.write(sc["images"][v][:h, :w].astype(np.uint8).tobytes())
+        common = ["--iters", "1", "--passes", "2", "--min-scale", "1", "--seed", "9", "--no-fusion"]
+        t0 = time.time()
+        if tag == "single":
+            procs = [_apd(d, "--jacobi", *common)]
+        else:
+            procs = [_apd(d, "--rank", str(r), "--world", "8", "--job", "job8", "--transport", "host", "--collective-timeout", "300", *common) for r in range(7, -1, -1)]
+        texts = []
+        for p in procs:
+            so, se = p.communicate(timeout=1500)
+            assert p.returncode == 0, so[-1500:] + se[-1500:]
+            texts.append(so)
+        wall[tag] = time.time() - t0
+        if tag == "world8":
+            cores = os.cpu_count()
+            seen = sorted((int(m.group(1)), int(m.group(2))) for t in texts for m in re.finditer(r"rank (\d+) of 8: (\d+) host threads", t))
+            assert [r for r, _ in seen] == list(range(8)), seen
+            if "DVP_HOST_THREADS" not in os.environ:
+                assert all(n == max(1, min(32, cores // 8)) for _, n in seen), (seen, cores)
+        outs[tag] = [read_binmat(os.path.join(d, "APD", "%08d" % v, "depths.dmb")) for v in range(NV)]
+    print("apd 17 views, whole schedule (--passes 2): single rank %.1f s, 8 ranks on one GPU (host transport) %.1f s" % (wall["single"], wall["world8"]))
+    shapes = {o.shape for o in outs["single"]}
+    assert len(shapes) == 4, shapes
+    for v in range(NV):
+        assert outs["single"][v].shape == outs["world8"][v].shape and np.array_equal(outs["single"][v], outs["world8"][v]), v
+
+
 def test_apd_rank_failure_takes_the_job_down(tmp_path):
     """A rank that hits a fatal error (here: the image of one of ITS views is unreadable) must not leave its peer hanging
     in a collective: DvpFatal -> RankComm::Abort drops the .abort marker, the peer's wait sees it and exits non-zero too."""
