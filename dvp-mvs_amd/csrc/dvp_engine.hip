@@ -157,7 +157,10 @@ __device__ __forceinline__ void strong_decide_body(const Dev& d, const LaunchArg
 // the cost vectors of the 8 directions live in registers: one instantiation per view-count bracket
 // (4 waves per SIMD: the kernel waits for its cost loads 70 % of the time; 128 VGPRs cost the v10 instantiation 20 spilled registers and
 // win 1.7 ms of 10 per cfg3 launch; 5 waves the same, 6 less)
-#define DVP_DECIDE_KERNEL(MV) extern "C" __global__ void __launch_bounds__(256, 4) dvp_strong_decide_v##MV(const Dev d, const LaunchArgs a) { strong_decide_body<MV>(d, a); }
+#ifndef DVP_LB_DECIDE
+#define DVP_LB_DECIDE 4
+#endif
+#define DVP_DECIDE_KERNEL(MV) extern "C" __global__ void __launch_bounds__(256, DVP_LB_DECIDE) dvp_strong_decide_v##MV(const Dev d, const LaunchArgs a) { strong_decide_body<MV>(d, a); }
 DVP_DECIDE_KERNEL(4)
 DVP_DECIDE_KERNEL(6)
 DVP_DECIDE_KERNEL(8)
