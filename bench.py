@@ -88,8 +88,13 @@ def decide_kernel(S):
     return "dvp_strong_decide_v%d" % next(m for m in (4, 6, 8, 10, 12, 16) if S <= m)
 
 
+GEOM = True   # the timed pass has the geometric term on (set in main)
+
+
 def sweep_split():
-    return os.environ.get("DVP_SWEEP_SPLIT", "1") != "0"
+    """DepthToWeak + LocalRefine run as view-compacted passes where the geometric term is on (dvp_engine.hip: launch_stage)"""
+    e = os.environ.get("DVP_SWEEP_SPLIT", "1")
+    return e != "0" and (GEOM or e == "2")
 
 
 def extra_kernels(stage, S):
@@ -101,7 +106,7 @@ def extra_kernels(stage, S):
         return [(decide_kernel(S), 1), ("dvp_strong_refine", 1)]
     if stage == "depth_to_weak" and sweep_split():   # DepthToWeak + LocalRefine as view-compacted passes
         return [("dvp_sweep_prepare", 1), ("dvp_sweep_decide1", 1), ("dvp_sweep_decide2", 1), ("dvp_depth_to_weak_refine", 1)] + \
-               ([("dvp_sweep_geom", 2)] if os.environ.get("DVP_SWEEP_GEOM_KERNEL", "1") != "0" else [])
+               []
     return []
 
 
@@ -414,8 +419,9 @@ def main():
     del sids, flats, edge_t, label_t
 
     ctx = capi.Context(W, H, NI, device=local_rank)
-    global LOADED_BUILD_ID, RIG
+    global LOADED_BUILD_ID, RIG, GEOM
     RIG = args.rig
+    GEOM = bool(cfg["refine"])
     LOADED_BUILD_ID = ctx.L.dvp_build_id().decode()
     ctx.set_images_device([imgs[i].data_ptr() for i in order], W)
     global IMAGE_FORMAT

@@ -710,6 +710,7 @@ struct dvp_ctx {
 	bool strong_split = true;    // DVP_STRONG_SPLIT=0 in the environment: the monolithic kernel (A/B measurements)
 	f4* sweep_rec = nullptr; float* sweep_cost = nullptr; float* sweep_pc = nullptr;   // DepthToWeak + LocalRefine as view-compacted passes (allocated at the first fused launch)
 	bool sweep_split = true;     // DVP_SWEEP_SPLIT=0, or the buffers did not fit: the fused per-pixel kernel
+	bool sweep_force = false;    // DVP_SWEEP_SPLIT=2: the passes also without the geometric term (tests)
 	bool gn_wave = false;        // DVP_GN_WAVE=1: GenNeighbours' search as one wave per WEAK pixel (dvp_gen_neighbours_search; measured slower)
 	float* costs = nullptr; float* costs_snap = nullptr; float* complex_ = nullptr;
 	uint32_t* selected_views = nullptr;
@@ -815,7 +816,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	c->device = device; c->W = width; c->H = height; c->NI = num_images;
 	c->no_images8 = getenv("DVP_NO_IMAGES8") != nullptr;
 	if (const char* e = getenv("DVP_STRONG_SPLIT")) c->strong_split = atoi(e) != 0;
-	if (const char* e = getenv("DVP_SWEEP_SPLIT")) c->sweep_split = atoi(e) != 0;
+	if (const char* e = getenv("DVP_SWEEP_SPLIT")) { c->sweep_split = atoi(e) != 0; c->sweep_force = atoi(e) == 2; }
 	if (const char* e = getenv("DVP_WEAK_ANCHOR_TAB")) c->anchor_tab_off = atoi(e) == 0;   // A/B measurements and the tests of the per-item form
 	if (const char* e = getenv("DVP_GN_WAVE")) c->gn_wave = atoi(e) != 0;
 	c->pitch = (width + 2 * kImgPad + 63) / 64 * 64;
@@ -1324,8 +1325,11 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 		break;
 	case DVP_ST_GET_DEPTH_NORMAL: hipLaunchKernelGGL(c->d.sampler ? dvp_get_depth_normal_exact : dvp_get_depth_normal, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_FILTER_STRONG: hipLaunchKernelGGL(c->d.sampler ? dvp_filter_strong_exact : dvp_filter_strong, grid, block, 0, c->stream, c->d, a); break;
-	case DVP_ST_DEPTH_TO_WEAK:
-		if (fused && c->sweep_split && !c->sweep_cost) {
+	case DVP_ST_DEPTH_TO_WEAK: {
+		// the passes pay where the views diverge and the geometric term rides along (cfg3: 622 -> 536 ms, cfg5: 48 -> 44); a pass
+		// without the geometric term (FIRST_INIT; cfg2, S = 5) measures 63 ms against the fused kernel's 59: DVP_SWEEP_SPLIT=2 forces the passes there too
+		const bool sweep_passes = fused && c->sweep_split && (c->d.params.geom_consistency || c->sweep_force);
+		if (sweep_passes && !c->sweep_cost) {
 			// 73 floats per (pixel, view) + 61 + 8 per pixel (67 GB at 6208x4128, S = 9): a context that cannot have them keeps the fused kernel
 			const size_t L = c->L;
 			void *r = nullptr, *sc = nullptr, *pc = nullptr;
@@ -1342,7 +1346,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 				sync_dev_struct(c);
 			}
 		}
-		if (fused && c->sweep_split) {
+		if (sweep_passes && c->sweep_split) {
 			const bool ex = c->d.sampler != 0;
 			LaunchArgs s0 = a, s1 = a, sb = a;
 			s0.iter = 0; s1.iter = 1; sb.iter = kSweepBorderOnly;
@@ -1361,6 +1365,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 		else if (fused) hipLaunchKernelGGL(c->d.sampler ? dvp_depth_to_weak_refine_exact : dvp_depth_to_weak_refine, grid, block, 0, c->stream, c->d, a);
 		else hipLaunchKernelGGL(c->d.sampler ? dvp_depth_to_weak_exact : dvp_depth_to_weak, grid, block, 0, c->stream, c->d, a);
 		break;
+	}
 	case DVP_ST_LOCAL_REFINE: hipLaunchKernelGGL(c->d.sampler ? dvp_local_refine_exact : dvp_local_refine, grid, block, 0, c->stream, c->d, a); break;
 	}
 	HIP_TRY(c, hipGetLastError());

@@ -442,7 +442,7 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 	case kStageSweeps: {
 		// the engine issues the fused launch site as view-compacted passes unless DVP_SWEEP_SPLIT=0; the emulation follows the switch
 		const char* sp = getenv("DVP_SWEEP_SPLIT");
-		if (sp && atoi(sp) == 0) { launch<kStageSweeps>(e, iter, colour); break; }
+		if ((sp && atoi(sp) == 0) || !(e.d.params.geom_consistency || (sp && atoi(sp) == 2))) { launch<kStageSweeps>(e, iter, colour); break; }   // (the engine's rule: the passes where the geometric term is on, DVP_SWEEP_SPLIT=2 everywhere)
 		const size_t L = (size_t)e.W * e.H;
 		const int S = e.NI - 1;
 		e.sweep_rec.assign(2 * L, mk4(0, 0, 0, 0));

@@ -80,7 +80,7 @@ def test_fused_sweeps_equal_the_two_launches(geom, form, wpr, monkeypatch):
     apart.  Same bits either way, and both equal the oracle: border pixels, sweep slots outside the depth range
     and the geometric term included."""
     W, H, S = 90, 61, 3
-    monkeypatch.setenv("DVP_SWEEP_SPLIT", "1" if form == "passes" else "0")
+    monkeypatch.setenv("DVP_SWEEP_SPLIT", "2" if form == "passes" else "0")   # 2: the passes also where the geometric term is off (the default takes the fused kernel there)
     sc = synth.make_scene(W, H, S)
     p = make_params(S + 1, max_iterations=1, state=synth.FIRST_INIT, use_APD=0, geom_consistency=geom)
     if wpr is not None:

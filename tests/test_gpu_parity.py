@@ -140,7 +140,7 @@ def test_fused_sweeps_equal_the_two_launches(geom, form, wpr, monkeypatch):
     them separate.  Both must leave the same bits (and both equal the oracle's two functions, checked by the
     full-run tests): border pixels, out-of-range sweep slots and the geometric term included."""
     W, H, S = 150, 97, 4
-    monkeypatch.setenv("DVP_SWEEP_SPLIT", "1" if form == "passes" else "0")
+    monkeypatch.setenv("DVP_SWEEP_SPLIT", "2" if form == "passes" else "0")   # 2: the passes also where the geometric term is off (the default takes the fused kernel there)
     sc = synth.make_scene(W, H, S)
     p = make_params(S + 1, max_iterations=2, state=synth.FIRST_INIT, use_APD=0, geom_consistency=geom)
     if wpr is not None:
