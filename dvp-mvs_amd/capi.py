@@ -28,9 +28,9 @@ BUFFERS = dict(planes=(0, np.float32, 4), costs=(1, np.float32, 1), selected_vie
 
 # every symbol include/dvp_mvs.h declares
 EXPORTS = ["dvp_ctx_create", "dvp_ctx_destroy", "dvp_last_error", "dvp_upload_images", "dvp_upload_depths",
-           "dvp_upload_images_device", "dvp_upload_depths_device", "dvp_upload_cameras", "dvp_upload_state",
+           "dvp_upload_images_device", "dvp_upload_depths_device", "dvp_upload_cameras", "dvp_upload_state", "dvp_upload_state_rescaled",
            "dvp_reset_state", "dvp_save_state", "dvp_restore_state", "dvp_set_params", "dvp_set_seed", "dvp_set_sampler", "dvp_set_profiling", "dvp_image_format", "dvp_run_patchmatch",
-           "dvp_run_stage", "dvp_synchronize", "dvp_download_state", "dvp_buffer_bytes", "dvp_download_buffer",
+           "dvp_run_stage", "dvp_synchronize", "dvp_download_state", "dvp_download_maps", "dvp_buffer_bytes", "dvp_download_buffer",
            "dvp_upload_buffer", "dvp_weak_count", "dvp_get_timings", "dvp_reset_timings", "dvp_eval_cost_vectors",
            "dvp_bench_cost_kernel", "dvp_build_id"]
 
@@ -64,6 +64,7 @@ def lib():
             getattr(L, n).argtypes = [vp, vp, ci]
         L.dvp_upload_cameras.argtypes = [vp, vp, ci]
         L.dvp_upload_state.argtypes = [vp] * 7
+        L.dvp_upload_state_rescaled.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp]
         L.dvp_reset_state.argtypes = [vp]
         L.dvp_save_state.argtypes = [vp]
         L.dvp_restore_state.argtypes = [vp]
@@ -76,6 +77,7 @@ def lib():
         L.dvp_run_stage.argtypes = [vp, ci, ci, ci]
         L.dvp_synchronize.argtypes = [vp]
         L.dvp_download_state.argtypes = [vp] * 5
+        L.dvp_download_maps.argtypes = [vp] * 6
         L.dvp_buffer_bytes.restype = ctypes.c_longlong
         L.dvp_buffer_bytes.argtypes = [vp, ci]
         L.dvp_download_buffer.argtypes = [vp, ci, vp]
@@ -174,6 +176,13 @@ class Context:
         args = [c(planes, np.float32), c(views, np.uint32), c(weak, np.uint8), c(edge, np.uint8), c(label, np.int32), c(radius, np.int32)]
         self._ck(self.L.dvp_upload_state(self.h, *[_p(a) for a in args]))
 
+    def upload_state_rescaled(self, src_w, src_h, depth, normal, views, weak=None, radius=None, radius_fallback=5, edge=None, label=None):
+        """the coarser level's maps at their own size, up-sampled on the device (include/dvp_mvs.h)"""
+        c = lambda a, dt: None if a is None else np.ascontiguousarray(a, dt)
+        args = [c(depth, np.float32), c(normal, np.float32), c(views, np.uint32), c(weak, np.uint8), c(radius, np.int32)]
+        tail = [c(edge, np.uint8), c(label, np.int32)]
+        self._ck(self.L.dvp_upload_state_rescaled(self.h, int(src_w), int(src_h), *[_p(a) for a in args], int(radius_fallback), *[_p(a) for a in tail]))
+
     def reset_state(self):
         self._ck(self.L.dvp_reset_state(self.h))
 
@@ -195,6 +204,17 @@ class Context:
         radius = np.empty(L, np.int32)
         self._ck(self.L.dvp_download_state(self.h, _p(planes), _p(views), _p(weak), _p(radius)))
         return planes, views, weak, radius
+
+    def download_maps(self):
+        """depth / normal / selected_views / states / radius as the driver stores them (include/dvp_mvs.h)"""
+        L = self.W * self.H
+        depth = np.empty(L, np.float32)
+        normal = np.empty((L, 3), np.float32)
+        views = np.empty(L, np.uint32)
+        weak = np.empty(L, np.uint8)
+        radius = np.empty(L, np.int32)
+        self._ck(self.L.dvp_download_maps(self.h, _p(depth), _p(normal), _p(views), _p(weak), _p(radius)))
+        return depth, normal, views, weak, radius
 
     def get(self, name):
         bid, dt, k = BUFFERS[name]

@@ -546,6 +546,47 @@ extern "C" __global__ void __launch_bounds__(256) dvp_weak_fill(const uint8_t* _
 	}
 }
 
+// RescaleMatToTargetSize (APD.cpp:1773-1795) for the five maps a REFINE_INIT pass inherits from the coarser pyramid level
+// (APD.cpp:1428-1456 depth + normal -> planes, selected views, :1169-1181 pixel states, :1648-1667 radius map): nearest
+// neighbour with the source's index rule — the ROW index is divided by the WIDTH ratio and the column index by the height
+// ratio (`o_r = r / scale_x`, `o_c = c / scale_y`, :1787-1788; the same unless the aspect ratios differ) — one IEEE float
+// division and a truncation each; a pixel whose source index falls outside the coarse map stays zero.  Then the radius
+// rule of APD.cpp:1660-1666: a pixel whose state is UNKNOWN restarts with the default patch radius.
+struct RescaleArgs {
+	int W, H, sw, sh;
+	float scale_x, scale_y;
+	const float* depth; const float* normal; const uint32_t* views; const uint8_t* weak; const int* radius;   // coarse maps; weak / radius may be null
+	f4* planes; uint32_t* out_views; uint8_t* out_weak; int* out_radius;
+	int radius_fallback;
+};
+extern "C" __global__ void __launch_bounds__(256) dvp_rescale_state(const RescaleArgs a) {
+	const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+	if (c >= a.W) return;
+	const int o_r = static_cast<int>(r / a.scale_x);
+	const int o_c = static_cast<int>(c / a.scale_y);
+	const bool in = o_r >= 0 && o_c >= 0 && o_r < a.sh && o_c < a.sw;
+	const size_t o = (size_t)r * a.W + c, i = in ? (size_t)o_r * a.sw + o_c : 0;
+	a.planes[o] = in ? mk4(a.normal[3 * i], a.normal[3 * i + 1], a.normal[3 * i + 2], a.depth[i]) : mk4(0.0f, 0.0f, 0.0f, 0.0f);
+	a.out_views[o] = in ? a.views[i] : 0u;
+	const uint8_t st = a.weak ? (in ? a.weak[i] : (uint8_t)0) : (uint8_t)DVP_STRONG;
+	a.out_weak[o] = st;
+	if (a.radius) a.out_radius[o] = st == DVP_UNKNOWN ? a.radius_fallback : (in ? a.radius[i] : 0);
+}
+
+// What the driver makes of the downloaded planes (main.cpp:300-309): depth map = plane.w where it lies inside
+// [depth_min, depth_max], else 0 and the pixel's state becomes UNKNOWN; normal map = plane.xyz.  (`!(w < min || w > max)`
+// as the source writes it: a NaN depth is kept.)
+extern "C" __global__ void __launch_bounds__(256) dvp_unpack_maps(const f4* __restrict__ planes, const uint8_t* __restrict__ weak, size_t L, float dmin, float dmax,
+                                                                 float* __restrict__ depth, float* __restrict__ normal, uint8_t* __restrict__ state) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= L) return;
+	const f4 ph = planes[i];
+	const bool usable = !(ph.w < dmin || ph.w > dmax);
+	depth[i] = usable ? ph.w : 0.0f;
+	normal[3 * i] = ph.x; normal[3 * i + 1] = ph.y; normal[3 * i + 2] = ph.z;
+	state[i] = usable ? weak[i] : (uint8_t)DVP_UNKNOWN;
+}
+
 extern "C" __global__ void dvp_prepare_views(const DvpCamera* cams, ViewConst* views, int n) {
 	const int v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= 1 && v < n) compute_view_const(cams[0], cams[v], &views[v]);
@@ -728,6 +769,9 @@ struct dvp_ctx {
 	size_t weak_list_alloc = 0;
 	int* weak_counts = nullptr;  // scratch of the device-side compaction: per-slot black / red counts, per-chunk counts, then 3 totals
 	int* weak_totals_host = nullptr;   // pinned: (black, red, all)
+	uint8_t* coarse = nullptr;   // staging of the coarser level's maps (dvp_upload_state_rescaled)
+	uint8_t* maps_out = nullptr; // staging of dvp_download_maps: depth [L] f32, normal [L][3] f32, states [L] u8
+	size_t coarse_alloc = 0;
 	// dvp_save_state / dvp_restore_state: device-side copy of the per-pixel input state
 	f4* saved_planes = nullptr; uint32_t* saved_views = nullptr; uint8_t* saved_weak = nullptr; int* saved_radius = nullptr;
 	bool have_saved = false;
@@ -993,16 +1037,9 @@ static int ensure_weak_buffers(dvp_ctx* c, size_t weak_count) {
 	return 0;
 }
 
-int dvp_upload_state(dvp_ctx* c, const float* planes, const uint32_t* views, const uint8_t* weak,
-                     const uint8_t* edge, const int32_t* label, const int32_t* radius) {
-	c->anchor_tab_valid = false;
-	if (set_device(c)) return 1;
+// weak_info (on the device) -> neighbours_map, the compacted WEAK lists, the per-WEAK buffers
+static int rebuild_weak_lists(dvp_ctx* c) {
 	const size_t L = c->L;
-	if (planes) HIP_TRY(c, hipMemcpyAsync(c->planes, planes, L * 16, hipMemcpyHostToDevice, c->stream));
-	if (views) HIP_TRY(c, hipMemcpyAsync(c->selected_views, views, L * 4, hipMemcpyHostToDevice, c->stream));
-	if (edge) HIP_TRY(c, hipMemcpyAsync(c->edge, edge, L, hipMemcpyHostToDevice, c->stream));
-	if (label) HIP_TRY(c, hipMemcpyAsync(c->label, label, L * 4, hipMemcpyHostToDevice, c->stream));
-	if (radius) HIP_TRY(c, hipMemcpyAsync(c->radius, radius, L * 4, hipMemcpyHostToDevice, c->stream));
 	// weak_info -> neighbours_map (running index of WEAK pixels, APD.cpp:1182-1193) and the compacted WEAK lists of the
 	// list kernels (black, then red; rows the reference's half grid never reaches, APD.cu:4421-4424, are kept like in the
 	// full-grid launch), all on the device: see dvp_weak_counts / dvp_scan3 / dvp_weak_fill.  List order = 64 x 64
@@ -1010,7 +1047,6 @@ int dvp_upload_state(dvp_ctx* c, const float* planes, const uint32_t* views, con
 	// the ~8 consecutive workgroups of a super-tile share their anchors and the source lines those touch; stage_body_list
 	// hands such runs to ONE XCD.  (16x16 vs 16x8 / 32x4 / row-major: 592.7 / 599 / 609 / 622 ms per REFINE pass, r01.)
 	// Every list kernel is order-independent (a WEAK pixel only reads STRONG pixels' state).
-	if (weak) HIP_TRY(c, hipMemcpyAsync(c->weak_info, weak, L, hipMemcpyHostToDevice, c->stream));
 	const int supers_x = (c->W + kWeakSuper - 1) / kWeakSuper, supers_y = (c->H + kWeakSuper - 1) / kWeakSuper;
 	const int n_slots = supers_x * supers_y * 16, n_chunks = (int)((L + kWeakChunk - 1) / kWeakChunk);
 	const int n_units = n_slots + n_chunks;
@@ -1045,6 +1081,58 @@ int dvp_upload_state(dvp_ctx* c, const float* planes, const uint32_t* views, con
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	sync_dev_struct(c);
 	return 0;
+}
+
+int dvp_upload_state(dvp_ctx* c, const float* planes, const uint32_t* views, const uint8_t* weak,
+                     const uint8_t* edge, const int32_t* label, const int32_t* radius) {
+	c->anchor_tab_valid = false;
+	if (set_device(c)) return 1;
+	const size_t L = c->L;
+	if (planes) HIP_TRY(c, hipMemcpyAsync(c->planes, planes, L * 16, hipMemcpyHostToDevice, c->stream));
+	if (views) HIP_TRY(c, hipMemcpyAsync(c->selected_views, views, L * 4, hipMemcpyHostToDevice, c->stream));
+	if (edge) HIP_TRY(c, hipMemcpyAsync(c->edge, edge, L, hipMemcpyHostToDevice, c->stream));
+	if (label) HIP_TRY(c, hipMemcpyAsync(c->label, label, L * 4, hipMemcpyHostToDevice, c->stream));
+	if (radius) HIP_TRY(c, hipMemcpyAsync(c->radius, radius, L * 4, hipMemcpyHostToDevice, c->stream));
+	if (weak) HIP_TRY(c, hipMemcpyAsync(c->weak_info, weak, L, hipMemcpyHostToDevice, c->stream));
+	return rebuild_weak_lists(c);
+}
+
+// The per-pixel input state of a REFINE_INIT pass from the coarser level's result maps, up-sampled on the device
+// (dvp_rescale_state): 25 bytes per COARSE pixel cross the bus instead of 25 per fine one, and the host neither rescales
+// nor assembles planes.
+int dvp_upload_state_rescaled(dvp_ctx* c, int src_w, int src_h, const float* depth, const float* normal_xyz, const uint32_t* views,
+                              const uint8_t* weak, const int32_t* radius, int radius_fallback, const uint8_t* edge, const int32_t* label) {
+	c->anchor_tab_valid = false;
+	if (set_device(c)) return 1;
+	if (src_w <= 0 || src_h <= 0 || !depth || !normal_xyz || !views) { c->error = "dvp_upload_state_rescaled: depth, normal and selected_views are required"; return 1; }
+	const size_t L = c->L, n = (size_t)src_w * src_h;
+	const size_t off_normal = n * 4, off_views = off_normal + n * 12, off_radius = off_views + n * 4, off_weak = off_radius + n * 4, bytes = off_weak + n;
+	if (bytes > c->coarse_alloc) {
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		dfree(c, &c->coarse);
+		if (dalloc(c, &c->coarse, bytes, false)) return 1;
+		c->coarse_alloc = bytes;
+	}
+	HIP_TRY(c, hipMemcpyAsync(c->coarse, depth, n * 4, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->coarse + off_normal, normal_xyz, n * 12, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->coarse + off_views, views, n * 4, hipMemcpyHostToDevice, c->stream));
+	if (radius) HIP_TRY(c, hipMemcpyAsync(c->coarse + off_radius, radius, n * 4, hipMemcpyHostToDevice, c->stream));
+	if (weak) HIP_TRY(c, hipMemcpyAsync(c->coarse + off_weak, weak, n, hipMemcpyHostToDevice, c->stream));
+	if (edge) HIP_TRY(c, hipMemcpyAsync(c->edge, edge, L, hipMemcpyHostToDevice, c->stream));
+	if (label) HIP_TRY(c, hipMemcpyAsync(c->label, label, L * 4, hipMemcpyHostToDevice, c->stream));
+	RescaleArgs a;
+	a.W = c->W; a.H = c->H; a.sw = src_w; a.sh = src_h;
+	a.scale_x = c->W / static_cast<float>(src_w);
+	a.scale_y = c->H / static_cast<float>(src_h);
+	a.depth = reinterpret_cast<const float*>(c->coarse); a.normal = reinterpret_cast<const float*>(c->coarse + off_normal);
+	a.views = reinterpret_cast<const uint32_t*>(c->coarse + off_views);
+	a.radius = radius ? reinterpret_cast<const int*>(c->coarse + off_radius) : nullptr;
+	a.weak = weak ? c->coarse + off_weak : nullptr;
+	a.planes = c->planes; a.out_views = c->selected_views; a.out_weak = c->weak_info; a.out_radius = c->radius;
+	a.radius_fallback = radius_fallback;
+	hipLaunchKernelGGL(dvp_rescale_state, dim3((unsigned)((c->W + 255) / 256), (unsigned)c->H), dim3(256), 0, c->stream, a);
+	HIP_TRY(c, hipGetLastError());
+	return rebuild_weak_lists(c);
 }
 
 int dvp_reset_state(dvp_ctx* c) {
@@ -1451,6 +1539,26 @@ int dvp_download_state(dvp_ctx* c, float* planes, uint32_t* views, uint8_t* weak
 	if (planes) HIP_TRY(c, hipMemcpyAsync(planes, c->planes, L * 16, hipMemcpyDeviceToHost, c->stream));
 	if (views) HIP_TRY(c, hipMemcpyAsync(views, c->selected_views, L * 4, hipMemcpyDeviceToHost, c->stream));
 	if (weak) HIP_TRY(c, hipMemcpyAsync(weak, c->weak_info, L, hipMemcpyDeviceToHost, c->stream));
+	if (radius) HIP_TRY(c, hipMemcpyAsync(radius, c->radius, L * 4, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+int dvp_download_maps(dvp_ctx* c, float* depth, float* normal_xyz, uint32_t* views, uint8_t* weak, int32_t* radius) {
+	if (set_device(c)) return 1;
+	if (!depth || !normal_xyz || !weak) { c->error = "dvp_download_maps: depth, normal and weak_info are required"; return 1; }
+	const size_t L = c->L;
+	if (!c->maps_out && dalloc(c, &c->maps_out, L * 17, false)) return 1;
+	float* d_depth = reinterpret_cast<float*>(c->maps_out);
+	float* d_normal = d_depth + L;
+	uint8_t* d_state = c->maps_out + L * 16;
+	hipLaunchKernelGGL(dvp_unpack_maps, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, c->stream, c->planes, c->weak_info, L, c->d.params.depth_min, c->d.params.depth_max,
+	                   d_depth, d_normal, d_state);
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipMemcpyAsync(depth, d_depth, L * 4, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(normal_xyz, d_normal, L * 12, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(weak, d_state, L, hipMemcpyDeviceToHost, c->stream));
+	if (views) HIP_TRY(c, hipMemcpyAsync(views, c->selected_views, L * 4, hipMemcpyDeviceToHost, c->stream));
 	if (radius) HIP_TRY(c, hipMemcpyAsync(radius, c->radius, L * 4, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	return 0;

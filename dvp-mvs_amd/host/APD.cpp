@@ -20,6 +20,21 @@ void APD::SetDevice(int device) { g_device = device; }   // cudaSetDevice(argv[2
 void APD::SetSeed(uint64_t seed) { g_seed = seed; }      // the reference seeds with clock64() (APD.cu:1270)
 static bool g_use_label_files = false;
 void APD::SetUseLabelFiles(bool on) { g_use_label_files = on; }
+// DVP_HOST_TIMING=1: wall time of the parts of the host steps (tools/e2e_timing.sh folds them per pass)
+namespace {
+struct HostLap {
+	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+	const bool on = std::getenv("DVP_HOST_TIMING") != nullptr;
+	void operator()(const char* what) {
+		if (!on) return;
+		const auto now = std::chrono::steady_clock::now();
+		std::cout << "  [host]   . " << what << ": " << std::chrono::duration_cast<std::chrono::microseconds>(now - t).count() / 1000.0 << " ms" << std::endl;
+		t = now;
+	}
+};
+}
+static bool g_device_rescale = true;
+void APD::SetDeviceRescale(bool on) { g_device_rescale = on; }
 
 APD::APD(const Problem& problem) {   // APD.cpp:984-987
 	params_host = problem.params;
@@ -74,11 +89,76 @@ struct PooledCtx {
 } g_pool;
 }
 static std::atomic<int> g_prefetch_threads{0};
+// The next pyramid level's engine context, created by a helper thread while the GPU is still on the current level's last
+// pass (allocating and clearing ~15 GB takes ~0.3 s at full resolution — once per level, but on the critical path of its
+// first view otherwise).
+namespace {
+struct PrewarmedCtx {
+	std::thread worker;
+	dvp_ctx* ctx = nullptr;
+	int device = 0, w = 0, h = 0, ni = 0;
+	bool active = false;
+} g_prewarm;
+dvp_ctx* take_prewarmed(int device, int w, int h, int ni) {   // nullptr when there is none that fits
+	if (!g_prewarm.active) return nullptr;
+	if (g_prewarm.worker.joinable()) g_prewarm.worker.join();
+	g_prewarm.active = false;
+	dvp_ctx* c = g_prewarm.ctx;
+	g_prewarm.ctx = nullptr;
+	if (c && (g_prewarm.device != device || g_prewarm.w != w || g_prewarm.h != h || g_prewarm.ni != ni)) { dvp_ctx_destroy(c); c = nullptr; }
+	return c;
+}
+}
+void APD::PrewarmContext(int w, int h, int ni) {
+	if (g_prewarm.active || w <= 0 || h <= 0) return;
+	g_prewarm.active = true;
+	g_prewarm.device = g_device; g_prewarm.w = w; g_prewarm.h = h; g_prewarm.ni = ni;
+	const int device = g_device;
+	g_prewarm.worker = std::thread([device, w, h, ni]() {
+		dvp_ctx* c = nullptr;
+		if (dvp_ctx_create(device, w, h, ni, &c) != 0) c = nullptr;   // (the view that needs it will try again and report)
+		g_prewarm.ctx = c;
+	});
+}
+// size of a view at a pyramid level, as load_image makes it (APD.cpp:1119-1131)
+bool APD::LevelSize(const Problem& problem, int scale, int* w, int* h) {
+	const Mat gray = DecodedGray(problem.dense_folder / path("images") / path(ToFormatIndex(problem.ref_image_id) + ".jpg"));
+	if (gray.empty()) return false;
+	const float factor = 1.0f / (float)scale;
+	*w = scale != 1 ? (int)std::round(gray.cols * factor) : gray.cols;
+	*h = scale != 1 ? (int)std::round(gray.rows * factor) : gray.rows;
+	return true;
+}
+// the float images of these views at `scale` (reference role), made by a helper thread ahead of the level's first pass
+void APD::PrefetchLevelImages(std::vector<Problem> views, int scale) {
+	++g_prefetch_threads;
+	std::thread([views, scale]() mutable {
+		for (Problem& p : views) {
+			p.scale_size = scale;
+			int oc, orr;
+			(void)CachedImage(p, p.ref_image_id, &oc, &orr);
+		}
+		// ... and the level's result maps: every view of its first pass downloads into five maps nobody has released yet
+		// (the result cache still holds the coarser level's) — fresh blocks whose pages would be faulted in by the
+		// download.  Touch one set per view here and give it to the recycling pool (Mat.h).
+		int w = 0, h = 0;
+		if (!views.empty() && LevelSize(views[0], scale, &w, &h)) {
+			std::vector<Mat> sets;
+			for (size_t v = 0; v < views.size(); ++v)
+				for (int type : { CV_32FC1, CV_32FC3, CV_32SC1, CV_32SC1, CV_8UC1 }) {
+					sets.emplace_back(h, w, type);
+					std::memset(sets.back().data, 0, sets.back().step * (size_t)h);
+				}
+		}
+		--g_prefetch_threads;
+	}).detach();
+}
 void APD::ReserveImageCache(size_t views) { std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex); g_img_cache_capacity = std::max<size_t>(96, 2 * views + 8); }   // reference + padded source role
 void APD::ReleasePooledContext() {
 	while (g_prefetch_threads.load() > 0) std::this_thread::sleep_for(std::chrono::milliseconds(2));   // (they use the caches cleared below)
 	if (g_pool.ctx) dvp_ctx_destroy(g_pool.ctx);
 	g_pool.ctx = nullptr;
+	if (dvp_ctx* c = take_prewarmed(-1, 0, 0, 0)) dvp_ctx_destroy(c);   // (never fits: joined and freed)
 	std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
 	g_img_cache.clear();
 	g_decoded.clear();
@@ -217,6 +297,7 @@ APD::~APD() {                        // APD.cpp:989-1043
 
 // APD.cpp:1045-1495 (the Depth-Anything prior block :1210-1424 lives in prior.cpp)
 void APD::InuputInitialization() {
+	HostLap lap;
 	images.clear();
 	cameras.clear();
 	path image_folder = problem.dense_folder / path("images");
@@ -278,6 +359,7 @@ void APD::InuputInitialization() {
 		std::cout << "Scale images and cameras done\n";
 	}
 	std::cout << "Image size: " << width << " * " << height << std::endl;
+	lap("images + cameras");
 	if (params_host.geom_consistency) {   // APD.cpp:1147-1166
 		depths.clear();
 		depths_device.clear();
@@ -308,30 +390,35 @@ void APD::InuputInitialization() {
 			}
 		}
 	}
+	lap("source depth maps");
 	if (params_host.use_APD) {            // APD.cpp:1169-1195
 		path weak_info_path = problem.result_folder / path("weak.bin");
 		if (!ResultExists(weak_info_path)) {
 			DvpFatal("Can't find weak info file: " + weak_info_path.string());
 		}
 		LoadResult(weak_info_path, weak_info_host, true);   // RunPatchMatch downloads the new states into this buffer
-		if (weak_info_host.cols != width || weak_info_host.rows != height) {
-			std::cerr << "Weak info doesn't match the images' size!\n";
-			RescaleMatToTargetSize<uint8_t>(weak_info_host, weak_info_host, width, height);
-			std::cout << "Scale done\n";
+		// With the device rescale the previous pass' maps stay as they are — of this pass' size, or of the coarser pyramid
+		// level's in the first pass of a finer one — and the engine up-samples them, assembles the planes and applies the
+		// radius rule (CudaSpaceInitialization; at equal size the rescale is the identity, as RescaleMatToTargetSize's early
+		// return is); the depth / normal / selected-views maps below have to agree in size.
+		coarse_state = g_device_rescale && params_host.state != FIRST_INIT && !weak_info_host.empty();
+		if (coarse_state) {
+			coarse_weak = weak_info_host;
+			weak_info_host = Mat(height, width, CV_8UC1);
+		} else {
+			if (weak_info_host.cols != width || weak_info_host.rows != height) {
+				std::cerr << "Weak info doesn't match the images' size!\n";
+				RescaleMatToTargetSize<uint8_t>(weak_info_host, weak_info_host, width, height);
+				std::cout << "Scale done\n";
+			}
+			CountWeak();
 		}
-		long long wc = 0;
-#pragma omp parallel for reduction(+ : wc) schedule(static) num_threads(HostThreads())
-		for (int r = 0; r < height; ++r) {
-			const uint8_t* row = weak_info_host.ptr<uint8_t>(r);
-			for (int c = 0; c < width; ++c) wc += row[c] == WEAK;
-		}
-		weak_count = (int)wc;
-		std::cout << "Weak count: " << weak_count << " / " << width * height << " = " << (float)weak_count / (float)(width * height) * 100 << "%" << std::endl;
 	} else {                              // APD.cpp:1196-1204
 		weak_info_host = Mat(height, width, CV_8UC1);
 		weak_count = 0;
 		std::memset(weak_info_host.data, STRONG, weak_info_host.step * (size_t)height);
 	}
+	lap("pixel states");
 	plane_hypotheses_host = new float4[(size_t)width * height];
 	if (params_host.state == FIRST_INIT) std::memset(plane_hypotheses_host, 0, sizeof(float4) * (size_t)width * height);   // (else every entry is assigned below)
 	// FIRST_INIT: plane prior from the Depth-Anything map + sparse SfM points (dep/<id>.dmb,
@@ -341,7 +428,7 @@ void APD::InuputInitialization() {
 		if (BuildPlanePrior(problem, cameras[0], width, height, plane_hypotheses_host)) std::cout << "Plane prior from dep/ and sfm/\n";
 		else std::cout << "No dep/ + sfm/ prior: random plane initialisation\n";
 	}
-	selected_views_host = Mat::zeros(height, width, CV_32SC1);
+	if (params_host.state == FIRST_INIT) selected_views_host = Mat::zeros(height, width, CV_32SC1);   // (else loaded below)
 	if (params_host.state != FIRST_INIT) {   // APD.cpp:1428-1456: the previous pass' maps are this pass' start
 		Mat depth, normal;
 		LoadResult(problem.result_folder / path("depths.dmb"), depth);
@@ -349,6 +436,26 @@ void APD::InuputInitialization() {
 		LoadResult(problem.result_folder / path("selected_views.bin"), selected_views_host, true);   // downloaded into by RunPatchMatch
 		if (depth.empty() || normal.empty() || selected_views_host.empty()) DvpFatal("Can't find the previous pass' maps in " + problem.result_folder.string());
 		const bool fits = depth.cols == width && depth.rows == height && normal.cols == width && normal.rows == height;
+		{   // device rescale: all maps of the previous pass at ONE size (else the host flow below)
+			const bool same = normal.cols == depth.cols && normal.rows == depth.rows && selected_views_host.cols == depth.cols && selected_views_host.rows == depth.rows;
+			const bool can = g_device_rescale && same && (params_host.use_APD ? (coarse_state && coarse_weak.cols == depth.cols && coarse_weak.rows == depth.rows) : true);
+			if (coarse_state && !can) {   // the pixel states were kept back for nothing
+				weak_info_host = coarse_weak;
+				coarse_weak = Mat();
+				coarse_state = false;
+				RescaleMatToTargetSize<uint8_t>(weak_info_host, weak_info_host, width, height);
+				CountWeak();
+			}
+			coarse_state = can;
+		}
+		if (coarse_state) {
+			coarse_depth = depth;
+			coarse_normal = normal;
+			coarse_views = selected_views_host;
+			selected_views_host = Mat(height, width, CV_32SC1);   // RunPatchMatch downloads into it
+			lap("previous maps (kept at their size)");
+			return;
+		}
 		if (!fits) {
 			std::cerr << "Depth and Normal doesn't match the images' size!\n";
 			RescaleMatToTargetSize<float>(depth, depth, width, height);
@@ -365,7 +472,41 @@ void APD::InuputInitialization() {
 			float4* out = plane_hypotheses_host + (size_t)row * width;
 			for (int col = 0; col < width; ++col) out[col] = float4{ n[col][0], n[col][1], n[col][2], z[col] };
 		}
+		lap("previous maps -> planes");
 	}
+}
+
+void APD::CountWeak() {   // APD.cpp:1182-1193 (the running index itself is made on the device, dvp_upload_state)
+	long long wc = 0;
+#pragma omp parallel for reduction(+ : wc) schedule(static) num_threads(HostThreads())
+	for (int r = 0; r < height; ++r) {
+		const uint8_t* row = weak_info_host.ptr<uint8_t>(r);
+		for (int c = 0; c < width; ++c) wc += row[c] == WEAK;
+	}
+	weak_count = (int)wc;
+	std::cout << "Weak count: " << weak_count << " / " << width * height << " = " << (float)weak_count / (float)(width * height) * 100 << "%" << std::endl;
+}
+
+// the host flow after all: what InuputInitialization would have done without the device rescale
+void APD::CoarseStateToHost() {
+	if (!coarse_state) return;
+	coarse_state = false;
+	if (!coarse_weak.empty()) {
+		RescaleMatToTargetSize<uint8_t>(coarse_weak, weak_info_host, width, height);
+		CountWeak();
+	}
+	Mat depth, normal;
+	RescaleMatToTargetSize<float>(coarse_depth, depth, width, height);
+	RescaleMatToTargetSize<Vec3f>(coarse_normal, normal, width, height);
+	RescaleMatToTargetSize<unsigned int>(coarse_views, selected_views_host, width, height);
+#pragma omp parallel for schedule(static) num_threads(HostThreads())
+	for (int row = 0; row < height; ++row) {
+		const float* z = depth.ptr<float>(row);
+		const Vec3f* n = normal.ptr<Vec3f>(row);
+		float4* out = plane_hypotheses_host + (size_t)row * width;
+		for (int col = 0; col < width; ++col) out[col] = float4{ n[col][0], n[col][1], n[col][2], z[col] };
+	}
+	coarse_depth = coarse_normal = coarse_views = coarse_weak = coarse_radius = Mat();
 }
 
 // APD.cpp:1615-1668
@@ -385,10 +526,11 @@ void APD::SupportInitialization() {
 		// (APD.cpp:1636-1645) and uploads it regardless; here: load if present, else zeros
 		Mat ref_dep;
 		path p = problem.dense_folder / path("MVS4") / path(ToFormatIndex(problem.ref_image_id) + ".dmb");
-		label_host = Mat::zeros(height, width, CV_32SC1);
+		label_host = Mat();   // empty = all zero: nothing is uploaded, the context's label map is zero (fresh, or dvp_reset_state)
 		if (std::filesystem::exists(p) && ReadBinMat(p, ref_dep) && (ref_dep.cols != width || ref_dep.rows != height)) {
 			Mat tmp;
 			RescaleMatToTargetSize<float>(ref_dep, tmp, width, height);
+			label_host = Mat(height, width, CV_32SC1);
 			std::memcpy(label_host.data, tmp.data, (size_t)width * height * 4);   // float bits reinterpreted, as the reference does
 		} else if (g_use_label_files) {   // the commented-out load of APD.cpp:1630-1633
 			Mat lab;
@@ -405,6 +547,14 @@ void APD::SupportInitialization() {
 			radius_host = Mat(height, width, CV_32S);
 			std::fill(radius_host.ptr<int>(0), radius_host.ptr<int>(0) + (size_t)width * height, fallback);
 		}
+		if (coarse_state) {   // the radius map travels with the other coarse maps; the UNKNOWN rule below runs on the device too
+			if (radius_host.cols == coarse_depth.cols && radius_host.rows == coarse_depth.rows) {
+				coarse_radius = radius_host;
+				radius_host = Mat(height, width, CV_32S);   // RunPatchMatch downloads into it
+				return;
+			}
+			CoarseStateToHost();   // no radius.bin of the coarse size (fallback map above): everything on the host
+		}
 		if (radius_host.cols != width || radius_host.rows != height) {
 			std::cerr << "Radius map doesn't match the images' size!\n";
 			RescaleMatToTargetSize<int>(radius_host, radius_host, width, height);
@@ -420,18 +570,22 @@ void APD::SupportInitialization() {
 
 // APD.cpp:1497-1613: every cudaMalloc/cudaMemcpy/texture creation becomes one C-ABI upload
 void APD::CudaSpaceInitialization() {
+	HostLap lap;
 	ctx_device = g_device;
 	if (g_pool.ctx && g_pool.device == g_device && g_pool.w == width && g_pool.h == height && g_pool.ni == num_images) {
 		ctx = g_pool.ctx;
 		g_pool.ctx = nullptr;
 		DVP_SAFE_CALL(ctx, dvp_reset_state(ctx));
 		DVP_SAFE_CALL(ctx, dvp_reset_timings(ctx));
+	} else if ((ctx = take_prewarmed(g_device, width, height, num_images)) != nullptr) {
 	} else if (dvp_ctx_create(g_device, width, height, num_images, &ctx) != 0) {
 		DvpFatal(std::string("dvp_ctx_create failed: ") + dvp_last_error(nullptr));
 	}
+	lap("context");
 	std::vector<const float*> ptrs(num_images);
 	for (int i = 0; i < num_images; ++i) ptrs[i] = images[i].ptr<float>(0);
 	DVP_SAFE_CALL(ctx, dvp_upload_images(ctx, ptrs.data(), width));
+	lap("images upload");
 	if (params_host.geom_consistency) {
 		if (!depths_device.empty()) {
 			DVP_SAFE_CALL(ctx, dvp_upload_depths_device(ctx, depths_device.data(), width));
@@ -441,11 +595,25 @@ void APD::CudaSpaceInitialization() {
 		}
 	}
 	DVP_SAFE_CALL(ctx, dvp_upload_cameras(ctx, reinterpret_cast<const DvpCamera*>(cameras.data()), num_images));
+	lap("depth maps + cameras upload");
+	if (coarse_state) {   // REFINE_INIT from the coarser level: RescaleMatToTargetSize + plane assembly + radius rule on the device
+		DVP_SAFE_CALL(ctx, dvp_upload_state_rescaled(ctx, coarse_depth.cols, coarse_depth.rows, coarse_depth.ptr<float>(0), coarse_normal.ptr<float>(0),
+			coarse_views.ptr<uint32_t>(0), coarse_weak.empty() ? nullptr : coarse_weak.ptr<uint8_t>(0),
+			coarse_radius.empty() ? nullptr : coarse_radius.ptr<int32_t>(0), problem.params.strong_radius,
+			(problem.params.use_edge || problem.params.use_limit) ? edge_host.ptr<uint8_t>(0) : nullptr,
+			(problem.params.use_label && !label_host.empty()) ? label_host.ptr<int32_t>(0) : nullptr));
+		weak_count = dvp_weak_count(ctx);
+		std::cout << "Weak count: " << weak_count << " / " << width * height << " = " << (float)weak_count / (float)(width * height) * 100 << "%" << std::endl;
+		coarse_depth = coarse_normal = coarse_views = coarse_weak = coarse_radius = Mat();
+		lap("state upload (coarse maps, rescaled on the device)");
+		return;
+	}
 	DVP_SAFE_CALL(ctx, dvp_upload_state(ctx, reinterpret_cast<const float*>(plane_hypotheses_host),
 		selected_views_host.ptr<uint32_t>(0), weak_info_host.ptr<uint8_t>(0),
 		(problem.params.use_edge || problem.params.use_limit) ? edge_host.ptr<uint8_t>(0) : nullptr,
-		problem.params.use_label ? label_host.ptr<int32_t>(0) : nullptr,
+		(problem.params.use_label && !label_host.empty()) ? label_host.ptr<int32_t>(0) : nullptr,
 		problem.params.use_radius ? radius_host.ptr<int32_t>(0) : nullptr));
+	lap("state upload");
 }
 
 // APD.cpp:1670-1704: the DataPassHelper lives inside the context; what is left is params + seed
@@ -459,6 +627,18 @@ void APD::RunPatchMatch() {
 	DVP_SAFE_CALL(ctx, dvp_run_patchmatch(ctx));
 	if (!problem.params.use_radius) radius_host = Mat::zeros(height, width, CV_32S);
 	DVP_SAFE_CALL(ctx, dvp_download_state(ctx, reinterpret_cast<float*>(plane_hypotheses_host), selected_views_host.ptr<uint32_t>(0),
+		weak_info_host.ptr<uint8_t>(0), problem.params.use_radius ? radius_host.ptr<int32_t>(0) : nullptr));
+	DVP_SAFE_CALL(ctx, dvp_get_timings(ctx, &timings));
+}
+
+// extension: the same run, results downloaded as the maps the driver stores (main.cpp:300-309 done on the device,
+// dvp_download_maps) instead of planes the caller unpacks; GetPlaneHypothesis is not served afterwards.
+void APD::RunPatchMatchToMaps(Mat& depth, Mat& normal) {
+	DVP_SAFE_CALL(ctx, dvp_run_patchmatch(ctx));
+	if (!problem.params.use_radius) radius_host = Mat::zeros(height, width, CV_32S);
+	depth = Mat(height, width, CV_32FC1);
+	normal = Mat(height, width, CV_32FC3);
+	DVP_SAFE_CALL(ctx, dvp_download_maps(ctx, depth.ptr<float>(0), normal.ptr<float>(0), selected_views_host.ptr<uint32_t>(0),
 		weak_info_host.ptr<uint8_t>(0), problem.params.use_radius ? radius_host.ptr<int32_t>(0) : nullptr));
 	DVP_SAFE_CALL(ctx, dvp_get_timings(ctx, &timings));
 }

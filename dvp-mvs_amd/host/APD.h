@@ -78,6 +78,7 @@ public:
 	void SupportInitialization();
 	void SetDataPassHelperInCuda();
 	void RunPatchMatch();
+	void RunPatchMatchToMaps(Mat& depth, Mat& normal);   // extension: results as the driver's depth / normal maps (APD.cpp)
 	float4 GetPlaneHypothesis(int r, int c);
 	int GetPixelSelectedViews(int r, int c);
 	void SetPixelSelectedViews(int r, int c, int temp_selected_views);
@@ -97,12 +98,19 @@ public:
 	// APD.cpp:1630-1633): its label map stays zero unless MVS4/<id>.dmb needs rescaling.  true: load
 	// labels_<s>.dmb in SupportInitialization (what the commented-out lines do).  Default false.
 	static void SetUseLabelFiles(bool on);
+	// true (default): a pass that starts from maps of another size (REFINE_INIT on a finer pyramid level) hands them to the
+	// engine at their own size and RescaleMatToTargetSize runs there (dvp_upload_state_rescaled); false: the five host-side
+	// rescales + the plane assembly of the reference's flow (APD.cpp:1176-1180, 1440-1456, 1656-1659).  Same maps either way.
+	static void SetDeviceRescale(bool on);
 	// multi-GPU hooks of the driver (comm.h).  Image cache: the decoded + rescaled float image of a view in
 	// its reference role at the problem's scale — rank 0 fills it from disk, the others from a broadcast.
 	static Mat CachedImage(const Problem& problem, int image_id, int* orig_cols, int* orig_rows);
 	static void InsertCachedImage(const Problem& problem, int image_id, const Mat& image, int orig_cols, int orig_rows);
 	static Mat DecodedGray(const path& image_file);   // cv::imread(GRAYSCALE) through a per-file cache (read-only result)
 	static void PrefetchDecoded(const std::vector<path>& image_files);   // decode in the background (detached worker threads)
+	static void PrewarmContext(int width, int height, int num_images);   // the next level's engine context, made by a helper thread
+	static bool LevelSize(const Problem& problem, int scale, int* width, int* height);
+	static void PrefetchLevelImages(std::vector<Problem> views, int scale);   // float images of a level ahead of its first pass
 	static void ReserveImageCache(size_t views);   // the cache holds at least this many images before it evicts
 	// Depth maps of the previous pass resident on this process' device (row-major, pitch = width).  When
 	// the maps of a view and all its sources are registered, a geometric-consistency pass takes them from
@@ -125,6 +133,11 @@ private:
 	float4* plane_hypotheses_host = nullptr;
 	Mat edge_host, radius_host, label_host, selected_views_host;
 	PatchMatchParams params_host;
+	// device rescale: the previous pass' maps at the coarser level's size, handed to the engine by CudaSpaceInitialization
+	bool coarse_state = false;
+	Mat coarse_depth, coarse_normal, coarse_views, coarse_weak, coarse_radius;
+	void CountWeak();
+	void CoarseStateToHost();   // undo: rescale on the host after all (a map is missing or sizes disagree)
 	dvp_ctx* ctx = nullptr;
 	int ctx_device = 0;
 	DvpTimings timings{};

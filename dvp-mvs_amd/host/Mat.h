@@ -5,8 +5,11 @@
 #ifndef DVP_MAT_H_
 #define DVP_MAT_H_
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 enum { CV_8UC1 = 0, CV_8U = 0, CV_8UC3 = 16, CV_32SC1 = 4, CV_32S = 4, CV_32FC1 = 5, CV_32F = 5, CV_32FC3 = 21 };
@@ -19,6 +22,51 @@ struct Rect {                                                                   
 	bool contains(const Point& p) const { return x <= p.x && p.x < x + width && y <= p.y && p.y < y + height; }
 };
 struct Vec3f { float v[3]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
+
+// Large pixel buffers are recycled: a fresh 100 MB block comes from mmap as untouched pages, and the first write — a
+// memset, a file read, the engine's download — then takes 25 000 page faults (measured 20-50 ms per map at 6208x4128, on
+// the critical path of every view).  A released block of >= 1 MB is kept (up to DVP_MAT_POOL_GB, default 8) and handed
+// to the next request of the same size with its pages still mapped.  Contents are unspecified either way (as cv::Mat's);
+// DVP_MAT_POISON=1 fills every recycled block with 0xA5 so that a reader of never-written memory shows up in the tests.
+namespace matpool {
+struct Pool {
+	std::mutex m;
+	std::multimap<size_t, uint8_t*> free_blocks;
+	size_t bytes = 0, cap = 0;
+	bool poison = false;
+	Pool() {
+		const char* e = std::getenv("DVP_MAT_POOL_GB");
+		cap = (size_t)(e ? std::atoi(e) : 8) << 30;
+		poison = std::getenv("DVP_MAT_POISON") != nullptr;
+	}
+};
+inline Pool& pool() { static Pool* p = new Pool; return *p; }   // never destroyed (buffers may be released at exit)
+constexpr size_t kMinPooled = (size_t)1 << 20;
+inline uint8_t* acquire(size_t n) {
+	if (n >= kMinPooled) {
+		Pool& p = pool();
+		std::unique_lock<std::mutex> lk(p.m);
+		auto it = p.free_blocks.find(n);
+		if (it != p.free_blocks.end()) {
+			uint8_t* b = it->second;
+			p.free_blocks.erase(it);
+			p.bytes -= n;
+			lk.unlock();
+			if (p.poison) std::memset(b, 0xA5, n);
+			return b;
+		}
+	}
+	return new uint8_t[n];
+}
+inline void release(uint8_t* b, size_t n) {
+	if (n >= kMinPooled) {
+		Pool& p = pool();
+		std::lock_guard<std::mutex> lk(p.m);
+		if (p.bytes + n <= p.cap) { p.free_blocks.emplace(n, b); p.bytes += n; return; }
+	}
+	delete[] b;
+}
+}  // namespace matpool
 
 class Mat {
 public:
@@ -35,7 +83,8 @@ public:
 	void create(int r, int c, int type) {
 		rows = r; cols = c; type_ = type;
 		step = (size_t)c * elem_size(type);
-		buf_ = std::shared_ptr<uint8_t[]>(new uint8_t[step * (size_t)(r > 0 ? r : 1) + 8]);
+		const size_t n = step * (size_t)(r > 0 ? r : 1) + 8;
+		buf_ = std::shared_ptr<uint8_t[]>(matpool::acquire(n), [n](uint8_t* b) { matpool::release(b, n); });
 		data = buf_.get();
 	}
 	static Mat zeros(int r, int c, int type) { Mat m(r, c, type); std::memset(m.data, 0, m.step * r); return m; }

@@ -36,6 +36,7 @@ struct Options {
 	bool fusion = true, jacobi = false, label_files = false;
 	int collective_timeout_s = 600;
 	bool sync_io = false;
+	bool host_rescale = false;
 	std::string job, transport = "rccl";
 	std::string fusion_kind = "eth";   // eth | tat-intermediate | tat-advanced (APD.h:52-54; the reference's main calls the first)
 };
@@ -108,7 +109,8 @@ void ConfigurePass(Problem& problem, const Pass& pass, int iteration, int iters,
 	}
 }
 
-struct ViewResult { Mat depth; };   // what the exchange step needs from a finished view
+struct ViewResult { Mat depth; };
+bool g_device_maps = true;   // false (--sync-io / --host-rescale): planes are downloaded and unpacked on the host   // what the exchange step needs from a finished view
 
 ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	std::cout << "Processing image: " << std::setw(8) << std::setfill('0') << problem.ref_image_id << "..." << std::endl;
@@ -131,20 +133,24 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	APD.CudaSpaceInitialization();
 	lap("CudaSpaceInitialization (context + uploads)");
 	APD.SetDataPassHelperInCuda();
-	APD.RunPatchMatch();
-	lap("RunPatchMatch + download");
-
 	const int width = APD.GetWidth(), height = APD.GetHeight();
 	const int nsrc = (int)problem.src_image_ids.size();
 	const float dmin = APD.GetDepthMin(), dmax = APD.GetDepthMax();
-	Mat depth(height, width, CV_32FC1), normal(height, width, CV_32FC3);
+	Mat depth, normal;
+	if (g_device_maps) APD.RunPatchMatchToMaps(depth, normal);   // the unpack loop below, done by the engine before the download
+	else {
+		APD.RunPatchMatch();
+		depth = Mat(height, width, CV_32FC1);
+		normal = Mat(height, width, CV_32FC3);
+	}
+	lap("RunPatchMatch + download");
 	Mat pixel_states = APD.GetPixelStates();
 	Mat views = APD.GetSelectedViews();
 	Mat radius = problem.params.use_radius ? APD.GetRadiusMap() : Mat();
 	// planes -> depth / normal maps; depths outside the admissible range are dropped and the pixel loses
 	// its state (main.cpp:300-309)
 #pragma omp parallel for schedule(static) num_threads(HostThreads())
-	for (int r = 0; r < height; ++r) {
+	for (int r = 0; r < (g_device_maps ? 0 : height); ++r) {
 		float* z = depth.ptr<float>(r);
 		Vec3f* n = normal.ptr<Vec3f>(r);
 		uint8_t* st = pixel_states.ptr<uint8_t>(r);
@@ -335,7 +341,8 @@ Options ParseOptions(int argc, char** argv) {
 		else if (s == "--jacobi") o.jacobi = true;
 		else if (s == "--labels") o.label_files = true;          // load labels_<s>.dmb (APD::SetUseLabelFiles)
 		else if (s == "--no-fusion") o.fusion = false;
-		else if (s == "--sync-io") o.sync_io = true;               // no result cache / background worker: the reference's synchronous file flow
+		else if (s == "--sync-io") o.sync_io = true;               // no result cache / background worker / device rescale: the reference's synchronous file flow
+		else if (s == "--host-rescale") o.host_rescale = true;     // the coarser level's maps are up-sampled on the host (APD::SetDeviceRescale(false))
 		else if (s == "--fusion") { if (a + 1 < argc) o.fusion_kind = argv[++a]; }
 	}
 	if (o.world > 1) o.jacobi = true;
@@ -360,6 +367,8 @@ int main(int argc, char** argv) {
 	APD::SetSeed(opt.seed);
 	APD::SetUseLabelFiles(opt.label_files);
 	SetResultCache(!opt.sync_io);
+	APD::SetDeviceRescale(!opt.sync_io && !opt.host_rescale);
+	g_device_maps = !opt.sync_io && !opt.host_rescale;
 	RankComm comm(opt.rank, opt.world, opt.gpu, (opt.dense_folder / "APD" / ".rccl_id").string(), opt.job, opt.collective_timeout_s, opt.transport);
 	// every print-and-exit of the host library (unreadable image, missing weak.bin, engine error ...) becomes an agreed
 	// abort of the whole job when there are peers
@@ -406,6 +415,14 @@ int main(int argc, char** argv) {
 		for (Problem& problem : problems) {
 			ConfigurePass(problem, pass, (int)it, opt.iters, round_num);
 			if (problem.index % opt.world == opt.rank) owned.push_back(&problem);
+		}
+		// last pass of a level: the next level's context and float images are made by helper threads while the GPU works
+		if (!opt.sync_io && it + 1 < plan.size() && plan[it + 1].scale != pass.scale && !owned.empty()) {
+			int nw = 0, nh = 0;
+			if (APD::LevelSize(*owned[0], plan[it + 1].scale, &nw, &nh)) APD::PrewarmContext(nw, nh, (int)owned[0]->src_image_ids.size() + 1);
+			std::vector<Problem> mine_next;
+			for (const Problem* p : owned) mine_next.push_back(*p);
+			APD::PrefetchLevelImages(mine_next, plan[it + 1].scale);
 		}
 		for (size_t k = 0; k < owned.size(); ++k) {
 			Problem& problem = *owned[k];

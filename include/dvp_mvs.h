@@ -149,6 +149,16 @@ int dvp_upload_cameras(dvp_ctx* ctx, const DvpCamera* cams, int n);            /
 int dvp_upload_state(dvp_ctx* ctx, const float* planes_xyzw, const uint32_t* selected_views,
                      const uint8_t* weak_info, const uint8_t* edge, const int32_t* label,
                      const int32_t* radius);
+/* The same per-pixel input state for a REFINE_INIT pass whose previous maps come from the COARSER pyramid level
+ * (src_w x src_h): replaces the five host-side RescaleMatToTargetSize calls of APD::InuputInitialization /
+ * SupportInitialization (APD.cpp:1176-1180, 1440-1449, 1656-1659; the function itself APD.cpp:1773-1795, nearest
+ * neighbour, row index / width ratio and column index / height ratio as the source has it), the plane assembly
+ * (APD.cpp:1450-1456) and the radius rule for UNKNOWN pixels (APD.cpp:1660-1666) by one kernel on the maps at their own
+ * size.  depth, normal_xyz (3 floats per pixel) and selected_views are required; weak_info NULL = every pixel STRONG
+ * (APD.cpp:1196-1204); radius NULL = radius map untouched; edge / label are full-size maps as in dvp_upload_state. */
+int dvp_upload_state_rescaled(dvp_ctx* ctx, int src_w, int src_h, const float* depth, const float* normal_xyz,
+                              const uint32_t* selected_views, const uint8_t* weak_info, const int32_t* radius,
+                              int radius_fallback, const uint8_t* edge, const int32_t* label);
 /* device-side reset to the state a freshly constructed APD has before a FIRST_INIT pass without
  * prior: planes = 0 (out of range -> random init, APD.cu:1289-1291), selected_views = 0, every
  * pixel STRONG (APD.cpp:1196-1204), radius = strong_radius (APD.cpp:1649-1653), fit planes = 0
@@ -183,6 +193,12 @@ int dvp_synchronize(dvp_ctx* ctx);
 /* any pointer may be NULL. planes: (world normal xyz, depth w) per pixel. */
 int dvp_download_state(dvp_ctx* ctx, float* planes_xyzw, uint32_t* selected_views,
                        uint8_t* weak_info, int32_t* radius);
+/* The same results in the form the reference's driver stores them (ProcessProblem, main.cpp:300-309, which loops over
+ * GetPlaneHypothesis): depth map = plane.w where depth_min <= w <= depth_max, else 0 and the pixel's state becomes
+ * UNKNOWN (in the downloaded copy; the device state is untouched); normal map = 3 floats per pixel.  depth, normal_xyz
+ * and weak_info are required. */
+int dvp_download_maps(dvp_ctx* ctx, float* depth, float* normal_xyz, uint32_t* selected_views,
+                      uint8_t* weak_info, int32_t* radius);
 long long dvp_buffer_bytes(dvp_ctx* ctx, int buffer);
 int dvp_download_buffer(dvp_ctx* ctx, int buffer, void* dst);
 int dvp_upload_buffer(dvp_ctx* ctx, int buffer, const void* src);

@@ -310,18 +310,23 @@ def test_apd_source_image_smaller_than_the_reference(tmp_path):
     assert count_diff(dep, d2) == 0
 
 
-def test_apd_result_cache_and_background_worker_leave_the_same_files(tmp_path):
+@pytest.mark.parametrize("W,H,NV,levels", [(160, 120, 4, 1), (838, 126, 3, 2)])
+def test_apd_result_cache_and_background_worker_leave_the_same_files(tmp_path, W, H, NV, levels):
     """The driver's write-back result cache, background finisher (visibility clean-up + writes behind the next view),
-    resident depth maps and decode prefetch (host/store.cpp, main.cpp) against the synchronous file flow of the reference
-    (--sync-io: every pass re-reads its inputs from the files the previous one wrote): every result file byte-identical."""
+    resident depth maps, decode prefetch (host/store.cpp, main.cpp) and — second case, two pyramid levels — the device-side
+    up-sampling of the coarser level's maps (dvp_upload_state_rescaled; 419x63 -> 838x126) against the synchronous file
+    flow of the reference (--sync-io: every pass re-reads its inputs from the files the previous one wrote and rescales
+    them on the host): every result file byte-identical.  (Until round 4 this test started both runs with the same
+    command line — the flag was never passed.)"""
     import filecmp
-    W, H, NV = 160, 120, 4
     outs = {}
     for tag, extra in (("async", []), ("sync", ["--sync-io"])):
         d = str(tmp_path / tag)
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), "3", "--jpg"])
-        out = subprocess.run([os.path.join(ROOT, "dvp-mvs_amd", "apd"), d, "0", "--iters", "2", "--passes", "2", "--min-scale", "1", "--seed", "11", "--labels"],
+        out = subprocess.run([os.path.join(ROOT, "dvp-mvs_amd", "apd"), d, "0", "--iters", "2", "--passes", "2", "--min-scale", "1", "--seed", "11", "--labels"] + extra,
                              capture_output=True, text=True, timeout=600)
+        if tag == "async" and levels > 1:
+            assert out.stdout.count("Weak count") > 0
         assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
         outs[tag] = d
     n = 0

@@ -298,6 +298,80 @@ def test_reset_state_equals_fresh_context():
     assert count_diff(first, g.get("planes")) == 0
 
 
+def _rescale_reference_rule(src, tw, th):
+    """RescaleMatToTargetSize as the source text has it (APD.cpp:1773-1795): nearest neighbour, the ROW index divided by
+    the WIDTH ratio and the column index by the height ratio (both binary32), truncated; outside the source: zero
+    (the reference leaves those pixels uninitialised; defined as zero here).  Written from the source, array-wise."""
+    sh, sw = src.shape[:2]
+    scale_x = np.float32(tw) / np.float32(sw)
+    scale_y = np.float32(th) / np.float32(sh)
+    o_r = (np.arange(th, dtype=np.float32) / scale_x).astype(np.int64)
+    o_c = (np.arange(tw, dtype=np.float32) / scale_y).astype(np.int64)
+    ok = (o_r[:, None] < sh) & (o_c[None, :] < sw)
+    out = np.zeros((th, tw) + src.shape[2:], src.dtype)
+    out[ok] = src[np.minimum(o_r, sh - 1)[:, None], np.minimum(o_c, sw - 1)[None, :]][ok]
+    return out
+
+
+@pytest.mark.parametrize("W,H,sw,sh", [(96, 64, 48, 32), (101, 67, 50, 33), (90, 70, 45, 33), (97, 61, 51, 30)])
+def test_upload_state_rescaled_is_the_reference_rescale(W, H, sw, sh):
+    """dvp_upload_state_rescaled (the coarser pyramid level's maps up-sampled on the device) against the reference's rule
+    read from the source: planes = (normal, depth), selected views, pixel states (+ WEAK count), radius with the
+    UNKNOWN -> strong_radius rule (APD.cpp:1660-1666); sizes whose ratios differ per axis (the swapped scale factors
+    matter, and some target pixels fall outside the source)."""
+    rng = np.random.default_rng(W * 131 + sh)
+    depth = rng.uniform(1.0, 9.0, (sh, sw)).astype(np.float32)
+    normal = rng.normal(size=(sh, sw, 3)).astype(np.float32)
+    views = rng.integers(0, 2 ** 9, (sh, sw)).astype(np.uint32)
+    weak = rng.integers(0, 3, (sh, sw)).astype(np.uint8)
+    radius = rng.integers(1, 12, (sh, sw)).astype(np.int32)
+    g = capi().Context(W, H, 4)
+    g.upload_state_rescaled(sw, sh, depth, normal, views, weak, radius, radius_fallback=7)
+    planes, gv, gw, gr = g.download_state()
+    e_w = _rescale_reference_rule(weak, W, H)
+    e_r = _rescale_reference_rule(radius, W, H)
+    e_r[e_w == synth.UNKNOWN] = 7
+    e_p = np.concatenate([_rescale_reference_rule(normal, W, H), _rescale_reference_rule(depth, W, H)[..., None]], -1)
+    assert count_diff(planes.reshape(H, W, 4), e_p) == 0
+    assert (gv.reshape(H, W) == _rescale_reference_rule(views, W, H)).all()
+    assert (gw.reshape(H, W) == e_w).all()
+    assert (gr.reshape(H, W) == e_r).all()
+    assert g.weak_count() == int((e_w == synth.WEAK).sum())
+    nm = g.get("neighbours_map").reshape(H, W)
+    assert (nm[e_w == synth.WEAK] == np.arange(int((e_w == synth.WEAK).sum()))).all()   # running index, raster order (APD.cpp:1182-1193)
+    # without pixel states / radius map: every pixel STRONG, radius untouched
+    before = g.get("radius").copy()
+    g.upload_state_rescaled(sw, sh, depth, normal, views)
+    _, _, gw2, gr2 = g.download_state()
+    assert (gw2 == synth.STRONG).all() and (gr2 == before.reshape(-1)).all()
+
+
+def test_download_maps_is_the_drivers_unpack_loop():
+    """dvp_download_maps against the loop of the reference's driver (main.cpp:300-309): depth = plane.w inside
+    [depth_min, depth_max], else 0 and the state UNKNOWN; normal = plane.xyz; a NaN depth passes both comparisons and is
+    kept.  The device state itself is not modified."""
+    W, H, S = 96, 64, 3
+    sc = synth.make_scene(W, H, S)
+    p = make_params(S + 1, max_iterations=1, state=synth.FIRST_INIT, use_APD=0)
+    g = capi().from_scene(sc, p, seed=5)
+    rng = np.random.default_rng(3)
+    planes = rng.normal(size=(H * W, 4)).astype(np.float32)
+    planes[:, 3] = rng.uniform(0.5 * float(p["depth_min"]), 1.5 * float(p["depth_max"]), H * W)
+    planes[::97, 3] = np.nan
+    planes[5, 3] = p["depth_min"]
+    planes[6, 3] = p["depth_max"]
+    weak = rng.integers(0, 3, H * W).astype(np.uint8)
+    g.upload_state(planes=planes, weak=weak)
+    depth, normal, views, st, radius = g.download_maps()
+    usable = ~((planes[:, 3] < p["depth_min"]) | (planes[:, 3] > p["depth_max"]))
+    assert usable[5] and usable[6] and usable[0::97].all() and (~usable).sum() > 100
+    assert count_diff(depth, np.where(usable, planes[:, 3], np.float32(0))) == 0
+    assert count_diff(normal, planes[:, :3]) == 0
+    assert (st == np.where(usable, weak, synth.UNKNOWN)).all()
+    p2, v2, w2, r2 = g.download_state()
+    assert (w2 == weak).all() and (v2 == views).all() and (r2 == radius).all() and count_diff(p2, planes) == 0
+
+
 def test_golden_weak_pass_engine():
     """the committed REFINE_ITER / weak-path fixture through the C ABI"""
     from test_oracle_kat import _golden_weak_pass

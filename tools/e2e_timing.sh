@@ -10,5 +10,5 @@ DS=/tmp/ds_e2e
 rm -rf $DS
 python tools/make_dataset.py $DS $W $H $NV $NS --jpg --torch > /dev/null
 ( time DVP_HOST_TIMING=1 ./dvp-mvs_amd/apd $DS 0 --iters 3 --passes 1 --min-scale 1 --seed 3 --no-fusion ) > "$OUT/e2e_apd.log" 2>&1
-python tools/e2e_summary.py "$OUT/e2e_apd.log" $W $H > "$OUT/r03_e2e_apd.txt"
-cat "$OUT/r03_e2e_apd.txt"
+python tools/e2e_summary.py "$OUT/e2e_apd.log" $W $H > "$OUT/e2e_apd.txt"
+cat "$OUT/e2e_apd.txt"
