@@ -486,6 +486,8 @@ DVP_HD int first_set_bit_in(const uint32_t* bits, int tiles_x, int fixed, int a,
 	return -1;
 }
 
+DVP_HD int dvp_ctz(uint32_t v) { return __builtin_ctz(v); }   // v != 0
+
 // ---- small geometry helpers (APD.cu:181-194, 331-422, 467-499, 750-768) ----------------------
 DVP_HD int is_set(uint32_t v, unsigned n) { return (v >> n) & 1; }
 DVP_HD void set_bit(uint32_t* v, unsigned n) { *v |= (1u << n); }

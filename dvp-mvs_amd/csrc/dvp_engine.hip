@@ -148,6 +148,7 @@ DVP_KERNEL_MV(dvp_strong_update_v16, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY, 16)
 // split strong update (dvp_strong.hpp): evaluations of the 17 snapshot planes, decisions, refinement (S <= 16)
 DVP_KERNEL64(dvp_strong_eval, kStageStrongEval, DVP_LB_HEAVY)
 DVP_KERNEL64(dvp_strong_refine, kStageStrongRefine, DVP_LB_HEAVY)
+DVP_KERNEL64(dvp_strong_refine_lanes, kStageStrongRefineLanes, DVP_LB_HEAVY)
 template <int MV>
 __device__ __forceinline__ void strong_decide_body(const Dev& d, const LaunchArgs& a) {
 	int px, py;
@@ -749,6 +750,7 @@ struct dvp_ctx {
 	float* slot_costs = nullptr; // [17][S][half_w * H]: split strong update (allocated at its first launch)
 	float* strong_rec = nullptr; // [SR_FIELDS][half_w * H]
 	bool strong_split = true;    // DVP_STRONG_SPLIT=0 in the environment: the monolithic kernel (A/B measurements)
+	bool refine_lanes = true;    // DVP_REFINE_LANES=0: dvp_strong_refine with the wave in lock step over hypotheses and views
 	f4* sweep_rec = nullptr; float* sweep_cost = nullptr; float* sweep_pc = nullptr;   // DepthToWeak + LocalRefine as view-compacted passes (allocated at the first fused launch)
 	bool sweep_split = true;     // DVP_SWEEP_SPLIT=0, or the buffers did not fit: the fused per-pixel kernel
 	bool sweep_force = false;    // DVP_SWEEP_SPLIT=2: the passes also without the geometric term (tests)
@@ -860,6 +862,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	c->device = device; c->W = width; c->H = height; c->NI = num_images;
 	c->no_images8 = getenv("DVP_NO_IMAGES8") != nullptr;
 	if (const char* e = getenv("DVP_STRONG_SPLIT")) c->strong_split = atoi(e) != 0;
+	if (const char* e = getenv("DVP_REFINE_LANES")) c->refine_lanes = atoi(e) != 0;
 	if (const char* e = getenv("DVP_SWEEP_SPLIT")) { c->sweep_split = atoi(e) != 0; c->sweep_force = atoi(e) == 2; }
 	if (const char* e = getenv("DVP_WEAK_ANCHOR_TAB")) c->anchor_tab_off = atoi(e) == 0;   // A/B measurements and the tests of the per-item form
 	if (const char* e = getenv("DVP_GN_WAVE")) c->gn_wave = atoi(e) != 0;
@@ -1405,7 +1408,10 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 			else if (S <= 10) hipLaunchKernelGGL(dvp_strong_decide_v10, grid, block, 0, c->stream, c->d, a);
 			else if (S <= 12) hipLaunchKernelGGL(dvp_strong_decide_v12, grid, block, 0, c->stream, c->d, a);
 			else hipLaunchKernelGGL(dvp_strong_decide_v16, grid, block, 0, c->stream, c->d, a);
-			hipLaunchKernelGGL(c->d.sampler ? dvp_strong_refine_exact : dvp_strong_refine, wave_grid, wave_block, 0, c->stream, c->d, a);
+			// every lane on its own (hypothesis, view) sequence; the lanes' image planes are 32-bit byte offsets from the set's base
+			if (c->refine_lanes && (size_t)c->pitch * (c->H + 2 * kImgPad) * 8 * c->NI < ((size_t)1 << 32))
+				hipLaunchKernelGGL(c->d.sampler ? dvp_strong_refine_lanes_exact : dvp_strong_refine_lanes, wave_grid, wave_block, 0, c->stream, c->d, a);
+			else hipLaunchKernelGGL(c->d.sampler ? dvp_strong_refine_exact : dvp_strong_refine, wave_grid, wave_block, 0, c->stream, c->d, a);
 		}
 		else if (c->NI - 1 <= kNarrowViews) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v8_exact : dvp_strong_update_v8, grid, block, 0, c->stream, c->d, a);
 		else if (c->NI - 1 <= 16) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_update_v16_exact : dvp_strong_update_v16, grid, block, 0, c->stream, c->d, a);

@@ -275,6 +275,19 @@ DVP_HD float ncc_old(const Dev& d, const PatchCtx& c, int px, int py, int v, con
 	return ncc_patch_generic(d, H, src, px, py, c.radius, c.inc, 0);
 }
 
+// The same for a LANE-VARYING view (dvp_strong_refine's per-lane walk): the view record comes through vector loads and the
+// lane's image plane is a byte offset from the set's base (the caller checks that the whole set lies below 4 GiB).
+template <int SMP>
+DVP_HD float ncc_old_lane(const Dev& d, const PatchCtx& c, int px, int py, int v, const f4 plane) {
+	const ViewConst vc = d.views[v];
+	float H[9];
+	homography(vc, plane, H);
+	const f2 pt = apply_homography(H, px, py);
+	if (pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f) return 2.0f;
+	if (c.fast) return ncc_patch_fast<SMP>(d, c, H, d.images, px, py, (unsigned)((size_t)v * d.plane_stride * 8));
+	return ncc_patch_generic(d, H, d.images + (size_t)v * d.plane_stride * 2, px, py, c.radius, c.inc, 0);
+}
+
 // ComputeGeomConsistencyCost (APD.cu:1218-1256) in two pieces: the forward point depends on the pixel and the
 // plane only, so a caller that tests one plane against several views forms it once.
 DVP_HD f3 geom_forward_point(const Dev& d, int px, int py, const f4 plane) {

@@ -73,7 +73,7 @@ constexpr int kNarrowViews = 8;   // view capacity of the narrow strong-update i
 constexpr int kStageSweeps = 100;
 constexpr int kSweepBorderOnly = -1;
 // internal launch sites of the split strong update (dvp_strong.hpp: strong_eval_px / strong_decide_px / strong_refine_px)
-constexpr int kStageStrongEval = 101, kStageStrongRefine = 102;
+constexpr int kStageStrongEval = 101, kStageStrongRefine = 102, kStageStrongRefineLanes = 103;   // 103: every lane walks its own (hypothesis, view) sequence
 template <int STAGE, int SMP, int MV = 32>
 DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long* nevals, PatchTab tab) {
 	const int center = px + py * d.width;
@@ -103,6 +103,7 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 	else if (STAGE == DVP_ST_STRONG_UPDATE) { if (d.weak_info[center] != DVP_WEAK) strong_update_px<SMP, MV>(d, px, py, tab, iter, nevals); }
 	else if (STAGE == kStageStrongEval) { if (d.weak_info[center] != DVP_WEAK) strong_eval_px<SMP>(d, px, py, tab, nevals); }
 	else if (STAGE == kStageStrongRefine) { if (d.weak_info[center] != DVP_WEAK) strong_refine_px<SMP>(d, px, py, tab, nevals); }
+	else if (STAGE == kStageStrongRefineLanes) { if (d.weak_info[center] != DVP_WEAK) strong_refine_px<SMP, true>(d, px, py, tab, nevals); }
 	else if (STAGE == DVP_ST_RANSAC_FIT) ransac_fit_plane_px(d, px, py, iter);
 	else if (STAGE == DVP_ST_WEAK_UPDATE) {
 		// device: own launch shape (one wave per WEAK pixel, dvp_weak_update_wave); this branch is the

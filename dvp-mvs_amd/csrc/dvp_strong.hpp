@@ -694,7 +694,7 @@ DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
 }
 
 // PlaneHypothesisRefinementStrong's evaluations and acceptance (APD.cu:1361-1383) + the write-back (APD.cu:2725-2737)
-template <int SMP>
+template <int SMP, bool LANE_WALK = false>
 DVP_HD void strong_refine_px(const Dev& d, int px, int py, PatchTab tab, unsigned long long* nevals) {
 	const int W = d.width;
 	const int center = py * W + px;
@@ -731,14 +731,59 @@ DVP_HD void strong_refine_px(const Dev& d, int px, int py, PatchTab tab, unsigne
 	const float depth_entry = depth_now;
 	const f4 plane_entry = plane_now;
 	(void)depth_entry; (void)plane_entry;
+	// A hypothesis is adopted iff its depth is in range and its weighted cost is below the running best (strict).
+	// Two exact short cuts (the cost itself is only kept when adopted): (i) out of range -> not evaluated; (ii) the
+	// weighted sum only grows — every term is a weight > 0 times a cost in [0, 2], IEEE addition and division are
+	// monotone — so once the partial sum / weight_norm is not below cost_now the final one cannot be: the remaining
+	// views are not evaluated.  Random hypotheses are rejected after one or two views instead of all selected ones.
+	if (LANE_WALK) {
+		// Round 4: every lane walks its OWN (hypothesis, view) sequence — one evaluation per trip of the loop below for
+		// every lane that still has one — instead of the wave stepping through hypotheses and views together (where a
+		// lane waits while any neighbour evaluates a view it did not select or a hypothesis it has already rejected:
+		// lane utilisation 0.47).  Same evaluations per pixel in the same order, hence the same bits; the view index is
+		// a per-lane value (ncc_old_lane).
+		uint32_t sel = 0;     // views with a weight > 0
+		for (int j = 0; j < S; ++j)
+			if (((wq[j >> 2] >> (8 * (j & 3))) & 255u) > 0) sel |= 1u << j;
+		int hyp = 0;
+		bool busy = false;
+		f4 plane = plane_now;
+		float db = 0.0f, tc = 0.0f;
+		uint32_t todo = 0;    // views of the current hypothesis not yet evaluated
+		for (;;) {
+			while (!busy && hyp < 5) {
+				plane = hyp_normal[hyp];
+				plane.w = distance_to_origin(rc, px, py, hyp_depth[hyp], plane);
+				db = depth_from_plane(rc, plane, px, py);
+				++hyp;
+				if (!(db >= P.depth_min && db <= P.depth_max)) continue;
+				if (!(weight_norm > 0.0f)) continue;      // no selected view: 0 / 0 = NaN, never below cost_now
+				tc = 0.0f;
+				todo = sel;
+				busy = true;
+			}
+			if (!busy) break;
+			const int j = dvp_ctz(todo);
+			todo &= todo - 1;
+			uint32_t q = wq[0];
+#pragma unroll
+			for (int k = 1; k < 8; ++k) q = (j >> 2) == k ? wq[k] : q;
+			const int wv = (int)((q >> (8 * (j & 3))) & 255u);
+			tc += wv * ncc_old_lane<SMP>(d, c, px, py, j + 1, plane);
+			if (nevals) *nevals += 1;
+			const bool alive = tc / weight_norm < cost_now;
+			if (!alive) busy = false;
+			else if (todo == 0) {      // the complete sum is below the running best
+				depth_now = db;
+				plane_now = plane;
+				cost_now = tc / weight_norm;
+				busy = false;
+			}
+		}
+	} else
 	for (int i = 0; i < 5; ++i) {
 		f4 plane = hyp_normal[i];
 		plane.w = distance_to_origin(rc, px, py, hyp_depth[i], plane);
-		// A hypothesis is adopted iff its depth is in range and its weighted cost is below the running best (strict).
-		// Two exact short cuts (the cost itself is only kept when adopted): (i) out of range -> not evaluated; (ii) the
-		// weighted sum only grows — every term is a weight > 0 times a cost in [0, 2], IEEE addition and division are
-		// monotone — so once the partial sum / weight_norm is not below cost_now the final one cannot be: the remaining
-		// views are not evaluated.  Random hypotheses are rejected after one or two views instead of all selected ones.
 		const float db = depth_from_plane(rc, plane, px, py);
 		if (!(db >= P.depth_min && db <= P.depth_max)) continue;
 		float tc = 0.0f;

@@ -400,6 +400,8 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 		// the engine issues the update as three launches for S <= 16 (dvp_strong_eval / _decide / _refine) unless
 		// DVP_STRONG_SPLIT=0; the emulation follows the same switch, so both forms are checked against the oracle
 		const char* sp = getenv("DVP_STRONG_SPLIT");
+		const char* rl = getenv("DVP_REFINE_LANES");
+		const bool refine_lanes = !(rl && atoi(rl) == 0);   // dvp_strong_refine_lanes / dvp_strong_refine
 		const int S = e.NI - 1;
 		if (S <= 16 && !(sp && atoi(sp) == 0)) {
 			unsigned long long total = 0;
@@ -423,6 +425,7 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 								else if (S <= 12) strong_decide_px<12>(e.d, px, py, iter);
 								else strong_decide_px<16>(e.d, px, py, iter);
 							}
+							else if (refine_lanes) { if (e.d.sampler) strong_refine_px<1, true>(e.d, px, py, tab, e.count ? &n : nullptr); else strong_refine_px<0, true>(e.d, px, py, tab, e.count ? &n : nullptr); }
 							else { if (e.d.sampler) strong_refine_px<1>(e.d, px, py, tab, e.count ? &n : nullptr); else strong_refine_px<0>(e.d, px, py, tab, e.count ? &n : nullptr); }
 							total += n;
 						}

@@ -258,14 +258,19 @@ def test_launch_geometry_covers_every_pixel_once():
             assert L.emu_tile_map_check(w, h, 1, colour) == 0, (w, h, "half", colour)
 
 
-@pytest.mark.parametrize("form", ["split", "monolithic"])
+@pytest.mark.parametrize("form", ["split", "split_lockstep_refine", "monolithic"])
 @pytest.mark.parametrize("S", [3, 5, 9, 12])
 def test_strong_update_forms_equal_the_oracle(form, S, monkeypatch):
+    strong_update_forms_case(_pair, _run_and_compare, form, S, monkeypatch)
+
+
+def strong_update_forms_case(_pair, _run_and_compare, form, S, monkeypatch):
     """The engine issues the strong update as three launches (dvp_strong_eval / _decide_vN / _refine: evaluator-only kernel,
     register-resident decisions, refinement with the exact early exits) or, with DVP_STRONG_SPLIT=0, as the one monolithic
     kernel; the emulation follows the same switch.  Both forms, every view-count bracket of the decision kernel, REFINE_INIT's
     write-back rule included: bit-identical to the oracle after every launch."""
-    monkeypatch.setenv("DVP_STRONG_SPLIT", "1" if form == "split" else "0")
+    monkeypatch.setenv("DVP_STRONG_SPLIT", "0" if form == "monolithic" else "1")
+    monkeypatch.setenv("DVP_REFINE_LANES", "0" if form == "split_lockstep_refine" else "1")   # dvp_strong_refine[_lanes]
     W, H = 72, 56
     sc = synth.make_scene(W, H, S)
     for state in (synth.FIRST_INIT, synth.REFINE_INIT):

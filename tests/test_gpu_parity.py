@@ -182,6 +182,15 @@ def test_gen_neighbours_search_forms_equal_the_oracle(form, seed, monkeypatch):
     gen_neighbours_case(seed, _pair)
 
 
+@pytest.mark.parametrize("form", ["split", "split_lockstep_refine", "monolithic"])
+@pytest.mark.parametrize("S", [3, 5, 9, 12])
+def test_strong_update_forms_equal_the_oracle(form, S, monkeypatch):
+    """the three launches with dvp_strong_refine_lanes (every lane on its own (hypothesis, view) sequence) or
+    dvp_strong_refine (the wave in lock step), and the monolithic kernel: see test_emul_parity"""
+    from test_emul_parity import strong_update_forms_case
+    strong_update_forms_case(_pair, _run_and_compare, form, S, monkeypatch)
+
+
 @pytest.mark.parametrize("S", [12, 18])
 def test_many_views_weak_path(S):
     """More than 9 and more than 16 source views: the 16- and 32-view instantiations of the strong update, several
