@@ -487,6 +487,7 @@ DVP_HD int first_set_bit_in(const uint32_t* bits, int tiles_x, int fixed, int a,
 }
 
 DVP_HD int dvp_ctz(uint32_t v) { return __builtin_ctz(v); }   // v != 0
+DVP_HD uint32_t f32_bits(float x) { return __builtin_bit_cast(uint32_t, x); }
 
 // ---- small geometry helpers (APD.cu:181-194, 331-422, 467-499, 750-768) ----------------------
 DVP_HD int is_set(uint32_t v, unsigned n) { return (v >> n) & 1; }

@@ -147,6 +147,79 @@ DVP_KERNEL_MV(dvp_strong_update_v8, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY, kNarrowV
 DVP_KERNEL_MV(dvp_strong_update_v16, DVP_ST_STRONG_UPDATE, DVP_LB_HEAVY, 16)
 // split strong update (dvp_strong.hpp): evaluations of the 17 snapshot planes, decisions, refinement (S <= 16)
 DVP_KERNEL64(dvp_strong_eval, kStageStrongEval, DVP_LB_HEAVY)
+// dvp_strong_eval with the (pixel, slot) items of the wave's 64 pixels compacted over its lanes.  With a pixel per lane a
+// wave makes 17 trips x S views whatever its lanes hold: WEAK and off-image lanes idle, edge pixels have 9 slots instead of
+// 17, and 11 % of the remaining planes are bitwise repeats of an earlier slot (strong_slot_sources) — 18 % of the lane-trips
+// at cfg3.  Here every lane first builds its pixel's patch table (LDS, [tap][pixel]) and lists its distinct slots; the
+// items are then numbered across the wave (prefix sum of the counts) and taken 64 per round: lane l evaluates item
+// round * 64 + l = (pixel p, slot s) against the S views with p's table column and p's reference sums (fetched from the
+// owner lane by ds_bpermute).  Same evaluations as strong_eval_px, hence the same bits.  LDS: 18 KB table + 1088 B of item
+// list = 8 workgroups per CU, as before.
+template <int SMP>
+__device__ __forceinline__ void strong_eval_items_body(const Dev& d, const LaunchArgs& a) {
+	const int lane = threadIdx.x;
+	const int b = blockIdx.x;
+	const int tile = (b >> 5) * 8 + (b & 7), wave = (b >> 3) & 3;
+	__shared__ f2 lds_tab[kTaps * kTaps * 64];
+	__shared__ uint8_t items[64 * kSlotCount];
+	int px = 0, py = 0;
+	bool active = block_to_pixel(tile, lane, wave, a.tiles_x, a.tiles, a.rows, a.half, a.colour, d.width, d.height, &px, &py);
+	if (active && d.weak_info[px + py * d.width] == DVP_WEAK) active = false;
+	PatchCtx c;
+	c.tab = PatchTab{&lds_tab[lane], 64};
+	c.sum_ref = c.sum_ref_ref = c.wsum = 0.0f;
+	c.radius = c.inc = c.fast = 0;
+	uint32_t uniq = 0;
+	if (active) {
+		const int center = px + py * d.width;
+		int radius, inc;
+		patch_geometry(d, center, &radius, &inc);
+		build_patch_ctx(d, px, py, radius, inc, 0, c.tab, &c);
+		uint32_t w[3];
+		uniq = strong_slot_sources(d, center, w);
+		const size_t Lh = (size_t)d.half_w * (size_t)d.height;
+		uint32_t* dup = reinterpret_cast<uint32_t*>(d.strong_rec) + half_index(d, px, py);
+		dup[SR_DUP * Lh] = w[0]; dup[(SR_DUP + 1) * Lh] = w[1]; dup[(SR_DUP + 2) * Lh] = w[2];
+	}
+	// exclusive prefix sum of the lanes' item counts
+	const int n = __popc(uniq);
+	int incl = n;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const int t = __shfl_up(incl, o, 64);
+		if (lane >= o) incl += t;
+	}
+	const int off = incl - n;
+	const int total = __shfl(incl, 63, 64);
+	{
+		int k = 0;
+		for (uint32_t m = uniq; m; m &= m - 1, ++k) items[off + k] = (uint8_t)lane;
+	}
+	__syncthreads();
+	unsigned long long cnt = 0;
+	for (int i0 = 0; i0 < total; i0 += 64) {
+		const bool valid = i0 + lane < total;
+		const int i = valid ? i0 + lane : total - 1;   // the tail of the last round repeats its last item without storing
+		const int pl = items[i];
+		const int k = i - __shfl(off, pl, 64);
+		uint32_t m = (uint32_t)__shfl((int)uniq, pl, 64);
+		for (int j = 0; j < k; ++j) m &= m - 1;
+		const int slot = dvp_ctz(m);
+		PatchCtx ci;
+		ci.tab = PatchTab{&lds_tab[pl], 64};
+		ci.sum_ref = __shfl(c.sum_ref, pl, 64);
+		ci.sum_ref_ref = __shfl(c.sum_ref_ref, pl, 64);
+		ci.wsum = __shfl(c.wsum, pl, 64);
+		ci.radius = __shfl(c.radius, pl, 64);
+		ci.inc = __shfl(c.inc, pl, 64);
+		ci.fast = __shfl(c.fast, pl, 64);
+		const int ipx = __shfl(px, pl, 64), ipy = __shfl(py, pl, 64);
+		strong_eval_item<SMP>(d, ci, ipx, ipy, slot, valid, d.eval_counter ? &cnt : nullptr);
+	}
+	if (d.eval_counter && cnt) atomicAdd(d.eval_counter, cnt);
+}
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_HEAVY) dvp_strong_eval_items(const Dev d, const LaunchArgs a) { strong_eval_items_body<0>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_HEAVY) dvp_strong_eval_items_exact(const Dev d, const LaunchArgs a) { strong_eval_items_body<1>(d, a); }
 DVP_KERNEL64(dvp_strong_refine, kStageStrongRefine, DVP_LB_HEAVY)
 DVP_KERNEL64(dvp_strong_refine_lanes, kStageStrongRefineLanes, DVP_LB_HEAVY)
 template <int MV>
@@ -750,6 +823,7 @@ struct dvp_ctx {
 	float* slot_costs = nullptr; // [17][S][half_w * H]: split strong update (allocated at its first launch)
 	float* strong_rec = nullptr; // [SR_FIELDS][half_w * H]
 	bool strong_split = true;    // DVP_STRONG_SPLIT=0 in the environment: the monolithic kernel (A/B measurements)
+	bool eval_items = true;      // DVP_EVAL_ITEMS=0: dvp_strong_eval with a pixel per lane instead of (pixel, slot) items over the lanes
 	bool refine_lanes = true;    // DVP_REFINE_LANES=0: dvp_strong_refine with the wave in lock step over hypotheses and views
 	f4* sweep_rec = nullptr; float* sweep_cost = nullptr; float* sweep_pc = nullptr;   // DepthToWeak + LocalRefine as view-compacted passes (allocated at the first fused launch)
 	bool sweep_split = true;     // DVP_SWEEP_SPLIT=0, or the buffers did not fit: the fused per-pixel kernel
@@ -863,6 +937,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	c->no_images8 = getenv("DVP_NO_IMAGES8") != nullptr;
 	if (const char* e = getenv("DVP_STRONG_SPLIT")) c->strong_split = atoi(e) != 0;
 	if (const char* e = getenv("DVP_REFINE_LANES")) c->refine_lanes = atoi(e) != 0;
+	if (const char* e = getenv("DVP_EVAL_ITEMS")) c->eval_items = atoi(e) != 0;
 	if (const char* e = getenv("DVP_SWEEP_SPLIT")) { c->sweep_split = atoi(e) != 0; c->sweep_force = atoi(e) == 2; }
 	if (const char* e = getenv("DVP_WEAK_ANCHOR_TAB")) c->anchor_tab_off = atoi(e) == 0;   // A/B measurements and the tests of the per-item form
 	if (const char* e = getenv("DVP_GN_WAVE")) c->gn_wave = atoi(e) != 0;
@@ -1401,7 +1476,8 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 		}
 		if (c->strong_split && c->NI - 1 <= 16) {
 			const int S = c->NI - 1;
-			hipLaunchKernelGGL(c->d.sampler ? dvp_strong_eval_exact : dvp_strong_eval, wave_grid, wave_block, 0, c->stream, c->d, a);
+			if (c->eval_items) hipLaunchKernelGGL(c->d.sampler ? dvp_strong_eval_items_exact : dvp_strong_eval_items, wave_grid, wave_block, 0, c->stream, c->d, a);
+			else hipLaunchKernelGGL(c->d.sampler ? dvp_strong_eval_exact : dvp_strong_eval, wave_grid, wave_block, 0, c->stream, c->d, a);
 			if (S <= 4) hipLaunchKernelGGL(dvp_strong_decide_v4, grid, block, 0, c->stream, c->d, a);
 			else if (S <= 6) hipLaunchKernelGGL(dvp_strong_decide_v6, grid, block, 0, c->stream, c->d, a);
 			else if (S <= 8) hipLaunchKernelGGL(dvp_strong_decide_v8, grid, block, 0, c->stream, c->d, a);

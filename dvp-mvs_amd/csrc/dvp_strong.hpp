@@ -469,31 +469,82 @@ DVP_HD void strong_update_px(const Dev& d, int px, int py, PatchTab tab, int ite
 // strong_update_px stays the definition (host emulation, S > 16, dvp_run_stage A/B with DVP_STRONG_SPLIT=0).
 constexpr int kSlotCur = 16;                 // slot_costs slot of the pixel's current plane
 constexpr int kSlotCount = 17;
-enum { SR_PLANE = 0, SR_DEPTH = 4, SR_COST = 5, SR_CENTER = 6, SR_DRAND = 7, SR_DPERT = 8, SR_NRAND = 9, SR_FIELDS = 12 };
+enum { SR_PLANE = 0, SR_DEPTH = 4, SR_COST = 5, SR_CENTER = 6, SR_DRAND = 7, SR_DPERT = 8, SR_NRAND = 9, SR_DUP = 12 /* 3 words: strong_slot_sources */, SR_FIELDS = 15 };
 DVP_HD size_t half_index(const Dev& d, int px, int py) { return (size_t)py * d.half_w + (size_t)(px >> 1); }
 DVP_HD size_t slot_cost_index(const Dev& d, int slot, int v, int px, int py) {
 	const size_t Lh = (size_t)d.half_w * (size_t)d.height;
 	return (size_t)(slot * (d.params.num_images - 1) + v) * Lh + half_index(d, px, py);
 }
+// Round 4: the cost vector of a slot is a pure function of (pixel, plane), and the 17 planes of a pixel repeat — the
+// edge-adaptive and the fixed search of a direction often end on the same pixel, and propagation itself makes neighbours
+// carry bit-identical planes (11 % of the launch site's evaluations at cfg3).  Every bitwise-DISTINCT plane is evaluated
+// once; a slot whose plane an earlier slot has already had is served by that slot's vector (same inputs through the same
+// code: the same bits): src[slot] = the earliest slot with the same plane (itself when it is the first), 4 bits per slot in
+// w[0] (slots 0-7) and w[1] (8-15), w[2] = src[16].  Returns the mask of the slots to evaluate.
+DVP_HD bool same_plane_bits(const f4 a, const f4 b) {
+	return f32_bits(a.x) == f32_bits(b.x) && f32_bits(a.y) == f32_bits(b.y) && f32_bits(a.z) == f32_bits(b.z) && f32_bits(a.w) == f32_bits(b.w);
+}
+DVP_HD uint32_t strong_slot_sources(const Dev& d, int center, uint32_t w[3]) {
+	const size_t L = (size_t)d.width * d.height;
+	f4 pl[kSlotCount];
+	uint32_t have = 0, uniq = 0;
+#pragma unroll
+	for (int slot = 0; slot < kSlotCount; ++slot) {
+		const int pos = slot < 16 ? d.search_pos[(size_t)slot * L + center] : center;
+		pl[slot] = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (pos >= 0) { pl[slot] = d.planes_snap[pos]; have |= 1u << slot; }
+	}
+	w[0] = w[1] = w[2] = 0;
+#pragma unroll
+	for (int slot = 0; slot < kSlotCount; ++slot) {
+		int src = slot;
+#pragma unroll
+		for (int u = slot - 1; u >= 0; --u)     // ends with the EARLIEST equal slot, which is an evaluated one
+			if (((have >> u) & 1u) && same_plane_bits(pl[u], pl[slot])) src = u;
+		if (!((have >> slot) & 1u)) continue;
+		if (src == slot) uniq |= 1u << slot;
+		if (slot < 8) w[0] |= (uint32_t)src << (4 * slot);
+		else if (slot < 16) w[1] |= (uint32_t)src << (4 * (slot - 8));
+		else w[2] = (uint32_t)src;
+	}
+	return uniq;
+}
+DVP_HD int strong_slot_source(uint32_t w0, uint32_t w1, uint32_t w2, int slot) {
+	return slot < 8 ? (int)((w0 >> (4 * slot)) & 15u) : slot < 16 ? (int)((w1 >> (4 * (slot - 8))) & 15u) : (int)w2;
+}
+// one (pixel, slot) item: the slot's plane against all S views -> slot_costs
+template <int SMP>
+DVP_HD void strong_eval_item(const Dev& d, const PatchCtx& c, int px, int py, int slot, bool store, unsigned long long* nevals) {
+	const int W = d.width;
+	const int center = py * W + px;
+	const int S = d.params.num_images - 1;
+	const size_t L = (size_t)W * d.height;
+	const int pos = slot < 16 ? d.search_pos[(size_t)slot * L + center] : center;
+	const f4 plane = d.planes_snap[pos];
+	for (int v = 0; v < S; ++v) {
+		const float cost = ncc_old<SMP>(d, c, px, py, v + 1, plane);
+		if (store) d.slot_costs[slot_cost_index(d, slot, v, px, py)] = cost;
+	}
+	if (nevals && store) *nevals += (unsigned long long)S;
+}
+// the pixel's share of the evaluation launch, one lane per pixel (the definition: host emulation, DVP_EVAL_ITEMS=0; the
+// engine's default is the same items compacted over the lanes of a wave, dvp_strong_eval_items)
 template <int SMP>
 DVP_HD void strong_eval_px(const Dev& d, int px, int py, PatchTab tab, unsigned long long* nevals) {
 	const int W = d.width;
 	const int center = py * W + px;
-	const int S = d.params.num_images - 1;
 	PatchCtx c;
 	{
 		int radius, inc;
 		patch_geometry(d, center, &radius, &inc);
 		build_patch_ctx(d, px, py, radius, inc, 0, tab, &c);
 	}
-	const size_t L = (size_t)W * d.height;
-	for (int slot = 0; slot < kSlotCount; ++slot) {
-		const int pos = slot < 16 ? d.search_pos[(size_t)slot * L + center] : center;
-		if (pos < 0) continue;
-		const f4 plane = d.planes_snap[pos];
-		for (int v = 0; v < S; ++v) d.slot_costs[slot_cost_index(d, slot, v, px, py)] = ncc_old<SMP>(d, c, px, py, v + 1, plane);
-		if (nevals) *nevals += (unsigned long long)S;
-	}
+	uint32_t w[3];
+	const uint32_t uniq = strong_slot_sources(d, center, w);
+	const size_t Lh = (size_t)d.half_w * (size_t)d.height, hi = half_index(d, px, py);
+	uint32_t* dup = reinterpret_cast<uint32_t*>(d.strong_rec) + hi;
+	dup[SR_DUP * Lh] = w[0]; dup[(SR_DUP + 1) * Lh] = w[1]; dup[(SR_DUP + 2) * Lh] = w[2];
+	for (uint32_t m = uniq; m; m &= m - 1) strong_eval_item<SMP>(d, c, px, py, dvp_ctz(m), true, nevals);
 }
 
 // Everything of strong_update_px between the propagation evaluations and the refinement evaluations, statement for
@@ -511,6 +562,9 @@ DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
 	float ca[8][MV];
 	uint32_t flag = 0;
 	int positions[8];
+	// which slot's vector serves a slot (strong_slot_sources, written by the evaluation launch)
+	const uint32_t* dup = reinterpret_cast<const uint32_t*>(d.strong_rec) + hi;
+	const uint32_t dw0 = dup[SR_DUP * Lh], dw1 = dup[(SR_DUP + 1) * Lh], dw2 = dup[(SR_DUP + 2) * Lh];
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
 		positions[k] = 0;
@@ -524,9 +578,10 @@ DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
 		if (pos >= 0) {
 			flag |= 1u << k;
 			positions[k] = pos;
+			const float* sc = d.slot_costs + (size_t)(strong_slot_source(dw0, dw1, dw2, k) * S) * Lh + hi;
 #pragma unroll
 			for (int v = 0; v < MV; ++v)
-				if (v < S) ca[k][v] = d.slot_costs[(size_t)(k * S + v) * Lh + hi];
+				if (v < S) ca[k][v] = sc[(size_t)v * Lh];
 		}
 	}
 #pragma unroll
@@ -537,11 +592,12 @@ DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
 			flag |= 1u << k;
 			float cb[MV];
 			int good0 = 0, good1 = 0, bad0 = 0, bad1 = 0;
+			const float* sc = d.slot_costs + (size_t)(strong_slot_source(dw0, dw1, dw2, 8 + k) * S) * Lh + hi;
 #pragma unroll
 			for (int j = 0; j < MV; ++j) {
 				cb[j] = 0.0f;
 				if (j < S) {
-					cb[j] = d.slot_costs[(size_t)((8 + k) * S + j) * Lh + hi];
+					cb[j] = sc[(size_t)j * Lh];
 					const float a = ca[k][j], b = cb[j];
 					if (a < good_thr) good0++;
 					if (a > 1.2f) bad0++;
@@ -654,7 +710,7 @@ DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
 	float cn = 0.0f;
 #pragma unroll
 	for (int v = 0; v < MV; ++v)
-		if (v < S && vw[v] > 0) cn += vw[v] * d.slot_costs[(size_t)(kSlotCur * S + v) * Lh + hi];
+		if (v < S && vw[v] > 0) cn += vw[v] * d.slot_costs[(size_t)((int)dw2 * S + v) * Lh + hi];
 	float cost_now = cn / weight_norm;
 	const float costs_center = cost_now;
 	f4 plane_now = d.planes_snap[center];

@@ -261,6 +261,9 @@ def test_launch_geometry_covers_every_pixel_once():
 @pytest.mark.parametrize("form", ["split", "split_lockstep_refine", "monolithic"])
 @pytest.mark.parametrize("S", [3, 5, 9, 12])
 def test_strong_update_forms_equal_the_oracle(form, S, monkeypatch):
+    """split: evaluation of the bitwise-distinct planes of a pixel's 17 slots ((pixel, slot) items over the lanes on the
+    engine, dvp_strong_eval_items), decisions through the slot -> source-slot table, refinement with every lane on its own
+    (hypothesis, view) sequence; split_lockstep_refine: a pixel per lane in both (dvp_strong_eval, dvp_strong_refine)."""
     strong_update_forms_case(_pair, _run_and_compare, form, S, monkeypatch)
 
 
@@ -271,6 +274,7 @@ def strong_update_forms_case(_pair, _run_and_compare, form, S, monkeypatch):
     write-back rule included: bit-identical to the oracle after every launch."""
     monkeypatch.setenv("DVP_STRONG_SPLIT", "0" if form == "monolithic" else "1")
     monkeypatch.setenv("DVP_REFINE_LANES", "0" if form == "split_lockstep_refine" else "1")   # dvp_strong_refine[_lanes]
+    monkeypatch.setenv("DVP_EVAL_ITEMS", "0" if form == "split_lockstep_refine" else "1")     # engine: dvp_strong_eval[_items]
     W, H = 72, 56
     sc = synth.make_scene(W, H, S)
     for state in (synth.FIRST_INIT, synth.REFINE_INIT):
