@@ -106,7 +106,7 @@ def extra_kernels(stage, S):
     if stage == "strong_update" and S <= 16 and os.environ.get("DVP_STRONG_SPLIT", "1") != "0":
         return [(decide_kernel(S), 1), ("dvp_strong_refine_lanes" if os.environ.get("DVP_REFINE_LANES", "1") != "0" else "dvp_strong_refine", 1)]
     if stage == "depth_to_weak" and sweep_split():   # DepthToWeak + LocalRefine as view-compacted passes
-        return [("dvp_sweep_prepare", 1), ("dvp_sweep_decide1", 1), ("dvp_sweep_decide2", 1), ("dvp_depth_to_weak_refine", 1)] + \
+        return [("dvp_sweep_prepare", 1), ("dvp_sweep_decide1", 1), ("dvp_sweep_decide2", 1), ("dvp_sweep_border", 1)] + \
                []
     return []
 

@@ -310,6 +310,33 @@ __device__ __forceinline__ void sweep_eval_body(const Dev& d, const LaunchArgs& 
 	}
 	if (d.eval_counter && cnt) atomicAdd(d.eval_counter, cnt);
 }
+// The 6-pixel frame of the view-compacted form (UNKNOWN for DepthToWeak, a full LocalRefine: the fused kernel's per-pixel
+// code) over the frame's pixels only: lane t of the launch = the t-th frame pixel (6 rows on top, 6 at the bottom, 2 x 6
+// columns between them).  The full-grid launch kept 8 800 waves resident for 6 active lanes each at 6208 x 4128 (6.6 ms).
+template <int SMP>
+__device__ __forceinline__ void sweep_border_body(const Dev& d, const LaunchArgs& a) {
+	__shared__ f2 lds_tab[kTaps * kTaps * 64];
+	const PatchTab tab{&lds_tab[threadIdx.x], 64};
+	const int W = d.width, H = d.height;
+	const long long t = (long long)blockIdx.x * 64 + threadIdx.x;
+	int px, py;
+	if (t < 12ll * W) {
+		const int r = (int)(t / W);
+		px = (int)(t - (long long)r * W);
+		py = r < 6 ? r : H - 12 + r;
+	} else {
+		const long long u = t - 12ll * W;
+		const int r = (int)(u / 12), cidx = (int)(u - 12ll * r);
+		if (r >= H - 12) return;
+		py = 6 + r;
+		px = cidx < 6 ? cidx : W - 12 + cidx;
+	}
+	unsigned long long n = 0;
+	run_pixel<kStageSweeps, SMP>(d, px, py, kSweepBorderOnly, d.eval_counter ? &n : nullptr, tab);
+	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
+}
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_HEAVY) dvp_sweep_border(const Dev d, const LaunchArgs a) { sweep_border_body<0>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, DVP_LB_HEAVY) dvp_sweep_border_exact(const Dev d, const LaunchArgs a) { sweep_border_body<1>(d, a); }
 extern "C" __global__ void __launch_bounds__(64, DVP_LB_HEAVY) dvp_sweep_eval(const Dev d, const LaunchArgs a) { sweep_eval_body<0>(d, a); }
 extern "C" __global__ void __launch_bounds__(64, DVP_LB_HEAVY) dvp_sweep_eval_exact(const Dev d, const LaunchArgs a) { sweep_eval_body<1>(d, a); }
 
@@ -1530,7 +1557,11 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 				hipLaunchKernelGGL(ex ? dvp_sweep_eval_exact : dvp_sweep_eval, egrid, dim3(64), 0, c->stream, c->d, s1);
 			}
 			hipLaunchKernelGGL(dvp_sweep_decide2, grid, block, 0, c->stream, c->d, a);
-			hipLaunchKernelGGL(ex ? dvp_depth_to_weak_refine_exact : dvp_depth_to_weak_refine, grid, block, 0, c->stream, c->d, sb);
+			if (c->W >= 12 && c->H >= 12) {
+				const long long frame = 12ll * c->W + 12ll * (c->H - 12);
+				hipLaunchKernelGGL(ex ? dvp_sweep_border_exact : dvp_sweep_border, dim3((unsigned)((frame + 63) / 64)), dim3(64), 0, c->stream, c->d, sb);
+			}
+			else hipLaunchKernelGGL(ex ? dvp_depth_to_weak_refine_exact : dvp_depth_to_weak_refine, grid, block, 0, c->stream, c->d, sb);
 		}
 		else if (fused) hipLaunchKernelGGL(c->d.sampler ? dvp_depth_to_weak_refine_exact : dvp_depth_to_weak_refine, grid, block, 0, c->stream, c->d, a);
 		else hipLaunchKernelGGL(c->d.sampler ? dvp_depth_to_weak_exact : dvp_depth_to_weak, grid, block, 0, c->stream, c->d, a);
