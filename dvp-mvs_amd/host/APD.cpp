@@ -98,7 +98,8 @@ struct PrewarmedCtx {
 	dvp_ctx* ctx = nullptr;
 	int device = 0, w = 0, h = 0, ni = 0;
 	bool active = false;
-} g_prewarm;
+};
+PrewarmedCtx& g_prewarm = *new PrewarmedCtx;   // never destroyed: an exit() while the helper runs must not meet a joinable std::thread's destructor
 dvp_ctx* take_prewarmed(int device, int w, int h, int ni) {   // nullptr when there is none that fits
 	if (!g_prewarm.active) return nullptr;
 	if (g_prewarm.worker.joinable()) g_prewarm.worker.join();
