@@ -285,6 +285,12 @@ std::map<int, ResidentDepth> g_resident_depths;
 }
 void APD::SetResidentDepth(int image_id, const float* device_ptr, int width, int height) { g_resident_depths[image_id] = ResidentDepth{ device_ptr, width, height }; }
 void APD::ClearResidentDepths() { g_resident_depths.clear(); }
+namespace {
+struct ResidentImage { const float* ptr; int w, h; };
+std::map<std::pair<int, int>, ResidentImage> g_resident_images;   // (image id, scale)
+}
+void APD::SetResidentImage(int image_id, int scale, const float* device_ptr, int width, int height) { g_resident_images[{ image_id, scale }] = ResidentImage{ device_ptr, width, height }; }
+void APD::ClearResidentImages() { g_resident_images.clear(); }
 namespace { void (*g_resident_download)(float*, const float*, size_t) = nullptr; }
 void APD::SetResidentDownloader(void (*copy)(float*, const float*, size_t)) { g_resident_download = copy; }
 
@@ -584,8 +590,18 @@ void APD::CudaSpaceInitialization() {
 	}
 	lap("context");
 	std::vector<const float*> ptrs(num_images);
-	for (int i = 0; i < num_images; ++i) ptrs[i] = images[i].ptr<float>(0);
-	DVP_SAFE_CALL(ctx, dvp_upload_images(ctx, ptrs.data(), width));
+	bool resident_images = !g_resident_images.empty();
+	for (int i = 0; i < num_images && resident_images; ++i) {
+		// (a source image of another size than the reference is padded / cropped on the host, APD.cpp:1071-1079: not this path)
+		auto it = g_resident_images.find({ i == 0 ? problem.ref_image_id : problem.src_image_ids[i - 1], problem.scale_size });
+		resident_images = it != g_resident_images.end() && it->second.w == width && it->second.h == height;
+		if (resident_images) ptrs[i] = it->second.ptr;
+	}
+	if (resident_images) DVP_SAFE_CALL(ctx, dvp_upload_images_device(ctx, ptrs.data(), width));
+	else {
+		for (int i = 0; i < num_images; ++i) ptrs[i] = images[i].ptr<float>(0);
+		DVP_SAFE_CALL(ctx, dvp_upload_images(ctx, ptrs.data(), width));
+	}
 	lap("images upload");
 	if (params_host.geom_consistency) {
 		if (!depths_device.empty()) {

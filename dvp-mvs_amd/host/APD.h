@@ -115,6 +115,11 @@ public:
 	// Depth maps of the previous pass resident on this process' device (row-major, pitch = width).  When
 	// the maps of a view and all its sources are registered, a geometric-consistency pass takes them from
 	// there (dvp_upload_depths_device) instead of reading APD/<id>/depths.dmb (APD.cpp:1147-1166).
+	// The float image of a view at the current pyramid level, resident on this process' device (row-major, pitch = width):
+	// when the reference image and all sources of a view are registered at the view's size, CudaSpaceInitialization hands
+	// them over with dvp_upload_images_device instead of re-sending ~100 MB per image and per reference view that uses it.
+	static void SetResidentImage(int image_id, int scale, const float* device_ptr, int width, int height);
+	static void ClearResidentImages();
 	static void SetResidentDepth(int image_id, const float* device_ptr, int width, int height);
 	static void ClearResidentDepths();
 	static void SetResidentDownloader(void (*copy)(float* host, const float* device, size_t count));   // device -> host copy used when a resident map of another size has to be rescaled on the host

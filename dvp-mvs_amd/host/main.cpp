@@ -25,6 +25,7 @@
 #include "comm.h"
 #include <cstdlib>
 #include <map>
+#include <set>
 #include <memory>
 
 namespace {
@@ -297,6 +298,45 @@ private:
 	std::map<int, Slot> maps_;
 };
 
+// The float images of a pyramid level resident on the device: every image this rank's views use (as reference or as
+// source) is uploaded ONCE per level; a view then takes its ten planes with device-to-device copies instead of the host
+// re-sending 100 MB per image and per view that uses it (20 of the 50 ms of host time per full-resolution view).  Bounded
+// by DVP_RESIDENT_IMAGES_GB (default 24): what does not fit keeps the host path.  Images whose size differs from the
+// view's (padded / cropped sources) are simply not matched by APD::CudaSpaceInitialization.
+class LevelImages {
+public:
+	~LevelImages() { Release(); }
+	void Fill(const std::vector<Problem*>& owned, int scale) {
+		Release();
+		const char* e = std::getenv("DVP_RESIDENT_IMAGES_GB");
+		const size_t budget = (size_t)(e ? std::max(0, std::atoi(e)) : 24) << 30;
+		size_t used = 0;
+		std::set<int> ids;
+		for (const Problem* p : owned) { ids.insert(p->ref_image_id); ids.insert(p->src_image_ids.begin(), p->src_image_ids.end()); }
+		if (owned.empty()) return;
+		Problem q = *owned[0];
+		q.scale_size = scale;
+		for (int id : ids) {
+			int oc = 0, orr = 0;
+			const Mat img = APD::CachedImage(q, id, &oc, &orr);   // reference role: the image at its own size
+			const size_t count = (size_t)img.cols * img.rows;
+			if (img.empty() || used + count * 4 > budget) continue;
+			float* dev = RankComm::DeviceAlloc(count);
+			RankComm::HostToDevice(dev, img.ptr<float>(0), count);
+			blocks_.push_back(dev);
+			used += count * 4;
+			APD::SetResidentImage(id, scale, dev, img.cols, img.rows);
+		}
+	}
+	void Release() {
+		APD::ClearResidentImages();
+		for (float* b : blocks_) RankComm::DeviceFree(b);
+		blocks_.clear();
+	}
+private:
+	std::vector<float*> blocks_;
+};
+
 // The owner of a view (rank v % world) decodes + resizes its image at this level and broadcasts it; the others
 // take it from the broadcast into their image cache: every image file is read by exactly one process and the
 // decode work is spread over the ranks.
@@ -403,9 +443,11 @@ int main(int argc, char** argv) {
 	if (opt.jacobi) { exchange.reset(new DepthExchange(comm, problems)); APD::SetResidentDownloader(&RankComm::DeviceToHost); }
 	else if (!opt.sync_io) inplace.reset(new InPlaceDepths());
 	int shared_scale = -1;
+	LevelImages level_images;
 	for (size_t it = 0; it < plan.size(); ++it) {
 		const Pass& pass = plan[it];
-		if (pass.scale != shared_scale) {
+		const bool new_level = pass.scale != shared_scale;
+		if (new_level) {
 			ShareLevelImages(comm, problems, pass.scale);
 			shared_scale = pass.scale;
 			if (exchange) exchange->Release();   // maps of the coarser level do not fit this one (and its A pass has no geometric term)
@@ -416,6 +458,7 @@ int main(int argc, char** argv) {
 			ConfigurePass(problem, pass, (int)it, opt.iters, round_num);
 			if (problem.index % opt.world == opt.rank) owned.push_back(&problem);
 		}
+		if (new_level && !opt.sync_io) level_images.Fill(owned, pass.scale);
 		// last pass of a level: the next level's context and float images are made by helper threads while the GPU works
 		if (!opt.sync_io && it + 1 < plan.size() && plan[it + 1].scale != pass.scale && !owned.empty()) {
 			int nw = 0, nh = 0;
@@ -451,6 +494,7 @@ int main(int argc, char** argv) {
 	if (exchange) exchange->Release();
 	exchange.reset();
 	inplace.reset();
+	level_images.Release();
 	APD::ReleasePooledContext();
 	FlushResults();          // every result file of this rank is on disk before anyone (rank 0's fusion) reads the folder
 	comm.Barrier();
