@@ -275,3 +275,88 @@ def depth_to_weak(images, depth_maps, cams, x, y, plane_world, views, weights, d
         if abs(var - 0.2) < eps:
             fragile = True
     return (None if fragile else st), line, min_peak
+
+
+def local_refine(images, depth_maps, cams, x, y, plane_world, views, weights, depth_min, depth_max, geom, geom_factor=0.2,
+                 radius=5, increment=2):
+    """APD.cu:4053-4139 for one pixel.  Returns (new depth or None = unchanged, fragile): fragile where the acceptance
+    test or the choice between two sweep slots sits within 1e-4 of flipping (float32 vs float64)."""
+    R = cams[0]["R"]
+    n = tuple(R[3 * r] * plane_world[0] + R[3 * r + 1] * plane_world[1] + R[3 * r + 2] * plane_world[2] for r in range(3))   # TransformNormal2RefCam
+    z0 = float(plane_world[3])
+    if z0 == 0:
+        return None, False
+    S = len(cams) - 1
+    sel = [s for s in range(1, S + 1) if (views >> (s - 1)) & 1]
+    wn = float(sum(weights[s - 1] for s in sel))
+    if wn == 0 or not sel:
+        return None, False
+    base = sum(math.sqrt(sum((cams[0]["c"][k] - cams[s]["c"][k]) ** 2 for k in range(3))) for s in sel) / len(sel)
+
+    def total(z, separate):
+        pl = (n[0], n[1], n[2], distance_to_origin(cams[0], x, y, z, n))
+        acc = 0.0
+        for s in sel:
+            c = ncc_old(images, cams, x, y, s, pl, radius, increment)
+            g = geom_factor * geom_cost(depth_maps, cams, x, y, s, pl) if geom else 0.0
+            acc += (c * weights[s - 1] + g * weights[s - 1]) if separate else (c + g) * weights[s - 1]
+        return acc / wn
+
+    cost_now = total(z0, False)                       # :4085-4089: (ncc + factor * geom) * weight
+    disp = cams[0]["K"][0] * base / z0
+    eps = 1e-4
+    fragile = False
+    min_cost, best = 2.0, z0
+    for pd in range(-5, 6):
+        with np.errstate(divide="ignore"):
+            z = float(np.float64(cams[0]["K"][0] * base) / np.float64(disp + pd))
+        if z < depth_min or z > depth_max:
+            continue
+        t = total(z, True)                            # :4124-4126: ncc * weight and factor * geom * weight added one after the other
+        if abs(t - min_cost) < eps:
+            fragile = True
+        if t < min_cost:
+            min_cost, best = t, z
+    if abs(cost_now - min_cost - 0.1) < eps:
+        fragile = True
+    return (best if cost_now - min_cost > 0.1 else None), fragile
+
+
+def filter_strong(depth, costs, weak, W, H, x, y, STRONG=1):
+    """CheckerboardFilterStrong (APD.cu:3184-3294) for one pixel on float32 arrays: the new depth, or None = untouched."""
+    c = y * W + x
+    if costs[c] < np.float32(0.001):
+        return None
+    taps = [(0, -1, y > 0), (0, -3, y > 2), (0, -5, y > 4), (0, 1, y < H - 1), (0, 3, y < H - 3), (0, 5, y < H - 5),
+            (-1, 0, x > 0), (-3, 0, x > 2), (-5, 0, x > 4), (1, 0, x < W - 1), (3, 0, x < W - 3), (5, 0, x < W - 5),
+            (2, -1, y > 0 and x < W - 2), (2, 1, y < H - 1 and x < W - 2), (-2, -1, y > 0 and x > 1), (-2, 1, y < H - 1 and x > 1),
+            (-1, -2, x > 0 and y > 2), (1, -2, x < W - 1 and y > 2), (-1, 2, x > 0 and y < H - 2), (1, 2, x < W - 1 and y < H - 2)]
+    vals = [depth[c]]
+    for dx, dy, ok in taps:
+        if ok and weak[(y + dy) * W + x + dx] == STRONG:
+            vals.append(depth[(y + dy) * W + x + dx])
+    vals = np.sort(np.array(vals, np.float32))
+    m = len(vals) // 2
+    return np.float32((vals[m - 1] + vals[m]) / np.float32(2)) if len(vals) % 2 == 0 else vals[m]
+
+
+def get_depth_normal(cam, pl, x, y):
+    """GetDepthandNormal (APD.cu:3167-3182): depth of the plane at the pixel, normal rotated to the world (TransformNormal)."""
+    z = depth_from_plane(cam, pl, x, y)
+    R = cam["R"]
+    return (R[0] * pl[0] + R[3] * pl[1] + R[6] * pl[2], R[1] * pl[0] + R[4] * pl[1] + R[7] * pl[2], R[2] * pl[0] + R[5] * pl[1] + R[8] * pl[2], z)
+
+
+def find_nearest_strong(weak, W, H, x, y, STRONG=1, max_radius=100):
+    """FindNearestStrongPoint (APD.cu:4159-4193): rings of growing Chebyshev radius, x outer, y inner, first STRONG pixel."""
+    for r in range(max_radius + 1):
+        for dx in range(-r, r + 1):
+            for dy in range(-r, r + 1):
+                if abs(dx) != r and abs(dy) != r:
+                    continue
+                qx, qy = x + dx, y + dy
+                if qx < 0 or qy < 0 or qx >= W or qy >= H:
+                    continue
+                if weak[qy * W + qx] == STRONG:
+                    return qx, qy
+    return -1, -1

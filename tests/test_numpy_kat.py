@@ -207,3 +207,90 @@ def test_depth_to_weak_rotated_cameras_vs_numpy():
     print("depth_to_weak oracle vs numpy64: %d / %d agree (%d fragile skipped), states %s" % (agree, total, fragile, hist))
     assert total >= 60 and hist[1] > 10
     assert agree >= total - 1     # a float32-vs-float64 flip inside the 61-entry line is possible, rarely
+
+
+def test_local_refine_rotated_cameras_vs_numpy():
+    """LocalRefine (APD.cu:4053-4139): the cost at the current depth, the sweep over disparity offsets -5..5 with the source's
+    two ways of adding the geometric term, the 0.1 acceptance rule — numpy float64 reading against the oracle's launch."""
+    S = 3
+    sc, cams, imgs, deps = _scene(112, 80, S)
+    o, p = _two_pass(sc, S, 1)
+    o.run_patchmatch()
+    W, H = sc["width"], sc["height"]
+    o.run_stage("depth_to_weak")
+    planes = o.get("planes").copy()
+    # a converged pass leaves nothing to refine: push a third of the depths off by 8-30 % (one to four disparity steps at this scale) so that the sweep has something to find
+    rng = np.random.default_rng(12)
+    off = rng.random(H * W) < 0.33
+    planes[off, 3] *= (1.0 + rng.choice([-1.0, 1.0], int(off.sum())) * rng.uniform(0.08, 0.3, int(off.sum()))).astype(np.float32)
+    o.set("planes", planes)
+    views, vw, radius = o.get("selected_views"), o.get("view_weight").reshape(-1, 32), o.get("radius")
+    o.run_stage("local_refine")
+    after = o.get("planes")
+    rng = np.random.default_rng(10)
+    agree = total = fragile = moved = 0
+    for c in rng.choice(H * W, 120, replace=False):
+        x, y = int(c % W), int(c // W)
+        r = int(radius[c])
+        z, frag = M.local_refine(imgs, deps, cams, x, y, planes[c].astype(np.float64), int(views[c]), vw[c].astype(np.float64),
+                                 float(p["depth_min"]), float(p["depth_max"]), True, radius=r, increment=max(2, int(2.0 * r / 5.0)))
+        if frag:
+            fragile += 1
+            continue
+        total += 1
+        want = float(planes[c][3]) if z is None else z
+        moved += z is not None
+        agree += abs(float(after[c][3]) - want) <= 2e-5 * abs(want) and (after[c][:3] == planes[c][:3]).all()
+    print("local_refine oracle vs numpy64: %d / %d agree (%d fragile skipped), %d moved" % (agree, total, fragile, moved))
+    assert total >= 80 and moved >= 3
+    assert agree >= total - 1
+
+
+def test_filter_get_depth_normal_nearest_strong_vs_numpy():
+    """The three array-shaped launch sites against readings written from the source: CheckerboardFilterStrong (APD.cu:3184-3294,
+    exact: a median of float32 depths), GetDepthandNormal (APD.cu:3167-3182), FindNearestStrongPoint (APD.cu:4159-4193, exact)."""
+    S = 3
+    sc, cams, imgs, deps = _scene(112, 80, S)
+    o, p = _two_pass(sc, S, 1)
+    W, H = sc["width"], sc["height"]
+    rng = np.random.default_rng(11)
+    # FindNearestStrongPoint
+    weak = o.get("weak_info").copy()
+    o.run_stage("find_nearest_strong")
+    wns = o.get("weak_nearest_strong").reshape(-1, 2)
+    wk = np.flatnonzero(weak == synth.WEAK)
+    assert len(wk) > 50
+    for c in rng.choice(wk, 60, replace=False):
+        assert tuple(int(t) for t in wns[c]) == M.find_nearest_strong(weak, W, H, int(c % W), int(c // W), STRONG=synth.STRONG)
+    assert (wns[weak != synth.WEAK] == -1).all()
+    # the pass up to the conversion: planes in the camera frame with the plane offset in .w
+    for st, colour in (("gen_edge_inform", 0), ("gen_neighbours", 0), ("neighbour_update", 0), ("random_init", 0), ("strong_update", 0), ("strong_update", 1)):
+        o.run_stage(st, 0, colour)
+    before = o.get("planes").copy()
+    o.run_stage("get_depth_normal")
+    after = o.get("planes").copy()
+    d = []
+    for c in rng.choice(H * W, 200, replace=False):
+        x, y = int(c % W), int(c // W)
+        want = np.array(M.get_depth_normal(cams[0], before[c].astype(np.float64), x, y))
+        d.append(np.max(np.abs(after[c] - want) / np.maximum(1e-3, np.abs(want))))
+    print("get_depth_normal oracle vs numpy64: max rel %.2e" % max(d))
+    assert max(d) < 2e-5
+    # CheckerboardFilterStrong, black then red
+    costs = o.get("costs")
+    state = o.get("weak_info")
+    for colour in (0, 1):
+        depth = o.get("planes")[:, 3].copy()
+        o.run_stage("filter_strong", 0, colour)
+        new = o.get("planes")[:, 3]
+        checked = 0
+        for c in rng.choice(H * W, 400, replace=False):
+            x, y = int(c % W), int(c // W)
+            if (x + y) % 2 != colour or state[c] == synth.WEAK:   # the launch's half of the checkerboard (APD.cu:3296-3328); WEAK pixels are skipped
+                assert new[c].view(np.uint32) == depth[c].view(np.uint32) or np.isnan(new[c])
+                continue
+            want = M.filter_strong(depth, costs, state, W, H, x, y, STRONG=synth.STRONG)
+            want = depth[c] if want is None else want
+            assert np.float32(want).view(np.uint32) == new[c].view(np.uint32), (x, y, want, new[c], depth[c])
+            checked += 1
+        assert checked > 100
