@@ -145,10 +145,13 @@ void APD::PrefetchLevelImages(std::vector<Problem> views, int scale) {
 		int w = 0, h = 0;
 		if (!views.empty() && LevelSize(views[0], scale, &w, &h)) {
 			std::vector<Mat> sets;
-			for (size_t v = 0; v < views.size(); ++v)
+			size_t bytes = 0;
+			const size_t keep = matpool::pool().cap;   // what the pool will not hold would be touched for nothing
+			for (size_t v = 0; v < views.size() && bytes + 25 * (size_t)w * h <= keep; ++v)
 				for (int type : { CV_32FC1, CV_32FC3, CV_32SC1, CV_32SC1, CV_8UC1 }) {
 					sets.emplace_back(h, w, type);
 					std::memset(sets.back().data, 0, sets.back().step * (size_t)h);
+					bytes += sets.back().step * (size_t)h;
 				}
 		}
 		--g_prefetch_threads;
