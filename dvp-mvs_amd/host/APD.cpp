@@ -134,8 +134,14 @@ bool APD::LevelSize(const Problem& problem, int scale, int* w, int* h) {
 void APD::PrefetchLevelImages(std::vector<Problem> views, int scale) {
 	++g_prefetch_threads;
 	std::thread([views, scale]() mutable {
+		int lw = 0, lh = 0;
+		const bool sized = !views.empty() && LevelSize(views[0], scale, &lw, &lh);
 		for (Problem& p : views) {
 			p.scale_size = scale;
+			{   // never at the price of the level in use: a full cache evicts the OTHER levels' images first (make_room)
+				std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
+				if (g_img_cache.size() + 1 >= g_img_cache_capacity || (sized && cache_bytes_locked() + (size_t)lw * lh * 4 > g_img_cache_byte_limit)) break;
+			}
 			int oc, orr;
 			(void)CachedImage(p, p.ref_image_id, &oc, &orr);
 		}
