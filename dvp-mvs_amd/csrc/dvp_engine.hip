@@ -181,27 +181,30 @@ __device__ __forceinline__ void strong_eval_items_body(const Dev& d, const Launc
 		uint32_t* dup = reinterpret_cast<uint32_t*>(d.strong_rec) + half_index(d, px, py);
 		dup[SR_DUP * Lh] = w[0]; dup[(SR_DUP + 1) * Lh] = w[1]; dup[(SR_DUP + 2) * Lh] = w[2];
 	}
-	// exclusive prefix sum of the lanes' item counts
+	// Item order: rank-major — the first distinct slot of every pixel, then the second of every pixel that has one, ... —
+	// so that the lanes of a round are neighbouring pixels with (mostly) the same direction's sample, as in the
+	// pixel-per-lane kernel: their taps share cache lines.  (Pixel-major order — all slots of pixel 0, then pixel 1 — put
+	// up to 17 unrelated planes of one pixel side by side: L2 hit rate of the launch site 0.87 -> 0.58.)
+	// start[k] = number of items of the ranks below k (wave-uniform: 17 ballots).
 	const int n = __popc(uniq);
-	int incl = n;
+	int start[kSlotCount + 1];
+	start[0] = 0;
 #pragma unroll
-	for (int o = 1; o < 64; o <<= 1) {
-		const int t = __shfl_up(incl, o, 64);
-		if (lane >= o) incl += t;
+	for (int k = 0; k < kSlotCount; ++k) {
+		const unsigned long long mk = __ballot(n > k);
+		if (n > k) items[start[k] + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+		start[k + 1] = start[k] + __popcll(mk);
 	}
-	const int off = incl - n;
-	const int total = __shfl(incl, 63, 64);
-	{
-		int k = 0;
-		for (uint32_t m = uniq; m; m &= m - 1, ++k) items[off + k] = (uint8_t)lane;
-	}
+	const int total = start[kSlotCount];
 	__syncthreads();
 	unsigned long long cnt = 0;
 	for (int i0 = 0; i0 < total; i0 += 64) {
 		const bool valid = i0 + lane < total;
 		const int i = valid ? i0 + lane : total - 1;   // the tail of the last round repeats its last item without storing
 		const int pl = items[i];
-		const int k = i - __shfl(off, pl, 64);
+		int k = 0;
+#pragma unroll
+		for (int r = 1; r < kSlotCount; ++r) k += i >= start[r] ? 1 : 0;
 		uint32_t m = (uint32_t)__shfl((int)uniq, pl, 64);
 		for (int j = 0; j < k; ++j) m &= m - 1;
 		const int slot = dvp_ctz(m);

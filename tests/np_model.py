@@ -360,3 +360,152 @@ def find_nearest_strong(weak, W, H, x, y, STRONG=1, max_radius=100):
                 if weak[qy * W + qx] == STRONG:
                     return qx, qy
     return -1, -1
+
+
+def strong_propagation(images, cams, x, y, planes, costs, edge, edge_neigh, selected_views, W, H, it, uniforms, depth_min, depth_max,
+                       radius=5, increment=2):
+    """CheckerboardPropagationStrong, use_edge branch, up to the adoption of the best propagated plane (APD.cu:2010-2141,
+    2462-2567), for one pixel.  planes / costs: the buffers as they stand BEFORE the launch (the contract's snapshot),
+    camera-frame planes (n, offset).  uniforms: the 15 numbers of curand_uniform's place for this pixel and iteration.
+    Returns dict(view_weight[S], selected (or None = not adopted), adopted position or None, fragile)."""
+    S = len(cams) - 1
+    f32 = np.float32
+    eps = 2e-4
+    fragile = False
+    cost_array = [[0.0] * S for _ in range(8)]
+    cost_array[0][0] = 2.0          # `= { 2.0f }` sets one element (APD.cu:2032)
+    flag = [False] * 8
+    positions = [0] * 8
+    dirs = [(0, -1), (0, 1), (-1, 0), (1, 0), (-1, -1), (1, 1), (-1, 1), (1, -1)]
+    c = y * W + x
+    max_edge_dist = f32(max(H, W)) / f32(30.0)
+    min_step = 2
+
+    def vector(pos):
+        pl = planes[pos].astype(np.float64)
+        return [ncc_old(images, cams, x, y, v, pl, radius, increment) for v in range(1, S + 1)]
+
+    def scan(di, step_num, step_len):
+        dx, dy = dirs[di]
+        best, best_cost = None, None
+        for step in range(step_num):
+            fx = fy = 0
+            if di > 4:                    # (`> 4`, not `>= 4`: the source's test)
+                if di % 2:
+                    fx = dx
+                else:
+                    fy = dy
+            tx, ty = x + 5 * dx + step * step_len * dx + fx, y + 5 * dy + step * step_len * dy + fy
+            if not (0 <= tx < W and 0 <= ty < H):
+                continue
+            cst = costs[tx + ty * W]
+            if best_cost is None or best_cost > cst:       # min_cost starts at FLT_MAX; `min_cost > cost`: a NaN never wins
+                if cst == cst and cst < np.finfo(np.float32).max:
+                    best, best_cost = tx + ty * W, cst
+        return best
+
+    for di in range(8):
+        ex, ey = int(edge_neigh[c, di, 0]), int(edge_neigh[c, di, 1])
+        dist = f32(math.sqrt(float(ex - x) ** 2 + float(ey - y) ** 2))
+        if di >= 4:
+            dist = f32(np.float64(dist) / math.sqrt(2.0))
+        if edge[c]:
+            dist = f32(11 * min_step)
+        elif ey == -1 or dist >= max_edge_dist:          # `!edge_pt.x == -1` is never true (APD.cu:2059)
+            dist = max_edge_dist
+            if di >= 4:
+                dist = f32(np.float64(dist) / math.sqrt(2.0))
+        q = f32(f32(1.0) * dist / f32(min_step))
+        if 0 < abs(float(q) - round(float(q))) < 1e-4:      # (an exact integer is exact in binary32 too)
+            fragile = True
+        step_num = min(max(11, int(q)), 22)
+        q2 = f32(f32(1.0) * dist / f32(step_num))
+        if 0 < abs(float(q2) - round(float(q2))) < 1e-4:
+            fragile = True
+        step_len = max(int(q2), min_step)
+        if di < 4 and step_len % 2 == 1:
+            step_len -= 1
+        pos = scan(di, step_num, step_len)
+        if pos is not None:
+            flag[di] = True
+            positions[di] = pos
+            cost_array[di] = vector(pos)
+    good_thr = 0.8 * math.exp(it * it / -90.0)
+    if not edge[c]:
+        for di in range(8):
+            had = flag[di]
+            pos = scan(di, 11, min_step)
+            if pos is None:
+                continue
+            flag[di] = True
+            tv = vector(pos)
+            for val in cost_array[di][:S] + tv:
+                if abs(val - good_thr) < eps or abs(val - 1.2) < eps:
+                    fragile = True
+            g0 = sum(v < good_thr for v in cost_array[di][:S]); b0 = sum(v > 1.2 for v in cost_array[di][:S])
+            g1 = sum(v < good_thr for v in tv); b1 = sum(v > 1.2 for v in tv)
+            if (not had) or g1 > g0 or (g1 == g0 and b1 < b0):
+                positions[di] = pos
+                cost_array[di] = tv
+    # joint view selection (APD.cu:2462-2530)
+    priors = [0.0] * S
+    for i, nb in enumerate((c - W, c + W, c - 1, c + 1)):
+        if flag[2 * i]:
+            for j in range(S):
+                priors[j] += 0.9 if (int(selected_views[nb]) >> j) & 1 else 0.1
+    probs = [0.0] * S
+    for i in range(S):
+        count = cf = 0
+        tmpw = 0.0
+        for j in range(8):
+            v = cost_array[j][i]
+            if abs(v - good_thr) < eps or abs(v - 1.2) < eps:
+                fragile = True
+            if v < good_thr:
+                tmpw += math.exp(v * v / -0.18)
+                count += 1
+            if v > 1.2:
+                cf += 1
+        if count > 2 and cf < 3:
+            probs[i] = tmpw / count
+        elif cf < 3:
+            probs[i] = math.exp(good_thr * good_thr / -0.32)
+        probs[i] *= priors[i]
+    tot = sum(probs)
+    vw = [0] * S
+    if tot > 0:
+        cdf, cum = [], 0.0
+        for pr in probs:
+            cum += pr / tot
+            cdf.append(cum)
+        for u in uniforms:
+            rp = u - 1.1920929e-07
+            for j in range(S):
+                if abs(cdf[j] - rp) < 1e-5:
+                    fragile = True
+                if cdf[j] > rp:
+                    vw[j] += 1
+                    break
+    else:
+        fragile = True          # 1 / 0 and NaN comparisons: float32 territory
+    wn = float(sum(vw))
+    out = dict(view_weight=vw, selected=None, adopted=None, fragile=fragile)
+    if wn == 0:
+        return out
+    final = [sum(vw[j] * cost_array[i][j] for j in range(S) if vw[j] > 0) / wn for i in range(8)]
+    mi, mc = 0, final[0]
+    for i in range(1, 8):                      # FindMinCostIndex: ties go to the LAST (APD.cu:155-166)
+        if abs(final[i] - mc) < eps and final[i] != mc:
+            out["fragile"] = True
+        if final[i] <= mc:
+            mc, mi = final[i], i
+    now = vector(c)
+    cost_now = sum(vw[j] * now[j] for j in range(S)) / wn
+    if flag[mi]:
+        z = depth_from_plane(cams[0], planes[positions[mi]].astype(np.float64), x, y)
+        if abs(final[mi] - cost_now) < eps:
+            out["fragile"] = True
+        if depth_min <= z <= depth_max and final[mi] < cost_now:
+            out["selected"] = sum(1 << j for j in range(S) if vw[j] > 0)
+            out["adopted"] = positions[mi]
+    return out

@@ -294,3 +294,58 @@ def test_filter_get_depth_normal_nearest_strong_vs_numpy():
             assert np.float32(want).view(np.uint32) == new[c].view(np.uint32), (x, y, want, new[c], depth[c])
             checked += 1
         assert checked > 100
+
+
+def test_strong_propagation_and_view_selection_vs_numpy():
+    """The decision half of CheckerboardPropagationStrong (APD.cu:2010-2141, 2462-2567) read from the source into numpy — the
+    edge-adaptive and the fixed sample scan with their quirks (`!edge_pt.x == -1`, `dir_index > 4`, `= { 2.0f }`), the
+    replacement rule, the joint view selection from the 8 cost vectors and the neighbours' priors, the 15 draws against the
+    CDF, FindMinCostIndex' tie rule, the adoption test — against what the oracle's launch leaves in view_weight and
+    selected_views.  The random numbers are the contract's (ora_rand_u32 at the documented site); the costs are the float64
+    model's, so pixels where a comparison sits within 2e-4 of flipping are skipped."""
+    S = 3
+    sc, cams, imgs, _ = _scene(112, 80, S)
+    W, H = sc["width"], sc["height"]
+    p = make_params(S + 1, max_iterations=2, state=synth.FIRST_INIT, use_APD=0)
+    seed = 4242
+    o = O.from_scene(sc, p, seed=seed, sampler=1)
+    o.upload_state(**first_pass_state(sc))
+    for st in ("gen_edge_inform", "random_init"):
+        o.run_stage(st)
+    # one full iteration first, so that costs / planes / selected views are a real mid-pass state
+    o.run_stage("strong_update", 0, 0)
+    o.run_stage("strong_update", 0, 1)
+    it = 1
+    planes, costs = o.get("planes").copy(), o.get("costs").copy()
+    views_before = o.get("selected_views").copy()
+    edge, en = o.get("edge"), o.get("edge_neigh").reshape(H * W, 8, 2)
+    radius = o.get("radius")
+    o.run_stage("strong_update", it, 0)
+    vw_after = o.get("view_weight").reshape(-1, 32)
+    views_after = o.get("selected_views")
+    site = (2 << 16) | ((it & 0xFF) << 8) | 0          # rng_site(PH_STRONG, iter, SUB_VIEW), oracle/ora_common.h
+    L = O.lib()
+    rng = np.random.default_rng(13)
+    black = [c for c in range(H * W) if (c % W + c // W) % 2 == 0 and 12 <= c % W < W - 12 and 12 <= c // W < H - 12]
+    checked = adopted = fragile = on_edge = 0
+    on_edges = [c for c in black if edge[c] != 0]
+    sample = list(rng.choice(black, 70, replace=False)) + list(rng.choice(on_edges, min(20, len(on_edges)), replace=False))
+    for c in sample:
+        x, y = int(c % W), int(c // W)
+        u = [((L.ora_rand_u32(seed, int(c), site, k) >> 8) + 1) / 16777216.0 for k in range(15)]
+        r = int(radius[c])
+        m = M.strong_propagation(imgs, cams, x, y, planes, costs, edge, en, views_before, W, H, it, u, float(p["depth_min"]), float(p["depth_max"]),
+                                 radius=r, increment=max(2, int(2.0 * r / 5.0)) if int(p["use_radius"]) else int(p["strong_increment"]))
+        if m["fragile"]:
+            fragile += 1
+            continue
+        checked += 1
+        on_edge += int(edge[c] != 0)
+        assert list(vw_after[c][:S]) == m["view_weight"], (x, y, list(vw_after[c][:S]), m["view_weight"])
+        if m["selected"] is not None:
+            adopted += 1
+            assert int(views_after[c]) == m["selected"], (x, y)
+        else:
+            assert int(views_after[c]) == int(views_before[c]), (x, y)
+    print("strong propagation oracle vs numpy: %d pixels checked (%d fragile skipped), %d adoptions, %d edge pixels" % (checked, fragile, adopted, on_edge))
+    assert checked >= 40 and adopted >= 5 and on_edge >= 5
