@@ -489,7 +489,7 @@ def strong_propagation(images, cams, x, y, planes, costs, edge, edge_neigh, sele
     else:
         fragile = True          # 1 / 0 and NaN comparisons: float32 territory
     wn = float(sum(vw))
-    out = dict(view_weight=vw, selected=None, adopted=None, fragile=fragile)
+    out = dict(view_weight=vw, selected=None, adopted=None, fragile=fragile, wn=wn, plane=None, cost=None)
     if wn == 0:
         return out
     final = [sum(vw[j] * cost_array[i][j] for j in range(S) if vw[j] > 0) / wn for i in range(8)]
@@ -501,6 +501,7 @@ def strong_propagation(images, cams, x, y, planes, costs, edge, edge_neigh, sele
             mc, mi = final[i], i
     now = vector(c)
     cost_now = sum(vw[j] * now[j] for j in range(S)) / wn
+    out["plane"], out["cost"] = planes[c].astype(np.float64), cost_now
     if flag[mi]:
         z = depth_from_plane(cams[0], planes[positions[mi]].astype(np.float64), x, y)
         if abs(final[mi] - cost_now) < eps:
@@ -508,4 +509,91 @@ def strong_propagation(images, cams, x, y, planes, costs, edge, edge_neigh, sele
         if depth_min <= z <= depth_max and final[mi] < cost_now:
             out["selected"] = sum(1 << j for j in range(S) if vw[j] > 0)
             out["adopted"] = positions[mi]
+            out["plane"], out["cost"] = planes[positions[mi]].astype(np.float64), final[mi]
     return out
+
+
+def _view_direction(cam, px, py, depth):
+    """GetViewDirection (APD.cu:386-398)."""
+    K = cam["K"]
+    X = (depth * (px - K[2]) / K[0], depth * (py - K[5]) / K[4], depth)
+    nrm = math.sqrt(X[0] ** 2 + X[1] ** 2 + X[2] ** 2)
+    return (X[0] / nrm, X[1] / nrm, X[2] / nrm)
+
+
+def random_normal_yzl(cams, x, y, depth, selected, uniforms):
+    """GenerateRandomNormal_YZL (APD.cu:501-585) without the geometric term (src_depth = 1): the view directions of the
+    reference and of the selected sources — the latter through the source's quirks: (x, y, x) as the direction vector and
+    A[7] twice in the last row of matMul3x1 — then up to 200 rejection rounds of a uniform point on the sphere.
+    uniforms: callable k -> the k-th number of the stream.  Returns (normal, fragile)."""
+    dirs = [_view_direction(cams[0], x, y, depth)]
+    Rr = cams[0]["R"]
+    for s in range(1, len(cams)):
+        if not (selected >> (s - 1)) & 1:
+            continue
+        fwd = point_on_world(x, y, depth, cams[0])
+        sx, sy, _ = project_on_camera(fwd, cams[s])
+        ix, iy = int(float(int(sx)) + 0.5), int(float(int(sy)) + 0.5)      # make_int2((int)x + 0.5f, ...)
+        d = _view_direction(cams[s], ix, iy, 1.0)
+        Rs = cams[s]["R"]
+        Rt = [Rs[j * 3 + i] for i in range(3) for j in range(3)]            # transpose
+        Rc = [sum(Rr[i * 3 + k] * Rt[k * 3 + j] for k in range(3)) for i in range(3) for j in range(3)]
+        v = (d[0], d[1], d[0])                                              # {x, y, x} (APD.cu:543)
+        f = (Rc[0] * v[0] + Rc[1] * v[1] + Rc[2] * v[2], Rc[3] * v[0] + Rc[4] * v[1] + Rc[5] * v[2], Rc[6] * v[0] + Rc[7] * v[1] + Rc[7] * v[2])   # A[7] twice (APD.cu:17)
+        nrm = math.sqrt(f[0] ** 2 + f[1] ** 2 + f[2] ** 2)
+        if len(dirs) < 20:
+            dirs.append((f[0] / nrm, f[1] / nrm, f[2] / nrm))
+    k = 0
+    fragile = False
+    n = (0.0, 0.0, 0.0)
+    times = 200
+    while times > 0:
+        s_ = 2.0
+        while s_ >= 1.0:
+            q1 = 2.0 * uniforms(k) - 1.0
+            q2 = 2.0 * uniforms(k + 1) - 1.0
+            k += 2
+            s_ = q1 * q1 + q2 * q2
+            if abs(s_ - 1.0) < 1e-6:
+                fragile = True
+        sq = math.sqrt(1.0 - s_)
+        n = (2.0 * q1 * sq, 2.0 * q2 * sq, 1.0 - 2.0 * s_)
+        ok = True
+        for dv in dirs:
+            dot = n[0] * dv[0] + n[1] * dv[1] + n[2] * dv[2]
+            if abs(dot) < 1e-6:
+                fragile = True
+            if dot > 0.0:
+                ok = False
+                break
+        if ok:
+            break
+        times -= 1
+    nrm = math.sqrt(n[0] ** 2 + n[1] ** 2 + n[2] ** 2)
+    return (n[0] / nrm, n[1] / nrm, n[2] / nrm), fragile
+
+
+def strong_refinement(images, cams, x, y, plane, cost, vw, wn, selected, depth_min, depth_max, u_depth, u_pert, u_normal, radius=5, increment=2):
+    """PlaneHypothesisRefinementStrong (APD.cu:1311-1383): six hypotheses built from the values at entry, each adopted when its
+    depth is in range and its weighted cost is below the running best.  Returns (plane, cost, fragile)."""
+    S = len(cams) - 1
+    depth = depth_from_plane(cams[0], plane, x, y)
+    depth_rand = u_depth * (depth_max - depth_min) + depth_min
+    n_rand, fragile = random_normal_yzl(cams, x, y, depth, selected, u_normal)
+    lo, hi = (1 - 0.02) * depth, (1 + 0.02) * depth
+    depth_pert = u_pert * (hi - lo) + lo
+    nn = math.sqrt(plane[0] ** 2 + plane[1] ** 2 + plane[2] ** 2)
+    n_pert = (plane[0] / nn, plane[1] / nn, plane[2] / nn)                  # GeneratePerturbedNormal returns the normalised input (APD.cu:617-661)
+    n0 = (plane[0], plane[1], plane[2])
+    hyps = [(depth_rand, n0), (depth, n_rand), (depth_rand, n_rand), (depth, n_pert), (depth, n_pert), (depth_pert, n0)]
+    best_plane, best_cost = tuple(plane), cost
+    for z, n in hyps:
+        pl = (n[0], n[1], n[2], distance_to_origin(cams[0], x, y, z, n))
+        t = sum(vw[j] * ncc_old(images, cams, x, y, j + 1, pl, radius, increment) for j in range(S) if vw[j] > 0) / wn
+        zb = depth_from_plane(cams[0], pl, x, y)
+        same = max(abs(a - b) / max(1e-2, abs(b)) for a, b in zip(pl, best_plane)) < 5e-5   # (the re-normalised current plane: either answer is the same plane)
+        if abs(t - best_cost) < 2e-4 and not same:
+            fragile = True
+        if depth_min <= zb <= depth_max and t < best_cost:
+            best_plane, best_cost = pl, t
+    return best_plane, best_cost, fragile

@@ -323,6 +323,8 @@ def test_strong_propagation_and_view_selection_vs_numpy():
     o.run_stage("strong_update", it, 0)
     vw_after = o.get("view_weight").reshape(-1, 32)
     views_after = o.get("selected_views")
+    planes_after, costs_after = o.get("planes"), o.get("costs")
+    refined = improved = fragile2 = 0
     site = (2 << 16) | ((it & 0xFF) << 8) | 0          # rng_site(PH_STRONG, iter, SUB_VIEW), oracle/ora_common.h
     L = O.lib()
     rng = np.random.default_rng(13)
@@ -347,5 +349,23 @@ def test_strong_propagation_and_view_selection_vs_numpy():
             assert int(views_after[c]) == m["selected"], (x, y)
         else:
             assert int(views_after[c]) == int(views_before[c]), (x, y)
-    print("strong propagation oracle vs numpy: %d pixels checked (%d fragile skipped), %d adoptions, %d edge pixels" % (checked, fragile, adopted, on_edge))
+        # ... and the refinement that follows (APD.cu:1311-1383 with GenerateRandomNormal_YZL, :501-585): the plane and the
+        # cost the launch leaves
+        if m["plane"] is None:
+            continue
+        uni = lambda sub: (lambda k: ((L.ora_rand_u32(seed, int(c), (2 << 16) | ((it & 0xFF) << 8) | sub, k) >> 8) + 1) / 16777216.0)
+        inc = max(2, int(2.0 * r / 5.0)) if int(p["use_radius"]) else int(p["strong_increment"])
+        pl, cost, frag2 = M.strong_refinement(imgs, cams, x, y, m["plane"], m["cost"], m["view_weight"], m["wn"], int(views_after[c]),
+                                              float(p["depth_min"]), float(p["depth_max"]), uni(1)(0), uni(3)(0), uni(2), radius=r, increment=inc)
+        if frag2:
+            fragile2 += 1
+            continue
+        refined += 1
+        improved += tuple(pl) != tuple(m["plane"])
+        got = planes_after[c].astype(np.float64)
+        assert np.max(np.abs(got - np.array(pl)) / np.maximum(1e-2, np.abs(pl))) < 2e-4, (x, y, got, pl)
+        assert abs(float(costs_after[c]) - cost) < 5e-4, (x, y, costs_after[c], cost)
+    print("strong propagation oracle vs numpy: %d pixels checked (%d fragile skipped), %d adoptions, %d edge pixels; refinement: %d checked (%d fragile), %d changed the plane"
+          % (checked, fragile, adopted, on_edge, refined, fragile2, improved))
     assert checked >= 40 and adopted >= 5 and on_edge >= 5
+    assert refined >= 30 and improved >= 3
