@@ -597,3 +597,88 @@ def strong_refinement(images, cams, x, y, plane, cost, vw, wn, selected, depth_m
         if depth_min <= zb <= depth_max and t < best_cost:
             best_plane, best_cost = pl, t
     return best_plane, best_cost, fragile
+
+
+def gen_edge_inform(image, selected_views, edge, label, weak, W, H, x, y, S, weak_radius=5, strong_radius=5, sigma_color=3.0, WEAK=0):
+    """GenEdgeInform (APD.cu:3731-3890) for one pixel: the visibility-prior offsets per source view (the best-weighted
+    neighbour that selected the view in each 30-degree sector, the sectors then ranked by that weight, the first eight
+    kept), the nearest edge pixel in the eight directions, the edge density sigmoid of a WEAK pixel and — with a positive
+    label — the farthest pixel of the own label before a label -1 in the eight directions.
+    Returns dict(candidates[S][8] (or None where a ranking is fragile), edge_neigh[8], complex, label_boundary)."""
+    c = y * W + x
+    cands = []
+    centre = float(image[y, x])
+    for v in range(S):
+        regions = [[] for _ in range(12)]
+        for i in range(-weak_radius, weak_radius + 1):
+            for j in range(-weak_radius, weak_radius + 1):
+                if i == 0 and j == 0:
+                    continue
+                qx, qy = x + i, y + j
+                if not (0 <= qx < W and 0 <= qy < H):
+                    continue
+                if not (int(selected_views[qx + qy * W]) >> v) & 1:
+                    continue
+                ang = math.degrees(math.atan2(float(j), float(i)))
+                if ang < 0:
+                    ang += 360.0
+                ang = float(np.float32(ang))           # `float angle = calculateAngle(i, j)` (APD.cu:3759)
+                w = math.exp(-abs(float(image[qy, qx]) - centre) / (2.0 * sigma_color * sigma_color))   # ComputeBilateralWeight_YZL: colour only
+                r = int(ang // 30.0) if 0 <= ang < 360 else -1
+                if len(regions[r]) < 20:               # Point regions[12][20] (APD.cu:3751)
+                    regions[r].append((w, i, j))
+        fragile = False
+        heads = []
+        for r in range(12):
+            if not regions[r]:
+                heads.append((0.0, 0, 0))              # regions[i][0] of an empty sector: defined as offset (0, 0), weight 0
+                continue
+            best = regions[r][0]
+            for t in regions[r][1:]:                   # bubbleSort descending, swaps on strict `<`: the first of equals stays first
+                if abs(t[0] - best[0]) < 1e-6 * max(best[0], 1e-30) and t[0] != best[0]:
+                    fragile = True
+                if t[0] > best[0]:
+                    best = t
+            heads.append(best)
+        order = sorted(range(12), key=lambda r: -heads[r][0])      # stable: ties keep sector order, like the bubble sort
+        for a in range(11):
+            wa, wb = heads[order[a]][0], heads[order[a + 1]][0]
+            if wa != wb and abs(wa - wb) < 1e-6 * max(wa, 1e-30):
+                fragile = True
+        cands.append(None if fragile else [(heads[r][1], heads[r][2]) for r in order[:8]])
+    dirs = [(0, -1), (0, 1), (-1, 0), (1, 0), (-1, -1), (1, 1), (-1, 1), (1, -1)]
+    en = []
+    for dx, dy in dirs:
+        nx, ny, hit = x + dx, y + dy, (-1, -1)
+        while 0 <= nx < W and 0 <= ny < H:
+            if edge[nx + ny * W]:
+                hit = (nx, ny)
+                break
+            nx += dx
+            ny += dy
+        en.append(hit)
+    out = dict(candidates=cands, edge_neigh=en, complex=None, label_boundary=None)
+    if weak[c] == WEAK:
+        ep = tot = 0
+        for i in range(-strong_radius, strong_radius + 1):
+            for j in range(-strong_radius, strong_radius + 1):
+                nx, ny = x + i, y + j
+                if 0 <= nx < W and 0 <= ny < H:
+                    ep += int(edge[ny * W + nx] != 0)
+                    tot += 1
+        out["complex"] = 1.0 / (1.0 + math.exp(-25.0 * (ep / tot - 0.35)))
+        if label[c] > 0:
+            lb = []
+            for dx, dy in dirs:
+                nx, ny, last = x + dx, y + dy, (-1, -1)
+                while 0 <= nx < W and 0 <= ny < H:
+                    nl = label[nx + ny * W]
+                    if nl == label[c]:
+                        last = (nx, ny)
+                    elif nl == -1:
+                        break
+                    nx += dx
+                    ny += dy
+                lb.append(last)
+            out["label_boundary"] = lb
+    return out

@@ -369,3 +369,42 @@ def test_strong_propagation_and_view_selection_vs_numpy():
           % (checked, fragile, adopted, on_edge, refined, fragile2, improved))
     assert checked >= 40 and adopted >= 5 and on_edge >= 5
     assert refined >= 30 and improved >= 3
+
+
+def test_gen_edge_inform_vs_numpy():
+    """GenEdgeInform (APD.cu:3731-3890) read into numpy: visibility-prior offsets (sector winners ranked by colour weight: exact
+    integers), nearest edge pixels (exact), the edge-density sigmoid of WEAK pixels, label boundaries (exact)."""
+    S = 4
+    sc, cams, imgs, _ = _scene(128, 96, S)
+    o, p = _two_pass(sc, S, 1)
+    W, H = sc["width"], sc["height"]
+    views, edge, label, weak = o.get("selected_views").copy(), o.get("edge").copy(), o.get("label").copy(), o.get("weak_info").copy()
+    o.run_stage("gen_edge_inform")
+    cand = o.get("candidate").reshape(H * W, S, 8, 2)
+    en = o.get("edge_neigh").reshape(H * W, 8, 2)
+    nmap = o.get("neighbours_map")
+    cx, lb = o.get("complex"), o.get("label_boundary").reshape(-1, 8, 2)
+    rng = np.random.default_rng(14)
+    wk = np.flatnonzero(weak == synth.WEAK)
+    sample = list(rng.choice(H * W, 60, replace=False)) + list(rng.choice(wk, 40, replace=False))
+    n_c = n_f = n_lab = 0
+    dc = []
+    for c in sample:
+        x, y = int(c % W), int(c // W)
+        m = M.gen_edge_inform(imgs[0], views, edge, label, weak, W, H, x, y, S, weak_radius=int(p["weak_radius"]), strong_radius=int(p["strong_radius"]),
+                              sigma_color=float(p["sigma_color"]), WEAK=synth.WEAK)
+        assert [tuple(int(t) for t in q) for q in en[c]] == m["edge_neigh"], (x, y)
+        for v in range(S):
+            if m["candidates"][v] is None:
+                n_f += 1
+                continue
+            n_c += 1
+            assert [tuple(int(t) for t in q) for q in cand[c, v]] == m["candidates"][v], (x, y, v)
+        if weak[c] == synth.WEAK:
+            dc.append(abs(float(cx[nmap[c]]) - m["complex"]))
+            if m["label_boundary"] is not None:
+                n_lab += 1
+                assert [tuple(int(t) for t in q) for q in lb[nmap[c]]] == m["label_boundary"], (x, y)
+    print("gen_edge_inform oracle vs numpy: %d candidate lists exact (%d fragile skipped), complex max diff %.1e on %d WEAK pixels, %d label boundaries exact"
+          % (n_c, n_f, max(dc), len(dc), n_lab))
+    assert n_c > 250 and len(dc) >= 40 and max(dc) < 1e-5 and n_lab >= 10
