@@ -682,3 +682,140 @@ def gen_edge_inform(image, selected_views, edge, label, weak, W, H, x, y, S, wea
                 lb.append(last)
             out["label_boundary"] = lb
     return out
+
+
+def bresenham_hits_edge(edge, W, H, A, B):
+    """BresenhamLine(A, B) (APD.cu:267-311): walks from B towards A for at most max(H, W) / 30 steps; true when it meets an
+    edge pixel.  False at once for long segments and for segments whose END POINTS lie on an edge."""
+    max_step = int(max(H, W) / 30.0)
+    x0, y0, x1, y1 = B[0], B[1], A[0], A[1]
+    if (A[0] - B[0]) ** 2 + (A[1] - B[1]) ** 2 > 9 * max_step * max_step:
+        return False
+    if edge[x0 + y0 * W] or edge[x1 + y1 * W]:
+        return False
+    dx, sx = abs(x1 - x0), (1 if x0 < x1 else -1)
+    dy, sy = abs(y1 - y0), (1 if y0 < y1 else -1)
+    err = (dx if dx > dy else dy) // 2
+    step = 0
+    tagx = tagy = True
+    while tagx or tagy:
+        if x0 == x1:
+            tagx = False
+        if y0 == y1:
+            tagy = False
+        e2 = err
+        if e2 > -dx:
+            err -= dy
+            x0 += sx
+        if e2 < dy:
+            err += dx
+            y0 += sy
+        if edge[x0 + y0 * W]:
+            return True
+        step += 1
+        if step >= max_step:
+            break
+    return False
+
+
+def _point_in_triangle(A, B, C, P):
+    """PointinTriangle (APD.cu:244-265)."""
+    ab = math.hypot(B[0] - A[0], B[1] - A[1]); bc = math.hypot(C[0] - B[0], C[1] - B[1]); ca = math.hypot(A[0] - C[0], A[1] - C[1])
+    if ab <= 2 or bc <= 2 or ca <= 2:
+        return False
+    if not (ab + bc > ca and bc + ca > ab and ab + ca > bc):
+        return False
+    pa, pb, pc = (A[0] - P[0], A[1] - P[1]), (B[0] - P[0], B[1] - P[1]), (C[0] - P[0], C[1] - P[1])
+    cr = lambda u, v: u[0] * v[1] - u[1] * v[0]
+    t1, t2, t3 = cr(pa, pb), cr(pb, pc), cr(pc, pa)
+    return t1 * t2 >= 0 and t1 * t3 >= 0
+
+
+def ransac_fit_plane(cam, planes, anchors, edge, edge_neigh, label_boundary, W, H, x, y, draws, edge_limit, use_radius, use_edge, use_label, strong_radius=5):
+    """RANSACToGetFitPlane (APD.cu:4195-4405) for one WEAK pixel.  anchors: neighbours[1..11] ((-1, -1) = none); planes:
+    camera-frame planes; draws(k): the k-th 32-bit number of the pixel's stream.  Returns (fit plane or None = (0,0,0,0),
+    radius or None = unchanged, fragile)."""
+    pts = [a for a in anchors if a[0] != -1 and a[1] != -1]
+    c = y * W + x
+    if len(pts) < 3:
+        return tuple(planes[c].astype(np.float64)), None, False
+    K = cam["K"]
+    P3, N = [], []
+    for a in pts:
+        pl = planes[a[0] + a[1] * W].astype(np.float64)
+        z = depth_from_plane(cam, pl, a[0], a[1])
+        P3.append((z * (a[0] - K[2]) / K[0], z * (a[1] - K[5]) / K[4], z))
+        N.append(pl[:3])
+    n = len(pts)
+    cache = {}
+    best, best_cost, tri = None, None, None
+    fragile = False
+    k = 0
+    for _ in range(50):
+        ia, ib, ic = draws(k) % n, draws(k + 1) % n, draws(k + 2) % n
+        k += 3
+        if ia == ib or ib == ic or ia == ic:
+            continue
+        dots = (float(np.dot(N[ia], N[ib])), float(np.dot(N[ia], N[ic])), float(np.dot(N[ib], N[ic])))
+        if any(abs(d - 0.9) < 1e-5 for d in dots):
+            fragile = True
+        if dots[0] < 0.9 or dots[1] < 0.9 or dots[2] < 0.9:
+            continue
+        if not _point_in_triangle(pts[ia], pts[ib], pts[ic], (x, y)):
+            continue
+        if edge_limit:
+            for u, v in ((ia, ib), (ib, ic), (ic, ia)):         # symmetric cache, the first asker's orientation (APD.cu:4260-4299)
+                if (u, v) not in cache:
+                    cache[(u, v)] = cache[(v, u)] = bresenham_hits_edge(edge, W, H, pts[u], pts[v])
+            if cache[(ia, ib)] or cache[(ib, ic)] or cache[(ic, ia)]:
+                continue
+        A, B, C = P3[ia], P3[ib], P3[ic]
+        ac = (A[0] - C[0], A[1] - C[1], A[2] - C[2]); bc = (B[0] - C[0], B[1] - C[1], B[2] - C[2])
+        cv = (ac[1] * bc[2] - bc[1] * ac[2], -(ac[0] * bc[2] - bc[0] * ac[2]), ac[0] * bc[1] - bc[0] * ac[1])
+        nn = math.sqrt(cv[0] ** 2 + cv[1] ** 2 + cv[2] ** 2)
+        if nn == 0 or nn != nn:
+            continue
+        cv = (cv[0] / nn, cv[1] / nn, cv[2] / nn)
+        w = -(cv[0] * A[0] + cv[1] * A[1] + cv[2] * A[2])
+        cost = 0.0
+        for si in range(n):
+            if si in (ia, ib, ic):
+                continue
+            fx, fy = (pts[si][0] - K[2]) / K[0], (pts[si][1] - K[5]) / K[4]
+            cost += abs(-w / (cv[0] * fx + cv[1] * fy + cv[2]) - P3[si][2])
+        if best_cost is not None and abs(cost - best_cost) < 1e-5 * max(1.0, best_cost) and cost != best_cost:
+            fragile = True
+        if best_cost is None or cost < best_cost:
+            best_cost, best, tri = cost, (cv[0], cv[1], cv[2], w), (ia, ib, ic)
+    if best is None:
+        return None, (strong_radius if use_radius else None), fragile
+    z = depth_from_plane(cam, planes[c].astype(np.float64), x, y)
+    vd = _view_direction(cam, x, y, z)
+    if best[0] * vd[0] + best[1] * vd[1] + best[2] * vd[2] > 0:
+        best = tuple(-t for t in best)
+    radius = None
+    if use_radius:
+        A, B, C = pts[tri[0]], pts[tri[1]], pts[tri[2]]      # (use_a_index is never assigned in the source: defined as the winning triangle)
+        a, b, c_ = math.hypot(A[0] - B[0], A[1] - B[1]), math.hypot(B[0] - C[0], B[1] - C[1]), math.hypot(C[0] - A[0], C[1] - A[1])
+        p = (a + b + c_) / 2.0
+        area = math.sqrt(max(0.0, p * (p - a) * (p - b) * (p - c_)))
+        q = math.sqrt(area) / 2.0
+        if abs(q - round(q)) < 1e-4:
+            fragile = True
+        radius = int(math.floor(q))
+        md = min(math.hypot(A[0] - x, A[1] - y), math.hypot(B[0] - x, B[1] - y), math.hypot(C[0] - x, C[1] - y))
+        if 2.5 * md < radius:
+            radius = int(md)
+        if edge_limit:
+            if use_edge:
+                ds = [math.hypot(e[0] - x, e[1] - y) for e in edge_neigh if e[0] != -1 and e[1] != -1]
+                if ds and min(ds) < radius:
+                    radius = int(min(ds))
+            if use_label and label_boundary is not None:
+                ds = [math.hypot(e[0] - x, e[1] - y) for e in label_boundary if e[0] != -1 and e[1] != -1]
+                if ds and min(ds) < radius:
+                    radius = int(min(ds))
+        while (radius << 1) % 5 != 0:
+            radius -= 1
+        radius = 0 if radius < strong_radius else radius
+    return best, radius, fragile

@@ -408,3 +408,68 @@ def test_gen_edge_inform_vs_numpy():
     print("gen_edge_inform oracle vs numpy: %d candidate lists exact (%d fragile skipped), complex max diff %.1e on %d WEAK pixels, %d label boundaries exact"
           % (n_c, n_f, max(dc), len(dc), n_lab))
     assert n_c > 250 and len(dc) >= 40 and max(dc) < 1e-5 and n_lab >= 10
+
+
+def test_ransac_fit_plane_vs_numpy():
+    """RANSACToGetFitPlane (APD.cu:4195-4405) read into numpy — anchors -> 3-D points, 50 index triplets from the contract's
+    stream, normal / triangle / edge-line rejections with the symmetric first-asker cache and BresenhamLine's walk from its
+    SECOND argument, the plane through three anchors, the summed depth residual, orientation, the patch-radius rule (Heron,
+    nearest anchor, edge and label limits, multiples of 2.5) — against the fit planes and radii the oracle's launch leaves."""
+    S = 3
+    sc, cams, imgs, _ = _scene(128, 96, S)
+    o, p = _two_pass(sc, S, 1)
+    W, H = sc["width"], sc["height"]
+    for st in ("gen_edge_inform", "find_nearest_strong", "gen_neighbours", "neighbour_update", "random_init"):
+        o.run_stage(st)
+    o.run_stage("strong_update", 0, 0)
+    o.run_stage("strong_update", 0, 1)
+    it = 0
+    planes, weak, edge = o.get("planes").copy(), o.get("weak_info").copy(), o.get("edge")
+    nmap, nbr = o.get("neighbours_map"), o.get("neighbours").reshape(-1, 12, 2)
+    en, lb, cx = o.get("edge_neigh").reshape(H * W, 8, 2), o.get("label_boundary").reshape(-1, 8, 2), o.get("complex")
+    label = o.get("label")
+    radius_before = o.get("radius").copy()
+    o.run_stage("ransac_fit", it, 0)
+    fit, radius_after = o.get("fit_planes"), o.get("radius")
+    L = O.lib()
+    seed = 778
+    site = lambda sub: (3 << 16) | ((it & 0xFF) << 8) | sub       # rng_site(PH_RANSAC, iter, sub)
+    rng = np.random.default_rng(15)
+    wk = np.flatnonzero(weak == synth.WEAK)
+    checked = fitted = none = frag = limited = 0
+    for c in rng.choice(wk, min(150, len(wk)), replace=False):
+        x, y = int(c % W), int(c // W)
+        edge_limit = False
+        if int(p["use_limit"]):
+            edge_limit = True
+            if int(p["use_edge"]):
+                u = ((L.ora_rand_u32(seed, int(c), site(4), 0) >> 8) + 1) / 16777216.0 - 1.1920929e-07
+                if abs(u - float(cx[nmap[c]])) < 1e-6:
+                    continue
+                if u < float(cx[nmap[c]]):
+                    edge_limit = False
+        anchors = [tuple(int(t) for t in a) for a in nbr[nmap[c]][1:]]
+        lbc = [tuple(int(t) for t in q) for q in lb[nmap[c]]] if label[c] > 0 else None
+        pl, rad, fragile = M.ransac_fit_plane(cams[0], planes, anchors, edge, [tuple(int(t) for t in q) for q in en[c]], lbc, W, H, x, y,
+                                              lambda k: L.ora_rand_u32(seed, int(c), site(6), k), edge_limit, int(p["use_radius"]), int(p["use_edge"]),
+                                              int(p["use_label"]), strong_radius=int(p["strong_radius"]))
+        if fragile:
+            frag += 1
+            continue
+        checked += 1
+        limited += int(edge_limit)
+        got = fit[c].astype(np.float64)
+        if pl is None:
+            none += 1
+            assert (got == 0).all(), (x, y, got)
+        else:
+            fitted += 1
+            assert np.max(np.abs(got - np.array(pl)) / np.maximum(1e-2, np.abs(pl))) < 5e-4, (x, y, got, pl)
+        if rad is not None:
+            assert int(radius_after[c]) == rad, (x, y, int(radius_after[c]), rad)
+        else:
+            assert int(radius_after[c]) == int(radius_before[c])
+    print("ransac_fit_plane oracle vs numpy: %d WEAK pixels checked (%d fragile skipped): %d planes fitted, %d without a plane, %d with the edge limit on"
+          % (checked, frag, fitted, none, limited))
+    assert checked >= 80 and fitted >= 20 and limited >= 20
+    assert (fit[weak != synth.WEAK] == planes[weak != synth.WEAK]).all()      # APD.cu:4208-4211
