@@ -521,7 +521,7 @@ def _view_direction(cam, px, py, depth):
     return (X[0] / nrm, X[1] / nrm, X[2] / nrm)
 
 
-def random_normal_yzl(cams, x, y, depth, selected, uniforms):
+def random_normal_yzl(cams, x, y, depth, selected, uniforms, depth_maps=None):
     """GenerateRandomNormal_YZL (APD.cu:501-585) without the geometric term (src_depth = 1): the view directions of the
     reference and of the selected sources — the latter through the source's quirks: (x, y, x) as the direction vector and
     A[7] twice in the last row of matMul3x1 — then up to 200 rejection rounds of a uniform point on the sphere.
@@ -534,7 +534,10 @@ def random_normal_yzl(cams, x, y, depth, selected, uniforms):
         fwd = point_on_world(x, y, depth, cams[0])
         sx, sy, _ = project_on_camera(fwd, cams[s])
         ix, iy = int(float(int(sx)) + 0.5), int(float(int(sy)) + 0.5)      # make_int2((int)x + 0.5f, ...)
-        d = _view_direction(cams[s], ix, iy, 1.0)
+        src_depth = 1.0                                                     # geom off; outside the image: uninitialised in the source, defined as 1
+        if depth_maps is not None and 0 <= ix < cams[0]["width"] and 0 <= iy < cams[0]["height"]:
+            src_depth = float(tex_point(depth_maps[s], int(sx), int(sy)))     # tex2D(depth_image, (int)x + 0.5f, (int)y + 0.5f)
+        d = _view_direction(cams[s], ix, iy, src_depth)
         Rs = cams[s]["R"]
         Rt = [Rs[j * 3 + i] for i in range(3) for j in range(3)]            # transpose
         Rc = [sum(Rr[i * 3 + k] * Rt[k * 3 + j] for k in range(3)) for i in range(3) for j in range(3)]
@@ -819,3 +822,133 @@ def ransac_fit_plane(cam, planes, anchors, edge, edge_neigh, label_boundary, W, 
             radius -= 1
         radius = 0 if radius < strong_radius else radius
     return best, radius, fragile
+
+
+def weak_update(images, depth_maps, cams, x, y, planes, weak, selected_views, anchors, cand, fit_plane, W, H, it, u_view, u_depth, u_pert, u_normal,
+                depth_min, depth_max, geom, geom_factor, radius, increment, STRONG=1):
+    """CheckerboardPropagationWeak + PlaneHypothesisRefinementWeak (APD.cu:2739-3089, 1897-2008) for one WEAK pixel, REFINE_ITER
+    write-back.  anchors: neighbours[0..11]; cand[pixel][view][8][2]: visibility-prior offsets.  Returns dict(view_weight,
+    selected or None, plane, fragile).  (The launch's last step, the plain NCC of the final plane, is ncc_old.)"""
+    S = len(cams) - 1
+    eps = 2e-4
+    fragile = False
+    c = y * W + x
+    av = [0 if a[0] == -1 else int(selected_views[a[0] + a[1] * W]) for a in anchors]
+
+    def vector(pl):
+        out = []
+        for v in range(1, S + 1):
+            offs = [None if a[0] == -1 else cand[a[0] + a[1] * W, v - 1] for a in anchors]
+            out.append(ncc_new(images, cams, x, y, v, pl, anchors, av, offs, radius=radius, increment=increment))
+        return out
+
+    def with_geom(vec, pl, vw):
+        return sum(vw[j] * (vec[j] + (geom_factor * geom_cost(depth_maps, cams, x, y, j + 1, pl) if geom else 0.0)) for j in range(S) if vw[j] > 0)
+
+    cost_array = [[0.0] * S for _ in range(8)]
+    cost_array[0][0] = 2.0
+    flag, pos = [False] * 8, [0] * 8
+    for i in range(8):
+        a = anchors[i + 1]
+        if a[0] == -1 or a[1] == -1 or weak[a[0] + a[1] * W] != STRONG:
+            continue
+        flag[i], pos[i] = True, a[0] + a[1] * W
+        cost_array[i] = vector(planes[pos[i]].astype(np.float64))
+    priors = [0.0] * S
+    for i in range(8):
+        a = anchors[i + 1]
+        if a[0] == -1 or a[1] == -1:
+            continue
+        for j in range(S):
+            priors[j] += 0.9 if (int(selected_views[a[0] + a[1] * W]) >> j) & 1 else 0.1
+    thr = 0.8 * math.exp(it * it / -90.0)
+    probs = [0.0] * S
+    for i in range(S):
+        count = cf = 0
+        tmpw = 0.0
+        for j in range(8):
+            v = cost_array[j][i]
+            if abs(v - thr) < eps or abs(v - 1.2) < eps:
+                fragile = True
+            if v < thr:
+                tmpw += math.exp(v * v / -0.18)
+                count += 1
+            if v > 1.2:
+                cf += 1
+        if count > 2 and cf < 3:
+            probs[i] = tmpw / count
+        elif cf < 3:
+            probs[i] = math.exp(thr * thr / -0.32)
+        probs[i] *= priors[i]
+    tot = sum(probs)
+    vw = [0] * S
+    out = dict(view_weight=vw, selected=None, plane=None, fragile=True)
+    if not tot > 0:
+        return out
+    cdf, cum = [], 0.0
+    for pr in probs:
+        cum += pr / tot
+        cdf.append(cum)
+    for u in u_view:
+        rp = u - 1.1920929e-07
+        for j in range(S):
+            if abs(cdf[j] - rp) < 1e-5:
+                fragile = True
+            if cdf[j] > rp:
+                vw[j] += 1
+                break
+    wn = float(sum(vw))
+    if wn == 0:
+        return out
+    final = []
+    for i in range(8):
+        if geom:
+            t = sum(vw[j] * (cost_array[i][j] + geom_factor * (geom_cost(depth_maps, cams, x, y, j + 1, planes[pos[i]].astype(np.float64)) if flag[i] else 3.0))
+                    for j in range(S) if vw[j] > 0)
+        else:
+            t = sum(vw[j] * cost_array[i][j] for j in range(S) if vw[j] > 0)
+        final.append(t / wn)
+    mi, mc = 0, final[0]
+    for i in range(1, 8):
+        if abs(final[i] - mc) < eps and final[i] != mc:
+            fragile = True
+        if final[i] <= mc:
+            mc, mi = final[i], i
+    plane = planes[c].astype(np.float64)
+    cost = with_geom(vector(plane), plane, vw) / wn
+    selected = None
+    sel_live = int(selected_views[c])
+    if flag[mi]:
+        cand_pl = planes[pos[mi]].astype(np.float64)
+        z = depth_from_plane(cams[0], cand_pl, x, y)
+        if abs(final[mi] - cost) < eps:
+            fragile = True
+        if depth_min <= z <= depth_max and final[mi] < cost:
+            plane, cost = cand_pl, final[mi]
+            selected = sel_live = sum(1 << j for j in range(S) if vw[j] > 0)
+    # PlaneHypothesisRefinementWeak
+    fp = fit_plane.astype(np.float64)
+    if not (fp[0] == 0 and fp[1] == 0 and fp[2] == 0):
+        def consider(pl, plane, cost, fragile):
+            t = with_geom(vector(pl), pl, vw) / wn
+            zb = depth_from_plane(cams[0], pl, x, y)
+            same = max(abs(a - b) / max(1e-2, abs(b)) for a, b in zip(pl, plane)) < 5e-5
+            if abs(t - cost) < eps and not same:
+                fragile = True
+            if depth_min <= zb <= depth_max and t < cost:
+                return tuple(pl), t, fragile
+            return plane, cost, fragile
+        plane, cost, fragile = consider(tuple(fp), tuple(plane), cost, fragile)
+        depth = depth_from_plane(cams[0], plane, x, y)
+        depth_rand = u_depth * (depth_max - depth_min) + depth_min
+        n_rand, fr = random_normal_yzl(cams, x, y, depth, sel_live, u_normal, depth_maps if geom else None)
+        fragile = fragile or fr
+        lo, hi = (1 - 0.02) * depth, (1 + 0.02) * depth
+        depth_pert = u_pert * (hi - lo) + lo
+        nn = math.sqrt(plane[0] ** 2 + plane[1] ** 2 + plane[2] ** 2)
+        n_pert = (plane[0] / nn, plane[1] / nn, plane[2] / nn)
+        n0 = (plane[0], plane[1], plane[2])
+        for z, n in [(depth_rand, n0), (depth, n_rand), (depth_rand, n_rand), (depth, n_pert), (depth, n_pert), (depth_pert, n0)]:
+            pl = (n[0], n[1], n[2], distance_to_origin(cams[0], x, y, z, n))
+            plane, cost, fragile = consider(pl, plane, cost, fragile)
+    return dict(view_weight=vw, selected=selected, plane=tuple(plane), fragile=fragile, wn=wn)

@@ -473,3 +473,61 @@ def test_ransac_fit_plane_vs_numpy():
           % (checked, frag, fitted, none, limited))
     assert checked >= 80 and fitted >= 20 and limited >= 20
     assert (fit[weak != synth.WEAK] == planes[weak != synth.WEAK]).all()      # APD.cu:4208-4211
+
+
+def test_weak_update_vs_numpy():
+    """CheckerboardPropagationWeak + PlaneHypothesisRefinementWeak (APD.cu:2739-3089, 1897-2008) read into numpy on top of the
+    NCCNew model: the anchors' planes as candidates, the priors from the anchors' selected views, view selection, the geometric
+    term in the weighted costs (3.0 for an absent anchor), adoption, the fit-plane test (and its early return), the six
+    refinement hypotheses with GenerateRandomNormal_YZL reading the source depth maps, and the launch's final plain-NCC cost —
+    against the view weights, selected views, planes and costs the oracle's launch leaves."""
+    S = 3
+    sc, cams, imgs, deps = _scene(128, 96, S)
+    o, p = _two_pass(sc, S, 1)
+    W, H = sc["width"], sc["height"]
+    for st in ("gen_edge_inform", "find_nearest_strong", "gen_neighbours", "neighbour_update", "random_init"):
+        o.run_stage(st)
+    it = 0
+    o.run_stage("strong_update", it, 0)
+    o.run_stage("strong_update", it, 1)
+    o.run_stage("ransac_fit", it, 0)
+    planes, weak, views_before = o.get("planes").copy(), o.get("weak_info").copy(), o.get("selected_views").copy()
+    nmap, nbr = o.get("neighbours_map"), o.get("neighbours").reshape(-1, 12, 2)
+    cand = o.get("candidate").reshape(H * W, S, 8, 2)
+    fit, radius = o.get("fit_planes").copy(), o.get("radius").copy()
+    o.run_stage("weak_update", it, 0)
+    vw_after, views_after = o.get("view_weight").reshape(-1, 32), o.get("selected_views")
+    planes_after, costs_after = o.get("planes"), o.get("costs")
+    L = O.lib()
+    seed = 778
+    uni = lambda c, sub: (lambda k: ((L.ora_rand_u32(seed, int(c), (4 << 16) | ((it & 0xFF) << 8) | sub, k) >> 8) + 1) / 16777216.0)   # rng_site(PH_WEAK, ...)
+    rng = np.random.default_rng(16)
+    wk = [c for c in np.flatnonzero(weak == synth.WEAK) if (c % W + c // W) % 2 == 0]
+    checked = frag = adopted = moved = 0
+    for c in rng.choice(wk, min(60, len(wk)), replace=False):
+        x, y = int(c % W), int(c // W)
+        anchors = [tuple(int(t) for t in a) for a in nbr[nmap[c]]]
+        r = int(radius[c])
+        m = M.weak_update(imgs, deps, cams, x, y, planes, weak, views_before, anchors, cand, fit[c], W, H, it, [uni(c, 0)(k) for k in range(15)],
+                          uni(c, 1)(0), uni(c, 3)(0), uni(c, 2), float(p["depth_min"]), float(p["depth_max"]), True, float(p["geom_factor"]),
+                          r, max(2, int(2.0 * r / 5.0)), STRONG=synth.STRONG)
+        if m["fragile"]:
+            frag += 1
+            continue
+        checked += 1
+        assert list(vw_after[c][:S]) == m["view_weight"], (x, y, list(vw_after[c][:S]), m["view_weight"])
+        if m["selected"] is not None:
+            adopted += 1
+            assert int(views_after[c]) == m["selected"], (x, y)
+        else:
+            assert int(views_after[c]) == int(views_before[c]), (x, y)
+        got = planes_after[c].astype(np.float64)
+        assert np.max(np.abs(got - np.array(m["plane"])) / np.maximum(1e-2, np.abs(m["plane"]))) < 3e-4, (x, y, got, m["plane"])
+        moved += int(np.max(np.abs(got - planes[c])) > 0)
+        # the launch's last step (APD.cu:3072-3088): plain NCC of the final plane at the default radius
+        sr = int(p["strong_radius"])
+        inc = max(2, int(2.0 * sr / 5.0)) if int(p["use_radius"]) else int(p["strong_increment"])
+        want = sum(m["view_weight"][j] * M.ncc_old(imgs, cams, x, y, j + 1, m["plane"], sr, inc) for j in range(S)) / m["wn"]
+        assert abs(float(costs_after[c]) - want) < 1e-3, (x, y, costs_after[c], want)
+    print("weak update oracle vs numpy: %d WEAK pixels checked (%d fragile skipped), %d adoptions, %d planes changed" % (checked, frag, adopted, moved))
+    assert checked >= 25 and moved >= 5
