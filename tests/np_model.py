@@ -952,3 +952,241 @@ def weak_update(images, depth_maps, cams, x, y, planes, weak, selected_views, an
             pl = (n[0], n[1], n[2], distance_to_origin(cams[0], x, y, z, n))
             plane, cost, fragile = consider(pl, plane, cost, fragile)
     return dict(view_weight=vw, selected=selected, plane=tuple(plane), fragile=fragile, wn=wn)
+
+
+def gen_neighbours(cam, planes_world, weak, nearest_strong, edge, label, label_boundary, complex_val, W, H, x, y, u_limit, search, ransac,
+                   depth_min, depth_max, rotate_time, ransac_threshold, use_limit, use_edge, use_label, STRONG=1):
+    """GenNeighbours (APD.cu:3330-3711) for one WEAK pixel: the directional search (8 base directions x rotate_time, radii
+    2, 4, 8, ... with four randomly shifted tries each, WEAK candidates mapped to their nearest STRONG pixel, duplicate /
+    angle / edge-line tests), the label extension along 16 rays, the RANSAC plane through the candidates (inlier count,
+    "strong plane" rule, ties by the pixel's own distance) and the ranking of the candidates by their distance to it.
+    planes_world: (world normal, depth) per pixel — the pass' input state.  search(k) / ransac(k): the k-th 32-bit numbers
+    of the two streams.  Returns (neighbours[1..11], reliable, fragile, tiny): the first `tiny` anchors lie on the fitted plane
+    and their mutual order is rounding noise."""
+    f32 = np.float32
+    fragile = False
+    min_margin = 6
+    c = y * W + x
+    depth_diff = depth_max - depth_min
+    K, R = cam["K"], cam["R"]
+    angle = 45.0 / rotate_time
+    cos_a, sin_a = math.cos(angle * math.pi / 180.0), math.sin(angle * math.pi / 180.0)
+    thresh = math.cos((angle / 2.0) * math.pi / 180.0)
+    shift_range = max(int(math.tan((angle / 2.0) * math.pi / 180.0) * 20), 1)
+    edge_limit = False
+    if use_limit:
+        edge_limit = True
+        if use_edge:
+            rp = u_limit - 1.1920929e-07
+            if abs(rp - complex_val) < 1e-6:
+                fragile = True
+            if rp < complex_val:
+                edge_limit = False
+    pts = [(-1, -1)] * 160
+    valid = [False] * 160
+    size = 0
+    k = 0
+
+    def to_short(v):
+        nonlocal fragile
+        if 0 < abs(v - round(v)) < 2e-4:
+            fragile = True
+        return int(v)               # float -> short: truncation toward zero
+
+    def map_strong(q):
+        if q[0] < min_margin or q[1] < min_margin or q[0] >= W - min_margin or q[1] >= H - min_margin:
+            return None
+        if weak[q[0] + q[1] * W] != STRONG:
+            q = (int(nearest_strong[q[0] + q[1] * W][0]), int(nearest_strong[q[0] + q[1] * W][1]))
+            if q[0] == -1 or q[1] == -1:
+                return None
+        return q
+
+    odi = -1
+    for odx in (-1, 0, 1):
+        for ody in (-1, 0, 1):
+            if odx == 0 and ody == 0:
+                continue
+            n = math.hypot(odx, ody)
+            od = (odx / n, ody / n)
+            odi += 1
+            for rot in range(rotate_time):
+                di = odi * 4 + rot
+                radius = 2
+                while radius <= 4096:
+                    tx, ty = x + od[0] * radius, y + od[1] * radius
+                    if 0 < min(abs(tx), abs(ty), abs(tx - W), abs(ty - H)) < 1e-4:
+                        fragile = True
+                    if tx < 0 or ty < 0 or tx >= W or ty >= H:
+                        break
+                    for _ in range(4):
+                        sgx = 1 if search(k) % 2 == 0 else 0xFFFFFFFF
+                        xs = ((sgx * search(k + 1)) & 0xFFFFFFFF) % shift_range       # unsigned arithmetic: (+-1 * curand) % range (APD.cu:3404)
+                        sgy = 1 if search(k + 2) % 2 == 0 else 0xFFFFFFFF
+                        ys = ((sgy * search(k + 3)) & 0xFFFFFFFF) % shift_range
+                        k += 4
+                        d = (od[0] * 20 + xs, od[1] * 20 + ys)
+                        dn = math.hypot(d[0], d[1])
+                        q = map_strong((to_short(x + d[0] / dn * radius), to_short(y + d[1] / dn * radius)))
+                        if q is None:
+                            continue
+                        if any(pts[j] == q for j in range(di)):
+                            continue
+                        td = (q[0] - x, q[1] - y)
+                        tn = math.hypot(td[0], td[1])
+                        cosang = (td[0] * od[0] + td[1] * od[1]) / tn if tn > 0 else float("nan")
+                        if abs(cosang - thresh) < 1e-5:
+                            fragile = True
+                        if cosang > thresh and (not edge_limit or not bresenham_hits_edge(edge, W, H, (x, y), q)):
+                            pts[di], valid[di] = q, True
+                            size += 1
+                            break
+                    if valid[di]:
+                        break
+                    radius = min(radius * 2, radius + 25)
+                rd = (od[0] * cos_a - od[1] * sin_a, od[0] * sin_a + od[1] * cos_a)
+                rn = math.hypot(rd[0], rd[1])
+                od = (rd[0] / rn, rd[1] / rn)
+    ext = 31
+    if use_label and label[c] > 0:
+        dirs = [(0, -1), (0, 1), (-1, 0), (1, 0), (-1, -1), (1, 1), (-1, 1), (1, -1), (1, 0), (0, 1), (0, 1), (-1, 0), (-1, 0), (0, -1), (0, -1), (1, 0)]   # `const int dir[][2]` with 0.5 entries: truncated to 0
+        bd, ds = [0.0] * 16, [0] * 16
+        for i in range(8):
+            b = label_boundary[i]
+            dist = 0.0
+            if b[0] != -1 and b[1] != -1:
+                dist = float(f32(math.sqrt(float((x - b[0]) ** 2 + (y - b[1]) ** 2))))     # `float dist = std::sqrt(std::pow(..) + ..)`: rounded to binary32 ...
+                if i >= 4:
+                    dist = float(f32(dist / math.sqrt(2.0)))                                # ... and again after `dist /= std::sqrt(2.0)` (48 on a diagonal becomes 47.999996)
+            bd[i] = dist
+            if i % 2 == 1:
+                opp = bd[i - 1]
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    t = np.float32(4 * rotate_time) * np.float32(bd[i]) / (np.float32(bd[i]) + np.float32(opp))
+                ti = int(t) if np.isfinite(t) else -2147483648       # (int)NaN: what the conversion gives
+                step = min(1, max(4 * rotate_time - 1, ti))          # MIN(1, MAX(...)): 1 (APD.cu:3478)
+                ds[i - 1], ds[i] = 4 * rotate_time - step, step
+        for a, (p_, q_) in zip(range(8, 16), ((3, 5), (1, 5), (1, 6), (2, 6), (2, 4), (4, 0), (7, 0), (7, 3))):
+            ds[a] = (ds[p_] + ds[q_]) // 2
+            bd[a] = float(f32((f32(bd[p_]) + f32(bd[q_])) / f32(2)))
+        for i in range(16):
+            gap = ds[i] + 1
+            q0 = bd[i] / gap
+            if 0 < abs(q0 - round(q0)) < 1e-4:
+                fragile = True
+            step_len = max(1, int(math.floor(1.0 * bd[i] / gap)))
+            for step in range(1, ds[i] + 1):
+                q = map_strong((x + step * step_len * dirs[i][0], y + step * step_len * dirs[i][1]))
+                if q is None:
+                    continue
+                if any(pts[j] == q for j in range(ext + 1)):
+                    continue
+                ext += 1
+                pts[ext], valid[ext] = q, True
+                size += 1
+    if size <= 3:
+        return None, 0, fragile, 0
+    vp = [pts[i] for i in range(160) if valid[i]]
+    n = len(vp)
+
+    def cam_point(px_, py_, z):
+        return (z * (px_ - K[2]) / K[0], z * (py_ - K[5]) / K[4], z)
+
+    centre_z = float(planes_world[c][3])
+    P3 = [cam_point(q[0], q[1], float(planes_world[q[0] + q[1] * W][3])) for q in vp]
+    N = []
+    for q in vp:
+        pw = planes_world[q[0] + q[1] * W].astype(np.float64)
+        N.append(tuple(R[3 * r] * pw[0] + R[3 * r + 1] * pw[1] + R[3 * r + 2] * pw[2] for r in range(3)))   # TransformNormal2RefCam
+    iteration, max_iter = 300, 200
+    max_count = 3
+    min_cost = None
+    best = None
+    has_strong = False
+    cache = {}
+    k = 0
+    fx0, fy0 = (x - K[2]) / K[0], (y - K[5]) / K[4]
+    while iteration > 0 and max_iter > 0:
+        max_iter -= 1
+        ia, ib, ic = ransac(k) % n, ransac(k + 1) % n, ransac(k + 2) % n
+        k += 3
+        if ia == ib or ib == ic or ia == ic:
+            continue
+        if not _point_in_triangle(vp[ia], vp[ib], vp[ic], (x, y)):
+            continue
+        if edge_limit:
+            for u, v in ((ia, ib), (ib, ic), (ic, ia)):
+                if (u, v) not in cache:
+                    cache[(u, v)] = cache[(v, u)] = bresenham_hits_edge(edge, W, H, vp[u], vp[v])
+            if cache[(ia, ib)] or cache[(ib, ic)] or cache[(ic, ia)]:
+                continue
+        AN = N[ia]                                     # AN, BN, CN are all the normal of point a (APD.cu:3594-3596)
+        dd = AN[0] * AN[0] + AN[1] * AN[1] + AN[2] * AN[2]
+        if abs(dd - 0.9) < 1e-5:
+            fragile = True
+        if dd < 0.9:
+            continue
+        A, B, C = P3[ia], P3[ib], P3[ic]
+        ac = (A[0] - C[0], A[1] - C[1], A[2] - C[2]); bc = (B[0] - C[0], B[1] - C[1], B[2] - C[2])
+        cv = (ac[1] * bc[2] - bc[1] * ac[2], -(ac[0] * bc[2] - bc[0] * ac[2]), ac[0] * bc[1] - bc[0] * ac[1])
+        nn = math.sqrt(cv[0] ** 2 + cv[1] ** 2 + cv[2] ** 2)
+        if nn == 0 or nn != nn:
+            continue
+        iteration -= 1
+        cv = (cv[0] / nn, cv[1] / nn, cv[2] / nn)
+        w = -(cv[0] * A[0] + cv[1] * A[1] + cv[2] * A[2])
+        strong_plane = True
+        if use_label and label[c] > 0:
+            da = abs(AN[0] * cv[0] + AN[1] * cv[1] + AN[2] * cv[2])
+            if abs(da - 0.9) < 1e-5:
+                fragile = True
+            if da < 0.9:
+                strong_plane = False
+        if has_strong and not strong_plane:
+            continue
+        cnt = 0
+        for si in range(n):
+            fx, fy = (vp[si][0] - K[2]) / K[0], (vp[si][1] - K[5]) / K[4]
+            dist = abs(-w / (cv[0] * fx + cv[1] * fy + cv[2]) - P3[si][2])
+            if abs(dist / depth_diff - ransac_threshold) < 1e-6:
+                fragile = True
+            if dist / depth_diff < ransac_threshold:
+                cnt += 1
+        if cnt < 6:
+            continue
+        cd = abs(-w / (cv[0] * fx0 + cv[1] * fy0 + cv[2]) - centre_z)
+        if cnt > max_count or (not has_strong and strong_plane):
+            if not has_strong and strong_plane:
+                has_strong = True
+            best, max_count, min_cost = (cv[0], cv[1], cv[2], w), cnt, cd
+        elif cnt == max_count:
+            if abs(cd - min_cost) < 1e-6 * max(1.0, min_cost):
+                fragile = True
+            if cd < min_cost:
+                best, min_cost = (cv[0], cv[1], cv[2], w), cd
+    if best is None:
+        return None, 0, fragile, 0
+    wts = []
+    out_pts = list(vp)
+    for i in range(n):
+        fx, fy = (vp[i][0] - K[2]) / K[0], (vp[i][1] - K[5]) / K[4]
+        dist = abs(-best[3] / (best[0] * fx + best[1] * fy + best[2]) - P3[i][2])
+        if abs(dist / depth_diff - ransac_threshold) < 1e-6:
+            fragile = True
+        if dist / depth_diff >= ransac_threshold:
+            out_pts[i] = (-1, -1)
+            wts.append(float("inf"))
+        else:
+            wts.append(dist)
+    order = sorted(range(n), key=lambda i: wts[i])          # insertion sort on strict `<`: stable
+    # the three points the plane goes through have distance ~0 — 1e-7 of rounding noise in binary32, 1e-16 here — and lead the
+    # list in an order only that noise decides: `tiny` = how many entries form that group (compare it as a set)
+    tiny = sum(1 for i in order[:11] if wts[i] < 1e-5)
+    for a in range(tiny, min(n - 1, 11)):
+        wa, wb = wts[order[a]], wts[order[a + 1]]
+        if wa != float("inf") and abs(wa - wb) < 1e-6:
+            fragile = True
+    if tiny < min(n, 11) and wts[order[tiny]] < 2e-5:
+        fragile = True
+    ranked = [out_pts[i] for i in order] + [(-1, -1)] * 11
+    return ranked[:11], 1, fragile, tiny

@@ -531,3 +531,51 @@ def test_weak_update_vs_numpy():
         assert abs(float(costs_after[c]) - want) < 1e-3, (x, y, costs_after[c], want)
     print("weak update oracle vs numpy: %d WEAK pixels checked (%d fragile skipped), %d adoptions, %d planes changed" % (checked, frag, adopted, moved))
     assert checked >= 25 and moved >= 5
+
+
+def test_gen_neighbours_vs_numpy():
+    """GenNeighbours (APD.cu:3330-3711) and NeigbourUpdate (:3713-3729) read into numpy: directional search with the unsigned
+    shift arithmetic, nearest-STRONG mapping, duplicate / angle / edge-line tests, the label extension (MIN(1, MAX(..)) = 1
+    step, the half-integer directions truncated to 0), the RANSAC with its one-normal test and strong-plane rule, the ranking —
+    against the anchors and the reliability flags the oracle's launches leave."""
+    S = 3
+    sc, cams, imgs, _ = _scene(128, 96, S)
+    o, p = _two_pass(sc, S, 1)
+    W, H = sc["width"], sc["height"]
+    for st in ("gen_edge_inform", "find_nearest_strong"):
+        o.run_stage(st)
+    planes, weak, edge, label = o.get("planes").copy(), o.get("weak_info").copy(), o.get("edge"), o.get("label")
+    wns = o.get("weak_nearest_strong").reshape(-1, 2)
+    nmap = o.get("neighbours_map")
+    lb, cx = o.get("label_boundary").reshape(-1, 8, 2), o.get("complex")
+    o.run_stage("gen_neighbours")
+    nbr, reliable = o.get("neighbours").reshape(-1, 12, 2), o.get("weak_reliable")
+    o.run_stage("neighbour_update")
+    weak_after = o.get("weak_info")
+    L = O.lib()
+    seed = 778
+    draw = lambda c, sub: (lambda k: L.ora_rand_u32(seed, int(c), (5 << 16) | sub, k))       # rng_site(PH_NEIGHBOURS, 0, sub)
+    rng = np.random.default_rng(17)
+    wk = np.flatnonzero(weak == synth.WEAK)
+    checked = frag = rel = lab = 0
+    for c in rng.choice(wk, min(200, len(wk)), replace=False):
+        x, y = int(c % W), int(c // W)
+        u = ((draw(c, 4)(0) >> 8) + 1) / 16777216.0
+        got, r, fragile, tiny = M.gen_neighbours(cams[0], planes, weak, wns, edge, label, [tuple(int(t) for t in q) for q in lb[nmap[c]]], float(cx[nmap[c]]),
+                                           W, H, x, y, u, draw(c, 5), draw(c, 6), float(p["depth_min"]), float(p["depth_max"]), int(p["rotate_time"]),
+                                           float(p["ransac_threshold"]), int(p["use_limit"]), int(p["use_edge"]), int(p["use_label"]), STRONG=synth.STRONG)
+        if fragile:
+            frag += 1
+            continue
+        checked += 1
+        lab += int(label[c] > 0)
+        assert int(reliable[c]) == r, (x, y, int(reliable[c]), r)
+        assert int(weak_after[c]) == (synth.WEAK if r == 1 else synth.UNKNOWN), (x, y)
+        mine = [tuple(int(t) for t in q) for q in nbr[nmap[c]]]
+        assert mine[0] == (x, y)
+        if r == 1:
+            rel += 1
+            assert set(mine[1:1 + tiny]) == set(got[:tiny]) and mine[1 + tiny:] == got[tiny:], (x, y, tiny, mine[1:], got)
+    print("gen_neighbours oracle vs numpy: %d WEAK pixels checked (%d fragile skipped), %d reliable with identical anchor lists, %d with a label"
+          % (checked, frag, rel, lab))
+    assert checked >= 60 and rel >= 30 and lab >= 20
