@@ -1190,3 +1190,45 @@ def gen_neighbours(cam, planes_world, weak, nearest_strong, edge, label, label_b
         fragile = True
     ranked = [out_pts[i] for i in order] + [(-1, -1)] * 11
     return ranked[:11], 1, fragile, tiny
+
+
+def random_initialization(images, cams, x, y, plane, selected, first_init, depth_min, depth_max, top_k, u_depth, u_normal, radius=5, increment=2):
+    """RandomInitialization (APD.cu:1273-1309) for one pixel.  FIRST_INIT: a plane whose .w lies outside the depth range is
+    replaced by a random hypothesis (GenerateRandomPlaneHypothesis_YZL), one inside is KEPT AS IT IS (a prior: world normal and
+    depth-as-offset, the source's behaviour); cost = mean of the top_k smallest NCCs, selected views = those not above the
+    k-th (ComputeMultiViewInitialCostandSelectedViews).  Otherwise: (world normal, depth) -> camera-frame plane, cost = mean
+    over the selected views whose NCC is below 2, the others dropped with unSetBit — which clears bits 0..n (APD.cu:186-189).
+    Returns (plane, cost, selected, fragile)."""
+    S = len(cams) - 1
+    fragile = False
+    if first_init:
+        pl = tuple(float(t) for t in plane)
+        if plane[3] > depth_max or plane[3] < depth_min:
+            z = u_depth * (depth_max - depth_min) + depth_min
+            n, fragile = random_normal_yzl(cams, x, y, z, selected, u_normal)
+            pl = (n[0], n[1], n[2], distance_to_origin(cams[0], x, y, z, n))
+        costs = [ncc_old(images, cams, x, y, v, pl, radius, increment) for v in range(1, S + 1)]
+        valid = sum(c < 2.0 for c in costs)
+        k = min(valid, top_k)
+        if k <= 0:
+            return pl, 2.0, 0, fragile
+        srt = sorted(costs)
+        thr = srt[k - 1]
+        if any(c != thr and abs(c - thr) < 2e-4 for c in costs):
+            fragile = True
+        sel = sum(1 << i for i in range(S) if costs[i] <= thr)
+        return pl, sum(srt[:k]) / k, sel, fragile
+    R = cams[0]["R"]
+    n = tuple(R[3 * r] * plane[0] + R[3 * r + 1] * plane[1] + R[3 * r + 2] * plane[2] for r in range(3))
+    pl = (n[0], n[1], n[2], distance_to_origin(cams[0], x, y, float(plane[3]), n))
+    sel = int(selected)
+    total, count = 0.0, 0
+    for i in range(1, S + 1):
+        if (sel >> (i - 1)) & 1:
+            c = ncc_old(images, cams, x, y, i, pl, radius, increment)
+            if c < 2.0:
+                count += 1
+                total += c
+            else:
+                sel &= (0xFFFFFFFE << (i - 1)) & 0xFFFFFFFF
+    return pl, (total / count if count else 2.0), sel, fragile

@@ -579,3 +579,61 @@ def test_gen_neighbours_vs_numpy():
     print("gen_neighbours oracle vs numpy: %d WEAK pixels checked (%d fragile skipped), %d reliable with identical anchor lists, %d with a label"
           % (checked, frag, rel, lab))
     assert checked >= 60 and rel >= 30 and lab >= 20
+
+
+def test_random_initialization_vs_numpy():
+    """RandomInitialization (APD.cu:1273-1309), both branches, against the oracle's launch: the random hypothesis of a first
+    pass (depth + GenerateRandomNormal_YZL from the contract's streams), the kept prior plane, the top-k cost / view rule;
+    and the conversion + selected-view pruning (unSetBit clears bits 0..n) of a later pass."""
+    S = 4
+    sc, cams, imgs, _ = _scene(112, 80, S)
+    W, H = sc["width"], sc["height"]
+    L = O.lib()
+    rng = np.random.default_rng(18)
+    # --- FIRST_INIT: zero planes (out of range -> random) with a band of prior planes
+    p1 = make_params(S + 1, max_iterations=1, state=synth.FIRST_INIT, use_APD=0)
+    seed = 909
+    o = O.from_scene(sc, p1, seed=seed, sampler=1)
+    st = first_pass_state(sc)
+    prior = np.zeros((H * W, 4), np.float32)
+    band = np.arange(H * W) % W < 30
+    prior[band] = np.concatenate([np.tile(sc["normal_gt"], (int(band.sum()), 1)), sc["depth_gt"][0].reshape(-1, 1)[band]], 1)
+    st["planes"] = prior
+    o.upload_state(**st)
+    o.run_stage("gen_edge_inform")
+    o.run_stage("random_init")
+    planes, costs, views, radius = o.get("planes"), o.get("costs"), o.get("selected_views"), o.get("radius")
+    uni = lambda c, sub: (lambda k: ((L.ora_rand_u32(seed, int(c), (1 << 16) | sub, k) >> 8) + 1) / 16777216.0)   # rng_site(PH_RANDOM_INIT, 0, sub)
+    n_rand = n_prior = frag = 0
+    for c in rng.choice(H * W, 120, replace=False):
+        x, y = int(c % W), int(c // W)
+        r = int(radius[c])
+        pl, cost, sel, fragile = M.random_initialization(imgs, cams, x, y, prior[c], 0, True, float(p1["depth_min"]), float(p1["depth_max"]), int(p1["top_k"]),
+                                                          uni(c, 1)(0), uni(c, 2), radius=r, increment=max(2, int(2.0 * r / 5.0)) if int(p1["use_radius"]) else int(p1["strong_increment"]))
+        if fragile:
+            frag += 1
+            continue
+        if band[c]:
+            n_prior += 1
+            assert (planes[c] == prior[c]).all()
+        else:
+            n_rand += 1
+            assert np.max(np.abs(planes[c] - np.array(pl)) / np.maximum(1e-2, np.abs(pl))) < 2e-4, (x, y, planes[c], pl)
+        assert abs(float(costs[c]) - cost) < 5e-4 and int(views[c]) == sel, (x, y, costs[c], cost, int(views[c]), sel)
+    # --- a later pass
+    o2, p2 = _two_pass(sc, S, 1)
+    before, vb = o2.get("planes").copy(), o2.get("selected_views").copy()
+    o2.run_stage("gen_edge_inform")
+    o2.run_stage("random_init")
+    planes2, costs2, views2, radius2 = o2.get("planes"), o2.get("costs"), o2.get("selected_views"), o2.get("radius")
+    pruned = 0
+    for c in rng.choice(H * W, 100, replace=False):
+        x, y = int(c % W), int(c // W)
+        r = int(radius2[c])
+        pl, cost, sel, _ = M.random_initialization(imgs, cams, x, y, before[c].astype(np.float64), int(vb[c]), False, float(p2["depth_min"]), float(p2["depth_max"]),
+                                                   int(p2["top_k"]), 0.0, None, radius=r, increment=max(2, int(2.0 * r / 5.0)))
+        assert np.max(np.abs(planes2[c] - np.array(pl)) / np.maximum(1e-2, np.abs(pl))) < 2e-5, (x, y)
+        assert abs(float(costs2[c]) - cost) < 5e-4 and int(views2[c]) == sel, (x, y, costs2[c], cost, int(views2[c]), sel)
+        pruned += int(sel != int(vb[c]))
+    print("random_initialization oracle vs numpy: first pass %d random + %d prior pixels (%d fragile skipped); later pass 100 pixels, %d with pruned views" % (n_rand, n_prior, frag, pruned))
+    assert n_rand >= 50 and n_prior >= 15
