@@ -187,13 +187,20 @@ def cpu_baseline(pkg, args, cfg, S, iters, device=0):
         p2 = wl.refine_iter_params(S, iters)
         st = wl.hand_over(o.get("planes"), o.get("selected_views"), o.get("weak_info"), o.get("radius"), p1, w, h,
                           extra_weak=wl.weak_mask(args.weak_layout, w, h, args.weak_frac, sc["flat"]))
+        deps = np.array(sc["depth_gt"], np.float32, copy=True)
+        if args.src_depths == "estimated":   # the same kind of source depth maps as the timed workload: noise + holes
+            r = np.random.default_rng(20240904)
+            deps *= (1.0 + 0.003 * r.standard_normal(deps.shape)).astype(np.float32)
+            blocks = r.random((deps.shape[0], (h + 15) // 16, (w + 15) // 16)) < 0.02
+            holes = np.repeat(np.repeat(blocks, 16, 1), 16, 2)[:, :h, :w] | (r.random(deps.shape) < 0.01)
+            deps[holes] = 0.0
         for e in (o, g):
             e.set_params(p2)
-            e.set_depths(sc["depth_gt"])
+            e.set_depths(deps)
             e.upload_state(planes=st[0], views=st[1], weak=st[2], radius=st[3])
         t0 = time.time()
         o.run_patchmatch()
-        timed, what = time.time() - t0, "REFINE_ITER pass (geom, %.1f %% WEAK) after an untimed FIRST_INIT pass" % (100.0 * o.weak_count() / L)
+        timed, what = time.time() - t0, "REFINE_ITER pass (geom against %s source depth maps, %.1f %% WEAK) after an untimed FIRST_INIT pass" % (args.src_depths, 100.0 * o.weak_count() / L)
         g.run_patchmatch()
     res = {"value": round(L * iters / timed / 1e6, 5), "unit": "Mpx/s/iter", "cores": ncores, "kind": "port",
            "sample": "%dx%d view, S=%d, %d iterations, whole RunPatchMatch of the %s, oracle/ (g++ -O3, OpenMP over row blocks), %.1f s" % (w, h, S, iters, what, timed)}
