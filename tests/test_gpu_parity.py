@@ -251,6 +251,15 @@ def test_error_paths():
     # there is no result to reproduce, the engine says so instead of inventing one
     with pytest.raises(c.DvpError, match="positions"):
         g.set_params(make_params(3, use_edge=0))
+    # the round-4 entry points: required maps missing
+    z, n, v = np.zeros((24, 32), np.float32), np.zeros((24, 32, 3), np.float32), np.zeros((24, 32), np.uint32)
+    with pytest.raises(c.DvpError, match="required"):
+        g.upload_state_rescaled(32, 24, None, n, v)
+    with pytest.raises(c.DvpError, match="required"):
+        g.upload_state_rescaled(0, 24, z, n, v)
+    L = g.L
+    assert L.dvp_download_maps(g.h, None, None, None, None, None) != 0 and b"required" in L.dvp_last_error(g.h)
+    g.upload_state_rescaled(32, 24, z, n, v)      # and the context is still usable
 
 
 def test_size_independent_properties_at_bench_size():
