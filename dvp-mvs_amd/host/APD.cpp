@@ -295,10 +295,12 @@ std::map<int, ResidentDepth> g_resident_depths;
 void APD::SetResidentDepth(int image_id, const float* device_ptr, int width, int height) { g_resident_depths[image_id] = ResidentDepth{ device_ptr, width, height }; }
 void APD::ClearResidentDepths() { g_resident_depths.clear(); }
 namespace {
-struct ResidentImage { const float* ptr; int w, h; };
+struct ResidentImage { const float* ptr; int w, h, orig_w, orig_h; };
 std::map<std::pair<int, int>, ResidentImage> g_resident_images;   // (image id, scale)
 }
-void APD::SetResidentImage(int image_id, int scale, const float* device_ptr, int width, int height) { g_resident_images[{ image_id, scale }] = ResidentImage{ device_ptr, width, height }; }
+void APD::SetResidentImage(int image_id, int scale, const float* device_ptr, int width, int height, int orig_width, int orig_height) {
+	g_resident_images[{ image_id, scale }] = ResidentImage{ device_ptr, width, height, orig_width, orig_height };
+}
 void APD::ClearResidentImages() { g_resident_images.clear(); }
 namespace { void (*g_resident_download)(float*, const float*, size_t) = nullptr; }
 void APD::SetResidentDownloader(void (*copy)(float*, const float*, size_t)) { g_resident_download = copy; }
@@ -328,6 +330,8 @@ void APD::InuputInitialization() {
 		orig_sizes.emplace_back(ci.orig_cols, ci.orig_rows);
 		width = ci.orig_cols;
 		height = ci.orig_rows;
+		ref_orig_width = ci.orig_cols;
+		ref_orig_height = ci.orig_rows;
 	}
 	for (const auto& src_idx : problem.src_image_ids) {
 		const ImageEntry ci = load(src_idx, width, height, false);
@@ -507,14 +511,21 @@ void APD::CountWeak() {   // APD.cpp:1182-1193 (the running index itself is made
 void APD::CoarseStateToHost() {
 	if (!coarse_state) return;
 	coarse_state = false;
+	// (RescaleMatToTargetSize returns early and leaves dst untouched when src already has the target size — every pass of a
+	// level but its first: hand the map over as it is then)
+	auto to_size = [&](auto tag, const Mat& src, Mat& dst) {
+		using T = decltype(tag);
+		if (src.cols == width && src.rows == height) dst = src;
+		else RescaleMatToTargetSize<T>(src, dst, width, height);
+	};
 	if (!coarse_weak.empty()) {
-		RescaleMatToTargetSize<uint8_t>(coarse_weak, weak_info_host, width, height);
+		to_size(uint8_t(), coarse_weak, weak_info_host);
 		CountWeak();
 	}
 	Mat depth, normal;
-	RescaleMatToTargetSize<float>(coarse_depth, depth, width, height);
-	RescaleMatToTargetSize<Vec3f>(coarse_normal, normal, width, height);
-	RescaleMatToTargetSize<unsigned int>(coarse_views, selected_views_host, width, height);
+	to_size(float(), coarse_depth, depth);
+	to_size(Vec3f(), coarse_normal, normal);
+	to_size((unsigned int)0, coarse_views, selected_views_host);
 #pragma omp parallel for schedule(static) num_threads(HostThreads())
 	for (int row = 0; row < height; ++row) {
 		const float* z = depth.ptr<float>(row);
@@ -601,9 +612,13 @@ void APD::CudaSpaceInitialization() {
 	std::vector<const float*> ptrs(num_images);
 	bool resident_images = !g_resident_images.empty();
 	for (int i = 0; i < num_images && resident_images; ++i) {
-		// (a source image of another size than the reference is padded / cropped on the host, APD.cpp:1071-1079: not this path)
+		// A source image of another ORIGINAL size than the reference is padded / cropped to the reference's original size on the
+		// host and resized after that (APD.cpp:1071-1079): the resident copy — the file resized at its own size — is not that
+		// image even when the rounded scaled sizes coincide (1001x800 and 1000x800 at scale 4 are both 250x200), so the
+		// original sizes have to agree, as load_image's shortcut requires.
 		auto it = g_resident_images.find({ i == 0 ? problem.ref_image_id : problem.src_image_ids[i - 1], problem.scale_size });
-		resident_images = it != g_resident_images.end() && it->second.w == width && it->second.h == height;
+		resident_images = it != g_resident_images.end() && it->second.w == width && it->second.h == height &&
+		                  it->second.orig_w == ref_orig_width && it->second.orig_h == ref_orig_height;
 		if (resident_images) ptrs[i] = it->second.ptr;
 	}
 	if (resident_images) DVP_SAFE_CALL(ctx, dvp_upload_images_device(ctx, ptrs.data(), width));

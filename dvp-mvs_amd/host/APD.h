@@ -118,7 +118,7 @@ public:
 	// The float image of a view at the current pyramid level, resident on this process' device (row-major, pitch = width):
 	// when the reference image and all sources of a view are registered at the view's size, CudaSpaceInitialization hands
 	// them over with dvp_upload_images_device instead of re-sending ~100 MB per image and per reference view that uses it.
-	static void SetResidentImage(int image_id, int scale, const float* device_ptr, int width, int height);
+	static void SetResidentImage(int image_id, int scale, const float* device_ptr, int width, int height, int orig_width, int orig_height);
 	static void ClearResidentImages();
 	static void SetResidentDepth(int image_id, const float* device_ptr, int width, int height);
 	static void ClearResidentDepths();
@@ -128,6 +128,7 @@ public:
 private:
 	int num_images = 0;
 	int width = 0, height = 0;
+	int ref_orig_width = 0, ref_orig_height = 0;   // the reference image before scaling (what sources are padded / cropped to)
 	Problem problem;
 	std::vector<Mat> images;
 	std::vector<Mat> depths;

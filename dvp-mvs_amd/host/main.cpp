@@ -111,6 +111,10 @@ void ConfigurePass(Problem& problem, const Pass& pass, int iteration, int iters,
 }
 
 struct ViewResult { Mat depth; };
+// The reference writes the ACMM-format maps of a view — depths_geom.dmb + normals.dmb, what ACMM-style fusers read — when
+// `problem.iteration == 15` (main.cpp:378-385): the last pass of its default schedule (4 levels x (1 + 3) passes).  Here: at
+// that literal index too, and at the last pass of whatever plan the driver was given (--min-scale / --geom-passes shorten it).
+int g_final_iteration = 15;
 bool g_device_maps = true;   // false (--sync-io / --host-rescale): planes are downloaded and unpacked on the host   // what the exchange step needs from a finished view
 
 ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
@@ -172,6 +176,7 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	for (const char* name : { "APD_normals.dmb", "weak.bin", "selected_views.bin" }) ExpectResult(folder / name);
 	if (problem.params.use_radius) ExpectResult(folder / "radius.bin");
 	const int scale_size = problem.scale_size;
+	const int iteration = problem.iteration;
 	const bool timing = host_timing;
 	RunInBackground([=]() mutable {
 		const auto t0 = std::chrono::steady_clock::now();
@@ -211,6 +216,10 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 		PublishResult(folder / "weak.bin", pixel_states);
 		PublishResult(folder / "selected_views.bin", views);
 		if (!radius.empty()) PublishResult(folder / "radius.bin", radius);
+		if (iteration == 15 || iteration == g_final_iteration) {   // main.cpp:378-382 (weak.png is a debug image: not written)
+			writeDepthDmb(folder / "depths_geom.dmb", depth);
+			writeNormalDmb(folder / "normals.dmb", normal);
+		}
 		if (timing) std::cout << "  [background] visibility-mask clean-up + publish: "
 		                      << std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() / 1000.0 << " ms" << std::endl;
 	});
@@ -325,7 +334,7 @@ public:
 			RankComm::HostToDevice(dev, img.ptr<float>(0), count);
 			blocks_.push_back(dev);
 			used += count * 4;
-			APD::SetResidentImage(id, scale, dev, img.cols, img.rows);
+			APD::SetResidentImage(id, scale, dev, img.cols, img.rows, oc, orr);
 		}
 	}
 	void Release() {
@@ -437,6 +446,8 @@ int main(int argc, char** argv) {
 		plan.push_back(Pass{ level, scale, -1 });
 		for (int j = 0; j < opt.geom_passes; ++j) plan.push_back(Pass{ level, scale, j });
 	}
+
+	g_final_iteration = (int)plan.size() - 1;
 
 	std::unique_ptr<DepthExchange> exchange;
 	std::unique_ptr<InPlaceDepths> inplace;

@@ -43,6 +43,11 @@ def test_apd_driver(tmp_path):
         assert m.mean() > 0.7 and np.median(rel) < 1.5e-2, (v, m.mean(), np.median(rel))
         nrm = read_binmat(os.path.join(r, "APD_normals.dmb"))
         assert nrm.shape == (H, W, 3)
+        # the last pass also leaves the ACMM-format maps (reference main.cpp:378-385: depths_geom.dmb + normals.dmb)
+        for fn, ref, ch in (("depths_geom.dmb", dep, 1), ("normals.dmb", nrm, 3)):
+            raw = open(os.path.join(r, fn), "rb").read()
+            assert tuple(np.frombuffer(raw[:16], np.int32)) == (1, H, W, ch), fn
+            assert np.array_equal(np.frombuffer(raw[16:], np.float32).reshape(ref.shape).view(np.uint32), ref.view(np.uint32)), fn
     ply = os.path.join(d, "APD", "APD.ply")
     assert os.path.exists(ply)
     head = open(ply, "rb").read(200).decode("latin1")
