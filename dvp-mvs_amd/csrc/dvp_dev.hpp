@@ -54,6 +54,7 @@ struct ViewConst {
 
 // The buffer bundle every kernel receives (the engine's DataPassHelper, APD.h:60-92).
 struct AnchorRec;   // dvp_weak_wave.hpp
+struct WeakRec;     // dvp_weak_phased.hpp
 struct Dev {
 	int width, height, num_images;
 	int pitch;                 // floats per padded image row (multiple of 64 -> 256 B aligned rows)
@@ -101,6 +102,10 @@ struct Dev {
 	f4* fit_planes;
 	s2* candidate;             // [view][pixel][8]: cand_ptr(); 64 x-adjacent pixels write/read 2 KB contiguous per view
 	AnchorRec* anchor_tab;     // [WEAK pixel][view][11]: reference side of the anchor sub-patches, built once per pass (dvp_weak_wave.hpp); null: the weak update forms it per item
+	// the weak update as seven launches (dvp_weak_phased.hpp), per WEAK pixel, or null (the one-wave form):
+	WeakRec* weak_rec;         // hand-over record between the launches
+	f2* weak_ctab;             // [36] centre-patch table (w, w * ref) of the update
+	float* weak_ev;            // [8][S] cost vectors of the planes an evaluation launch took
 	const uint8_t* edge;
 	int* search_pos;           // [16][L]: sample positions of the strong update's 16 propagation slots (strong_search_px)
 	// split strong update (dvp_strong_eval / _decide / _refine): the cost vectors of the 16 propagation slots + the current plane,

@@ -418,6 +418,68 @@ extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wa
 extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_exact_u8(const Dev d, const ListArgs a) { weak_wave_body<1, 1, 1>(d, a); }
 extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_u8_notab(const Dev d, const ListArgs a) { weak_wave_body<0, 1, 0>(d, a); }
 extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_exact_u8_notab(const Dev d, const ListArgs a) { weak_wave_body<1, 1, 0>(d, a); }
+// The same launch site as SEVEN launches (dvp_weak_phased.hpp): the evaluation launches E0 / E1 / E2 keep one wave per WEAK
+// pixel, the per-pixel decisions D1 / D2 / D3 and the final plain-NCC cost E3 run one LANE per WEAK pixel.
+template <int SMP, int FMT, int PART>
+__device__ __forceinline__ void weak_phase_wave_body(const Dev& d, const ListArgs& a) {
+	__shared__ WeakSharedT<1> sh[1];
+	const int t = list_block(blockIdx.x, gridDim.x, kWaveRun * 4);
+	if (t >= a.count) return;
+	const int center = d.weak_list[a.base + t];
+	const int py = center / d.width, px = center - py * d.width;
+	if (py >= a.covered_rows) return;
+	if (d.weak_info[center] != DVP_WEAK) return;
+	unsigned long long n = 0;
+	unsigned long long* np = d.eval_counter ? &n : nullptr;
+	if (PART == 0) weak_e0_wave<SMP, FMT, 1>(d, px, py, np, sh[0]);
+	else if (PART == 1) weak_e1_wave<SMP, FMT, 1>(d, px, py, np, sh[0]);
+	else weak_e2_wave<SMP, FMT, 1>(d, px, py, np, sh[0]);
+	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
+}
+#define DVP_WEAK_PHASE_KERNELS(NAME, PART)                                                                                                                   \
+	extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) NAME(const Dev d, const ListArgs a) { weak_phase_wave_body<0, 0, PART>(d, a); }           \
+	extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) NAME##_exact(const Dev d, const ListArgs a) { weak_phase_wave_body<1, 0, PART>(d, a); }   \
+	extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) NAME##_u8(const Dev d, const ListArgs a) { weak_phase_wave_body<0, 1, PART>(d, a); }      \
+	extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) NAME##_exact_u8(const Dev d, const ListArgs a) { weak_phase_wave_body<1, 1, PART>(d, a); }
+DVP_WEAK_PHASE_KERNELS(dvp_weak_eval_candidates, 0)
+DVP_WEAK_PHASE_KERNELS(dvp_weak_eval_planes, 1)
+DVP_WEAK_PHASE_KERNELS(dvp_weak_eval_hypotheses, 2)
+template <int PART>
+__device__ __forceinline__ void weak_phase_lane_body(const Dev& d, const ListArgs& a) {
+	const int t = list_block(blockIdx.x, gridDim.x, kListRun) * 256 + threadIdx.x;
+	if (t >= a.count) return;
+	const int center = d.weak_list[a.base + t];
+	const int py = center / d.width, px = center - py * d.width;
+	if (py >= a.covered_rows) return;
+	if (d.weak_info[center] != DVP_WEAK) return;
+	if (PART == 0) weak_d1_px(d, px, py, a.iter);
+	else if (PART == 1) weak_d2_px(d, px, py, a.iter);
+	else weak_d3_px(d, px, py);
+}
+#ifndef DVP_LB_WEAK_DECIDE
+#define DVP_LB_WEAK_DECIDE 2   // 256-lane workgroups per SIMD... (waves per SIMD = this; the kernels wait for scattered loads)
+#endif
+extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK_DECIDE) dvp_weak_select_views(const Dev d, const ListArgs a) { weak_phase_lane_body<0>(d, a); }
+extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK_DECIDE) dvp_weak_make_hypotheses(const Dev d, const ListArgs a) { weak_phase_lane_body<1>(d, a); }
+extern "C" __global__ void __launch_bounds__(256, DVP_LB_WEAK_DECIDE) dvp_weak_adopt(const Dev d, const ListArgs a) { weak_phase_lane_body<2>(d, a); }
+// E3: the per-lane evaluator of the strong path over the WEAK list (one-wave workgroups, 18 KB of patch table each)
+template <int SMP>
+__device__ __forceinline__ void weak_final_cost_body(const Dev& d, const ListArgs& a) {
+	__shared__ f2 lds_tab[kTaps * kTaps * 64];
+	const PatchTab tab{&lds_tab[threadIdx.x], 64};
+	const int t = list_block(blockIdx.x, gridDim.x, kListRun * 4) * 64 + threadIdx.x;
+	if (t >= a.count) return;
+	const int center = d.weak_list[a.base + t];
+	const int py = center / d.width, px = center - py * d.width;
+	if (py >= a.covered_rows) return;
+	if (d.weak_info[center] != DVP_WEAK) return;
+	unsigned long long n = 0;
+	weak_final_cost_px<SMP>(d, px, py, tab, d.eval_counter ? &n : nullptr);
+	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
+}
+extern "C" __global__ void __launch_bounds__(64, 2) dvp_weak_final_cost(const Dev d, const ListArgs a) { weak_final_cost_body<0>(d, a); }
+extern "C" __global__ void __launch_bounds__(64, 2) dvp_weak_final_cost_exact(const Dev d, const ListArgs a) { weak_final_cost_body<1>(d, a); }
+
 // the pass' table of anchor reference sides: thread = (WEAK list entry, view, anchor), anchor fastest (neighbouring lanes write
 // neighbouring 128-byte records)
 extern "C" __global__ void __launch_bounds__(256) dvp_weak_anchor_table(const Dev d, const ListArgs a) {
@@ -872,6 +934,10 @@ struct dvp_ctx {
 	size_t anchor_tab_alloc = 0;       // capacity in records
 	bool anchor_tab_valid = false;     // built for the current anchors / offsets / images (any launch or upload that can change them clears it)
 	bool anchor_tab_off = false;       // DVP_WEAK_ANCHOR_TAB=0, or the table did not fit: the weak update forms the reference side per item
+	// the weak update as seven launches (dvp_weak_phased.hpp): per-WEAK-pixel hand-over, allocated at the first weak update
+	WeakRec* weak_rec = nullptr; f2* weak_ctab = nullptr; float* weak_ev = nullptr;
+	size_t weak_phase_alloc = 0;       // capacity in WEAK pixels
+	bool weak_phased = true;           // DVP_WEAK_PHASED=0, no anchor table, or the buffers did not fit: the one-wave form
 	int* weak_list = nullptr;    // compacted WEAK pixel indices (black first, then red)
 	size_t weak_list_alloc = 0;
 	int* weak_counts = nullptr;  // scratch of the device-side compaction: per-slot black / red counts, per-chunk counts, then 3 totals
@@ -939,6 +1005,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.candidate = c->candidate; d.edge = c->edge; d.edge_bits = c->edge_bits; d.strong_bits = c->strong_bits; d.strong_bits_t = c->strong_bits_t; d.edge_sat = c->edge_sat; d.sat_cells_x = sat_cells(c->W); d.sat_cells_y = sat_cells(c->H); d.edge_tiles_x = edge_tiles_x(c->W); d.edge_neigh = c->edge_neigh; d.label = c->label;
 	d.label_boundary = c->label_boundary; d.label_stop = c->label_stop; d.complex_ = c->complex_; d.radius = c->radius;
 	d.weak_list = c->weak_list;
+	d.weak_rec = c->weak_rec; d.weak_ctab = c->weak_ctab; d.weak_ev = c->weak_ev;
 	d.eval_counter = c->profiling ? c->eval_counter : nullptr;
 }
 
@@ -972,6 +1039,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	if (const char* e = getenv("DVP_SWEEP_SPLIT")) { c->sweep_split = atoi(e) != 0; c->sweep_force = atoi(e) == 2; }
 	if (const char* e = getenv("DVP_WEAK_ANCHOR_TAB")) c->anchor_tab_off = atoi(e) == 0;   // A/B measurements and the tests of the per-item form
 	if (const char* e = getenv("DVP_GN_WAVE")) c->gn_wave = atoi(e) != 0;
+	if (const char* e = getenv("DVP_WEAK_PHASED")) c->weak_phased = atoi(e) != 0;
 	c->pitch = (width + 2 * kImgPad + 63) / 64 * 64;
 	c->L = (size_t)width * height;
 	auto fail = [&](int) { g_create_error = c->error; dvp_ctx_destroy(c); return 1; };
@@ -1374,6 +1442,34 @@ static int ensure_anchor_table(dvp_ctx* c, int covered_rows) {
 	return 0;
 }
 
+// hand-over buffers of the phased weak update (624 + 32 S bytes per WEAK pixel: 1.6 GB at 6208x4128 with 7 % WEAK, S = 9).  A
+// context that cannot have them keeps the one-wave kernel: the same bits.
+static int ensure_weak_phase_buffers(dvp_ctx* c) {
+	if (!c->weak_phased) return 0;
+	const size_t wc = (size_t)(c->d.weak_black + c->d.weak_red);
+	if (wc <= c->weak_phase_alloc) return 0;
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	dfree(c, &c->weak_rec); dfree(c, &c->weak_ctab); dfree(c, &c->weak_ev);
+	c->weak_phase_alloc = 0;
+	const size_t cap = std::min<size_t>(c->L, wc + wc / 4), S = (size_t)c->NI - 1;
+	void *r = nullptr, *t = nullptr, *e = nullptr;
+	if (getenv("DVP_TEST_WEAK_PHASE_ALLOC_FAIL") /* test hook: take the fallback */ || hipMalloc(&r, cap * sizeof(WeakRec)) != hipSuccess ||
+	    hipMalloc(&t, cap * kTaps * kTaps * sizeof(f2)) != hipSuccess || hipMalloc(&e, cap * 8 * S * sizeof(float)) != hipSuccess) {
+		(void)hipGetLastError();
+		if (r) (void)hipFree(r);
+		if (t) (void)hipFree(t);
+		c->weak_phased = false;
+		fprintf(stderr, "dvp: no room for the phased weak update's hand-over buffers (%.2f GB); using the one-wave kernel\n", (double)cap * (sizeof(WeakRec) + 288 + 32 * S) / 1e9);
+		sync_dev_struct(c);
+		return 0;
+	}
+	c->allocs.push_back(r); c->allocs.push_back(t); c->allocs.push_back(e);
+	c->weak_rec = (WeakRec*)r; c->weak_ctab = (f2*)t; c->weak_ev = (float*)e;
+	c->weak_phase_alloc = cap;
+	sync_dev_struct(c);
+	return 0;
+}
+
 static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused = false) {
 	if (stage < 0 || stage >= DVP_ST_LAUNCHABLE) { c->error = "bad stage id"; return 1; }
 	if (!c->sector_taps) { c->error = "dvp_set_params must be called before running kernels"; return 1; }
@@ -1456,7 +1552,20 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 			case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(ex ? dvp_ransac_fit_plane_list_exact : dvp_ransac_fit_plane_list, lg, block, 0, c->stream, c->d, la); break;
 			case DVP_ST_WEAK_UPDATE:
 				if (ensure_anchor_table(c, la.covered_rows)) return 1;
-				if (c->d.anchor_tab) {
+				if (c->d.anchor_tab && ensure_weak_phase_buffers(c)) return 1;
+				if (c->d.anchor_tab && c->weak_phased) {
+					const bool u8 = c->images8_ok;
+					const dim3 wg(la.count), w64(64), lg64((la.count + 63) / 64);
+#define DVP_PICK(NAME) (ex ? (u8 ? NAME##_exact_u8 : NAME##_exact) : (u8 ? NAME##_u8 : NAME))
+					hipLaunchKernelGGL(DVP_PICK(dvp_weak_eval_candidates), wg, w64, 0, c->stream, c->d, la);
+					hipLaunchKernelGGL(dvp_weak_select_views, lg, block, 0, c->stream, c->d, la);
+					hipLaunchKernelGGL(DVP_PICK(dvp_weak_eval_planes), wg, w64, 0, c->stream, c->d, la);
+					hipLaunchKernelGGL(dvp_weak_make_hypotheses, lg, block, 0, c->stream, c->d, la);
+					hipLaunchKernelGGL(DVP_PICK(dvp_weak_eval_hypotheses), wg, w64, 0, c->stream, c->d, la);
+					hipLaunchKernelGGL(dvp_weak_adopt, lg, block, 0, c->stream, c->d, la);
+					hipLaunchKernelGGL(ex ? dvp_weak_final_cost_exact : dvp_weak_final_cost, lg64, w64, 0, c->stream, c->d, la);
+#undef DVP_PICK
+				} else if (c->d.anchor_tab) {
 					if (c->images8_ok) hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact_u8 : dvp_weak_update_wave_u8, dim3(la.count), dim3(64), 0, c->stream, c->d, la);
 					else hipLaunchKernelGGL(ex ? dvp_weak_update_wave_exact : dvp_weak_update_wave, dim3(la.count), dim3(64), 0, c->stream, c->d, la);
 				} else {

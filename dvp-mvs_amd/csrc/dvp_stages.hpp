@@ -4,6 +4,7 @@
 #define DVP_STAGES_HPP_
 
 #include "dvp_weak_wave.hpp"
+#include "dvp_weak_phased.hpp"
 #include <vector>
 #include <cmath>
 

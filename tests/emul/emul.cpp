@@ -36,6 +36,9 @@ struct Emu {
 	std::vector<int> gn_count;
 	std::vector<AnchorRec> anchor_tab;   // the weak update's per-pass table (dvp_weak_wave.hpp), same validity rule as the engine's
 	bool anchor_tab_valid = false, anchor_tab_off = false;
+	std::vector<WeakRec> weak_rec;       // the weak update as seven launches (dvp_weak_phased.hpp)
+	std::vector<f2> weak_ctab;
+	std::vector<float> weak_ev;
 	std::vector<int> neighbours_map, label, radius;
 	unsigned long long evals = 0;
 	bool count = false;
@@ -77,6 +80,7 @@ void refresh(Emu& e) {
 	d.fit_planes = e.fit_planes.data();
 	d.candidate = e.candidate.data();
 	d.anchor_tab = (e.anchor_tab_off || !e.anchor_tab_valid) ? nullptr : e.anchor_tab.data();
+	d.weak_rec = e.weak_rec.data(); d.weak_ctab = e.weak_ctab.data(); d.weak_ev = e.weak_ev.data();
 	d.edge = e.edge.data();
 	d.edge_bits = e.edge_bits.data();
 	d.edge_sat = e.edge_sat.data();
@@ -437,7 +441,52 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 		break;
 	}
 	case DVP_ST_RANSAC_FIT: pack_edge(e); launch<DVP_ST_RANSAC_FIT>(e, iter, colour); break;
-	case DVP_ST_WEAK_UPDATE: launch<DVP_ST_WEAK_UPDATE>(e, iter, colour); break;
+	case DVP_ST_WEAK_UPDATE: {
+		// the engine issues the update as seven launches (dvp_weak_phased.hpp) where the anchor table is on, unless
+		// DVP_WEAK_PHASED=0; the emulation follows the same switch, so both forms are checked against the oracle
+		const char* ph = getenv("DVP_WEAK_PHASED");
+		if (!e.d.anchor_tab || (ph && atoi(ph) == 0)) { launch<DVP_ST_WEAK_UPDATE>(e, iter, colour); break; }
+		const int S = e.NI - 1;
+		const size_t n = (size_t)std::max(e.d.weak_count, 1);
+		WeakRec poison;
+		std::memset(&poison, 0xA5, sizeof(poison));   // (nothing may read a field no launch of THIS update wrote)
+		e.weak_rec.assign(n, poison);
+		e.weak_ctab.assign(n * kTaps * kTaps, mk2(-7.0f, -7.0f));
+		e.weak_ev.assign(n * 8 * S, -7.0f);
+		refresh(e);
+		const LaunchGeom g = make_geom(e.W, e.H, true);
+		unsigned long long total = 0;
+		for (int part = 0; part < 7; ++part) {
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+			for (int b = 0; b < g.grid(); ++b)
+				for (int wave = 0; wave < 4; ++wave)
+					for (int lane = 0; lane < 64; ++lane) {
+						int px, py;
+						if (!block_to_pixel(b, lane, wave, g.tiles_x, g.tiles, g.rows, 1, colour, e.W, e.H, &px, &py)) continue;
+						if (e.d.weak_info[px + py * e.W] != DVP_WEAK) continue;
+						unsigned long long k = 0;
+						unsigned long long* kp = e.count ? &k : nullptr;
+						WeakSharedT<1> sh;
+						f2 tab_mem[kTaps * kTaps];
+						const PatchTab tab{tab_mem, 1};
+						const bool ex = e.d.sampler != 0, u8 = e.d.images8 != nullptr;
+#define EMU_WAVE(F) { if (ex) { if (u8) F<1, 1, 1>(e.d, px, py, kp, sh); else F<1, 0, 1>(e.d, px, py, kp, sh); } else { if (u8) F<0, 1, 1>(e.d, px, py, kp, sh); else F<0, 0, 1>(e.d, px, py, kp, sh); } }
+						switch (part) {
+						case 0: EMU_WAVE(weak_e0_wave) break;
+						case 1: weak_d1_px(e.d, px, py, iter); break;
+						case 2: EMU_WAVE(weak_e1_wave) break;
+						case 3: weak_d2_px(e.d, px, py, iter); break;
+						case 4: EMU_WAVE(weak_e2_wave) break;
+						case 5: weak_d3_px(e.d, px, py); break;
+						case 6: if (ex) weak_final_cost_px<1>(e.d, px, py, tab, kp); else weak_final_cost_px<0>(e.d, px, py, tab, kp); break;
+						}
+#undef EMU_WAVE
+						total += k;
+					}
+		}
+		e.evals += total;
+		break;
+	}
 	case DVP_ST_GET_DEPTH_NORMAL: launch<DVP_ST_GET_DEPTH_NORMAL>(e, iter, colour); break;
 	case DVP_ST_FILTER_STRONG: launch<DVP_ST_FILTER_STRONG>(e, iter, colour); break;
 	case DVP_ST_DEPTH_TO_WEAK: launch<DVP_ST_DEPTH_TO_WEAK>(e, iter, colour); break;

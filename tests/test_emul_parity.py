@@ -35,15 +35,21 @@ def test_first_pass_strong_path(W, H, S, sampler):
     _run_and_compare(a, b, 2)
 
 
-@pytest.mark.parametrize("anchors", ["table", "per_item"])
+@pytest.mark.parametrize("anchors", ["table", "one_wave", "alloc_fail", "per_item"])
 @pytest.mark.parametrize("images", ["8bit", "float"])
 def test_two_pass_weak_path_with_geom(images, anchors, monkeypatch):
     """`anchors`: the reference side of the anchor sub-patches from the pass' table (built once, before the first weak
-    update of the pass) or formed per (view, anchor, plane) item as the source text does (DVP_WEAK_ANCHOR_TAB=0).
+    update of the pass) or formed per (view, anchor, plane) item as the source text does (DVP_WEAK_ANCHOR_TAB=0).  With the
+    table the update runs as seven launches (dvp_weak_phased.hpp: "table"); "one_wave" (DVP_WEAK_PHASED=0) and "alloc_fail"
+    (the hand-over buffers do not fit: DVP_TEST_WEAK_PHASE_ALLOC_FAIL) keep a pixel's whole update in one wave; all the same bits.
     pass 1 (FIRST_INIT) on the oracle, then a REFINE_ITER pass with WEAK pixels, labels, adaptive
     radius and geometric consistency on both.  `images`: integer grey levels (the weak update reads the
     byte planes) or non-integers (float planes)."""
-    monkeypatch.setenv("DVP_WEAK_ANCHOR_TAB", "1" if anchors == "table" else "0")
+    monkeypatch.setenv("DVP_WEAK_ANCHOR_TAB", "0" if anchors == "per_item" else "1")
+    if anchors == "one_wave":
+        monkeypatch.setenv("DVP_WEAK_PHASED", "0")
+    if anchors == "alloc_fail":
+        monkeypatch.setenv("DVP_TEST_WEAK_PHASE_ALLOC_FAIL", "1")
     W, H, S = 112, 80, 3
     sc = synth.make_scene(W, H, S)
     if images == "float":
