@@ -43,7 +43,7 @@ VALU_MEASURED_PEAK_GINST = 977.5
 VALU_CEILING_BY_WAVES = {1: 501.6, 2: 761.6, 3: 852.3, 4: 896.1, 6: 943.3, 8: 977.5}
 GATHER_ROOF_GLINES = 51.4   # tools/gather_peak.hip on MI355X (profiles/r02_gather_peak.txt): 128-byte line requests per second of 16-byte gathers = 6.6 TB/s
 WAVES_PER_SIMD = {"strong_update": 2, "depth_to_weak": 2, "local_refine": 2, "random_init": 2, "weak_update": 4}
-PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_r04.json")
+PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_r05.json")
 EVALUATOR_PEAK_GEVALS = 32.7   # the 36-tap evaluator alone at 2 waves per SIMD (tools/pv_probe.py, profiles/r03_pv_probe.txt): what a launch site of NCC evaluations can reach at best
 
 
@@ -98,6 +98,12 @@ def sweep_split():
     return e != "0" and (GEOM or e == "2")
 
 
+def weak_phased():
+    """the weak update runs as evaluation launches (a wave per group of WEAK pixels) + decision launches (a lane per WEAK pixel)
+    where the anchor table is on (dvp_engine.hip: launch_stage)"""
+    return os.environ.get("DVP_WEAK_PHASED", "1") != "0" and os.environ.get("DVP_WEAK_ANCHOR_TAB", "1") != "0"
+
+
 def extra_kernels(stage, S):
     """the other kernels a launch site's timer covers: [(kernel, launches per launch of the site)]; their counters are added to
     the first one's"""
@@ -105,6 +111,10 @@ def extra_kernels(stage, S):
         return [("dvp_gen_neighbours_fit", 1)]       # (dvp_gen_candidates runs on the side stream, outside its launch site's timer)
     if stage == "strong_update" and S <= 16 and os.environ.get("DVP_STRONG_SPLIT", "1") != "0":
         return [(decide_kernel(S), 1), ("dvp_strong_refine_lanes" if os.environ.get("DVP_REFINE_LANES", "1") != "0" else "dvp_strong_refine", 1)]
+    if stage == "weak_update" and weak_phased():     # the weak update as eight launches (dvp_weak_phased.hpp)
+        u8 = "_u8" if IMAGE_FORMAT else ""
+        return [("dvp_weak_select_views", 1), ("dvp_weak_eval_planes" + u8, 1), ("dvp_weak_make_hypotheses", 1), ("dvp_weak_eval_first_view" + u8, 1),
+                ("dvp_weak_eval_survivors" + u8, 1), ("dvp_weak_adopt", 1), ("dvp_weak_final_cost", 1)]
     if stage == "depth_to_weak" and sweep_split():   # DepthToWeak + LocalRefine as view-compacted passes
         return [("dvp_sweep_prepare", 1), ("dvp_sweep_decide1", 1), ("dvp_sweep_decide2", 1), ("dvp_sweep_border", 1)] + \
                []
@@ -119,7 +129,8 @@ def primary_launches(stage):
 def kernel_name(stage, S):
     split = S <= 16 and os.environ.get("DVP_STRONG_SPLIT", "1") != "0"
     return {"strong_update": ("dvp_strong_eval_items" if os.environ.get("DVP_EVAL_ITEMS", "1") != "0" else "dvp_strong_eval") if split else ("dvp_strong_update_v8" if S <= 8 else ("dvp_strong_update_v16" if S <= 16 else "dvp_strong_update")),
-            "weak_update": ("dvp_weak_update_wave_u8" if IMAGE_FORMAT else "dvp_weak_update_wave") + ("" if os.environ.get("DVP_WEAK_ANCHOR_TAB", "1") != "0" else "_notab"),
+            "weak_update": ("dvp_weak_eval_candidates" + ("_u8" if IMAGE_FORMAT else "")) if weak_phased() else
+                           (("dvp_weak_update_wave_u8" if IMAGE_FORMAT else "dvp_weak_update_wave") + ("" if os.environ.get("DVP_WEAK_ANCHOR_TAB", "1") != "0" else "_notab")),
             "depth_to_weak": "dvp_sweep_eval" if sweep_split() else "dvp_depth_to_weak_refine",   # dvp_run_patchmatch: DepthToWeak + LocalRefine as one launch site
             "gen_neighbours": "dvp_gen_neighbours_search" if os.environ.get("DVP_GN_WAVE", "0") not in ("", "0") else "dvp_gen_neighbours_list",
             "ransac_fit": "dvp_ransac_fit_plane_list", "find_nearest_strong": "dvp_find_nearest_strong_list",
@@ -213,7 +224,7 @@ def cpu_baseline(pkg, args, cfg, S, iters, device=0):
 
 
 def pmc_lookup(kernel, W, H, S):
-    """PMC counters of `kernel` at exactly this problem size (profiles/pmc_r04.json, written by
+    """PMC counters of `kernel` at exactly this problem size (profiles/pmc_r05.json, written by
     tools/pmc_table.py from separate rocprofv3 --pmc passes of this bench ON THE SAME KERNEL SOURCES) or None."""
     t, _ = pmc_table()
     if RIG != "rotated" or SRC_DEPTHS != "estimated":     # the table is collected on the default workload
@@ -223,7 +234,7 @@ def pmc_lookup(kernel, W, H, S):
 
 def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
     """Roofline entry of one launch site; a reader can recompute every fraction from profiles/ alone:
-      frac (bound "valu")  = SQ_INSTS_VALU per launch (profiles/pmc_r04.json) / live launch time / 1228.8 G/s
+      frac (bound "valu")  = SQ_INSTS_VALU per launch (profiles/pmc_r05.json) / live launch time / 1228.8 G/s
                              (guide peak: 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 v_fma_f32);
       valu_frac_of_measured_issue_peak = same rate / 977.5 G/s (tools/valu_peak.hip, 8 waves per SIMD);
       valu_frac_of_occupancy_ceiling   = same rate / the measured ceiling at the kernel's own waves per SIMD;
@@ -522,6 +533,12 @@ def main():
         ev_launch = {k: evals["ncc_evals"][k] / max(evals["stage_launches"][k], 1) for k in stage_ms}
         ranked = sorted((k for k in stage_ms if k != "strong_prep"), key=lambda k: -stage_ms[k])
         roofs = {k: roofline_of(k, S, W, H, per_launch[k], ev_launch[k]) for k in ranked[:4]}
+        # what a WEAK pixel costs against any pixel: the launch sites that only touch WEAK pixels (anchor search, fit plane, weak
+        # update) per WEAK pixel, everything else per pixel of the view (the regime must be visible in the line)
+        weak_sites = ("find_nearest_strong", "gen_neighbours", "neighbour_update", "ransac_fit", "weak_update")
+        weak_ms = sum(stage_ms.get(k, 0.0) for k in weak_sites) / args.steps
+        other_ms = dt * 1e3 / args.steps - weak_ms
+        n_weak = weak_frac * L
         dom = ranked[0]
         workload = "BASELINE %s stand-in: %dx%d, S=%d source views, %d PatchMatch iterations, %s" % (
             args.config if (W, H, S) == (cfg["W"], cfg["H"], cfg["S"]) else "custom(%s-like)" % args.config, W, H, S, iters,
@@ -539,6 +556,8 @@ def main():
             "rooflines_top_kernels": roofs,
             "iter_loop_value": round(float(W) * H * iters * args.steps / (tm["iter_loop_ms"] * 1e-3) / 1e6, 3) if tm["iter_loop_ms"] > 0 else None,
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
+            "ns_per_weak_pixel": round(weak_ms * 1e6 / n_weak, 1) if n_weak > 0 else None,
+            "ns_per_pixel_other": round(other_ms * 1e6 / L, 1),
             # every kernel of a launch site (the PMC tooling averages the last `n` dispatches of each)
             "launches_per_step": dict([(kernel_name(k, S), primary_launches(k) * tm["stage_launches"][k] // args.steps) for k in stage_ms if k != "strong_prep"] +
                                       [(extra, mult * tm["stage_launches"][k] // args.steps) for k in stage_ms for extra, mult in extra_kernels(k, S)] +

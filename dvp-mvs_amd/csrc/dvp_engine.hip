@@ -37,7 +37,7 @@ __device__ __forceinline__ void stage_body(const Dev& d, const LaunchArgs& a) {
 
 // Compacted launch for the weak-pixel path: lane t owns the t-th WEAK pixel of the list segment.
 // WEAK pixels are 1-30 % of a view; a lane-per-image-pixel launch leaves 70-99 % of the lanes idle.
-struct ListArgs { int base, count, iter, covered_rows; };
+struct ListArgs { int base, count, iter, covered_rows, group; };   // group: pixels per wave of the weak update's evaluation launches
 // XCD-aware block -> list-block map.  Workgroup b runs on XCD b % 8 (observed placement, a speed matter
 // only); the list is in super-tile order, so giving every XCD RUNS of kListRun consecutive list blocks
 // (instead of every 8th block) keeps the workgroups that share anchors — and the source-image lines
@@ -418,32 +418,40 @@ extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wa
 extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_exact_u8(const Dev d, const ListArgs a) { weak_wave_body<1, 1, 1>(d, a); }
 extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_u8_notab(const Dev d, const ListArgs a) { weak_wave_body<0, 1, 0>(d, a); }
 extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wave_exact_u8_notab(const Dev d, const ListArgs a) { weak_wave_body<1, 1, 0>(d, a); }
-// The same launch site as SEVEN launches (dvp_weak_phased.hpp): the evaluation launches E0 / E1 / E2 keep one wave per WEAK
-// pixel, the per-pixel decisions D1 / D2 / D3 and the final plain-NCC cost E3 run one LANE per WEAK pixel.
-template <int SMP, int FMT, int PART>
-__device__ __forceinline__ void weak_phase_wave_body(const Dev& d, const ListArgs& a) {
-	__shared__ WeakSharedT<1> sh[1];
-	const int t = list_block(blockIdx.x, gridDim.x, kWaveRun * 4);
-	if (t >= a.count) return;
-	const int center = d.weak_list[a.base + t];
-	const int py = center / d.width, px = center - py * d.width;
-	if (py >= a.covered_rows) return;
-	if (d.weak_info[center] != DVP_WEAK) return;
+// The same launch site as EIGHT launches (dvp_weak_phased.hpp): the evaluation launches E0 / E1 / E2a / E2b take one wave per
+// GROUP of a.group consecutive WEAK pixels of the list, the per-pixel decisions D1 / D2 / D3 and the final plain-NCC cost E3
+// run one LANE per WEAK pixel.
+template <int SMP, int FMT, int MODE>
+__device__ __forceinline__ void weak_group_body(const Dev& d, const ListArgs& a) {
+	__shared__ WeakGroupShared sh;
+	const int G = a.group;
+	const int run = kWaveRun * 4 / G;   // XCD runs of the same length in pixels as the one-wave kernel's
+	const int blk = list_block(blockIdx.x, gridDim.x, run < 1 ? 1 : run);
+	if (blk * G >= a.count) return;
+	if (threadIdx.x < (unsigned)kGrp) {
+		const int t = blk * G + (int)threadIdx.x;
+		int center = -1;
+		if ((int)threadIdx.x < G && t < a.count) {
+			center = d.weak_list[a.base + t];
+			// rows beyond the reference's half grid (APD.cu:4421-4424); NeigbourUpdate turned it UNKNOWN since the list was built (APD.cu:3119-3123)
+			if (center / d.width >= a.covered_rows || d.weak_info[center] != DVP_WEAK) center = -1;
+		}
+		sh.center[threadIdx.x] = center;
+	}
+	wave_sync();
 	unsigned long long n = 0;
-	unsigned long long* np = d.eval_counter ? &n : nullptr;
-	if (PART == 0) weak_e0_wave<SMP, FMT, 1>(d, px, py, np, sh[0]);
-	else if (PART == 1) weak_e1_wave<SMP, FMT, 1>(d, px, py, np, sh[0]);
-	else weak_e2_wave<SMP, FMT, 1>(d, px, py, np, sh[0]);
+	weak_group_eval<SMP, FMT, MODE>(d, G, d.eval_counter ? &n : nullptr, sh);
 	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
 }
-#define DVP_WEAK_PHASE_KERNELS(NAME, PART)                                                                                                                   \
-	extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) NAME(const Dev d, const ListArgs a) { weak_phase_wave_body<0, 0, PART>(d, a); }           \
-	extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) NAME##_exact(const Dev d, const ListArgs a) { weak_phase_wave_body<1, 0, PART>(d, a); }   \
-	extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) NAME##_u8(const Dev d, const ListArgs a) { weak_phase_wave_body<0, 1, PART>(d, a); }      \
-	extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) NAME##_exact_u8(const Dev d, const ListArgs a) { weak_phase_wave_body<1, 1, PART>(d, a); }
+#define DVP_WEAK_PHASE_KERNELS(NAME, MODE)                                                                                                              \
+	extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) NAME(const Dev d, const ListArgs a) { weak_group_body<0, 0, MODE>(d, a); }           \
+	extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) NAME##_exact(const Dev d, const ListArgs a) { weak_group_body<1, 0, MODE>(d, a); }   \
+	extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) NAME##_u8(const Dev d, const ListArgs a) { weak_group_body<0, 1, MODE>(d, a); }      \
+	extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) NAME##_exact_u8(const Dev d, const ListArgs a) { weak_group_body<1, 1, MODE>(d, a); }
 DVP_WEAK_PHASE_KERNELS(dvp_weak_eval_candidates, 0)
 DVP_WEAK_PHASE_KERNELS(dvp_weak_eval_planes, 1)
-DVP_WEAK_PHASE_KERNELS(dvp_weak_eval_hypotheses, 2)
+DVP_WEAK_PHASE_KERNELS(dvp_weak_eval_first_view, 2)
+DVP_WEAK_PHASE_KERNELS(dvp_weak_eval_survivors, 3)
 template <int PART>
 __device__ __forceinline__ void weak_phase_lane_body(const Dev& d, const ListArgs& a) {
 	const int t = list_block(blockIdx.x, gridDim.x, kListRun) * 256 + threadIdx.x;
@@ -938,6 +946,7 @@ struct dvp_ctx {
 	WeakRec* weak_rec = nullptr; f2* weak_ctab = nullptr; float* weak_ev = nullptr;
 	size_t weak_phase_alloc = 0;       // capacity in WEAK pixels
 	bool weak_phased = true;           // DVP_WEAK_PHASED=0, no anchor table, or the buffers did not fit: the one-wave form
+	int weak_group[4] = { 1, 4, 8, 8 };   // WEAK pixels per wave of E0 / E1 / E2a / E2b (DVP_WEAK_GROUPS=a,b,c,d: A/B measurements)
 	int* weak_list = nullptr;    // compacted WEAK pixel indices (black first, then red)
 	size_t weak_list_alloc = 0;
 	int* weak_counts = nullptr;  // scratch of the device-side compaction: per-slot black / red counts, per-chunk counts, then 3 totals
@@ -1040,6 +1049,11 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	if (const char* e = getenv("DVP_WEAK_ANCHOR_TAB")) c->anchor_tab_off = atoi(e) == 0;   // A/B measurements and the tests of the per-item form
 	if (const char* e = getenv("DVP_GN_WAVE")) c->gn_wave = atoi(e) != 0;
 	if (const char* e = getenv("DVP_WEAK_PHASED")) c->weak_phased = atoi(e) != 0;
+	if (const char* e = getenv("DVP_WEAK_GROUPS")) {
+		int g[4];
+		if (sscanf(e, "%d,%d,%d,%d", &g[0], &g[1], &g[2], &g[3]) == 4)
+			for (int i = 0; i < 4; ++i) c->weak_group[i] = g[i] < 1 ? 1 : (g[i] > kGrp ? kGrp : g[i]);
+	}
 	c->pitch = (width + 2 * kImgPad + 63) / 64 * 64;
 	c->L = (size_t)width * height;
 	auto fail = [&](int) { g_create_error = c->error; dvp_ctx_destroy(c); return 1; };
@@ -1555,13 +1569,16 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 				if (c->d.anchor_tab && ensure_weak_phase_buffers(c)) return 1;
 				if (c->d.anchor_tab && c->weak_phased) {
 					const bool u8 = c->images8_ok;
-					const dim3 wg(la.count), w64(64), lg64((la.count + 63) / 64);
+					const dim3 w64(64), lg64((la.count + 63) / 64);
 #define DVP_PICK(NAME) (ex ? (u8 ? NAME##_exact_u8 : NAME##_exact) : (u8 ? NAME##_u8 : NAME))
-					hipLaunchKernelGGL(DVP_PICK(dvp_weak_eval_candidates), wg, w64, 0, c->stream, c->d, la);
+#define DVP_GROUP_LAUNCH(NAME, PHASE) { la.group = c->weak_group[PHASE]; hipLaunchKernelGGL(DVP_PICK(NAME), dim3((la.count + la.group - 1) / la.group), w64, 0, c->stream, c->d, la); }
+					DVP_GROUP_LAUNCH(dvp_weak_eval_candidates, 0)
 					hipLaunchKernelGGL(dvp_weak_select_views, lg, block, 0, c->stream, c->d, la);
-					hipLaunchKernelGGL(DVP_PICK(dvp_weak_eval_planes), wg, w64, 0, c->stream, c->d, la);
+					DVP_GROUP_LAUNCH(dvp_weak_eval_planes, 1)
 					hipLaunchKernelGGL(dvp_weak_make_hypotheses, lg, block, 0, c->stream, c->d, la);
-					hipLaunchKernelGGL(DVP_PICK(dvp_weak_eval_hypotheses), wg, w64, 0, c->stream, c->d, la);
+					DVP_GROUP_LAUNCH(dvp_weak_eval_first_view, 2)
+					DVP_GROUP_LAUNCH(dvp_weak_eval_survivors, 3)
+#undef DVP_GROUP_LAUNCH
 					hipLaunchKernelGGL(dvp_weak_adopt, lg, block, 0, c->stream, c->d, la);
 					hipLaunchKernelGGL(ex ? dvp_weak_final_cost_exact : dvp_weak_final_cost, lg64, w64, 0, c->stream, c->d, la);
 #undef DVP_PICK

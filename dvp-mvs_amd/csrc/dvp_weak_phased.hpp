@@ -62,82 +62,291 @@ DVP_HD uint32_t wave_lane_bit(bool pred, int lane) {
 
 DVP_HD float* weak_ev_of(const Dev& d, int wi) { return d.weak_ev + (size_t)wi * 8 * (size_t)(d.params.num_images - 1); }
 
-// the centre-patch context the update's first launch left (record + table) -> sh.ctab, c
-template <class SH>
-DVP_HD void weak_load_ctx(const Dev& d, int wi, SH& sh, PatchCtx* c) {
-	const WeakRec& rec = d.weak_rec[wi];
-	c->tab = PatchTab{nullptr, 0};
-	c->radius = rec.radius;
-	c->inc = rec.inc;
-	c->fast = rec.fast;
-	c->sum_ref = rec.sum_ref;
-	c->sum_ref_ref = rec.sum_ref_ref;
-	c->wsum = rec.wsum;
-	DVP_LANES(t) {
-		if (t < kTaps * kTaps) sh.ctab[t] = d.weak_ctab[(size_t)wi * (kTaps * kTaps) + t];
-		if (t < 8) sh.pl[t] = rec.pl[t];
-	}
-	wave_sync();
-}
-// sh.ev[q][v] for q in pmask, v in vmask -> the pixel's cost vectors
-template <class SH>
-DVP_HD void weak_store_ev(const Dev& d, int wi, uint32_t pmask, uint32_t vmask, const SH& sh) {
-	const int S = d.params.num_images - 1;
-	float* ev = weak_ev_of(d, wi);
-	DVP_LANES(l) {
-		for (int i = l; i < 8 * S; i += 64) {
-			const int q = i / S, v = i - q * S;
-			if (((pmask >> q) & 1) && ((vmask >> v) & 1)) ev[i] = sh.ev[q][v];
+// ---- the evaluation launches: one wave per GROUP of WEAK pixels ------------------------------------------------------------
+// ComputeBilateralNCCNew (APD.cu:835-1021) for every (plane, view) PAIR the pixels of the group have to evaluate.  One pixel
+// per wave (wave_ncc_new_tab) fills its rounds only in the propagation launch (<= 8 planes x S views = 72 pairs); the later
+// ones hold 2 x ~5, 5 x 1 and (survivors) x ~4 pairs per pixel — a round of 64 lanes a third full behind a chain of dependent
+// loads (record -> anchors -> their views -> table -> gathers) that a single pixel cannot hide: measured 0.23 ms per pair and
+// 880 k pixels in the first launch against 0.7 and 1.7 in the other two.  Here the pairs of up to kGrp consecutive pixels of
+// the WEAK list are numbered flat and taken kWeakPairs per batch; the work items of a batch — (pair, anchor) sub-patches,
+// (pair, patch row) centre rows, pair totals — are numbered pair-fastest, so the lanes of a load instruction are the planes
+// of one (pixel, view) first (they share the anchor's table record and neighbouring texels), then the next view / pixel.
+// The arithmetic of an item is anchor_cost_tab / patch_row_sums / the totalling section of wave_ncc_new_tab, unchanged.
+//   MODE 0  E0: the anchors' planes against every view; also builds the pixel's centre-patch context and leaves it
+//   MODE 1  E1: the record's planes against its views
+//   MODE 2  E2a: the hypotheses in range against the FIRST selected view; decides which survive
+//   MODE 3  E2b: the survivors against the other selected views
+constexpr int kGrp = 8;
+struct WeakGroupShared {
+	// per pixel of the group
+	int center[kGrp];                        // pixel index, < 0: no pixel in this slot (filled by the caller)
+	f2 ctab[kGrp][kTaps * kTaps];            // centre patch: (w, w * ref) per tap, row-major
+	s2 nbs[kGrp][DVP_NEIGHBOUR_NUM];
+	uint32_t asel[kGrp][kAnchors];           // selected_views word of anchor k
+	float sum_ref[kGrp], sum_ref_ref[kGrp], wsum[kGrp];
+	int px[kGrp], py[kGrp], wi[kGrp], radius[kGrp], inc[kGrp], fast[kGrp];
+	uint32_t pmask[kGrp], vmask[kGrp], alive[kGrp];
+	// per pair of the batch
+	float Hq[kWeakPairs][9];
+	float rows[kWeakPairs][kTaps][3];        // centre-patch row sums (s_s, s_ss, s_rs); before the first batch of MODE 0: w * ref * ref per tap
+	float acost[kWeakPairs][kAnchors];       // anchor cost, < 0: does not count
+	uint32_t pair[kWeakPairs];               // pixel slot | view << 8 | plane << 16 | (centre projects inside the view) << 24
+};
+struct CtabView { const f2* ctab; };
+
+template <int SMP, int FMT, int MODE>
+DVP_HD void weak_group_eval(const Dev& d, int G, unsigned long long* nevals, WeakGroupShared& sh) {
+	const int W = d.width;
+	const DvpParams& P = d.params;
+	const int S = P.num_images - 1;
+	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
+	// ---- the pixels of the group ------------------------------------------------------------------------------------------
+	DVP_LANES(g) {
+		if (g < kGrp) {
+			uint32_t pm = 0, vm = 0;
+			int px = 0, py = 0, wi = 0;
+			const int center = g < G ? sh.center[g] : -1;
+			if (g >= G) sh.center[g] = -1;
+			if (center >= 0) {
+				py = center / W;
+				px = center - py * W;
+				wi = d.neighbours_map[center];
+				if (MODE == 0) vm = all_views;   // (pm: the anchors that count, below)
+				else {
+					const WeakRec& rec = d.weak_rec[wi];
+					pm = rec.pmask;
+					vm = rec.vmask;
+					if (MODE == 2) { if (pm && vm) vm = vm & (0u - vm); else pm = vm = 0u; }   // the first selected view
+					if (MODE == 3) vm = vm & (vm - 1u);                                        // the others
+					sh.radius[g] = rec.radius; sh.inc[g] = rec.inc; sh.fast[g] = rec.fast;
+					sh.sum_ref[g] = rec.sum_ref; sh.sum_ref_ref[g] = rec.sum_ref_ref; sh.wsum[g] = rec.wsum;
+				}
+			}
+			sh.px[g] = px; sh.py[g] = py; sh.wi[g] = wi;
+			sh.pmask[g] = pm; sh.vmask[g] = vm; sh.alive[g] = 0u;
 		}
 	}
-}
-
-// ---- E0: the propagation candidates ---------------------------------------------------------------------------------------
-template <int SMP, int FMT, int TAB>
-DVP_HD void weak_e0_wave(const Dev& d, int px, int py, unsigned long long* nevals, WeakSharedT<TAB>& sh) {
-	const int W = d.width;
-	const int center = py * W + px;
-	const int S = d.params.num_images - 1;
-	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
-	const int wi = d.neighbours_map[center];
-	const s2* nbs = d.neighbours + (size_t)wi * DVP_NEIGHBOUR_NUM;
-	const float cpix = ref_texel_t<FMT>(d, px, py);
-	PatchCtx c;
-	c.tab = PatchTab{nullptr, 0};
-	{
-		int radius, inc;
-		patch_geometry(d, center, &radius, &inc);
-		wave_patch_ctx<FMT>(d, px, py, radius, inc, 1, sh, &c);
+	wave_sync();
+	DVP_LANES(l) {
+		for (int it = l; it < G * DVP_NEIGHBOUR_NUM; it += 64) {
+			const int g = it / DVP_NEIGHBOUR_NUM, i = it - g * DVP_NEIGHBOUR_NUM;
+			sh.nbs[g][i] = sh.center[g] >= 0 ? d.neighbours[(size_t)sh.wi[g] * DVP_NEIGHBOUR_NUM + i] : mks2(-1, -1);
+		}
 	}
-	// the anchors' planes (APD.cu:2771-2779): lane k owns anchor k
-	uint32_t flag = 0;
-	DVP_LANES(k) {
-		bool ok = false;
-		if (k < 8) {
-			const s2 nb = nbs[k + 1];
-			if (!(nb.x == -1 || nb.y == -1) && d.weak_info[nb.x + nb.y * W] == DVP_STRONG) {
-				ok = true;
-				sh.pl[k] = d.planes[nb.x + nb.y * W];
+	wave_sync();
+	DVP_LANES(l) {
+		for (int it = l; it < G * kAnchors; it += 64) {
+			const int g = it / kAnchors, k = it - g * kAnchors;
+			const s2 nb = sh.nbs[g][k + 1];
+			uint32_t sv = 0;
+			if (!(nb.x == -1 || nb.y == -1)) {
+				const int nbc = nb.x + nb.y * W;
+				sv = d.selected_views[nbc];
+				if (MODE == 0 && k < 8 && d.weak_info[nbc] == DVP_STRONG) {   // the anchors' planes (APD.cu:2771-2779)
+					d.weak_rec[sh.wi[g]].pl[k] = d.planes[nbc];
+					wave_bits_or(&sh.pmask[g], 1u << k);
+				}
+			}
+			sh.asel[g][k] = sv;
+		}
+	}
+	// ---- the centre-patch context: built (MODE 0: wave_patch_ctx per pixel, colour-only weights) or fetched --------------------
+	if (MODE == 0) {
+		float* caa = &sh.rows[0][0][0];
+		DVP_LANES(l) {
+			for (int it = l; it < G * kTaps * kTaps; it += 64) {
+				const int g = it / (kTaps * kTaps), t = it - g * (kTaps * kTaps);
+				if (sh.center[g] < 0) continue;
+				int radius, inc;
+				patch_geometry(d, sh.center[g], &radius, &inc);
+				if (!(inc > 0 && (2 * radius) / inc + 1 == kTaps)) continue;
+				const int px = sh.px[g], py = sh.py[g];
+				const float cpix = ref_texel_t<FMT>(d, px, py);
+				const int ty = t / kTaps, tx = t - ty * kTaps;
+				const int i = -radius + tx * inc, j = -radius + ty * inc;
+				const float a = ref_texel_t<FMT>(d, px + i, py + j);
+				const float w = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
+				const float wa = w * a;
+				sh.ctab[g][t] = mk2(w, wa);
+				caa[it] = wa * a;
 			}
 		}
-		flag |= wave_lane_bit(ok, k);
+		wave_sync();
+		DVP_LANES(g) {
+			if (g < G && sh.center[g] >= 0) {
+				int radius, inc;
+				patch_geometry(d, sh.center[g], &radius, &inc);
+				const int fast = (inc > 0 && (2 * radius) / inc + 1 == kTaps) ? 1 : 0;
+				float sr = 0.0f, srr = 0.0f, ws = 0.0f;
+				if (fast) {
+					for (int ty = 0; ty < kTaps; ++ty) {
+						float sr_row = 0.0f, srr_row = 0.0f, ws_row = 0.0f;
+						for (int tx = 0; tx < kTaps; ++tx) {
+							const f2 t = sh.ctab[g][ty * kTaps + tx];
+							sr_row += t.y;
+							srr_row += caa[g * (kTaps * kTaps) + ty * kTaps + tx];
+							ws_row += t.x;
+						}
+						sr += sr_row;
+						srr += srr_row;
+						ws += ws_row;
+					}
+				}
+				sh.radius[g] = radius; sh.inc[g] = inc; sh.fast[g] = fast;
+				sh.sum_ref[g] = sr; sh.sum_ref_ref[g] = srr; sh.wsum[g] = ws;
+				WeakRec& rec = d.weak_rec[sh.wi[g]];
+				rec.flag = sh.pmask[g];
+				rec.radius = radius; rec.inc = inc; rec.fast = fast;
+				rec.sum_ref = sr; rec.sum_ref_ref = srr; rec.wsum = ws;
+			}
+		}
+		DVP_LANES(l) {
+			for (int it = l; it < G * kTaps * kTaps; it += 64) {
+				const int g = it / (kTaps * kTaps), t = it - g * (kTaps * kTaps);
+				if (sh.center[g] >= 0) d.weak_ctab[(size_t)sh.wi[g] * (kTaps * kTaps) + t] = sh.ctab[g][t];
+			}
+		}
+	} else {
+		DVP_LANES(l) {
+			for (int it = l; it < G * kTaps * kTaps; it += 64) {
+				const int g = it / (kTaps * kTaps), t = it - g * (kTaps * kTaps);
+				if (sh.center[g] >= 0) sh.ctab[g][t] = d.weak_ctab[(size_t)sh.wi[g] * (kTaps * kTaps) + t];
+			}
+		}
 	}
 	wave_sync();
-	if (flag) {
-		weak_eval<SMP, FMT>(d, c, nbs, cpix, px, py, all_views, flag, sh);
-		weak_store_ev(d, wi, flag, all_views, sh);
+	// ---- the pairs, numbered flat over the group: pixel, then view, then plane ------------------------------------------------
+	int base[kGrp];
+	int T = 0;
+#pragma unroll
+	for (int g = 0; g < kGrp; ++g) {
+		base[g] = T;
+		T += __builtin_popcount(sh.pmask[g]) * __builtin_popcount(sh.vmask[g]);
 	}
-	WeakRec& rec = d.weak_rec[wi];
-	DVP_LANES(t) {
-		if (t < kTaps * kTaps) d.weak_ctab[(size_t)wi * (kTaps * kTaps) + t] = sh.ctab[t];
-		if (t < 8 && ((flag >> t) & 1)) rec.pl[t] = sh.pl[t];
+	const DvpCamera rc = load_camera(d, 0);   // (MODE 2)
+	for (int b0 = 0; b0 < T; b0 += kWeakPairs) {
+		const int nb = DVP_MIN(kWeakPairs, T - b0);
+		const float inv_nb = 1.0f / (float)nb;
+		// section 0: lane = pair: which (pixel, view, plane) it is, its homography
+		DVP_LANES(l) {
+			if (l < nb) {
+				const int p = b0 + l;
+				int g = 0, bg = 0;
+#pragma unroll
+				for (int i = 1; i < kGrp; ++i)
+					if (p >= base[i]) { g = i; bg = base[i]; }
+				const uint32_t pm = sh.pmask[g], vm = sh.vmask[g];
+				const int np = __builtin_popcount(pm);
+				const int local = p - bg;
+				const int vslot = small_div(local, 1.0f / (float)np), qi = local - vslot * np;
+				const int v = nth_set_bit(vm, vslot), q = nth_set_bit(pm, qi);   // 0-based view, plane slot
+				f4 pl;
+				if (MODE == 0) { const s2 a = sh.nbs[g][q + 1]; pl = d.planes[a.x + a.y * W]; }
+				else pl = d.weak_rec[sh.wi[g]].pl[q];
+				const ViewConst vc = d.views[v + 1];
+				float H[9];
+				homography(vc, pl, H);
+				const f2 pt = apply_homography(H, sh.px[g], sh.py[g]);
+				const uint32_t inside = !(pt.x >= vc.fw || pt.x < 0.0f || pt.y >= vc.fh || pt.y < 0.0f) ? 1u : 0u;
+#pragma unroll
+				for (int i = 0; i < 9; ++i) sh.Hq[l][i] = H[i];
+				sh.pair[l] = (uint32_t)g | ((uint32_t)v << 8) | ((uint32_t)q << 16) | (inside << 24);
+			}
+		}
+		wave_sync();
+		// section 1: anchor items (anchor k, pair), pair fastest; then centre items (patch row, pair)
+		DVP_LANES(l) {
+			const int n_anchor = nb * kAnchors;
+			for (int it0 = 0; it0 < n_anchor; it0 += 64) {
+				const int it = it0 + l;
+				if (it >= n_anchor) continue;
+				const int k = small_div(it, inv_nb), pi = it - k * nb;
+				const uint32_t desc = sh.pair[pi];
+				if (!(desc >> 24)) continue;
+				const int g = (int)(desc & 255u), v = (int)((desc >> 8) & 255u);
+				const s2 nbk = sh.nbs[g][k + 1];
+				const int state = (nbk.x == -1 || nbk.y == -1) ? 0 : (is_set(sh.asel[g][k], v) ? 2 : 1);
+				float H[9];
+#pragma unroll
+				for (int i = 0; i < 9; ++i) H[i] = sh.Hq[pi][i];
+				sh.acost[pi][k] = anchor_cost_tab<SMP, FMT>(d, H, img_plane<FMT>(d, v + 1), nbk, state, d.anchor_tab + anchor_rec_index(d, sh.wi[g], v, k));
+			}
+			const int n_centre = nb * kTaps;
+			for (int it0 = 0; it0 < n_centre; it0 += 64) {
+				const int it = it0 + l;
+				if (it >= n_centre) continue;
+				const int r = small_div(it, inv_nb), pi = it - r * nb;
+				const uint32_t desc = sh.pair[pi];
+				if (!(desc >> 24)) continue;
+				const int g = (int)(desc & 255u), v = (int)((desc >> 8) & 255u);
+				const int fast = sh.fast[g];
+				if (!fast && r != 0) continue;
+				float Hc[9];
+#pragma unroll
+				for (int i = 0; i < 9; ++i) Hc[i] = sh.Hq[pi][i];
+				if (fast) {
+					float o[3];
+					const CtabView cv{ sh.ctab[g] };
+					patch_row_sums<SMP, FMT>(d, cv, Hc, img_plane<FMT>(d, v + 1), sh.px[g], sh.py[g], sh.radius[g], sh.inc[g], r, o);
+					sh.rows[pi][r][0] = o[0];
+					sh.rows[pi][r][1] = o[1];
+					sh.rows[pi][r][2] = o[2];
+				} else {   // generic (non-6-tap) patches sample the float planes
+					sh.rows[pi][0][0] = ncc_patch_generic(d, Hc, d.images + (size_t)(v + 1) * d.plane_stride * 2, sh.px[g], sh.py[g], sh.radius[g], sh.inc[g], 1);
+				}
+			}
+		}
+		wave_sync();
+		// section 2: lane = pair: rows and anchors summed in the reference's order -> the pixel's cost vectors
+		DVP_LANES(l) {
+			if (l < nb) {
+				const uint32_t desc = sh.pair[l];
+				const int g = (int)(desc & 255u), v = (int)((desc >> 8) & 255u), q = (int)((desc >> 16) & 255u);
+				float out = 2.0f;
+				if (desc >> 24) {
+					float cc;
+					if (sh.fast[g]) {
+						float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
+						for (int r = 0; r < kTaps; ++r) {
+							s_s += sh.rows[l][r][0];
+							s_ss += sh.rows[l][r][1];
+							s_rs += sh.rows[l][r][2];
+						}
+						cc = ncc_from_sums(sh.sum_ref[g], sh.sum_ref_ref[g], s_s, s_ss, s_rs, sh.wsum[g]);
+					} else {
+						cc = sh.rows[l][0][0];
+					}
+					float scost = 0.0f, scnt = 0.0f;
+					for (int k = 0; k < kAnchors; ++k) {
+						const float ac = sh.acost[l][k];
+						if (ac >= 0.0f) { scost += ac; scnt += 1.0f; }
+					}
+					out = cc;
+					if (scnt > 0.0f) {
+						float sc2 = scost / scnt;   // strong_cost /= strong_count (int -> float, exact)
+						sc2 = DVP_MIN(sc2, 2.0f);
+						out = (float)(0.25 * cc + 0.75 * sc2);
+					}
+				}
+				weak_ev_of(d, sh.wi[g])[q * S + v] = out;
+				if (MODE == 2) {
+					// The weighted sum only grows (weights > 0, costs >= 0, IEEE addition and division are monotone), so a hypothesis
+					// whose FIRST selected view alone is not below the best cost at entry can never be adopted (APD.cu:1361-1383).
+					const WeakRec& rec = d.weak_rec[sh.wi[g]];
+					const int w = d.view_weight[(size_t)sh.center[g] * 32 + v];
+					float tc = 0.0f;
+					if (P.geom_consistency) tc += w * (out + P.geom_factor * geom_cost_cams(d, rc, d.cameras[v + 1], v + 1, sh.px[g], sh.py[g], rec.pl[q]));
+					else tc += w * out;
+					if (tc / rec.weight_norm < rec.cost_now) wave_bits_or(&sh.alive[g], 1u << q);
+				}
+			}
+		}
+		wave_sync();
 	}
-	if (DVP_LANE0) {
-		rec.flag = flag;
-		rec.radius = c.radius; rec.inc = c.inc; rec.fast = c.fast;
-		rec.sum_ref = c.sum_ref; rec.sum_ref_ref = c.sum_ref_ref; rec.wsum = c.wsum;
-		if (nevals) *nevals += (unsigned long long)__builtin_popcount(flag) * (unsigned long long)__builtin_popcount(all_views);
+	if (MODE == 2) {
+		DVP_LANES(g) { if (g < G && sh.pmask[g]) d.weak_rec[sh.wi[g]].pmask = sh.alive[g]; }
 	}
+	if (DVP_LANE0 && nevals) *nevals += (unsigned long long)T;
 }
 
 // ---- D1: joint view selection and the candidates' weighted costs (APD.cu:2781-2874) -----------------------------------------
@@ -254,24 +463,6 @@ DVP_HD void weak_d1_px(const Dev& d, int px, int py, int iter) {
 	rec.skip_refine = skip_refine ? 1u : 0u;
 }
 
-// ---- E1: the planes of the record against its views ----------------------------------------------------------------------
-template <int SMP, int FMT, int TAB>
-DVP_HD void weak_e1_wave(const Dev& d, int px, int py, unsigned long long* nevals, WeakSharedT<TAB>& sh) {
-	const int W = d.width;
-	const int center = py * W + px;
-	const int wi = d.neighbours_map[center];
-	const s2* nbs = d.neighbours + (size_t)wi * DVP_NEIGHBOUR_NUM;
-	const WeakRec& rec = d.weak_rec[wi];
-	const uint32_t pmask = rec.pmask, vmask = rec.vmask;
-	if (!(pmask && vmask)) return;
-	const float cpix = ref_texel_t<FMT>(d, px, py);
-	PatchCtx c;
-	weak_load_ctx(d, wi, sh, &c);
-	weak_eval<SMP, FMT>(d, c, nbs, cpix, px, py, vmask, pmask, sh);
-	weak_store_ev(d, wi, pmask, vmask, sh);
-	if (DVP_LANE0 && nevals) *nevals += (unsigned long long)__builtin_popcount(pmask) * (unsigned long long)__builtin_popcount(vmask);
-}
-
 // weighted cost of plane `pl` over the selected views (APD.cu:2876-2890 and the like): sum_j w_j (ev_j [+ factor geom_j]) / norm
 DVP_HD float weak_weighted_cost(const Dev& d, const DvpCamera& rc, int px, int py, const uint8_t* vw, const float* evq, const f4 pl, float weight_norm) {
 	const DvpParams& P = d.params;
@@ -356,51 +547,6 @@ DVP_HD void weak_d2_px(const Dev& d, int px, int py, int iter) {
 	rec.depth_now = depth_now;
 	rec.plane_now = plane_now;
 	rec.sel_now = sel_now;
-}
-
-// ---- E2: the hypotheses against the first selected view, the survivors against the rest -------------------------------------
-template <int SMP, int FMT, int TAB>
-DVP_HD void weak_e2_wave(const Dev& d, int px, int py, unsigned long long* nevals, WeakSharedT<TAB>& sh) {
-	const int W = d.width;
-	const int center = py * W + px;
-	const DvpParams& P = d.params;
-	const int wi = d.neighbours_map[center];
-	const s2* nbs = d.neighbours + (size_t)wi * DVP_NEIGHBOUR_NUM;
-	WeakRec& rec = d.weak_rec[wi];
-	const uint32_t pmask = rec.pmask, vmask = rec.vmask;
-	if (!(pmask && vmask)) return;
-	const float cpix = ref_texel_t<FMT>(d, px, py);
-	const float cost_now = rec.cost_now, weight_norm = rec.weight_norm;
-	PatchCtx c;
-	weak_load_ctx(d, wi, sh, &c);
-	// (ii): the weighted sum only grows (weights > 0, costs >= 0, IEEE addition and division are monotone), so a hypothesis whose
-	// FIRST selected view alone is not below the best cost at entry can never be adopted
-	const int first = __builtin_ctz(vmask);
-	weak_eval<SMP, FMT>(d, c, nbs, cpix, px, py, 1u << first, pmask, sh);
-	unsigned long long evals = (unsigned long long)__builtin_popcount(pmask);
-	const int w = d.view_weight[(size_t)center * 32 + first];
-	const DvpCamera rc = load_camera(d, 0), fc = load_camera(d, first + 1);
-	uint32_t alive = 0;
-	DVP_LANES(i) {
-		bool ok = false;
-		if (i < 5 && ((pmask >> i) & 1)) {
-			float tc = 0.0f;
-			if (P.geom_consistency) tc += w * (sh.ev[i][first] + P.geom_factor * geom_cost_cams(d, rc, fc, first + 1, px, py, sh.pl[i]));
-			else tc += w * sh.ev[i][first];
-			ok = tc / weight_norm < cost_now;
-		}
-		alive |= wave_lane_bit(ok, i);
-	}
-	const uint32_t rest = vmask & ~(1u << first);
-	if (alive && rest) {
-		weak_eval<SMP, FMT>(d, c, nbs, cpix, px, py, rest, alive, sh);
-		evals += (unsigned long long)__builtin_popcount(alive) * (unsigned long long)__builtin_popcount(rest);
-	}
-	weak_store_ev(d, wi, alive, vmask, sh);
-	if (DVP_LANE0) {
-		rec.pmask = alive;
-		if (nevals) *nevals += evals;
-	}
 }
 
 // ---- D3: adoption of the hypotheses, the final plane (APD.cu:1361-1383, 3060-3070) ------------------------------------------

@@ -7,6 +7,7 @@
 // into tests/emul/; libdvp_mvs_hip.so neither contains nor falls back to it.
 #include "../../dvp-mvs_amd/csrc/dvp_stages.hpp"
 #include <cstring>
+#include <cstdio>
 #include <vector>
 #include <cstdlib>
 
@@ -455,35 +456,55 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 		e.weak_ev.assign(n * 8 * S, -7.0f);
 		refresh(e);
 		const LaunchGeom g = make_geom(e.W, e.H, true);
-		unsigned long long total = 0;
-		for (int part = 0; part < 7; ++part) {
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
-			for (int b = 0; b < g.grid(); ++b)
-				for (int wave = 0; wave < 4; ++wave)
-					for (int lane = 0; lane < 64; ++lane) {
-						int px, py;
-						if (!block_to_pixel(b, lane, wave, g.tiles_x, g.tiles, g.rows, 1, colour, e.W, e.H, &px, &py)) continue;
-						if (e.d.weak_info[px + py * e.W] != DVP_WEAK) continue;
-						unsigned long long k = 0;
-						unsigned long long* kp = e.count ? &k : nullptr;
-						WeakSharedT<1> sh;
-						f2 tab_mem[kTaps * kTaps];
-						const PatchTab tab{tab_mem, 1};
-						const bool ex = e.d.sampler != 0, u8 = e.d.images8 != nullptr;
-#define EMU_WAVE(F) { if (ex) { if (u8) F<1, 1, 1>(e.d, px, py, kp, sh); else F<1, 0, 1>(e.d, px, py, kp, sh); } else { if (u8) F<0, 1, 1>(e.d, px, py, kp, sh); else F<0, 0, 1>(e.d, px, py, kp, sh); } }
-						switch (part) {
-						case 0: EMU_WAVE(weak_e0_wave) break;
-						case 1: weak_d1_px(e.d, px, py, iter); break;
-						case 2: EMU_WAVE(weak_e1_wave) break;
-						case 3: weak_d2_px(e.d, px, py, iter); break;
-						case 4: EMU_WAVE(weak_e2_wave) break;
-						case 5: weak_d3_px(e.d, px, py); break;
-						case 6: if (ex) weak_final_cost_px<1>(e.d, px, py, tab, kp); else weak_final_cost_px<0>(e.d, px, py, tab, kp); break;
-						}
-#undef EMU_WAVE
-						total += k;
-					}
+		// the WEAK pixels of the launch in block order (the engine: the WEAK list of the colour), taken `group` at a time by the
+		// evaluation launches
+		std::vector<int> list;
+		for (int b = 0; b < g.grid(); ++b)
+			for (int wave = 0; wave < 4; ++wave)
+				for (int lane = 0; lane < 64; ++lane) {
+					int px, py;
+					if (block_to_pixel(b, lane, wave, g.tiles_x, g.tiles, g.rows, 1, colour, e.W, e.H, &px, &py) && e.d.weak_info[px + py * e.W] == DVP_WEAK) list.push_back(px + py * e.W);
+				}
+		int group[4] = { 1, 4, 8, 8 };
+		if (const char* gs = getenv("DVP_WEAK_GROUPS")) {
+			int q[4];
+			if (sscanf(gs, "%d,%d,%d,%d", &q[0], &q[1], &q[2], &q[3]) == 4)
+				for (int i = 0; i < 4; ++i) group[i] = q[i] < 1 ? 1 : (q[i] > kGrp ? kGrp : q[i]);
 		}
+		const bool ex = e.d.sampler != 0, u8 = e.d.images8 != nullptr;
+		const long long n_px = (long long)list.size();
+		unsigned long long total = 0;
+		auto eval = [&](int mode) {
+			const int G = group[mode];
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : total)
+			for (long long t0 = 0; t0 < n_px; t0 += G) {
+				WeakGroupShared sh;
+				for (int i = 0; i < kGrp; ++i) sh.center[i] = (i < G && t0 + i < n_px) ? list[(size_t)(t0 + i)] : -1;
+				unsigned long long k = 0;
+				unsigned long long* kp = e.count ? &k : nullptr;
+#define EMU_GROUP(M) { if (ex) { if (u8) weak_group_eval<1, 1, M>(e.d, G, kp, sh); else weak_group_eval<1, 0, M>(e.d, G, kp, sh); } else { if (u8) weak_group_eval<0, 1, M>(e.d, G, kp, sh); else weak_group_eval<0, 0, M>(e.d, G, kp, sh); } }
+				switch (mode) { case 0: EMU_GROUP(0) break; case 1: EMU_GROUP(1) break; case 2: EMU_GROUP(2) break; default: EMU_GROUP(3) break; }
+#undef EMU_GROUP
+				total += k;
+			}
+		};
+		auto each = [&](int part) {
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : total)
+			for (long long t = 0; t < n_px; ++t) {
+				const int c0 = list[(size_t)t], py = c0 / e.W, px = c0 - py * e.W;
+				unsigned long long k = 0;
+				f2 tab_mem[kTaps * kTaps];
+				const PatchTab tab{tab_mem, 1};
+				switch (part) {
+				case 1: weak_d1_px(e.d, px, py, iter); break;
+				case 2: weak_d2_px(e.d, px, py, iter); break;
+				case 3: weak_d3_px(e.d, px, py); break;
+				default: if (ex) weak_final_cost_px<1>(e.d, px, py, tab, e.count ? &k : nullptr); else weak_final_cost_px<0>(e.d, px, py, tab, e.count ? &k : nullptr); break;
+				}
+				total += k;
+			}
+		};
+		eval(0); each(1); eval(1); each(2); eval(2); eval(3); each(3); each(4);
 		e.evals += total;
 		break;
 	}

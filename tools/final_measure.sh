@@ -4,14 +4,14 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-T=${1:-r04}
-rm -f profiles/pmc_r04.json
+T=${1:-r05}
+rm -f profiles/pmc_r05.json
 for cfg in cfg3 cfg2 cfg5; do
   timeout 1500 bash tools/pmc_collect.sh gpurun_out/pmc_$cfg --config $cfg
-  python tools/pmc_table.py gpurun_out/pmc_$cfg profiles/pmc_r04.json
+  python tools/pmc_table.py gpurun_out/pmc_$cfg profiles/pmc_r05.json
   rm -rf gpurun_out/pmc_$cfg   # raw per-dispatch counter CSVs: tens of MB
 done
-cp profiles/pmc_r04.json gpurun_out/pmc_r04.json
+cp profiles/pmc_r05.json gpurun_out/pmc_r05.json
 timeout 900 bash tools/profile_bench.sh gpurun_out $T
 rm -rf gpurun_out/trace_$T
 timeout 600 python bench.py --config cfg2 --steps 5 --warmup 1 > gpurun_out/${T}_cfg2_bench.json 2> gpurun_out/${T}_cfg2.err

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes over the bench workload (counters only, one rocprofv3 run per counter group: TCC has 4
 # slots — FETCH_SIZE takes 3, WRITE_SIZE 2 — SQ has 8), then tools/pmc_table.py folds the per-launch
-# averages of the TIMED step into profiles/pmc_r04.json keyed by kernel|WxH|S.
+# averages of the TIMED step into profiles/pmc_r05.json keyed by kernel|WxH|S.
 # usage (GPU box, repo root): tools/pmc_collect.sh OUTDIR [bench.py args, e.g. --config cfg3]
 OUT=$1; shift
 export TMPDIR=/tmp

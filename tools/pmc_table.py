@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Fold the PMC passes of tools/pmc_collect.sh into profiles/pmc_r04.json.
-usage: pmc_table.py OUTDIR [TABLE=profiles/pmc_r04.json]
+"""Fold the PMC passes of tools/pmc_collect.sh into profiles/pmc_r05.json.
+usage: pmc_table.py OUTDIR [TABLE=profiles/pmc_r05.json]
 
 Per kernel only the launches of the bench's LAST step are averaged (the untimed FIRST_INIT pass and
 the counting warm-up step launch the same kernels earlier): the last `launches_per_step[kernel]`
@@ -43,7 +43,7 @@ def per_kernel_last(path, launches_per_step):
 
 def main():
     out = sys.argv[1]
-    table_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_r04.json")
+    table_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_r05.json")
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     sha = bench.csrc_sha256()
