@@ -37,7 +37,7 @@ __device__ __forceinline__ void stage_body(const Dev& d, const LaunchArgs& a) {
 
 // Compacted launch for the weak-pixel path: lane t owns the t-th WEAK pixel of the list segment.
 // WEAK pixels are 1-30 % of a view; a lane-per-image-pixel launch leaves 70-99 % of the lanes idle.
-struct ListArgs { int base, count, iter, covered_rows, group; };   // group: pixels per wave of the weak update's evaluation launches
+struct ListArgs { int base, count, iter, covered_rows, group, run; };   // group: pixels per wave of the weak update's evaluation launches
 // XCD-aware block -> list-block map.  Workgroup b runs on XCD b % 8 (observed placement, a speed matter
 // only); the list is in super-tile order, so giving every XCD RUNS of kListRun consecutive list blocks
 // (instead of every 8th block) keeps the workgroups that share anchors — and the source-image lines
@@ -423,12 +423,13 @@ extern "C" __global__ void __launch_bounds__(64, DVP_LB_WEAK) dvp_weak_update_wa
 // run one LANE per WEAK pixel.
 template <int SMP, int FMT, int MODE>
 __device__ __forceinline__ void weak_group_body(const Dev& d, const ListArgs& a) {
-	__shared__ WeakGroupShared sh;
-	const int G = a.group;
-	const int run = kWaveRun * 4 / G;   // XCD runs of the same length in pixels as the one-wave kernel's
+	constexpr int GRP = MODE == 0 ? kGrpWide : kGrp;
+	__shared__ WeakGroupSharedT<GRP> sh;
+	const int G = a.group < GRP ? a.group : GRP;
+	const int run = a.run / G;          // XCD runs of a.run pixels (the one-wave kernel's: kWaveRun * 4)
 	const int blk = list_block(blockIdx.x, gridDim.x, run < 1 ? 1 : run);
 	if (blk * G >= a.count) return;
-	if (threadIdx.x < (unsigned)kGrp) {
+	if (threadIdx.x < (unsigned)GRP) {
 		const int t = blk * G + (int)threadIdx.x;
 		int center = -1;
 		if ((int)threadIdx.x < G && t < a.count) {
@@ -440,7 +441,7 @@ __device__ __forceinline__ void weak_group_body(const Dev& d, const ListArgs& a)
 	}
 	wave_sync();
 	unsigned long long n = 0;
-	weak_group_eval<SMP, FMT, MODE>(d, G, d.eval_counter ? &n : nullptr, sh);
+	weak_group_eval<SMP, FMT, MODE, GRP>(d, G, d.eval_counter ? &n : nullptr, sh);
 	if (d.eval_counter && n) atomicAdd(d.eval_counter, n);
 }
 #define DVP_WEAK_PHASE_KERNELS(NAME, MODE)                                                                                                              \
@@ -946,7 +947,8 @@ struct dvp_ctx {
 	WeakRec* weak_rec = nullptr; f2* weak_ctab = nullptr; float* weak_ev = nullptr;
 	size_t weak_phase_alloc = 0;       // capacity in WEAK pixels
 	bool weak_phased = true;           // DVP_WEAK_PHASED=0, no anchor table, or the buffers did not fit: the one-wave form
-	int weak_group[4] = { 1, 4, 8, 8 };   // WEAK pixels per wave of E0 / E1 / E2a / E2b (DVP_WEAK_GROUPS=a,b,c,d: A/B measurements)
+	int weak_run[4] = { 64, 256, 1024, 1024 };   // WEAK pixels per XCD run of the same launches (DVP_WEAK_RUNS=a,b,c,d)
+	int weak_group[4] = { 1, 4, 4, 2 };   // WEAK pixels per wave of E0 / E1 / E2a / E2b (DVP_WEAK_GROUPS=a,b,c,d: A/B measurements)
 	int* weak_list = nullptr;    // compacted WEAK pixel indices (black first, then red)
 	size_t weak_list_alloc = 0;
 	int* weak_counts = nullptr;  // scratch of the device-side compaction: per-slot black / red counts, per-chunk counts, then 3 totals
@@ -1049,10 +1051,15 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	if (const char* e = getenv("DVP_WEAK_ANCHOR_TAB")) c->anchor_tab_off = atoi(e) == 0;   // A/B measurements and the tests of the per-item form
 	if (const char* e = getenv("DVP_GN_WAVE")) c->gn_wave = atoi(e) != 0;
 	if (const char* e = getenv("DVP_WEAK_PHASED")) c->weak_phased = atoi(e) != 0;
+	if (const char* e = getenv("DVP_WEAK_RUNS")) {
+		int g[4];
+		if (sscanf(e, "%d,%d,%d,%d", &g[0], &g[1], &g[2], &g[3]) == 4)
+			for (int i = 0; i < 4; ++i) c->weak_run[i] = g[i] < 1 ? 1 : g[i];
+	}
 	if (const char* e = getenv("DVP_WEAK_GROUPS")) {
 		int g[4];
 		if (sscanf(e, "%d,%d,%d,%d", &g[0], &g[1], &g[2], &g[3]) == 4)
-			for (int i = 0; i < 4; ++i) c->weak_group[i] = g[i] < 1 ? 1 : (g[i] > kGrp ? kGrp : g[i]);
+			for (int i = 0; i < 4; ++i) c->weak_group[i] = g[i] < 1 ? 1 : (g[i] > kGrp ? kGrp : g[i]);   // (E0: at most kGrpWide, applied at the launch)
 	}
 	c->pitch = (width + 2 * kImgPad + 63) / 64 * 64;
 	c->L = (size_t)width * height;
@@ -1571,7 +1578,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 					const bool u8 = c->images8_ok;
 					const dim3 w64(64), lg64((la.count + 63) / 64);
 #define DVP_PICK(NAME) (ex ? (u8 ? NAME##_exact_u8 : NAME##_exact) : (u8 ? NAME##_u8 : NAME))
-#define DVP_GROUP_LAUNCH(NAME, PHASE) { la.group = c->weak_group[PHASE]; hipLaunchKernelGGL(DVP_PICK(NAME), dim3((la.count + la.group - 1) / la.group), w64, 0, c->stream, c->d, la); }
+#define DVP_GROUP_LAUNCH(NAME, PHASE) { la.group = std::min(c->weak_group[PHASE], PHASE == 0 ? kGrpWide : kGrp); la.run = c->weak_run[PHASE]; hipLaunchKernelGGL(DVP_PICK(NAME), dim3((la.count + la.group - 1) / la.group), w64, 0, c->stream, c->d, la); }
 					DVP_GROUP_LAUNCH(dvp_weak_eval_candidates, 0)
 					hipLaunchKernelGGL(dvp_weak_select_views, lg, block, 0, c->stream, c->d, la);
 					DVP_GROUP_LAUNCH(dvp_weak_eval_planes, 1)

@@ -76,33 +76,38 @@ DVP_HD float* weak_ev_of(const Dev& d, int wi) { return d.weak_ev + (size_t)wi *
 //   MODE 1  E1: the record's planes against its views
 //   MODE 2  E2a: the hypotheses in range against the FIRST selected view; decides which survive
 //   MODE 3  E2b: the survivors against the other selected views
-constexpr int kGrp = 8;
-struct WeakGroupShared {
+constexpr int kGrp = 4;   // pixels per wave at most (E0: kGrpWide)
+constexpr int kGrpWide = 2;
+template <int GRP>
+struct WeakGroupSharedT {
 	// per pixel of the group
-	int center[kGrp];                        // pixel index, < 0: no pixel in this slot (filled by the caller)
-	f2 ctab[kGrp][kTaps * kTaps];            // centre patch: (w, w * ref) per tap, row-major
-	s2 nbs[kGrp][DVP_NEIGHBOUR_NUM];
-	uint32_t asel[kGrp][kAnchors];           // selected_views word of anchor k
-	float sum_ref[kGrp], sum_ref_ref[kGrp], wsum[kGrp];
-	int px[kGrp], py[kGrp], wi[kGrp], radius[kGrp], inc[kGrp], fast[kGrp];
-	uint32_t pmask[kGrp], vmask[kGrp], alive[kGrp];
+	int center[GRP];                        // pixel index, < 0: no pixel in this slot (filled by the caller)
+	f2 ctab[GRP][kTaps * kTaps];            // centre patch: (w, w * ref) per tap, row-major
+	s2 nbs[GRP][DVP_NEIGHBOUR_NUM];
+	uint32_t asel[GRP][kAnchors];           // selected_views word of anchor k
+	float sum_ref[GRP], sum_ref_ref[GRP], wsum[GRP];
+	int px[GRP], py[GRP], wi[GRP], radius[GRP], inc[GRP], fast[GRP];
+	uint32_t pmask[GRP], vmask[GRP], alive[GRP];
 	// per pair of the batch
 	float Hq[kWeakPairs][9];
 	float rows[kWeakPairs][kTaps][3];        // centre-patch row sums (s_s, s_ss, s_rs); before the first batch of MODE 0: w * ref * ref per tap
 	float acost[kWeakPairs][kAnchors];       // anchor cost, < 0: does not count
 	uint32_t pair[kWeakPairs];               // pixel slot | view << 8 | plane << 16 | (centre projects inside the view) << 24
+	// the (anchor, pair) items of the batch that really are sub-patches (the anchor exists and selected the view), in item order
+	uint16_t live[kWeakPairs * kAnchors];
+	int n_live;
 };
 struct CtabView { const f2* ctab; };
 
-template <int SMP, int FMT, int MODE>
-DVP_HD void weak_group_eval(const Dev& d, int G, unsigned long long* nevals, WeakGroupShared& sh) {
+template <int SMP, int FMT, int MODE, int GRP>
+DVP_HD void weak_group_eval(const Dev& d, int G, unsigned long long* nevals, WeakGroupSharedT<GRP>& sh) {
 	const int W = d.width;
 	const DvpParams& P = d.params;
 	const int S = P.num_images - 1;
 	const uint32_t all_views = (S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
 	// ---- the pixels of the group ------------------------------------------------------------------------------------------
 	DVP_LANES(g) {
-		if (g < kGrp) {
+		if (g < GRP) {
 			uint32_t pm = 0, vm = 0;
 			int px = 0, py = 0, wi = 0;
 			const int center = g < G ? sh.center[g] : -1;
@@ -216,10 +221,10 @@ DVP_HD void weak_group_eval(const Dev& d, int G, unsigned long long* nevals, Wea
 	}
 	wave_sync();
 	// ---- the pairs, numbered flat over the group: pixel, then view, then plane ------------------------------------------------
-	int base[kGrp];
+	int base[GRP];
 	int T = 0;
 #pragma unroll
-	for (int g = 0; g < kGrp; ++g) {
+	for (int g = 0; g < GRP; ++g) {
 		base[g] = T;
 		T += __builtin_popcount(sh.pmask[g]) * __builtin_popcount(sh.vmask[g]);
 	}
@@ -233,7 +238,7 @@ DVP_HD void weak_group_eval(const Dev& d, int G, unsigned long long* nevals, Wea
 				const int p = b0 + l;
 				int g = 0, bg = 0;
 #pragma unroll
-				for (int i = 1; i < kGrp; ++i)
+				for (int i = 1; i < GRP; ++i)
 					if (p >= base[i]) { g = i; bg = base[i]; }
 				const uint32_t pm = sh.pmask[g], vm = sh.vmask[g];
 				const int np = __builtin_popcount(pm);
@@ -253,23 +258,53 @@ DVP_HD void weak_group_eval(const Dev& d, int G, unsigned long long* nevals, Wea
 				sh.pair[l] = (uint32_t)g | ((uint32_t)v << 8) | ((uint32_t)q << 16) | (inside << 24);
 			}
 		}
+		if (DVP_LANE0) sh.n_live = 0;
 		wave_sync();
-		// section 1: anchor items (anchor k, pair), pair fastest; then centre items (patch row, pair)
-		DVP_LANES(l) {
-			const int n_anchor = nb * kAnchors;
-			for (int it0 = 0; it0 < n_anchor; it0 += 64) {
+		// section 0b: the (anchor k, pair) items, pair fastest.  An anchor that does not exist does not count (-1); one that did
+		// not select the view counts 2 where it projects inside (the reference's 0/0 path, anchor_cost_tab); the others — 71 % at
+		// cfg3 — are sub-patches: listed in item order, so that the rounds below are full (lane utilisation of the propagation
+		// launch 0.70 before) and the planes of one (pixel, view, anchor) still sit in adjacent lanes
+		const int n_anchor = nb * kAnchors;
+		for (int it0 = 0; it0 < n_anchor; it0 += 64) {
+			DVP_LANES(l) {
 				const int it = it0 + l;
-				if (it >= n_anchor) continue;
+				bool live = false;
+				if (it < n_anchor) {
+					const int k = small_div(it, inv_nb), pi = it - k * nb;
+					const uint32_t desc = sh.pair[pi];
+					if (desc >> 24) {
+						const int g = (int)(desc & 255u), v = (int)((desc >> 8) & 255u);
+						const s2 nbk = sh.nbs[g][k + 1];
+						if (nbk.x == -1 || nbk.y == -1) sh.acost[pi][k] = -1.0f;
+						else if (is_set(sh.asel[g][k], v)) live = true;
+						else {
+							float H[9];
+#pragma unroll
+							for (int i = 0; i < 9; ++i) H[i] = sh.Hq[pi][i];
+							const f2 nsp = apply_homography(H, nbk.x, nbk.y);
+							const bool outside = nsp.x < 0 || nsp.y < 0 || nsp.x >= W || nsp.y >= d.height;
+							sh.acost[pi][k] = outside ? -1.0f : 2.0f;
+						}
+					}
+				}
+				const int slot = wave_ordered_slot(live, &sh.n_live);
+				if (live) sh.live[slot] = (uint16_t)it;
+			}
+		}
+		wave_sync();
+		// section 1: the sub-patches; then centre items (patch row, pair)
+		DVP_LANES(l) {
+			const int n_live = sh.n_live;
+			for (int it0 = 0; it0 < n_live; it0 += 64) {
+				if (it0 + l >= n_live) continue;
+				const int it = sh.live[it0 + l];
 				const int k = small_div(it, inv_nb), pi = it - k * nb;
 				const uint32_t desc = sh.pair[pi];
-				if (!(desc >> 24)) continue;
 				const int g = (int)(desc & 255u), v = (int)((desc >> 8) & 255u);
-				const s2 nbk = sh.nbs[g][k + 1];
-				const int state = (nbk.x == -1 || nbk.y == -1) ? 0 : (is_set(sh.asel[g][k], v) ? 2 : 1);
 				float H[9];
 #pragma unroll
 				for (int i = 0; i < 9; ++i) H[i] = sh.Hq[pi][i];
-				sh.acost[pi][k] = anchor_cost_tab<SMP, FMT>(d, H, img_plane<FMT>(d, v + 1), nbk, state, d.anchor_tab + anchor_rec_index(d, sh.wi[g], v, k));
+				sh.acost[pi][k] = anchor_cost_tab<SMP, FMT>(d, H, img_plane<FMT>(d, v + 1), sh.nbs[g][k + 1], 2, d.anchor_tab + anchor_rec_index(d, sh.wi[g], v, k));
 			}
 			const int n_centre = nb * kTaps;
 			for (int it0 = 0; it0 < n_centre; it0 += 64) {

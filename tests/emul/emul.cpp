@@ -465,7 +465,7 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 					int px, py;
 					if (block_to_pixel(b, lane, wave, g.tiles_x, g.tiles, g.rows, 1, colour, e.W, e.H, &px, &py) && e.d.weak_info[px + py * e.W] == DVP_WEAK) list.push_back(px + py * e.W);
 				}
-		int group[4] = { 1, 4, 8, 8 };
+		int group[4] = { 1, 4, 4, 2 };
 		if (const char* gs = getenv("DVP_WEAK_GROUPS")) {
 			int q[4];
 			if (sscanf(gs, "%d,%d,%d,%d", &q[0], &q[1], &q[2], &q[3]) == 4)
@@ -475,15 +475,14 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 		const long long n_px = (long long)list.size();
 		unsigned long long total = 0;
 		auto eval = [&](int mode) {
-			const int G = group[mode];
+			const int G = std::min(group[mode], mode == 0 ? kGrpWide : kGrp);
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : total)
 			for (long long t0 = 0; t0 < n_px; t0 += G) {
-				WeakGroupShared sh;
-				for (int i = 0; i < kGrp; ++i) sh.center[i] = (i < G && t0 + i < n_px) ? list[(size_t)(t0 + i)] : -1;
 				unsigned long long k = 0;
 				unsigned long long* kp = e.count ? &k : nullptr;
-#define EMU_GROUP(M) { if (ex) { if (u8) weak_group_eval<1, 1, M>(e.d, G, kp, sh); else weak_group_eval<1, 0, M>(e.d, G, kp, sh); } else { if (u8) weak_group_eval<0, 1, M>(e.d, G, kp, sh); else weak_group_eval<0, 0, M>(e.d, G, kp, sh); } }
-				switch (mode) { case 0: EMU_GROUP(0) break; case 1: EMU_GROUP(1) break; case 2: EMU_GROUP(2) break; default: EMU_GROUP(3) break; }
+#define EMU_GROUP(M, GRP) { WeakGroupSharedT<GRP> sh; for (int i = 0; i < GRP; ++i) sh.center[i] = (i < G && t0 + i < n_px) ? list[(size_t)(t0 + i)] : -1; \
+	if (ex) { if (u8) weak_group_eval<1, 1, M, GRP>(e.d, G, kp, sh); else weak_group_eval<1, 0, M, GRP>(e.d, G, kp, sh); } else { if (u8) weak_group_eval<0, 1, M, GRP>(e.d, G, kp, sh); else weak_group_eval<0, 0, M, GRP>(e.d, G, kp, sh); } }
+				switch (mode) { case 0: EMU_GROUP(0, kGrpWide) break; case 1: EMU_GROUP(1, kGrp) break; case 2: EMU_GROUP(2, kGrp) break; default: EMU_GROUP(3, kGrp) break; }
 #undef EMU_GROUP
 				total += k;
 			}
