@@ -499,7 +499,10 @@ extern "C" __global__ void __launch_bounds__(256) dvp_weak_anchor_table(const De
 	const long long r = i / kAnchors;
 	const int v0 = (int)(r % S);
 	const int t = (int)(r / S);
-	build_anchor_record(d, d.weak_list[a.base + t], v0, k);
+	// (the records written through an LDS transpose — eight whole records per store instruction instead of 16 bytes into each of
+	// 64 lines — measure the same 19 ms per cfg3 pass: the launch does not wait for its stores)
+	if (d.images8) build_anchor_record<1>(d, d.weak_list[a.base + t], v0, k);
+	else build_anchor_record<0>(d, d.weak_list[a.base + t], v0, k);
 }
 
 // replicate the image border into the kImgPad-wide frame of a padded plane set

@@ -255,16 +255,19 @@ static_assert(sizeof(AnchorRec) == 128, "one cache line per (WEAK pixel, view, a
 DVP_HD size_t anchor_rec_index(const Dev& d, int weak_index, int v0, int k) {
 	return ((size_t)weak_index * (size_t)(d.params.num_images - 1) + (size_t)v0) * kAnchors + (size_t)k;
 }
-// record of anchor k (0-based: neighbours[k + 1]) of the WEAK pixel `center` for source view v0 (0-based)
-DVP_HD void build_anchor_record(const Dev& d, int center, int v0, int k) {
+// record of anchor k (0-based: neighbours[k + 1]) of the WEAK pixel `center` for source view v0 (0-based); FMT: the plane format
+// the reference texels are read from (the same values either way)
+// -> *out, *index (its place in Dev::anchor_tab); false: no anchor, the record is never read (state 0)
+template <int FMT>
+DVP_HD bool make_anchor_record(const Dev& d, int center, int v0, int k, AnchorRec* out, size_t* index) {
 	const int W = d.width;
 	const int py = center / W, px = center - py * W;
 	const int wi = d.neighbours_map[center];
 	const s2 nb = d.neighbours[(size_t)wi * DVP_NEIGHBOUR_NUM + k + 1];
-	if (nb.x == -1 || nb.y == -1) return;   // no anchor: the record is never read (state 0)
-	const float cpix = ref_texel_t<0>(d, px, py);
+	if (nb.x == -1 || nb.y == -1) return false;
+	const float cpix = ref_texel_t<FMT>(d, px, py);
 	const s2* cand = d.candidate + cand_index(d, nb.x + nb.y * W, v0);
-	AnchorRec r;
+	AnchorRec& r = *out;
 	float a_sr = 0.0f, a_srr = 0.0f, a_sw = 0.0f;
 #pragma unroll
 	for (int t = 0; t < 9; ++t) {
@@ -279,7 +282,7 @@ DVP_HD void build_anchor_record(const Dev& d, int center, int v0, int k) {
 			}
 		}
 		const int tx = nb.x + i, ty = nb.y + j;
-		const float av = ref_texel_t<0>(d, tx, ty);
+		const float av = ref_texel_t<FMT>(d, tx, ty);
 		const float w = bilateral_weight((float)i, (float)j, av, cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
 		const float wa = w * av;
 		a_sr += wa;
@@ -292,7 +295,25 @@ DVP_HD void build_anchor_record(const Dev& d, int center, int v0, int k) {
 	r.a_srr = a_srr;
 	r.a_sw = a_sw;
 	r.pad[0] = r.pad[1] = 0u;
-	d.anchor_tab[anchor_rec_index(d, wi, v0, k)] = r;
+	*index = anchor_rec_index(d, wi, v0, k);
+	return true;
+}
+template <int FMT = 0>
+DVP_HD void build_anchor_record(const Dev& d, int center, int v0, int k) {
+	AnchorRec r;
+	size_t index;
+	if (!make_anchor_record<FMT>(d, center, v0, k, &r, &index)) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+	{   // eight 16-byte stores
+		typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+		const u4* src4 = reinterpret_cast<const u4*>(&r);
+		u4* dst4 = reinterpret_cast<u4*>(d.anchor_tab + index);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) dst4[i] = src4[i];
+	}
+#else
+	d.anchor_tab[index] = r;
+#endif
 }
 
 // anchor_cost() with the reference side taken from the pass' table
