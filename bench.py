@@ -152,6 +152,7 @@ def parse():
     ap.add_argument("--rig", default="rotated", choices=["rotated", "axis"], help="camera rig of the synthetic scene: per-view rotations and intrinsics (default) or the round-1/2 rig (R = I, one K)")
     ap.add_argument("--src-depths", default="estimated", choices=["estimated", "gt"], help="depth maps the geometric term reads: 'estimated' = the rendered depths with 0.3 %% relative noise, 2 %% of 16x16 blocks and 1 %% of single pixels missing (depth 0), as maps estimated by a previous pass are; 'gt' = the rendered depths (rounds 1-4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the cfg5 / cfg2 lines that the default workload appends")
     ap.add_argument("--dry-launch", action="store_true", help="launcher check without a GPU: start the ranks, rendezvous over gloo, print one line with each rank's environment")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself (0: pick a free one)")
     ap.add_argument("--cpu-size", type=str, default="auto", help="WxH of the CPU-baseline view (auto: scaled to the core count)")
@@ -369,41 +370,39 @@ def dry_launch(args, json_fd, rank, local_rank, world):
         dist.destroy_process_group()
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "RANK" not in os.environ:
-        launch_ranks(args)       # does not return
-    # stdout carries ONE JSON line (rank 0).  Libraries write there too (RCCL prints its NCCL_DEBUG=VERSION banner and
-    # its warnings on stdout): from here on file descriptor 1 is stderr, the JSON line goes to the saved descriptor.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; n_gpus must be what was asked for" % (args.gpus, world))
-    if args.dry_launch:
-        return dry_launch(args, json_fd, rank, local_rank, world)
-    import torch   # device plumbing + torch.distributed (RCCL); loaded first so one HIP runtime is shared
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # DVP_BENCH_FORCE_DIST=1 exercises the RCCL path (init, broadcast, all_reduce) with one rank
-    use_dist = world > 1 or os.environ.get("DVP_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    pkg = importlib.import_module("dvp-mvs_amd")
-    importlib.import_module("dvp-mvs_amd.workloads")
+def per_iteration_ms(ctx, iters, view_index, weak):
+    """SURVEY 7 (hard part 4): early iterations gather worse than converged ones — the launch sites of the iteration loop
+    (APD.cu:4478-4492) timed iteration by iteration in one extra, untimed pass issued stage by stage (dvp_run_stage; the same
+    launches dvp_run_patchmatch issues)."""
+    ctx.set_seed(1234 + view_index)
+    ctx.set_profiling(False)
+    ctx.restore_state()
+    for st in ("gen_edge_inform", "find_nearest_strong", "gen_neighbours", "neighbour_update", "random_init"):
+        ctx.run_stage(st, 0, 0)
+    ctx.synchronize()
+    ctx.timings(reset=True)
+    res = []
+    for it in range(iters):
+        ctx.run_stage("strong_update", it, 0)
+        ctx.run_stage("strong_update", it, 1)
+        if weak:
+            ctx.run_stage("ransac_fit", it, 0)
+            ctx.run_stage("weak_update", it, 0)
+            ctx.run_stage("weak_update", it, 1)
+        ctx.synchronize()
+        t = ctx.timings(reset=True)
+        res.append({k: round(v, 3) for k, v in t["stage_ms"].items() if v > 0})
+    return res
+
+
+def measure(env, args, cfg_name, W, H, S, iters, weak_frac_arg, steps, warmup, primary):
+    """one workload on this rank's GPU: scene, context, (untimed FIRST_INIT + hand-over), warm-up, timed steps -> the line's dict (rank 0)"""
+    torch, dist, dev = env["torch"], env["dist"], env["dev"]
+    rank, local_rank, world, use_dist, pkg = env["rank"], env["local_rank"], env["world"], env["use_dist"], env["pkg"]
     synth, wl, capi = pkg.synth, pkg.workloads, pkg.get_capi()
-    cfg = dict(wl.CONFIGS[args.config])
-    W, H = args.width or cfg["W"], args.height or cfg["H"]
-    S, iters = args.src or cfg["S"], args.iters or cfg["iters"]
+    cfg = dict(wl.CONFIGS[cfg_name])
     NI, L = S + 1, W * H
+    _PMC_CACHE.pop("t", None)
 
     # ---- inputs: rank 0 renders the scene on its GPU; every rank gets it over RCCL (xGMI) ----------
     t_setup = time.time()
@@ -469,7 +468,7 @@ def main():
         # untimed FIRST_INIT pass -> hand-over -> the REFINE_ITER pass that is timed
         ctx.run_patchmatch()
         planes, views, weak, radius = ctx.download_state()
-        st = wl.hand_over(planes, views, weak, radius, p1, W, H, extra_weak=wl.weak_mask(args.weak_layout, W, H, args.weak_frac, flat))
+        st = wl.hand_over(planes, views, weak, radius, p1, W, H, extra_weak=wl.weak_mask(args.weak_layout, W, H, weak_frac_arg, flat))
         del planes, views, weak, radius
         ctx.set_params(wl.refine_iter_params(S, iters))
         ctx.set_depths_device([deps[i].data_ptr() for i in order], W)
@@ -497,7 +496,7 @@ def main():
 
     # ---- warm-up (the first warm-up step also counts NCC evaluations: deterministic per seed) -------
     evals = None
-    for w in range(max(args.warmup, 1)):
+    for w in range(max(warmup, 1)):
         one_step(rank, profile=(w == 0))
         if w == 0:
             ctx.synchronize()
@@ -509,7 +508,7 @@ def main():
     # ---- timed region ------------------------------------------------------------------------------
     barrier()
     t0 = time.perf_counter()
-    for s in range(args.steps):
+    for s in range(steps):
         one_step(rank + s * world)
     ctx.synchronize()
     busy = time.perf_counter() - t0          # this rank's own time (before waiting for the others)
@@ -526,7 +525,7 @@ def main():
         busy_all = [float(b.item()) for b in bt]
 
     if rank == 0:
-        total_px_iter = float(W) * H * iters * args.steps * world
+        total_px_iter = float(W) * H * iters * steps * world
         value = total_px_iter / dt / 1e6
         stage_ms = {k: v for k, v in tm["stage_ms"].items() if v > 0}
         per_launch = {k: stage_ms[k] / max(tm["stage_launches"][k], 1) for k in stage_ms}
@@ -536,40 +535,97 @@ def main():
         # what a WEAK pixel costs against any pixel: the launch sites that only touch WEAK pixels (anchor search, fit plane, weak
         # update) per WEAK pixel, everything else per pixel of the view (the regime must be visible in the line)
         weak_sites = ("find_nearest_strong", "gen_neighbours", "neighbour_update", "ransac_fit", "weak_update")
-        weak_ms = sum(stage_ms.get(k, 0.0) for k in weak_sites) / args.steps
-        other_ms = dt * 1e3 / args.steps - weak_ms
+        weak_ms = sum(stage_ms.get(k, 0.0) for k in weak_sites) / steps
+        other_ms = dt * 1e3 / steps - weak_ms
         n_weak = weak_frac * L
         dom = ranked[0]
         workload = "BASELINE %s stand-in: %dx%d, S=%d source views, %d PatchMatch iterations, %s" % (
-            args.config if (W, H, S) == (cfg["W"], cfg["H"], cfg["S"]) else "custom(%s-like)" % args.config, W, H, S, iters,
+            cfg_name if (W, H, S) == (cfg["W"], cfg["H"], cfg["S"]) else "custom(%s-like)" % cfg_name, W, H, S, iters,
             ("REFINE_ITER pass, geom_consistency on, use_APD on (%.1f %% WEAK pixels%s), edge/label/radius priors on, inputs from an untimed FIRST_INIT pass" % (100 * weak_frac, ", a few large connected regions" if args.weak_layout == "regions" else ""))
             if cfg["refine"] else "FIRST_INIT, geom off")
         out = {
             "metric": "Mpixels/sec/PatchMatch-iteration", "value": round(value, 3), "unit": "Mpx/s/iter",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (procedural texture quantised to 8-bit grey levels, as decoded image files are; image_format=%d; camera rig: %s)" % (IMAGE_FORMAT, "per-view rotations 5-30 deg, per-view K" if args.rig == "rotated" else "R = I, one K (round-1/2 rig)"),
-            "config": {"workload": workload + ", one reference view per step per GPU", "src_depths": args.src_depths if cfg["refine"] else None, "baseline_config": args.config,
+            "config": {"workload": workload + ", one reference view per step per GPU", "src_depths": args.src_depths if cfg["refine"] else None, "baseline_config": cfg_name,
                        "width": W, "height": H, "src_views": S, "iterations": iters, "weak_fraction": round(weak_frac, 4), "weak_layout": args.weak_layout,
                        "parallelism": "rank r takes view r mod %d of the scene as its reference view; %d rank(s), no data-path collective" % (NI, world)},
             "roofline": dict(roofs[dom], launch_site=dom, share_of_step=round(stage_ms[dom] / (dt * 1e3), 3)),
             "rooflines_top_kernels": roofs,
-            "iter_loop_value": round(float(W) * H * iters * args.steps / (tm["iter_loop_ms"] * 1e-3) / 1e6, 3) if tm["iter_loop_ms"] > 0 else None,
-            "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
+            "iter_loop_value": round(float(W) * H * iters * steps / (tm["iter_loop_ms"] * 1e-3) / 1e6, 3) if tm["iter_loop_ms"] > 0 else None,
+            "stage_ms_per_step": {k: round(v / steps, 3) for k, v in stage_ms.items()},
             "ns_per_weak_pixel": round(weak_ms * 1e6 / n_weak, 1) if n_weak > 0 else None,
             "ns_per_pixel_other": round(other_ms * 1e6 / L, 1),
             # every kernel of a launch site (the PMC tooling averages the last `n` dispatches of each)
-            "launches_per_step": dict([(kernel_name(k, S), primary_launches(k) * tm["stage_launches"][k] // args.steps) for k in stage_ms if k != "strong_prep"] +
-                                      [(extra, mult * tm["stage_launches"][k] // args.steps) for k in stage_ms for extra, mult in extra_kernels(k, S)] +
-                                      [(extra, tm["stage_launches"][k] // args.steps) for k, extra in
+            "launches_per_step": dict([(kernel_name(k, S), primary_launches(k) * tm["stage_launches"][k] // steps) for k in stage_ms if k != "strong_prep"] +
+                                      [(extra, mult * tm["stage_launches"][k] // steps) for k in stage_ms for extra, mult in extra_kernels(k, S)] +
+                                      [(extra, tm["stage_launches"][k] // steps) for k, extra in
                                        (("gen_edge_inform", "dvp_gen_candidates"), ("strong_prep", "dvp_strong_search")) if k in stage_ms]),
             "ncc_evals_per_step": {k: int(v) for k, v in evals["ncc_evals"].items() if v > 0},
-            "Gevals_per_s": {k: round(evals["ncc_evals"][k] / (tm["stage_ms"][k] / args.steps * 1e-3) / 1e9, 3)
+            "Gevals_per_s": {k: round(evals["ncc_evals"][k] / (tm["stage_ms"][k] / steps * 1e-3) / 1e9, 3)
                              for k in evals["ncc_evals"] if evals["ncc_evals"][k] > 0 and tm["stage_ms"][k] > 0},
             "library_build_id": LOADED_BUILD_ID,
-            "rank_busy_ms_per_step": [round(b / args.steps * 1e3, 1) for b in busy_all],
+            "rank_busy_ms_per_step": [round(b / steps * 1e3, 1) for b in busy_all],
             "setup_s": round(t_setup, 1),
         }
+        if world == 1:
+            out["stage_ms_per_iteration"] = per_iteration_ms(ctx, iters, rank, bool(cfg["refine"]) and weak_frac > 0)
+        ctx.close()
+        return out
+    ctx.close()
+    return None
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args)       # does not return
+    # stdout carries ONE JSON line (rank 0).  Libraries write there too (RCCL prints its NCCL_DEBUG=VERSION banner and
+    # its warnings on stdout): from here on file descriptor 1 is stderr, the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; n_gpus must be what was asked for" % (args.gpus, world))
+    if args.dry_launch:
+        return dry_launch(args, json_fd, rank, local_rank, world)
+    import torch   # device plumbing + torch.distributed (RCCL); loaded first so one HIP runtime is shared
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    # DVP_BENCH_FORCE_DIST=1 exercises the RCCL path (init, broadcast, all_reduce) with one rank
+    use_dist = world > 1 or os.environ.get("DVP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    pkg = importlib.import_module("dvp-mvs_amd")
+    importlib.import_module("dvp-mvs_amd.workloads")
+    wl = pkg.workloads
+    cfg = dict(wl.CONFIGS[args.config])
+    W, H = args.width or cfg["W"], args.height or cfg["H"]
+    S, iters = args.src or cfg["S"], args.iters or cfg["iters"]
+    env = dict(torch=torch, dist=dist, dev=dev, rank=rank, local_rank=local_rank, world=world, use_dist=use_dist, pkg=pkg)
+    out = measure(env, args, args.config, W, H, S, iters, args.weak_frac, args.steps, args.warmup, primary=True)
+    if rank == 0:
+        # The other single-GPU configurations in the same line (the driver's one command observes cfg3 only):
+        # a few steps each of cfg5 (>= 10 % WEAK as SURVEY 8d specifies) and cfg2, after the timed region of the primary one.
+        default_workload = args.config == "cfg3" and (W, H, S, iters) == (cfg["W"], cfg["H"], cfg["S"], cfg["iters"]) and args.rig == "rotated"
+        if world == 1 and default_workload and not args.no_secondary:
+            sec = {}
+            for name, wf in (("cfg5", 0.10), ("cfg2", 0.0)):
+                c2 = wl.CONFIGS[name]
+                o2 = measure(env, args, name, c2["W"], c2["H"], c2["S"], c2["iters"], wf, 5, 1, primary=False)
+                sec[name] = {k: o2[k] for k in ("value", "ms_per_step", "steps", "warmup", "stage_ms_per_step", "ns_per_weak_pixel", "ns_per_pixel_other", "stage_ms_per_iteration")}
+                sec[name].update(workload=o2["config"]["workload"], weak_fraction=o2["config"]["weak_fraction"],
+                                 roofline={k: o2["roofline"].get(k) for k in ("launch_site", "kernel", "avg_launch_ms", "bound", "frac", "achieved", "peak", "unit", "traffic", "lane_utilisation", "Gevals_per_s", "useful_eval_rate_frac", "share_of_step")})
+            out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, args, cfg, S, iters, device=local_rank)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
