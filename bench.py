@@ -152,6 +152,7 @@ def parse():
     ap.add_argument("--rig", default="rotated", choices=["rotated", "axis"], help="camera rig of the synthetic scene: per-view rotations and intrinsics (default) or the round-1/2 rig (R = I, one K)")
     ap.add_argument("--src-depths", default="estimated", choices=["estimated", "gt"], help="depth maps the geometric term reads: 'estimated' = the rendered depths with 0.3 %% relative noise, 2 %% of 16x16 blocks and 1 %% of single pixels missing (depth 0), as maps estimated by a previous pass are; 'gt' = the rendered depths (rounds 1-4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="override a PatchMatchParams field of the timed pass (ablations, e.g. --param use_limit=0); the line's workload string says so")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg5 / cfg2 lines that the default workload appends")
     ap.add_argument("--dry-launch", action="store_true", help="launcher check without a GPU: start the ranks, rendezvous over gloo, print one line with each rank's environment")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself (0: pick a free one)")
@@ -470,7 +471,11 @@ def measure(env, args, cfg_name, W, H, S, iters, weak_frac_arg, steps, warmup, p
         planes, views, weak, radius = ctx.download_state()
         st = wl.hand_over(planes, views, weak, radius, p1, W, H, extra_weak=wl.weak_mask(args.weak_layout, W, H, weak_frac_arg, flat))
         del planes, views, weak, radius
-        ctx.set_params(wl.refine_iter_params(S, iters))
+        p2 = wl.refine_iter_params(S, iters)
+        for kv in (args.param if primary else []):
+            k, v = kv.split("=")
+            p2[k] = float(v) if "." in v else int(v)
+        ctx.set_params(p2)
         ctx.set_depths_device([deps[i].data_ptr() for i in order], W)
         ctx.upload_state(planes=st[0], views=st[1], weak=st[2], radius=st[3])
         weak_frac = ctx.weak_count() / float(L)
@@ -542,7 +547,7 @@ def measure(env, args, cfg_name, W, H, S, iters, weak_frac_arg, steps, warmup, p
         workload = "BASELINE %s stand-in: %dx%d, S=%d source views, %d PatchMatch iterations, %s" % (
             cfg_name if (W, H, S) == (cfg["W"], cfg["H"], cfg["S"]) else "custom(%s-like)" % cfg_name, W, H, S, iters,
             ("REFINE_ITER pass, geom_consistency on, use_APD on (%.1f %% WEAK pixels%s), edge/label/radius priors on, inputs from an untimed FIRST_INIT pass" % (100 * weak_frac, ", a few large connected regions" if args.weak_layout == "regions" else ""))
-            if cfg["refine"] else "FIRST_INIT, geom off")
+            if cfg["refine"] else "FIRST_INIT, geom off") + ((" [params overridden: %s]" % ", ".join(args.param)) if (primary and args.param) else "")
         out = {
             "metric": "Mpixels/sec/PatchMatch-iteration", "value": round(value, 3), "unit": "Mpx/s/iter",
             "n_gpus": world, "steps": steps, "warmup": warmup,

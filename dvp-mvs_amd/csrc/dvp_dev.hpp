@@ -249,12 +249,18 @@ DVP_HD int img8_tiles_y(int H) { return (H + 2 * kImgPad + kT8H - 1) / kT8H; }
 // i0 >= -PAD, j0 >= -PAD (pixel coordinates; the PAD frame is part of the plane)
 DVP_HD unsigned img8_offset(int tiles_x, int i0, int j0) {
 	const unsigned px = (unsigned)(i0 + kImgPad), py = (unsigned)(j0 + kImgPad);
+	// px < 2^15 + PAD (dvp_ctx_create), kT8Mul < 2^17: the products fit 32 bits and both factors 24 — v_mul_u32_u24 (full rate)
+	// instead of v_mul_lo_u32 (quarter rate).  Round 3 measured no gain from this while the weak update waited for its gathers;
+	// its propagation launch now is VALU-bound (PMC r05: 0.56 of the issue peak, gather roof 0.35)
+#if defined(__HIP_DEVICE_COMPILE__)
+	const unsigned tx = __umul24(px, kT8Mul) >> 19;   // px / kT8W
+	const unsigned ex = px - __umul24((unsigned)kT8W, tx);
+	const unsigned ty = py / (unsigned)kT8H, ey = py % (unsigned)kT8H;
+	const unsigned tile = __umul24(ty, (unsigned)tiles_x) + tx;
+#else
 	const unsigned tx = (px * kT8Mul) >> 19;   // px / kT8W
 	const unsigned ex = px - (unsigned)kT8W * tx;
 	const unsigned ty = py / (unsigned)kT8H, ey = py % (unsigned)kT8H;
-#if defined(__HIP_DEVICE_COMPILE__)
-	const unsigned tile = __umul24(ty, (unsigned)tiles_x) + tx;
-#else
 	const unsigned tile = ty * (unsigned)tiles_x + tx;
 #endif
 	return (tile << 7) + ey * (unsigned)(kT8B * kT8E) + ex * (unsigned)kT8B;

@@ -344,6 +344,29 @@ DVP_HD float anchor_cost_tab(const Dev& d, const float* H, const void* src, s2 n
 	unsigned off[9];
 	TapW<SMP> tw[9];
 	float qd[9][4];
+#if defined(DVP_ABL_ANCHOR_BATCH_RCP)
+	// TIMING A/B OF A CONTRACT CHANGE (different bits): the nine projective divides of a sub-patch through ONE
+	// correctly rounded division (prefix products, as batch_rcp does for the six taps of a centre-patch row) instead of one each
+	{
+		float X[9], Y[9], Z[9], P[9], IZ[9];
+#pragma unroll
+		for (int t = 0; t < 9; ++t) {
+			const int tx = (int)(int16_t)(r.pos[t] & 0xffffu), ty = (int)(int16_t)(r.pos[t] >> 16);
+			X[t] = H[0] * tx + H[1] * ty + H[2];
+			Y[t] = H[3] * tx + H[4] * ty + H[5];
+			Z[t] = H[6] * tx + H[7] * ty + H[8];
+		}
+		P[0] = Z[0];
+#pragma unroll
+		for (int t = 1; t < 9; ++t) P[t] = P[t - 1] * Z[t];
+		float rr = 1.0f / P[8];
+#pragma unroll
+		for (int t = 8; t >= 1; --t) { IZ[t] = rr * P[t - 1]; rr = rr * Z[t]; }
+		IZ[0] = rr;
+#pragma unroll
+		for (int t = 0; t < 9; ++t) tex_coord_t<FMT>(d, X[t] * IZ[t], Y[t] * IZ[t], &off[t], &tw[t]);
+	}
+#else
 #pragma unroll
 	for (int t = 0; t < 9; ++t) {
 		const f2 sp = apply_homography(H, (int)(int16_t)(r.pos[t] & 0xffffu), (int)(int16_t)(r.pos[t] >> 16));
@@ -352,6 +375,7 @@ DVP_HD float anchor_cost_tab(const Dev& d, const float* H, const void* src, s2 n
 		off[t] = (unsigned)t * 4u;
 #endif
 	}
+#endif
 #pragma unroll
 	for (int t = 0; t < 9; ++t) load_quad_t<FMT>(src, off[t], &qd[t][0], &qd[t][1], &qd[t][2], &qd[t][3]);
 	float s_s = 0.0f, s_ss = 0.0f, s_rs = 0.0f;
