@@ -47,6 +47,7 @@ Mat DecodeJpeg(const path& file, int channels);     // 1: luma plane (libjpeg JC
 struct LabelStages { Mat quarter, texture, texture_lines, resized, cleaned; int weak_tex_num = 0; };
 Mat LabelSegment(const int scale, const Mat& src_image, LabelStages* stages = nullptr);   // EdgeSegment mode 1 (APD.cpp:348-401, 437-499), host/labels.cpp
 Mat ReadImageGray(const path& image_path_jpg);      // stands in for cv::imread(IMREAD_GRAYSCALE), APD.cpp:1057
+bool ImageFileSize(const path& image_path_jpg, int* width, int* height);   // from the file header, without decoding
 Mat ReadImageColor(const path& image_path_jpg);     // cv::imread(IMREAD_COLOR) (BGR), APD.cpp:1842
 Mat ResizeLinear(const Mat& src_f32, int new_cols, int new_rows);   // cv::resize(INTER_LINEAR), APD.cpp:1129
 // threads of the host-side pixel loops: min(32, hardware threads), DVP_HOST_THREADS overrides

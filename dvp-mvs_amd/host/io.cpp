@@ -235,6 +235,56 @@ static Mat read_image(const path& jpg, int channels) {
 	return Mat();
 }
 Mat ReadImageGray(const path& p) { return read_image(p, 1); }
+// size of images/<id>.jpg (or its .pgm / .ppm stand-in) from the file header alone — a 25-Mpx JPEG takes 0.3 s to decode, its
+// frame header sits in the first kilobytes.  What the driver's view -> rank assignment needs of every view on every rank.
+bool ImageFileSize(const path& jpg, int* w, int* h) {
+	const std::string ext = jpg.extension().string();
+	if ((ext == ".jpg" || ext == ".jpeg" || ext == ".JPG" || ext == ".JPEG") && std::filesystem::exists(jpg)) {
+		FILE* f = fopen(jpg.string().c_str(), "rb");
+		if (f) {
+			bool ok = false;
+			unsigned char b[8];
+			if (fread(b, 1, 2, f) == 2 && b[0] == 0xFF && b[1] == 0xD8) {
+				for (;;) {   // marker segments up to the first start-of-frame (SOF0..SOF15 but DHT / JPG / DAC)
+					int c = fgetc(f);
+					while (c != EOF && c != 0xFF) c = fgetc(f);
+					while (c == 0xFF) c = fgetc(f);
+					if (c == EOF) break;
+					if (c == 0xD8 || c == 0x01 || (c >= 0xD0 && c <= 0xD7)) continue;   // stand-alone markers
+					if (fread(b, 1, 2, f) != 2) break;
+					const int len = (b[0] << 8) | b[1];
+					if (c >= 0xC0 && c <= 0xCF && c != 0xC4 && c != 0xC8 && c != 0xCC) {
+						if (fread(b, 1, 5, f) == 5) { *h = (b[1] << 8) | b[2]; *w = (b[3] << 8) | b[4]; ok = *w > 0 && *h > 0; }
+						break;
+					}
+					if (c == 0xDA || len < 2 || fseek(f, len - 2, SEEK_CUR) != 0) break;
+				}
+			}
+			fclose(f);
+			if (ok) return true;
+		}
+	}
+	path p = jpg;
+	for (const char* e : { ".pgm", ".ppm" }) {
+		p.replace_extension(e);
+		FILE* f = fopen(p.string().c_str(), "rb");
+		if (!f) continue;
+		char magic[3] = { 0 };
+		int v[2] = { 0, 0 };
+		bool ok = fread(magic, 1, 2, f) == 2 && magic[0] == 'P' && (magic[1] == '5' || magic[1] == '6');
+		for (int i = 0; ok && i < 2; ++i) {
+			int c = fgetc(f);
+			while (c == '#' || c == ' ' || c == '\n' || c == '\r' || c == '\t') {
+				if (c == '#') while (c != '\n' && c != EOF) c = fgetc(f);
+				c = fgetc(f);
+			}
+			while (c >= '0' && c <= '9') { v[i] = v[i] * 10 + (c - '0'); c = fgetc(f); }
+		}
+		fclose(f);
+		if (ok && v[0] > 0 && v[1] > 0) { *w = v[0]; *h = v[1]; return true; }
+	}
+	return false;
+}
 Mat ReadImageColor(const path& p) { return read_image(p, 3); }
 
 // cv::resize(src, dst, Size(new_cols,new_rows), 0, 0, INTER_LINEAR) for CV_32FC1: pixel-centre

@@ -110,6 +110,34 @@ void ConfigurePass(Problem& problem, const Pass& pass, int iteration, int iters,
 	}
 }
 
+// View -> rank.  Round 4 dealt the views round-robin (v % world).  Views differ in cost — by their pixel count when the images
+// of a folder differ in size (APD.cpp:1071-1079 allows it), by their WEAK share (one WEAK pixel costs ~4 others) —, and a pass
+// ends when its busiest rank does: longest-predicted-first instead (the view with the largest predicted cost goes to the rank
+// with the least load so far; ties: lower view index, lower rank).  Predicted cost = the view's pixels (from the file header:
+// every rank computes the same table without decoding anything); the assignment holds for the whole job, so a view's
+// maps of the previous pass stay in its owner's result cache.  Equal-size views: the same table as v % world.
+// tools/scale_sim.py predicts what the policy is worth.
+std::vector<int> AssignViews(const std::vector<Problem>& problems, int world) {
+	std::vector<int> owner(problems.size(), 0);
+	if (world <= 1) return owner;
+	std::vector<std::pair<long long, int>> cost;   // (-pixels, view): ascending sort = largest first, lower index first
+	for (const Problem& p : problems) {
+		int w = 0, h = 0;
+		if (!ImageFileSize(p.dense_folder / "images" / (ToFormatIndex(p.ref_image_id) + ".jpg"), &w, &h)) { w = 1; h = 1; }   // unreadable: the owner will stop the job (DvpFatal) when it loads it
+		cost.emplace_back(-(long long)w * h, p.index);
+	}
+	std::sort(cost.begin(), cost.end());
+	std::vector<long long> load((size_t)world, 0);
+	for (const auto& c : cost) {
+		int best = 0;
+		for (int r = 1; r < world; ++r)
+			if (load[(size_t)r] < load[(size_t)best]) best = r;
+		owner[(size_t)c.second] = best;
+		load[(size_t)best] += -c.first;
+	}
+	return owner;
+}
+
 struct ViewResult { Mat depth; };
 // The reference writes the ACMM-format maps of a view — depths_geom.dmb + normals.dmb, what ACMM-style fusers read — when
 // `problem.iteration == 15` (main.cpp:378-385): the last pass of its default schedule (4 levels x (1 + 3) passes).  Here: at
@@ -237,21 +265,21 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 // map travels with its own dimensions.
 class DepthExchange {
 public:
-	DepthExchange(RankComm& comm, const std::vector<Problem>& problems) : comm_(comm), problems_(problems) {}
+	DepthExchange(RankComm& comm, const std::vector<Problem>& problems, const std::vector<int>& owner) : comm_(comm), problems_(problems), owner_(owner) {}
 	~DepthExchange() { Release(); }
 	// `mine`: view index -> the depth map this rank computed in the pass just finished
 	void Publish(const std::map<int, Mat>& mine) {
 		// agreed check first: a rank that lacks one of its maps must not leave the others inside a collective
 		bool ok = true;
 		for (size_t v = 0; v < problems_.size(); ++v)
-			if ((int)(v % (size_t)comm_.world()) == comm_.rank() && (mine.find((int)v) == mine.end() || mine.at((int)v).empty())) ok = false;
+			if (owner_[v] == comm_.rank() && (mine.find((int)v) == mine.end() || mine.at((int)v).empty())) ok = false;
 		if (!comm_.AllOk(ok)) {
 			std::cerr << "DepthExchange: a rank is missing a depth map of the pass" << std::endl;
 			if (comm_.world() > 1) comm_.Abort("DepthExchange: missing depth map");
 			exit(EXIT_FAILURE);
 		}
 		for (size_t v = 0; v < problems_.size(); ++v) {
-			const int owner = (int)(v % (size_t)comm_.world());
+			const int owner = owner_[v];
 			int dims[2] = { 0, 0 };
 			if (owner == comm_.rank()) { dims[0] = mine.at((int)v).cols; dims[1] = mine.at((int)v).rows; }
 			comm_.BroadcastHost(dims, sizeof(dims), owner);
@@ -277,6 +305,7 @@ private:
 	struct Slot { float* dev = nullptr; int w = 0, h = 0; };
 	RankComm& comm_;
 	const std::vector<Problem>& problems_;
+	const std::vector<int>& owner_;
 	std::map<int, Slot> maps_;
 };
 
@@ -349,12 +378,12 @@ private:
 // The owner of a view (rank v % world) decodes + resizes its image at this level and broadcasts it; the others
 // take it from the broadcast into their image cache: every image file is read by exactly one process and the
 // decode work is spread over the ranks.
-void ShareLevelImages(RankComm& comm, std::vector<Problem>& problems, int scale) {
+void ShareLevelImages(RankComm& comm, std::vector<Problem>& problems, const std::vector<int>& owner_of, int scale) {
 	if (comm.world() <= 1) return;
 	APD::ReserveImageCache(problems.size());
 	for (Problem& p : problems) {
 		p.scale_size = scale;
-		const int owner = p.index % comm.world();
+		const int owner = owner_of[(size_t)p.index];
 		int meta[4] = { 0, 0, 0, 0 };   // cols, rows, original cols, original rows
 		Mat img;
 		if (comm.rank() == owner) {
@@ -425,10 +454,16 @@ int main(int argc, char** argv) {
 
 	std::vector<Problem> problems = ReadViewGraph(opt.dense_folder, opt.max_src);
 	std::cout << "There are " << problems.size() << " problems needed to be processed!" << std::endl;
+	const std::vector<int> owner_of = AssignViews(problems, opt.world);
+	if (opt.world > 1) {
+		std::cout << "rank " << opt.rank << " owns views";
+		for (const Problem& p : problems) if (owner_of[(size_t)p.index] == opt.rank) std::cout << " " << p.index;
+		std::cout << std::endl;
+	}
 	{   // this rank's images are decoded in the background from now on (every pyramid level is made from the decoded file)
 		std::vector<path> mine;
 		for (const Problem& p : problems)
-			if (p.index % opt.world == opt.rank) mine.push_back(opt.dense_folder / "images" / (ToFormatIndex(p.ref_image_id) + ".jpg"));
+			if (owner_of[(size_t)p.index] == opt.rank) mine.push_back(opt.dense_folder / "images" / (ToFormatIndex(p.ref_image_id) + ".jpg"));
 		if (opt.world == 1)   // a single rank also reads every source image itself
 			for (const Problem& p : problems)
 				for (int id : p.src_image_ids) mine.push_back(opt.dense_folder / "images" / (ToFormatIndex(id) + ".jpg"));
@@ -451,7 +486,7 @@ int main(int argc, char** argv) {
 
 	std::unique_ptr<DepthExchange> exchange;
 	std::unique_ptr<InPlaceDepths> inplace;
-	if (opt.jacobi) { exchange.reset(new DepthExchange(comm, problems)); APD::SetResidentDownloader(&RankComm::DeviceToHost); }
+	if (opt.jacobi) { exchange.reset(new DepthExchange(comm, problems, owner_of)); APD::SetResidentDownloader(&RankComm::DeviceToHost); }
 	else if (!opt.sync_io) inplace.reset(new InPlaceDepths());
 	int shared_scale = -1;
 	LevelImages level_images;
@@ -459,7 +494,7 @@ int main(int argc, char** argv) {
 		const Pass& pass = plan[it];
 		const bool new_level = pass.scale != shared_scale;
 		if (new_level) {
-			ShareLevelImages(comm, problems, pass.scale);
+			ShareLevelImages(comm, problems, owner_of, pass.scale);
 			shared_scale = pass.scale;
 			if (exchange) exchange->Release();   // maps of the coarser level do not fit this one (and its A pass has no geometric term)
 		}
@@ -467,7 +502,7 @@ int main(int argc, char** argv) {
 		std::vector<Problem*> owned;
 		for (Problem& problem : problems) {
 			ConfigurePass(problem, pass, (int)it, opt.iters, round_num);
-			if (problem.index % opt.world == opt.rank) owned.push_back(&problem);
+			if (owner_of[(size_t)problem.index] == opt.rank) owned.push_back(&problem);
 		}
 		if (new_level && !opt.sync_io) level_images.Fill(owned, pass.scale);
 		// last pass of a level: the next level's context and float images are made by helper threads while the GPU works

@@ -149,6 +149,12 @@ int main(int argc, char** argv) {
 	if (argc > 4 && std::string(argv[1]) == "--edges") return dump_edges(argv[2], std::atoi(argv[3]), argv[4]);
 	if (argc > 6 && std::string(argv[1]) == "--prior") return dump_prior(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), argv[6]);
 	if (argc > 4 && std::string(argv[1]) == "--jpeg") return dump_jpeg(argv[2], argv[3], std::atoi(argv[4]));
+	if (argc > 2 && std::string(argv[1]) == "--image-size") {   // ImageFileSize: "<w> <h>" from the header alone
+		int w = 0, h = 0;
+		if (!ImageFileSize(argv[2], &w, &h)) return 2;
+		printf("%d %d\n", w, h);
+		return 0;
+	}
 	if (argc > 4 && std::string(argv[1]) == "--labels") return dump_labels(argv[2], std::atoi(argv[3]), argv[4]);
 	if (argc > 4 && std::string(argv[1]) == "--label-stages") return dump_label_stages(argv[2], std::atoi(argv[3]), argv[4]);
 	path tmp = argc > 1 ? path(argv[1]) : std::filesystem::temp_directory_path();

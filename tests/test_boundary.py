@@ -156,6 +156,7 @@ def test_jpeg_decoder_equals_libjpeg(tmp_path):
         rows, cols, ch = np.frombuffer(a[:12].tobytes(), np.int32)
         got = a[12:].reshape(rows, cols)
         assert got.shape == ref.shape and np.array_equal(got, ref), (i, int((got != ref).sum()))
+        assert _host_tool("--image-size", f).stdout.split() == [str(w), str(h)]   # the frame header alone (view -> rank assignment)
         r = _host_tool("--jpeg", f, out, 3)   # colour: JFIF equations, replicated chroma (documented deviation at chroma edges)
         a = np.fromfile(out, np.uint8)
         bgr = a[12:].reshape(rows, cols, 3)
@@ -165,6 +166,12 @@ def test_jpeg_decoder_equals_libjpeg(tmp_path):
     f = str(tmp_path / "prog.jpg")
     Image.fromarray(np.zeros((32, 32, 3), np.uint8)).save(f, progressive=True)
     assert _host_tool("--jpeg", f, str(tmp_path / "o.bin"), 1).returncode == 2
+    assert _host_tool("--image-size", f).stdout.split() == ["32", "32"]
+    # the loss-free stand-in of a synthetic folder: images/<id>.pgm next to a missing .jpg
+    with open(str(tmp_path / "v.pgm"), "wb") as fh:
+        fh.write(b"P5\n# comment\n41 23\n255\n" + bytes(41 * 23))
+    assert _host_tool("--image-size", str(tmp_path / "v.jpg")).stdout.split() == ["41", "23"]
+    assert _host_tool("--image-size", str(tmp_path / "none.jpg")).returncode == 2
 
 
 @pytest.mark.hostbox

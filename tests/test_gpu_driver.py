@@ -251,12 +251,52 @@ def test_apd_eight_ranks_host_transport(tmp_path):
             assert [r for r, _ in seen] == list(range(8)), seen
             if "DVP_HOST_THREADS" not in os.environ:
                 assert all(n == max(1, min(32, cores // 8)) for _, n in seen), (seen, cores)
+            # view -> rank: longest-predicted-first on the pixel counts of the image headers (host/main.cpp: AssignViews) — the 14
+            # full-size views first, then the cropped ones (14: 88x64, 9: 96x56, 2: 80x72) onto the least-loaded ranks; every rank
+            # prints the same table's row for itself
+            owned = {int(m.group(1)): [int(x) for x in m.group(2).split()] for t in texts for m in re.finditer(r"rank (\d+) owns views((?: \d+)+)", t)}
+            px = {v: W * H for v in range(NV)}
+            px.update({2: 80 * 72, 9: 96 * 56, 14: 88 * 64})
+            load, want = [0] * 8, {r: [] for r in range(8)}
+            for v in sorted(range(NV), key=lambda i: (-px[i], i)):
+                r = min(range(8), key=lambda q: (load[q], q))
+                want[r].append(v)
+                load[r] += px[v]
+            assert {r: sorted(v) for r, v in owned.items()} == {r: sorted(v) for r, v in want.items()}, (owned, want)
+            assert owned != {r: [v for v in range(NV) if v % 8 == r] for r in range(8)}   # (not round-robin on this folder)
         outs[tag] = [read_binmat(os.path.join(d, "APD", "%08d" % v, "depths.dmb")) for v in range(NV)]
     print("apd 17 views, whole schedule (--passes 2): single rank %.1f s, 8 ranks on one GPU (host transport) %.1f s" % (wall["single"], wall["world8"]))
     shapes = {o.shape for o in outs["single"]}
     assert len(shapes) == 4, shapes
     for v in range(NV):
         assert outs["single"][v].shape == outs["world8"][v].shape and np.array_equal(outs["single"][v], outs["world8"][v]), v
+
+
+def test_run_scenes_two_in_flight_equals_one_after_the_other(tmp_path):
+    """tools/run_scenes.py (BASELINE cfg4: several scenes over the GPUs of a node): two scenes IN FLIGHT on the same GPU(s) — the
+    way a node's ranks fill the waits at the per-pass exchange of one scene with the views of another — leave the files of the
+    scenes run one after the other: a scene's result does not depend on what else runs.  On the one GPU of the box that is
+    two `apd` processes sharing the device; the mode with one GPU per scene is exercised with its queue of one worker."""
+    scenes = []
+    for i, (W, H, NV) in enumerate(((112, 80, 4), (96, 64, 5), (128, 72, 3))):
+        for tag in ("seq", "par", "queue"):
+            d = str(tmp_path / ("%s_scene%d" % (tag, i)))
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), "2"], stdout=subprocess.DEVNULL)
+        scenes.append((W, H, NV))
+    common = ["--iters", "1", "--passes", "1", "--min-scale", "1", "--seed", "21", "--no-fusion"]
+    for i in range(len(scenes)):
+        so, se = _apd(str(tmp_path / ("seq_scene%d" % i)), *common).communicate(timeout=600)
+    tool = os.path.join(ROOT, "tools", "run_scenes.py")
+    for tag, extra in (("par", ["--mode", "node", "--in-flight", "2"]), ("queue", ["--mode", "scenes"])):
+        out = subprocess.run([sys.executable, tool, "--gpus", "1", "--log-dir", str(tmp_path / ("logs_" + tag))] + extra +
+                             [str(tmp_path / ("%s_scene%d" % (tag, i))) for i in range(len(scenes))] + ["--"] + common, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        assert "3 scene(s)" in out.stdout
+        for i, (W, H, NV) in enumerate(scenes):
+            for v in range(NV):
+                a = read_binmat(os.path.join(str(tmp_path / ("seq_scene%d" % i)), "APD", "%08d" % v, "depths.dmb"))
+                b = read_binmat(os.path.join(str(tmp_path / ("%s_scene%d" % (tag, i))), "APD", "%08d" % v, "depths.dmb"))
+                assert a.shape == (H, W) and np.array_equal(a, b), (tag, i, v)
 
 
 def test_apd_rank_failure_takes_the_job_down(tmp_path):
