@@ -254,14 +254,14 @@ DVP_HD bool point_in_triangle(s2 A, s2 B, s2 C, int px, int py) {
 	return t1 * t2 >= 0 && t1 * t3 >= 0;
 }
 
-// true = the segment B->A crosses an edge pixel (APD.cu:267-311).
+// true = the segment B->A crosses an edge pixel (APD.cu:267-311) — the definition: every step of the reference's walk is made.
 // The reference walks the line one pixel per loop iteration and tests the edge map after every step
 // (one dependent load per step, up to max(W,H)/30 of them).  The answer is "any visited pixel is
 // an edge pixel", so the walk is done in blocks of 8 steps: eight positions from the integer
 // line state, eight independent loads from the bit-tiled edge map (dvp_dev.hpp: edge_bit), one OR.
 // Visited set, step limit and the one-pixel
 // overshoot past the end point (the loop condition is tested after the step) are the reference's.
-DVP_HD bool bresenham_hits_edge(const Dev& d, int Ax, int Ay, int Bx, int By) {
+DVP_HD bool bresenham_hits_edge_steps(const Dev& d, int Ax, int Ay, int Bx, int By) {
 	const int W = d.width, H = d.height;
 	const int max_step = (int)(DVP_MAX(H, W) / 30.0);
 	int x0 = Bx, y0 = By;
@@ -304,6 +304,91 @@ DVP_HD bool bresenham_hits_edge(const Dev& d, int Ax, int Ay, int Bx, int By) {
 		unsigned hit = 0;
 #pragma unroll
 		for (int k = 0; k < 8; ++k) hit |= (d.edge_bits[wi[k] < 0 ? 0 : wi[k]] >> sh[k]) & (wi[k] < 0 ? 0u : 1u);
+		if (hit) return true;
+	}
+	return false;
+}
+
+// The same answer without making every step (round 5).  The reference's walk — e2 = err; if (e2 > -dx) { err -= dy; x += sx; }
+// if (e2 < dy) { err += dx; y += sy; }, err0 = max(dx, dy) / 2 — is autonomous: its state after k iterations has a closed
+// form (checked against the loop for all dx, dy < 120 and k <= 300, and through the engine's own tests):
+//   dx >= dy:  x steps every iteration,  y has stepped floor((k dy + dx - 1 - err0) / dx) times,  err_k = dx - 1 - remainder
+//   dx <  dy:  y steps every iteration,  x has stepped min(k, q), q = floor((err0 + k dx + dy - 1) / dy) times
+// and it tests the positions after iterations 1 .. N, N = min(max(dx, dy) + 1, max_step) (both end-point flags are down at
+// the start of iteration max(dx, dy), which still makes its step: the one-pixel overshoot).  Both coordinates are monotone
+// along the walk, so the eight positions of a block lie in the box of its first and last: a block whose box (widened to
+// whole 8 x 8 cells: the cell table, four loads) holds no edge pixel is skipped WITHOUT stepping through it; a block that may
+// hit restarts the reference's stepping from the closed-form state.  GenNeighbours' searches spent 36 + 14 of their 113 ms per
+// cfg3 pass in these walks (tools/gn_ablate.sh), most of it integer stepping through edge-free pixels on the way to the
+// one edge that blocks a direction.
+DVP_HD int line_div(int n, int dvs, float inv) {   // floor(n / dvs) for 0 <= n < 2^23, dvs >= 1: one multiplication + fix-up
+	int q = (int)((float)n * inv);
+	const int r = n - q * dvs;
+	q += (r >= dvs) ? 1 : 0;
+	q -= (r < 0) ? 1 : 0;
+	return q;
+}
+DVP_HD bool bresenham_hits_edge(const Dev& d, int Ax, int Ay, int Bx, int By) {
+	const int W = d.width, H = d.height;
+	const int max_step = (int)(DVP_MAX(H, W) / 30.0);
+	const int x0 = Bx, y0 = By;
+	const int x1 = Ax, y1 = Ay;
+	const int ABx = Ax - Bx, ABy = Ay - By;
+	if (ABx * ABx + ABy * ABy > 9 * max_step * max_step) return false;
+	if (edge_count_upper(d, DVP_MIN(x0, x1) - 2, DVP_MIN(y0, y1) - 2, DVP_MAX(x0, x1) + 2, DVP_MAX(y0, y1) + 2) == 0) return false;
+	if (edge_bit(d, x0, y0) || edge_bit(d, x1, y1)) return false;
+	const int dx = x1 > x0 ? x1 - x0 : x0 - x1, sx = x0 < x1 ? 1 : -1;
+	const int dy = y1 > y0 ? y1 - y0 : y0 - y1, sy = y0 < y1 ? 1 : -1;
+	if (dx == 0 && dy == 0) return false;   // the walk never leaves its first pixel, which is not an edge pixel
+	const bool xmaj = dx >= dy;
+	const int major = xmaj ? dx : dy;
+	const int e0 = major / 2;
+	const int N = DVP_MIN(major + 1, max_step);
+	if (N <= 0) return false;
+	const float inv = 1.0f / (float)major;
+	// state after k iterations: steps along x and y, the error term
+	auto state = [&](int k, int* a, int* b, int* e) {
+		if (xmaj) {
+			const int n = k * dy + dx - 1 - e0, q = line_div(n, dx, inv);
+			*a = k; *b = q; *e = dx - 1 - (n - q * dx);
+		} else {
+			const int n = e0 + k * dx + dy - 1, q = line_div(n, dy, inv);
+			*b = k;
+			if (q < k) { *a = q; *e = (n - q * dy) - dy + 1; }
+			else { *a = k; *e = e0 + k * (dx - dy); }
+		}
+	};
+	for (int k0 = 1; k0 <= N; k0 += 8) {
+		const int k1 = DVP_MIN(k0 + 7, N);
+		int a0, b0, e, a1, b1, e1, ap, bp;
+		state(k0 - 1, &ap, &bp, &e);   // where the block's first iteration starts
+		state(k1, &a1, &b1, &e1);
+		{   // first position of the block: one iteration from (ap, bp, e)
+			a0 = ap + ((e > -dx) ? 1 : 0);
+			b0 = bp + ((e < dy) ? 1 : 0);
+		}
+		const int xa = x0 + sx * a0, ya = y0 + sy * b0, xb = x0 + sx * a1, yb = y0 + sy * b1;
+		if (edge_count_upper(d, DVP_MIN(xa, xb), DVP_MIN(ya, yb), DVP_MAX(xa, xb), DVP_MAX(ya, yb)) == 0) continue;
+		// the reference's steps k0 .. k1 from the state after k0 - 1 iterations
+		int x = x0 + sx * ap, y = y0 + sy * bp, erro = e;
+		int wi[8], sh[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			wi[j] = -1;
+			sh[j] = 0;
+			if (k0 + j <= k1) {
+				const int e2 = erro;
+				if (e2 > -dx) { erro -= dy; x += sx; }
+				if (e2 < dy) { erro += dx; y += sy; }
+				if (x >= 0 && x < W && y >= 0 && y < H) {
+					wi[j] = tile_word(d.edge_tiles_x, x, y);
+					sh[j] = x & 31;
+				}
+			}
+		}
+		unsigned hit = 0;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) hit |= (d.edge_bits[wi[j] < 0 ? 0 : wi[j]] >> sh[j]) & (wi[j] < 0 ? 0u : 1u);
 		if (hit) return true;
 	}
 	return false;

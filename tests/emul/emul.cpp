@@ -574,6 +574,13 @@ int emu_run_patchmatch(void* c) {
 	return 0;
 }
 
+// the line test of the weak path, both forms (dvp_weak.hpp): which = 0 the closed-form block skipper the kernels call, 1 the
+// definition that makes every step; the edge map is the context's (packed here)
+int emu_line_test(void* c, int ax, int ay, int bx, int by, int which) {
+	Emu& e = *(Emu*)c;
+	return (which ? bresenham_hits_edge_steps(e.d, ax, ay, bx, by) : bresenham_hits_edge(e.d, ax, ay, bx, by)) ? 1 : 0;
+}
+void emu_pack_edges(void* c) { pack_edge(*(Emu*)c); }
 float emu_expf(float x) { return dvp_expf(x); }
 void emu_eval_cost_vectors(void* c, const int* px, const float* planes, int n, float* out) {
 	Emu& e = *(Emu*)c;

@@ -296,3 +296,46 @@ def strong_update_forms_case(_pair, _run_and_compare, form, S, monkeypatch):
             st["views"] = rng.integers(1, 1 << S, L).astype(np.uint32)
         a, b = _pair(sc, p, st)
         _run_and_compare(a, b, 2, names=("planes", "costs", "selected_views", "view_weight"))
+
+
+def test_line_test_closed_form_equals_the_stepping_walk():
+    """bresenham_hits_edge (csrc/dvp_weak.hpp): the kernels' form jumps over blocks of eight steps whose bounding box holds no
+    edge pixel, from the closed-form state of the reference's walk (BresenhamLine, APD.cu:267-311), instead of making every
+    step.  Against the stepping definition on sparse, medium and dense edge maps: every pair of end points with
+    |dx|, |dy| <= 40 around several centres (all the small slopes, both majors, the degenerate ones), long walks up to and
+    beyond the step limit, walks that leave the image."""
+    import ctypes
+    from emul.emul import Emul, lib as emul_lib
+    L = emul_lib()
+    L.emu_line_test.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5
+    L.emu_pack_edges.argtypes = [ctypes.c_void_p]
+    rng = np.random.default_rng(5)
+    for W, H, dens in ((300, 210, 0.002), (300, 210, 0.02), (640, 480, 0.0005), (200, 150, 0.3), (3100, 400, 0.001), (2400, 1800, 0.0002)):   # max_step = max(W, H) / 30 = 10, 10, 21, 6, 103, 80
+        e = Emul(W, H, 2)
+        edge = (rng.random((H, W)) < dens).astype(np.uint8)
+        edge[H // 3, W // 4:W // 2] = 1          # a wall
+        edge[H // 5:H // 2, 2 * W // 3] = 1
+        e.upload_state(planes=np.zeros((H * W, 4), np.float32), views=np.zeros(H * W, np.uint32), weak=np.full(H * W, synth.STRONG, np.uint8),
+                       edge=edge.reshape(-1), label=np.zeros(H * W, np.int32), radius=np.full(H * W, 5, np.int32))
+        L.emu_pack_edges(e.h)
+        n = hits = 0
+        cases = []
+        for cx, cy in ((W // 2, H // 2), (3, 4), (W - 2, H - 3), (W // 4 + 5, H // 3 + 2)):
+            for dx in range(-40, 41, 1 if dens > 0.001 else 3):
+                for dy in range(-40, 41, 1 if dens > 0.001 else 3):
+                    cases.append((cx, cy, cx + dx, cy + dy))
+        for _ in range(20000):
+            ax, ay = int(rng.integers(0, W)), int(rng.integers(0, H))
+            r = int(rng.integers(0, 4 * max(W, H) // 30))
+            bx, by = ax + int(rng.integers(-r, r + 1)), ay + int(rng.integers(-r, r + 1))
+            cases.append((ax, ay, bx, by))
+        for ax, ay, bx, by in cases:
+            if not (0 <= ax < W and 0 <= ay < H and 0 <= bx < W and 0 <= by < H):   # end points are image pixels (anchors, candidates)
+                continue
+            a = L.emu_line_test(e.h, ax, ay, bx, by, 0)
+            b = L.emu_line_test(e.h, ax, ay, bx, by, 1)
+            assert a == b, (W, H, dens, ax, ay, bx, by, a, b)
+            n += 1
+            hits += b
+        assert hits > 50 and hits < n, (hits, n)
+        e.close()
