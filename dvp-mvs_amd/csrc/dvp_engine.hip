@@ -1561,7 +1561,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 		la.iter = iter;
 		la.covered_rows = 2 * make_geom(c->W, c->H, true).rows;
 		la.base = (stage == DVP_ST_WEAK_UPDATE && colour == 1) ? c->d.weak_black : 0;
-		la.count = (stage == DVP_ST_WEAK_UPDATE) ? (colour == 0 ? c->d.weak_black : c->d.weak_red) : c->d.weak_black + c->d.weak_red;
+		la.count = (stage == DVP_ST_WEAK_UPDATE) ? (colour == 0 ? c->d.weak_black : (colour == 1 ? c->d.weak_red : c->d.weak_black + c->d.weak_red)) : c->d.weak_black + c->d.weak_red;   // colour 2 (dvp_run_patchmatch): both colours of the weak update in one launch site
 		if (la.count > 0) {
 			const dim3 lg((la.count + 255) / 256);
 			const bool ex = c->d.sampler != 0;
@@ -1768,8 +1768,15 @@ int dvp_run_patchmatch(dvp_ctx* c) {
 		if (launch_stage(c, DVP_ST_STRONG_UPDATE, i, 1)) return 1;
 		if (c->d.weak_count > 0) {   // these three only touch WEAK pixels
 			if (launch_stage(c, DVP_ST_RANSAC_FIT, i, 0)) return 1;
-			if (launch_stage(c, DVP_ST_WEAK_UPDATE, i, 0)) return 1;
-			if (launch_stage(c, DVP_ST_WEAK_UPDATE, i, 1)) return 1;
+			// Black then red (APD.cu:4487-4489).  A WEAK pixel's update reads other pixels' state only at its anchors, which are STRONG
+			// (GenNeighbours) and which no weak update writes: the two launches commute, and as the eight launches of the phased form
+			// they are issued once over the whole WEAK list (half the launches and their tails).  dvp_run_stage keeps the colours apart.
+			if (c->weak_phased && !c->anchor_tab_off && !getenv("DVP_WEAK_SPLIT_COLOURS")) {
+				if (launch_stage(c, DVP_ST_WEAK_UPDATE, i, 2)) return 1;
+			} else {
+				if (launch_stage(c, DVP_ST_WEAK_UPDATE, i, 0)) return 1;
+				if (launch_stage(c, DVP_ST_WEAK_UPDATE, i, 1)) return 1;
+			}
 		}
 	}
 	HIP_TRY(c, hipEventRecord(itl.b, c->stream));
