@@ -572,26 +572,21 @@ DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
 		for (int v = 0; v < MV; ++v) ca[k][v] = 0.0f;
 	}
 	ca[0][0] = 2.0f;   // `= { 2.0f }` sets one element (APD.cu:2032)
-	// slots 0-7 (APD.cu:2047-2090).  The kernel waits for its cost loads three quarters of its cycles (PMC r04 / r05): with the
-	// loads of a slot behind that slot's `pos >= 0` branch a wave makes sixteen dependent round trips.  The sixteen sample
-	// positions first, then the 8 x S costs of the first eight slots in ONE batch — unconditional loads from a valid address
-	// (slot 16, the pixel's own plane, always has a vector), the slot's condition applied to the loaded values.
-	int pos_all[16];
 #pragma unroll
-	for (int k = 0; k < 16; ++k) pos_all[k] = d.search_pos[(size_t)k * L + center];
+	for (int k = 0; k < 8; ++k) {      // slots 0-7 (APD.cu:2047-2090)
+		const int pos = d.search_pos[(size_t)k * L + center];
+		if (pos >= 0) {
+			flag |= 1u << k;
+			positions[k] = pos;
+			const float* sc = d.slot_costs + (size_t)(strong_slot_source(dw0, dw1, dw2, k) * S) * Lh + hi;
 #pragma unroll
-	for (int k = 0; k < 8; ++k) {
-		const bool has = pos_all[k] >= 0;
-		const float* sc = d.slot_costs + (size_t)((has ? strong_slot_source(dw0, dw1, dw2, k) : kSlotCur) * S) * Lh + hi;
-#pragma unroll
-		for (int v = 0; v < MV; ++v)
-			if (v < S) { const float t = sc[(size_t)v * Lh]; ca[k][v] = has ? t : ca[k][v]; }
-		if (has) { flag |= 1u << k; positions[k] = pos_all[k]; }
+			for (int v = 0; v < MV; ++v)
+				if (v < S) ca[k][v] = sc[(size_t)v * Lh];
+		}
 	}
-	sched_fence();
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {      // slots 8-15: the fixed-stride sample replaces the adaptive one if it is better (APD.cu:2104-2137)
-		const int pos = pos_all[8 + k];
+		const int pos = d.search_pos[(size_t)(8 + k) * L + center];
 		if (pos >= 0) {
 			const bool had = (flag >> k) & 1;
 			flag |= 1u << k;
