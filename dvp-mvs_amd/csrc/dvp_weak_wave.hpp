@@ -1289,7 +1289,15 @@ DVP_HD int gen_neighbours_extend_wave(const Dev& d, int px, int py, int wi, s2* 
 			int appended = 0;
 			DVP_LANES(l) {
 				int before = 0, total = 0;    // kept items in front of this one / in the batch
+#if defined(__HIP_DEVICE_COMPILE__)
+				{
+					const unsigned long long m = __ballot(keep[l] != 0);
+					total = __popcll(m);
+					before = __popcll(m & ((1ull << l) - 1ull));
+				}
+#else
 				for (int k = 0; k < 64; ++k) { total += keep[k]; before += k < l ? keep[k] : 0; }
+#endif
 				const int pos = extend_index + 1 + before;
 				if (keep[l] && pos < kGnMaxPoints) pts[pos] = cnp[l];
 				appended = DVP_MIN(total, kGnMaxPoints - 1 - extend_index);
@@ -1374,6 +1382,21 @@ DVP_HD void wave_bits_or(uint32_t* word, uint32_t bits) {
 #endif
 }
 
+// The RANSAC inlier test is `|fit_depth - z| / depth_diff < ransac_threshold` (APD.cu:3632) — one IEEE division per (candidate
+// plane, point) in the hottest loop of the launch (44 % of dvp_gen_neighbours_fit at 25 % WEAK, tools/ab_variant_trace.sh with
+// -DDVP_ABL_FIT=4), by the SAME positive divisor every time.  x -> fl(x / d) is monotone for d > 0 (correct rounding keeps
+// order), so { x >= 0 : fl(x / d) < t } is an initial segment of the floats: the test is x <= X* with X* = its largest element
+// — found once per pixel from the guess t * d by stepping to the neighbouring floats, the division itself deciding.  Same
+// decisions, bit for bit (NaN fails both forms).  Returns -1 when no x >= 0 passes.
+DVP_HD float largest_ratio_below(float d, float t) {
+	if (!(t > 0.0f)) return -1.0f;
+	const float g = t * d;
+	uint32_t b = (g >= 0.0f && g <= FLT_MAX) ? f32_bits(g) : 0x7F7FFFFFu;   // start at t * d (FLT_MAX if that overflows)
+	while (b > 0u && !(__builtin_bit_cast(float, b) / d < t)) --b;
+	while (b < 0x7F7FFFFFu && (__builtin_bit_cast(float, b + 1u) / d < t)) ++b;
+	return __builtin_bit_cast(float, b);   // (0 / d = 0 < t: the set is never empty here)
+}
+
 // plane through three camera-frame points, as the candidate step builds it (APD.cu:3609-3622)
 DVP_HD f4 gn_plane(const f3 A, const f3 B, const f3 C) {
 	const f3 AC = mk3(A.x - C.x, A.y - C.y, A.z - C.z);
@@ -1406,13 +1429,19 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 	DVP_LANES(l) { if (l < kGnDirSlots) sh.raw[l] = d.gn_points[(size_t)wi * kGnDirSlots + l]; }
 	wave_sync();
 	int n_extended = 0;
+#if defined(DVP_ABL_FIT) && DVP_ABL_FIT == 1   // timing ablation (wrong results): no label extension
+	const int listed = kGnDirSlots;
+#else
 	const int listed = 1 + gen_neighbours_extend_wave(d, px, py, wi, sh.raw, sh.spv, sh.req_from, sh.req_to, &n_extended);
+#endif
 	if (d.gn_count[wi] + n_extended <= 3) {   // fewer than four candidates (APD.cu:3562): not reliable, no plane
 		if (DVP_LANE0) d.weak_reliable[center] = 0;
 		return;
 	}
 	const DvpCamera cam = load_camera(d, 0);
 	const float depth_diff = P.depth_max - P.depth_min;
+	const bool by_limit = depth_diff > 0.0f;   // (else: the division, whatever it yields)
+	const float inlier_limit = by_limit ? largest_ratio_below(depth_diff, P.ransac_threshold) : 0.0f;
 	s2* neighbours = d.neighbours + (size_t)wi * DVP_NEIGHBOUR_NUM;
 	const uint32_t site = rng_site(PH_NEIGHBOURS, 0, SUB_RANSAC);
 	bool edge_limit = false;   // same draw as in the first half (APD.cu:3366-3374)
@@ -1482,7 +1511,11 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 	// Requests in the reference's order: draw t asks (a,b), (b,c), (c,a).  64 requests at a time: a request is
 	// a first asker when its pair is neither marked from an earlier batch nor asked by a lower lane of this
 	// batch; first askers mark the pair and queue the walk in THEIR orientation.
+#if defined(DVP_ABL_FIT) && DVP_ABL_FIT == 2   // timing ablation: no line tests at all (requests + walks)
+	if (false) {
+#else
 	if (edge_limit) {
+#endif
 		for (int r0 = 0; r0 < 3 * n_pass; r0 += 64) {   // only the draws that passed ask; plist keeps their order
 			DVP_LANES(l) {
 				const int r = r0 + l, j = r / 3, e = r - 3 * j;
@@ -1513,7 +1546,11 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 			}
 			wave_sync();
 		}
+#if defined(DVP_ABL_FIT) && DVP_ABL_FIT == 3   // timing ablation: requests, but no walks
+		const int n_walk = 0;
+#else
 		const int n_walk = sh.n_walk;
+#endif
 		for (int j0 = 0; j0 < n_walk; j0 += 64) {
 			DVP_LANES(l) {
 				const int j = j0 + l;
@@ -1551,7 +1588,18 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 			cv.w = -(cv.x * A.x + cv.y * A.y + cv.z * A.z);
 			const bool strong = !(label_test && fabsf(AN.x * cv.x + AN.y * cv.y + AN.z * cv.z) < 0.9f);
 			int count = 0;
+#if defined(DVP_ABL_FIT) && DVP_ABL_FIT == 4   // timing ablation: no inlier loop
+			for (int si = 0; si < 0; ++si) {
+#else
+			if (by_limit) {   // (two loops: as one loop with the choice inside, both forms are computed and selected)
+				for (int si = 0; si < valid_count; ++si) {
+					const f2 f = sh.fxy[si];
+					const float fit_depth = -cv.w / (cv.x * f.x + cv.y * f.y + cv.z);
+					if (fabsf(fit_depth - sh.sp3[si].z) <= inlier_limit) count++;
+				}
+			} else
 			for (int si = 0; si < valid_count; ++si) {
+#endif
 				const f2 f = sh.fxy[si];
 				const float fit_depth = -cv.w / (cv.x * f.x + cv.y * f.y + cv.z);
 				if (fabsf(fit_depth - sh.sp3[si].z) / depth_diff < P.ransac_threshold) count++;
@@ -1636,7 +1684,7 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 			const f2 f = sh.fxy[j];
 			const float fit_depth = -best_plane.w / (best_plane.x * f.x + best_plane.y * f.y + best_plane.z);
 			const float dist = fabsf(fit_depth - sh.sp3[j].z);
-			sh.weight[j] = (dist / depth_diff >= P.ransac_threshold) ? FLT_MAX : dist;
+			sh.weight[j] = (by_limit ? dist > inlier_limit : dist / depth_diff >= P.ransac_threshold) ? FLT_MAX : dist;
 		}
 	}
 	wave_sync();
