@@ -329,6 +329,9 @@ DVP_HD int line_div(int n, int dvs, float inv) {   // floor(n / dvs) for 0 <= n 
 	return q;
 }
 DVP_HD bool bresenham_hits_edge(const Dev& d, int Ax, int Ay, int Bx, int By) {
+#if defined(DVP_WALK_STEPS)   // A/B builds: the stepping definition
+	return bresenham_hits_edge_steps(d, Ax, Ay, Bx, By);
+#endif
 	const int W = d.width, H = d.height;
 	const int max_step = (int)(DVP_MAX(H, W) / 30.0);
 	const int x0 = Bx, y0 = By;

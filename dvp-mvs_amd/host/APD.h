@@ -52,6 +52,7 @@ Mat ReadImageColor(const path& image_path_jpg);     // cv::imread(IMREAD_COLOR) 
 Mat ResizeLinear(const Mat& src_f32, int new_cols, int new_rows);   // cv::resize(INTER_LINEAR), APD.cpp:1129
 // threads of the host-side pixel loops: min(32, hardware threads), DVP_HOST_THREADS overrides
 int HostThreads();
+void SetThisThreadHostThreads(int n);   // caps HostThreads() for the calling thread (helper threads beside the driver's main thread); 0: no cap
 void SetHostThreadShare(int world);   // caps HostThreads() at cores / world (one rank per GPU shares the host with its peers)
 // write-back cache of the per-view result files + background workers (host/store.cpp)
 void SetResultCache(bool enabled, size_t limit_bytes = 0);   // default: on, 32 GiB

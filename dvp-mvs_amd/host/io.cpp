@@ -333,7 +333,10 @@ void SetHostThreadShare(int world) {
 	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
 	g_thread_share = world > 1 ? (int)std::max(1u, hw / (unsigned)world) : 0;
 }
+static thread_local int t_thread_cap = 0;
+void SetThisThreadHostThreads(int n) { t_thread_cap = n > 0 ? n : 0; }
 int HostThreads() {
+	if (t_thread_cap > 0) return t_thread_cap;   // a helper thread's own (small) team: it must not take the cores of the thread that feeds the GPU
 	static const int env = [] { const char* e = std::getenv("DVP_HOST_THREADS"); return e ? std::max(1, std::atoi(e)) : 0; }();
 	if (env) return env;
 	const unsigned hw = std::thread::hardware_concurrency();

@@ -27,6 +27,10 @@
 #include <map>
 #include <set>
 #include <memory>
+#include <future>
+#include <mutex>
+#include <condition_variable>
+#include <algorithm>
 
 namespace {
 
@@ -255,6 +259,14 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	const auto end = std::chrono::steady_clock::now();
 	const DvpTimings& t = APD.GetTimings();
 	std::cout << "Processing image: " << std::setw(8) << std::setfill('0') << problem.ref_image_id << " done!" << std::endl;
+	if (host_timing) {   // where the GPU time of the view went, launch site by launch site (event pairs around each site: gaps between sites — a host that is late with the next launch — show as the difference to the total)
+		static const char* names[DVP_ST_COUNT] = { "gen_edge_inform", "find_nearest_strong", "gen_neighbours", "neighbour_update", "random_init", "strong_update", "ransac_fit", "weak_update", "get_depth_normal", "filter_strong", "depth_to_weak", "local_refine", "strong_prep" };
+		double sum = 0.0;
+		std::cout << "  [gpu]";
+		for (int i = 0; i < DVP_ST_COUNT; ++i)
+			if (t.stage_ms[i] > 0.0) { std::cout << " " << names[i] << " " << t.stage_ms[i]; sum += t.stage_ms[i]; }
+		std::cout << " | sites " << sum << " of total " << t.total_ms << " ms" << std::endl;
+	}
 	std::cout << "Cost time: " << std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count() << " ms (GPU RunPatchMatch "
 	          << t.total_ms << " ms, " << (double)width * height * problem.params.max_iterations / (t.total_ms * 1e3) << " Mpx/s/iter)" << std::endl;
 	return ViewResult{ depth };
@@ -513,17 +525,52 @@ int main(int argc, char** argv) {
 			for (const Problem* p : owned) mine_next.push_back(*p);
 			APD::PrefetchLevelImages(mine_next, plan[it + 1].scale);
 		}
+		// The edge / label maps of an A pass (main.cpp:480: GetProblemEdges before every view).  Round 4 made the NEXT view's maps
+		// while the GPU worked on the current one — on the one background worker, behind that view's clean-up job: at the coarse
+		// levels a view's kernels take 20-70 ms, its label map (Roberts cross + components + Hough lines on the FULL-size image)
+		// longer, and SupportInitialization waited 32 of 59 ms per view (profiles/r04g_e2e_apd.txt, pass 0).  Now every owned
+		// view's maps are announced at the start of the pass and made by a few helper threads in view order; a view only waits
+		// if its own maps are not there yet (LoadResult waits for announced files).  Same files (store.cpp).
+		std::vector<std::future<void>> edge_jobs;
+		auto start_edge_jobs = [&edge_jobs](const std::vector<Problem>& views) {
+			struct Queue { std::mutex m; size_t next = 0; std::vector<std::pair<Problem, std::vector<path>>> items; };
+			auto q = std::make_shared<Queue>();
+			for (const Problem& p : views) {
+				std::vector<path> outs = ProblemEdgeOutputs(p);   // (what exists or is announced already is not made again)
+				for (const path& f : outs) ExpectResult(f);
+				if (!outs.empty()) q->items.emplace_back(p, std::move(outs));
+			}
+			const int helpers = (int)std::min<size_t>(q->items.size(), (size_t)std::max(1, std::min(4, HostThreads() / 4)));
+			for (int h = 0; h < helpers; ++h)
+				edge_jobs.push_back(std::async(std::launch::async, [q]() {
+					// two threads per helper: with full-size teams the helpers starved the thread that issues the launches — the GPU
+					// idled between kernels (RunPatchMatch of a 1552x1032 view: 67 -> 131 ms)
+					SetThisThreadHostThreads(2);
+					for (;;) {
+						size_t i;
+						{ std::lock_guard<std::mutex> lk(q->m); i = q->next++; }
+						if (i >= q->items.size()) return;
+						GetProblemEdges(q->items[i].first, q->items[i].second);
+					}
+				}));
+		};
+		if (!opt.sync_io) {
+			std::vector<Problem> views;
+			if (pass.geom_index < 0)
+				for (const Problem* p : owned) views.push_back(*p);
+			// ... and during the last pass of a level, the maps of the NEXT level's A pass (its first view used to wait for its
+			// own label map: 0.6 s at full size)
+			if (it + 1 < plan.size() && plan[it + 1].scale != pass.scale && plan[it + 1].geom_index < 0)
+				for (const Problem* p : owned) {
+					Problem q = *p;
+					ConfigurePass(q, plan[it + 1], (int)it + 1, opt.iters, round_num);
+					views.push_back(q);
+				}
+			if (!views.empty()) start_edge_jobs(views);
+		}
 		for (size_t k = 0; k < owned.size(); ++k) {
 			Problem& problem = *owned[k];
-			if (pass.geom_index < 0) {   // main.cpp:480
-				GetProblemEdges(problem);      // (already there when the previous view's turn prefetched it)
-				if (k + 1 < owned.size()) {    // the next view's edge / label maps are made while the GPU works on this one
-					const Problem next = *owned[k + 1];
-					const std::vector<path> outs = ProblemEdgeOutputs(next);
-					for (const path& p : outs) ExpectResult(p);
-					if (!outs.empty()) RunInBackground([next, outs]() { GetProblemEdges(next, outs); });
-				}
-			}
+			if (pass.geom_index < 0 && opt.sync_io) GetProblemEdges(problem);   // main.cpp:480, synchronously
 			ViewResult r = ProcessProblem(problem);
 			if (exchange) mine[problem.index] = r.depth;
 			if (inplace) inplace->Update(problem.ref_image_id, r.depth);
@@ -532,6 +579,7 @@ int main(int argc, char** argv) {
 		// (APD.cpp fallback from the resident maps to LoadResult): the owner's background writer must have put this
 		// pass' files on disk BEFORE the barrier lets anyone into the next pass, or the reader sees the previous pass'
 		// map (or none) depending on timing.  One rank has no other reader: its cache serves its own next pass.
+		for (auto& j : edge_jobs) j.get();
 		if (opt.world > 1) FlushResults();
 		if (exchange) exchange->Publish(mine);   // collective: also the barrier between passes
 		else comm.Barrier();
