@@ -950,6 +950,7 @@ struct dvp_ctx {
 	WeakRec* weak_rec = nullptr; f2* weak_ctab = nullptr; float* weak_ev = nullptr;
 	size_t weak_phase_alloc = 0;       // capacity in WEAK pixels
 	bool weak_phased = true;           // DVP_WEAK_PHASED=0, no anchor table, or the buffers did not fit: the one-wave form
+	int weak_phased_min = 8192;        // WEAK pixels of a launch below which the one-wave kernel is used (DVP_WEAK_PHASED_MIN; tests: 0)
 	int weak_run[4] = { 64, 256, 1024, 1024 };   // WEAK pixels per XCD run of the same launches (DVP_WEAK_RUNS=a,b,c,d)
 	int weak_group[4] = { 1, 4, 4, 2 };   // WEAK pixels per wave of E0 / E1 / E2a / E2b (DVP_WEAK_GROUPS=a,b,c,d: A/B measurements)
 	int* weak_list = nullptr;    // compacted WEAK pixel indices (black first, then red)
@@ -1054,6 +1055,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	if (const char* e = getenv("DVP_WEAK_ANCHOR_TAB")) c->anchor_tab_off = atoi(e) == 0;   // A/B measurements and the tests of the per-item form
 	if (const char* e = getenv("DVP_GN_WAVE")) c->gn_wave = atoi(e) != 0;
 	if (const char* e = getenv("DVP_WEAK_PHASED")) c->weak_phased = atoi(e) != 0;
+	if (const char* e = getenv("DVP_WEAK_PHASED_MIN")) c->weak_phased_min = atoi(e);
 	if (const char* e = getenv("DVP_WEAK_RUNS")) {
 		int g[4];
 		if (sscanf(e, "%d,%d,%d,%d", &g[0], &g[1], &g[2], &g[3]) == 4)
@@ -1577,7 +1579,9 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 			case DVP_ST_WEAK_UPDATE:
 				if (ensure_anchor_table(c, la.covered_rows)) return 1;
 				if (c->d.anchor_tab && ensure_weak_phase_buffers(c)) return 1;
-				if (c->d.anchor_tab && c->weak_phased) {
+				// (a few thousand WEAK pixels do not fill the machine in any form: the eight launches then cost more than they save —
+				// 4.4 against 1.7 ms for the weak updates of a 3104x2064 view with 0.2 % WEAK pixels — and the one-wave kernel takes them)
+				if (c->d.anchor_tab && c->weak_phased && (la.count >= c->weak_phased_min || c->weak_phased_min <= 0)) {
 					const bool u8 = c->images8_ok;
 					const dim3 w64(64), lg64((la.count + 63) / 64);
 #define DVP_PICK(NAME) (ex ? (u8 ? NAME##_exact_u8 : NAME##_exact) : (u8 ? NAME##_u8 : NAME))

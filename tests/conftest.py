@@ -10,6 +10,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The engine hands a launch of fewer than 8192 WEAK pixels to the one-wave kernel (the eight launches of the phased weak update
+# cost more than they save there).  The parity scenes are small: without this every test would exercise the one-wave form only.
+os.environ.setdefault("DVP_WEAK_PHASED_MIN", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "hostbox: needs no GPU (host / numpy / literal-mode oracles); on a box WITH a GPU these also carry the gpu marker, "
