@@ -147,12 +147,13 @@ def parse():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--src", type=int, default=0)
     ap.add_argument("--iters", type=int, default=0)
-    ap.add_argument("--weak-frac", type=float, default=0.05, help="share of 32x32 tiles handed over as WEAK (refine configs)")
+    ap.add_argument("--weak-frac", type=float, default=None, help="share of 32x32 tiles handed over as WEAK (refine configs); default 0.05, cfg5: 0.10 (SURVEY 8d: >= 10 %% WEAK)")
     ap.add_argument("--weak-layout", default="tiles", choices=["tiles", "regions"], help="shape of the pixels handed over as WEAK: 32x32 tiles (default) or a few large connected regions (workloads.weak_regions)")
     ap.add_argument("--rig", default="rotated", choices=["rotated", "axis"], help="camera rig of the synthetic scene: per-view rotations and intrinsics (default) or the round-1/2 rig (R = I, one K)")
     ap.add_argument("--src-depths", default="estimated", choices=["estimated", "gt"], help="depth maps the geometric term reads: 'estimated' = the rendered depths with 0.3 %% relative noise, 2 %% of 16x16 blocks and 1 %% of single pixels missing (depth 0), as maps estimated by a previous pass are; 'gt' = the rendered depths (rounds 1-4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="override a PatchMatchParams field of the timed pass (ablations, e.g. --param use_limit=0); the line's workload string says so")
+    ap.add_argument("--no-per-iteration", action="store_true", help="skip the extra untimed pass that times the iteration loop iteration by iteration (PMC / trace runs: keeps the dispatch list to the timed steps)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg5 / cfg2 lines that the default workload appends")
     ap.add_argument("--dry-launch", action="store_true", help="launcher check without a GPU: start the ranks, rendezvous over gloo, print one line with each rank's environment")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself (0: pick a free one)")
@@ -574,7 +575,8 @@ def measure(env, args, cfg_name, W, H, S, iters, weak_frac_arg, steps, warmup, p
             "rank_busy_ms_per_step": [round(b / steps * 1e3, 1) for b in busy_all],
             "setup_s": round(t_setup, 1),
         }
-        if world == 1:
+        out["stage_ms_per_iteration"] = None
+        if world == 1 and not args.no_per_iteration:
             out["stage_ms_per_iteration"] = per_iteration_ms(ctx, iters, rank, bool(cfg["refine"]) and weak_frac > 0)
         ctx.close()
         return out
@@ -584,6 +586,8 @@ def measure(env, args, cfg_name, W, H, S, iters, weak_frac_arg, steps, warmup, p
 
 def main():
     args = parse()
+    if args.weak_frac is None:
+        args.weak_frac = 0.10 if args.config == "cfg5" else 0.05
     if args.gpus > 1 and "RANK" not in os.environ:
         launch_ranks(args)       # does not return
     # stdout carries ONE JSON line (rank 0).  Libraries write there too (RCCL prints its NCCL_DEBUG=VERSION banner and

@@ -6,7 +6,7 @@
 OUT=$1; shift
 export TMPDIR=/tmp
 mkdir -p "$OUT"
-run() { name=$1; ctrs=$2; shift 2; timeout 900 rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/$name" -o "$name" -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > "$OUT/$name.json" 2> "$OUT/$name.err"; echo "$name rc=$?"; }
+run() { name=$1; ctrs=$2; shift 2; timeout 900 rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/$name" -o "$name" -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-per-iteration "$@" > "$OUT/$name.json" 2> "$OUT/$name.err"; echo "$name rc=$?"; }
 run fetch "FETCH_SIZE" "$@"
 run write "WRITE_SIZE TCC_HIT TCC_MISS" "$@"
 run sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "$@"
