@@ -567,7 +567,8 @@ def measure(env, args, cfg_name, W, H, S, iters, weak_frac_arg, steps, warmup, p
             "launches_per_step": dict([(kernel_name(k, S), primary_launches(k) * tm["stage_launches"][k] // steps) for k in stage_ms if k != "strong_prep"] +
                                       [(extra, mult * tm["stage_launches"][k] // steps) for k in stage_ms for extra, mult in extra_kernels(k, S)] +
                                       [(extra, tm["stage_launches"][k] // steps) for k, extra in
-                                       (("gen_edge_inform", "dvp_gen_candidates"), ("strong_prep", "dvp_strong_search")) if k in stage_ms]),
+                                       (("gen_edge_inform", "dvp_gen_candidates"), ("strong_prep", "dvp_strong_search")) if k in stage_ms] +
+                                      ([("dvp_weak_anchor_table", 1)] if ("weak_update" in stage_ms and os.environ.get("DVP_WEAK_ANCHOR_TAB", "1") != "0") else [])),
             "ncc_evals_per_step": {k: int(v) for k, v in evals["ncc_evals"].items() if v > 0},
             "Gevals_per_s": {k: round(evals["ncc_evals"][k] / (tm["stage_ms"][k] / steps * 1e-3) / 1e9, 3)
                              for k in evals["ncc_evals"] if evals["ncc_evals"][k] > 0 and tm["stage_ms"][k] > 0},

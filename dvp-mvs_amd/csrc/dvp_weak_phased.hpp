@@ -60,7 +60,21 @@ DVP_HD uint32_t wave_lane_bit(bool pred, int lane) {
 #endif
 }
 
+// cost vectors of a WEAK pixel: [view][plane slot 0..7] — the eight candidates of a view are 32 contiguous bytes (the lane-per-pixel
+// decision launches read them with two 16-byte loads: as 4-byte loads at a stride of S floats they were most of those launches'
+// L2 requests)
 DVP_HD float* weak_ev_of(const Dev& d, int wi) { return d.weak_ev + (size_t)wi * 8 * (size_t)(d.params.num_images - 1); }
+DVP_HD int weak_ev_index(int q, int v) { return v * 8 + q; }
+// the eight plane slots of view v
+DVP_HD void weak_ev_load8(const float* ev, int v, float* out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	typedef float f4v __attribute__((ext_vector_type(4)));
+	const f4v a = reinterpret_cast<const f4v*>(ev + v * 8)[0], b = reinterpret_cast<const f4v*>(ev + v * 8)[1];
+	out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+#else
+	for (int k = 0; k < 8; ++k) out[k] = ev[v * 8 + k];
+#endif
+}
 
 // ---- the evaluation launches: one wave per GROUP of WEAK pixels ------------------------------------------------------------
 // ComputeBilateralNCCNew (APD.cu:835-1021) for every (plane, view) PAIR the pixels of the group have to evaluate.  One pixel
@@ -363,7 +377,7 @@ DVP_HD void weak_group_eval(const Dev& d, int G, unsigned long long* nevals, Wea
 						out = (float)(0.25 * cc + 0.75 * sc2);
 					}
 				}
-				weak_ev_of(d, sh.wi[g])[q * S + v] = out;
+				weak_ev_of(d, sh.wi[g])[weak_ev_index(q, v)] = out;
 				if (MODE == 2) {
 					// The weighted sum only grows (weights > 0, costs >= 0, IEEE addition and division are monotone), so a hypothesis
 					// whose FIRST selected view alone is not below the best cost at entry can never be adopted (APD.cu:1361-1383).
@@ -397,7 +411,7 @@ DVP_HD void weak_d1_px(const Dev& d, int px, int py, int iter) {
 	const uint32_t flag = rec.flag;
 	const float* ev = weak_ev_of(d, wi);
 	// cost_array: `= { 2.0f }` sets one element, the rest is 0 (APD.cu:2769); rows of the anchors that count hold their costs
-#define DVP_CA(k, j) (((flag >> (k)) & 1) ? ev[(k) * S + (j)] : (((k) | (j)) == 0 ? 2.0f : 0.0f))
+#define DVP_CA(k, j) (((flag >> (k)) & 1) ? e8[k] : (((k) | (j)) == 0 ? 2.0f : 0.0f))
 	uint32_t nsel[8];
 	bool nvalid[8];
 #pragma unroll
@@ -418,6 +432,9 @@ DVP_HD void weak_d1_px(const Dev& d, int px, int py, int iter) {
 		float count = 0;
 		int count_false = 0;
 		float tmpw = 0;
+		float e8[8];
+		weak_ev_load8(ev, j, e8);
+#pragma unroll
 		for (int k = 0; k < 8; k++) {
 			const float cst = DVP_CA(k, j);
 			if (cst < thr) { tmpw += dvp_expf(cst * cst / (-0.18f)); count++; }
@@ -460,6 +477,8 @@ DVP_HD void weak_d1_px(const Dev& d, int px, int py, int iter) {
 	for (int j = 0; j < S; ++j) {
 		const int w = vw[j];
 		if (w <= 0) continue;
+		float e8[8];
+		weak_ev_load8(ev, j, e8);
 		if (P.geom_consistency) {
 			const DvpCamera sc = load_camera(d, j + 1);
 #pragma unroll
@@ -499,15 +518,24 @@ DVP_HD void weak_d1_px(const Dev& d, int px, int py, int iter) {
 }
 
 // weighted cost of plane `pl` over the selected views (APD.cu:2876-2890 and the like): sum_j w_j (ev_j [+ factor geom_j]) / norm
-DVP_HD float weak_weighted_cost(const Dev& d, const DvpCamera& rc, int px, int py, const uint8_t* vw, const float* evq, const f4 pl, float weight_norm) {
+// the 32 view weights of a pixel: two 16-byte loads
+struct ViewWeights { uint32_t w[8]; DVP_HD int at(int j) const { return (int)((w[j >> 2] >> (8 * (j & 3))) & 255u); } };
+DVP_HD ViewWeights load_view_weights(const Dev& d, int center) {
+	ViewWeights r;
+	const uint32_t* g32 = reinterpret_cast<const uint32_t*>(d.view_weight + (size_t)center * 32);
+#pragma unroll
+	for (int i = 0; i < 8; ++i) r.w[i] = g32[i];
+	return r;
+}
+DVP_HD float weak_weighted_cost(const Dev& d, const DvpCamera& rc, int px, int py, const ViewWeights& vw, const float* ev, int q, const f4 pl, float weight_norm) {
 	const DvpParams& P = d.params;
 	const int S = P.num_images - 1;
 	float tc = 0.0f;
 	for (int j = 0; j < S; ++j) {
-		const int w = vw[j];
+		const int w = vw.at(j);
 		if (w > 0) {
-			if (P.geom_consistency) tc += w * (evq[j] + P.geom_factor * geom_cost_cams(d, rc, load_camera(d, j + 1), j + 1, px, py, pl));
-			else tc += w * evq[j];
+			if (P.geom_consistency) tc += w * (ev[weak_ev_index(q, j)] + P.geom_factor * geom_cost_cams(d, rc, load_camera(d, j + 1), j + 1, px, py, pl));
+			else tc += w * ev[weak_ev_index(q, j)];
 		}
 	}
 	return tc / weight_norm;
@@ -523,13 +551,13 @@ DVP_HD void weak_d2_px(const Dev& d, int px, int py, int iter) {
 	const int wi = d.neighbours_map[center];
 	WeakRec& rec = d.weak_rec[wi];
 	const float* ev = weak_ev_of(d, wi);
-	const uint8_t* vw = d.view_weight + (size_t)center * 32;
+	const ViewWeights vw = load_view_weights(d, center);
 	const float weight_norm = rec.weight_norm;
 	const uint32_t sel_mask = rec.sel_mask;
 	const bool skip_refine = rec.skip_refine != 0;
 	uint32_t sel_now = d.selected_views[center];   // what random_normal_yzl reads (updated on adoption)
 	const f4 pl0 = rec.pl[0];
-	float cost_now = weak_weighted_cost(d, rc, px, py, vw, ev, pl0, weight_norm);
+	float cost_now = weak_weighted_cost(d, rc, px, py, vw, ev, 0, pl0, weight_norm);
 	const float costs_center = cost_now;
 	f4 plane_now = pl0;
 	float depth_now = depth_from_plane(rc, plane_now, px, py);
@@ -547,7 +575,7 @@ DVP_HD void weak_d2_px(const Dev& d, int px, int py, int iter) {
 	uint32_t keep = 0;
 	if (!skip_refine) {   // fit-plane test, then the five hypotheses
 		const f4 pl1 = rec.pl[1];
-		const float tc = weak_weighted_cost(d, rc, px, py, vw, ev + S, pl1, weight_norm);
+		const float tc = weak_weighted_cost(d, rc, px, py, vw, ev, 1, pl1, weight_norm);
 		const float db = depth_from_plane(rc, pl1, px, py);
 		if (db >= P.depth_min && db <= P.depth_max && tc < cost_now) {
 			depth_now = db;
@@ -594,7 +622,7 @@ DVP_HD void weak_d3_px(const Dev& d, int px, int py) {
 	const int wi = d.neighbours_map[center];
 	const WeakRec& rec = d.weak_rec[wi];
 	const float* ev = weak_ev_of(d, wi);
-	const uint8_t* vw = d.view_weight + (size_t)center * 32;
+	const ViewWeights vw = load_view_weights(d, center);
 	const float weight_norm = rec.weight_norm;
 	float cost_now = rec.cost_now, depth_now = rec.depth_now;
 	f4 plane_now = rec.plane_now;
@@ -602,7 +630,7 @@ DVP_HD void weak_d3_px(const Dev& d, int px, int py) {
 	for (int i = 0; i < 5; ++i) {
 		if (!((pmask >> i) & 1)) continue;
 		const f4 h = rec.pl[i];
-		const float tc = weak_weighted_cost(d, rc, px, py, vw, ev + i * S, h, weight_norm);
+		const float tc = weak_weighted_cost(d, rc, px, py, vw, ev, i, h, weight_norm);
 		const float db = depth_from_plane(rc, h, px, py);
 		if (db >= P.depth_min && db <= P.depth_max && tc < cost_now) {
 			depth_now = db;
@@ -627,7 +655,7 @@ DVP_HD void weak_final_cost_px(const Dev& d, int px, int py, PatchTab tab, unsig
 	const DvpParams& P = d.params;
 	const int S = P.num_images - 1;
 	const int wi = d.neighbours_map[center];
-	const uint8_t* vw = d.view_weight + (size_t)center * 32;
+	const ViewWeights vw = load_view_weights(d, center);
 	const f4 final_plane = d.planes[center];
 	PatchCtx c2;
 	{
@@ -638,8 +666,8 @@ DVP_HD void weak_final_cost_px(const Dev& d, int px, int py, PatchTab tab, unsig
 	float cn = 0.0f;
 	unsigned long long evals = 0;
 	for (int v = 0; v < S; ++v) {
-		if (vw[v] == 0) continue;
-		cn += vw[v] * ncc_old<SMP>(d, c2, px, py, v + 1, final_plane);
+		if (vw.at(v) == 0) continue;
+		cn += (uint8_t)vw.at(v) * ncc_old<SMP>(d, c2, px, py, v + 1, final_plane);
 		evals += 1;
 	}
 	d.costs[center] = cn / d.weak_rec[wi].weight_norm;

@@ -266,7 +266,21 @@ DVP_HD bool make_anchor_record(const Dev& d, int center, int v0, int k, AnchorRe
 	const s2 nb = d.neighbours[(size_t)wi * DVP_NEIGHBOUR_NUM + k + 1];
 	if (nb.x == -1 || nb.y == -1) return false;
 	const float cpix = ref_texel_t<FMT>(d, px, py);
-	const s2* cand = d.candidate + cand_index(d, nb.x + nb.y * W, v0);
+	// the anchor's eight visibility-prior offsets for the view: one 32-byte record, two 16-byte loads (as eight 4-byte loads they
+	// were 8 of the thread's 20 L2 requests, and the launch issues 160 G requests/s: PMC r05)
+	s2 cand[8];
+	{
+		const s2* cp = d.candidate + cand_index(d, nb.x + nb.y * W, v0);
+#if defined(__HIP_DEVICE_COMPILE__)
+		typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+		const u4 lo = reinterpret_cast<const u4*>(cp)[0], hi = reinterpret_cast<const u4*>(cp)[1];
+		const uint32_t w[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+#pragma unroll
+		for (int t = 0; t < 8; ++t) cand[t] = mks2((int)(int16_t)(w[t] & 0xffffu), (int)(int16_t)(w[t] >> 16));
+#else
+		for (int t = 0; t < 8; ++t) cand[t] = cp[t];
+#endif
+	}
 	AnchorRec& r = *out;
 	float a_sr = 0.0f, a_srr = 0.0f, a_sw = 0.0f;
 #pragma unroll
