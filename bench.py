@@ -121,9 +121,15 @@ def extra_kernels(stage, S):
     return []
 
 
+WEAK_PEAK_RADIUS = 4   # of the timed pass (set in measure)
+
+
 def primary_launches(stage):
-    """launches of the site's first kernel per launch of the site"""
-    return 2 if (stage == "depth_to_weak" and sweep_split()) else 1
+    """launches of the site's first kernel per launch of the site: dvp_sweep_eval runs its second stage only when the central
+    window leaves slots over (dvp_engine.hip: sweep_window(params) < 30, i.e. weak_peak_radius + 1 < 30)"""
+    if stage == "depth_to_weak" and sweep_split():
+        return 2 if min(max(WEAK_PEAK_RADIUS + 1, 5), 30) < 30 else 1
+    return 1
 
 
 def kernel_name(stage, S):
@@ -476,6 +482,8 @@ def measure(env, args, cfg_name, W, H, S, iters, weak_frac_arg, steps, warmup, p
         for kv in (args.param if primary else []):
             k, v = kv.split("=")
             p2[k] = float(v) if "." in v else int(v)
+        global WEAK_PEAK_RADIUS
+        WEAK_PEAK_RADIUS = int(p2["weak_peak_radius"])
         ctx.set_params(p2)
         ctx.set_depths_device([deps[i].data_ptr() for i in order], W)
         ctx.upload_state(planes=st[0], views=st[1], weak=st[2], radius=st[3])

@@ -332,6 +332,13 @@ static std::atomic<int> g_thread_share{0};
 void SetHostThreadShare(int world) {
 	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
 	g_thread_share = world > 1 ? (int)std::max(1u, hw / (unsigned)world) : 0;
+	// ... and the recycled host blocks (host/Mat.h: up to DVP_MAT_POOL_GB = 8 per process) are shared out the same way:
+	// eight ranks keep 8 GB between them, not 64 next to their image and result caches
+	if (world > 1) {
+		matpool::Pool& p = matpool::pool();
+		std::lock_guard<std::mutex> lk(p.m);
+		p.cap = std::max<size_t>((size_t)1 << 30, p.cap / (size_t)world);
+	}
 }
 static thread_local int t_thread_cap = 0;
 void SetThisThreadHostThreads(int n) { t_thread_cap = n > 0 ? n : 0; }
