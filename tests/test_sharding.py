@@ -157,3 +157,26 @@ def test_bench_gpus_flag_without_the_gpus_fails_loudly():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "refusing" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_scale_sim_model_is_consistent():
+    """tools/scale_sim.py (the schedule model behind DESIGN.md section 6): one rank reproduces the measured total, no policy beats
+    the ideal, the longest-predicted-first table is never worse than round-robin, two scenes in flight beat one for the scene mix."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("scale_sim", os.path.join(ROOT, "tools", "scale_sim.py"))
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    passes = json.load(open(os.path.join(ROOT, "profiles", "r05_e2e_views.json")))["passes"]
+    one = [p["views_ms"] for p in passes]
+    total = sum(sum(r) for r in one)
+    assert abs(sim.job_time([one], 1, "rr", 2.0, 0.0) - total) < 1e-6
+    for n in (2, 4, 8):
+        ideal = sim.job_time([one], n, "ideal", 2.0, 0.0)
+        rr, lpt, ready = (sim.job_time([one], n, p, 2.0, 0.0) for p in ("rr", "lpt", "ready"))
+        assert ideal <= ready + 1e-6 and ready <= lpt + 1e-6 and lpt <= rr + 1e-6, (n, ideal, ready, lpt, rr)
+    # views of unequal cost: the table balances what round-robin does not
+    assert sim.lpt_table([10, 1, 1, 1, 10, 1, 1, 1], 2) == [0, 0, 0, 0, 1, 1, 1, 1] or sorted(sim.lpt_table([10, 1, 1, 1, 10, 1, 1, 1], 2)) == [0, 0, 0, 0, 1, 1, 1, 1]
+    mix = sim.synth_scenes(passes, [6, 9, 4, 12])
+    t1 = sim.job_time(mix, 1, "rr", 2.0, 1000.0, 3)
+    assert t1 / sim.job_time(mix, 8, "pool2", 2.0, 1000.0, 3) > t1 / sim.job_time(mix, 8, "lpt", 2.0, 1000.0, 3) > 1.0
