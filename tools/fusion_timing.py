@@ -18,7 +18,9 @@ def write_binmat(path, a, typ):
 def main():
     W, H, NV, NSRC = [int(a) for a in sys.argv[1:5]]
     kind = sys.argv[5] if len(sys.argv) > 5 else None
-    d = tempfile.mkdtemp(prefix="fuse_")
+    keep = os.environ.get("FUSE_KEEP")   # keep the folder there for more runs of `tests/host/test_host --fuse <folder>`
+    d = keep or tempfile.mkdtemp(prefix="fuse_")
+    if keep: subprocess.call(["rm", "-rf", d])
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), str(NSRC)], stdout=subprocess.DEVNULL)
     sc = synth.make_scene(W, H, NV - 1)
     rng = np.random.default_rng(21)
@@ -40,7 +42,7 @@ def main():
     dt = time.time() - t0
     tail = [l for l in out.stdout.split("\n") if "Fusion" in l or "[fusion]" in l]
     print("RunFusion %dx%d, %d views x %d sources: %.2f s   %s" % (W, H, NV, NSRC, dt, " | ".join(tail)))
-    subprocess.call(["rm", "-rf", d])
+    if not keep: subprocess.call(["rm", "-rf", d])
 
 
 if __name__ == "__main__":
