@@ -28,7 +28,7 @@ struct HostLap {
 	void operator()(const char* what) {
 		if (!on) return;
 		const auto now = std::chrono::steady_clock::now();
-		std::cout << "  [host]   . " << what << ": " << std::chrono::duration_cast<std::chrono::microseconds>(now - t).count() / 1000.0 << " ms" << std::endl;
+		ViewLog() << "  [host]   . " << what << ": " << std::chrono::duration_cast<std::chrono::microseconds>(now - t).count() / 1000.0 << " ms" << std::endl;
 		t = now;
 	}
 };
@@ -84,9 +84,36 @@ void make_room(int scale, size_t incoming_bytes) {
 struct PooledCtx {
 	dvp_ctx* ctx = nullptr;
 	int device = 0, w = 0, h = 0, ni = 0;
-	// no destructor: at static-destruction time the HIP runtime may already be gone; the driver
-	// calls APD::ReleasePooledContext() before it returns
-} g_pool;
+};
+// no destructors: at static-destruction time the HIP runtime may already be gone; the driver calls
+// APD::ReleasePooledContext() before it returns.  Several slots: the driver keeps up to that many views of a pass in
+// flight at the coarse levels, each on its own context (main.cpp).
+constexpr size_t kPoolSlots = 4;
+std::vector<PooledCtx>& g_pool = *new std::vector<PooledCtx>;
+std::mutex g_ctx_mutex;   // g_pool, g_prewarm, the resident-map registries
+dvp_ctx* take_pooled(int device, int w, int h, int ni) {
+	std::lock_guard<std::mutex> lock(g_ctx_mutex);
+	for (size_t i = 0; i < g_pool.size(); ++i)
+		if (g_pool[i].device == device && g_pool[i].w == w && g_pool[i].h == h && g_pool[i].ni == ni) {
+			dvp_ctx* c = g_pool[i].ctx;
+			g_pool.erase(g_pool.begin() + (long)i);
+			return c;
+		}
+	return nullptr;
+}
+void give_pooled(dvp_ctx* ctx, int device, int w, int h, int ni) {
+	std::vector<dvp_ctx*> drop;
+	{
+		std::lock_guard<std::mutex> lock(g_ctx_mutex);
+		// contexts of another shape belong to a level that is over (or to a view of another size): they go first
+		for (size_t i = 0; i < g_pool.size();)
+			if (g_pool[i].device != device || g_pool[i].w != w || g_pool[i].h != h || g_pool[i].ni != ni) { drop.push_back(g_pool[i].ctx); g_pool.erase(g_pool.begin() + (long)i); }
+			else ++i;
+		if (g_pool.size() >= kPoolSlots) drop.push_back(ctx);
+		else g_pool.push_back(PooledCtx{ ctx, device, w, h, ni });
+	}
+	for (dvp_ctx* c : drop) dvp_ctx_destroy(c);
+}
 }
 static std::atomic<int> g_prefetch_threads{0};
 // The next pyramid level's engine context, created by a helper thread while the GPU is still on the current level's last
@@ -101,6 +128,7 @@ struct PrewarmedCtx {
 };
 PrewarmedCtx& g_prewarm = *new PrewarmedCtx;   // never destroyed: an exit() while the helper runs must not meet a joinable std::thread's destructor
 dvp_ctx* take_prewarmed(int device, int w, int h, int ni) {   // nullptr when there is none that fits
+	std::lock_guard<std::mutex> lock(g_ctx_mutex);
 	if (!g_prewarm.active) return nullptr;
 	if (g_prewarm.worker.joinable()) g_prewarm.worker.join();
 	g_prewarm.active = false;
@@ -111,6 +139,7 @@ dvp_ctx* take_prewarmed(int device, int w, int h, int ni) {   // nullptr when th
 }
 }
 void APD::PrewarmContext(int w, int h, int ni) {
+	std::lock_guard<std::mutex> lock(g_ctx_mutex);
 	if (g_prewarm.active || w <= 0 || h <= 0) return;
 	g_prewarm.active = true;
 	g_prewarm.device = g_device; g_prewarm.w = w; g_prewarm.h = h; g_prewarm.ni = ni;
@@ -166,8 +195,11 @@ void APD::PrefetchLevelImages(std::vector<Problem> views, int scale) {
 void APD::ReserveImageCache(size_t views) { std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex); g_img_cache_capacity = std::max<size_t>(96, 2 * views + 8); }   // reference + padded source role
 void APD::ReleasePooledContext() {
 	while (g_prefetch_threads.load() > 0) std::this_thread::sleep_for(std::chrono::milliseconds(2));   // (they use the caches cleared below)
-	if (g_pool.ctx) dvp_ctx_destroy(g_pool.ctx);
-	g_pool.ctx = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(g_ctx_mutex);
+		for (PooledCtx& p : g_pool) dvp_ctx_destroy(p.ctx);
+		g_pool.clear();
+	}
 	if (dvp_ctx* c = take_prewarmed(-1, 0, 0, 0)) dvp_ctx_destroy(c);   // (never fits: joined and freed)
 	std::lock_guard<std::recursive_mutex> lock(g_img_cache_mutex);
 	g_img_cache.clear();
@@ -308,9 +340,7 @@ void APD::SetResidentDownloader(void (*copy)(float*, const float*, size_t)) { g_
 APD::~APD() {                        // APD.cpp:989-1043
 	delete[] plane_hypotheses_host;
 	if (!ctx) return;
-	if (g_pool.ctx) dvp_ctx_destroy(g_pool.ctx);
-	g_pool.ctx = ctx;
-	g_pool.device = ctx_device; g_pool.w = width; g_pool.h = height; g_pool.ni = num_images;
+	give_pooled(ctx, ctx_device, width, height, num_images);
 }
 
 // APD.cpp:1045-1495 (the Depth-Anything prior block :1210-1424 lives in prior.cpp)
@@ -359,9 +389,9 @@ void APD::InuputInitialization() {
 	params_host.depth_max = cameras[0].depth_max * 1.2f;
 	params_host.num_images = (int)images.size();
 	num_images = (int)images.size();
-	std::cout << "Read images and camera done\n";
-	std::cout << "Depth range: " << params_host.depth_min << " " << params_host.depth_max << std::endl;
-	std::cout << "Num images: " << params_host.num_images << std::endl;
+	ViewLog() << "Read images and camera done\n";
+	ViewLog() << "Depth range: " << params_host.depth_min << " " << params_host.depth_max << std::endl;
+	ViewLog() << "Num images: " << params_host.num_images << std::endl;
 	if (problem.scale_size != 1) {   // APD.cpp:1119-1143 (the images were rescaled by load())
 		for (int i = 0; i < num_images; ++i) {
 			const int new_cols = images[i].cols, new_rows = images[i].rows;
@@ -376,9 +406,9 @@ void APD::InuputInitialization() {
 			cameras[i].width = width;
 			cameras[i].height = height;
 		}
-		std::cout << "Scale images and cameras done\n";
+		ViewLog() << "Scale images and cameras done\n";
 	}
-	std::cout << "Image size: " << width << " * " << height << std::endl;
+	ViewLog() << "Image size: " << width << " * " << height << std::endl;
 	lap("images + cameras");
 	if (params_host.geom_consistency) {   // APD.cpp:1147-1166
 		depths.clear();
@@ -429,7 +459,7 @@ void APD::InuputInitialization() {
 			if (weak_info_host.cols != width || weak_info_host.rows != height) {
 				std::cerr << "Weak info doesn't match the images' size!\n";
 				RescaleMatToTargetSize<uint8_t>(weak_info_host, weak_info_host, width, height);
-				std::cout << "Scale done\n";
+				ViewLog() << "Scale done\n";
 			}
 			CountWeak();
 		}
@@ -445,8 +475,8 @@ void APD::InuputInitialization() {
 	// sfm/<id>.txt, APD.cpp:1210-1424; host/prior.cpp).  Without those inputs the planes stay zero
 	// (.w out of range) and RandomInitialization draws random planes (APD.cu:1289-1291).
 	if (params_host.state == FIRST_INIT) {
-		if (BuildPlanePrior(problem, cameras[0], width, height, plane_hypotheses_host)) std::cout << "Plane prior from dep/ and sfm/\n";
-		else std::cout << "No dep/ + sfm/ prior: random plane initialisation\n";
+		if (BuildPlanePrior(problem, cameras[0], width, height, plane_hypotheses_host)) ViewLog() << "Plane prior from dep/ and sfm/\n";
+		else ViewLog() << "No dep/ + sfm/ prior: random plane initialisation\n";
 	}
 	if (params_host.state == FIRST_INIT) selected_views_host = Mat::zeros(height, width, CV_32SC1);   // (else loaded below)
 	if (params_host.state != FIRST_INIT) {   // APD.cpp:1428-1456: the previous pass' maps are this pass' start
@@ -504,7 +534,7 @@ void APD::CountWeak() {   // APD.cpp:1182-1193 (the running index itself is made
 		for (int c = 0; c < width; ++c) wc += row[c] == WEAK;
 	}
 	weak_count = (int)wc;
-	std::cout << "Weak count: " << weak_count << " / " << width * height << " = " << (float)weak_count / (float)(width * height) * 100 << "%" << std::endl;
+	ViewLog() << "Weak count: " << weak_count << " / " << width * height << " = " << (float)weak_count / (float)(width * height) * 100 << "%" << std::endl;
 }
 
 // the host flow after all: what InuputInitialization would have done without the device rescale
@@ -599,9 +629,7 @@ void APD::SupportInitialization() {
 void APD::CudaSpaceInitialization() {
 	HostLap lap;
 	ctx_device = g_device;
-	if (g_pool.ctx && g_pool.device == g_device && g_pool.w == width && g_pool.h == height && g_pool.ni == num_images) {
-		ctx = g_pool.ctx;
-		g_pool.ctx = nullptr;
+	if ((ctx = take_pooled(g_device, width, height, num_images)) != nullptr) {
 		DVP_SAFE_CALL(ctx, dvp_reset_state(ctx));
 		DVP_SAFE_CALL(ctx, dvp_reset_timings(ctx));
 	} else if ((ctx = take_prewarmed(g_device, width, height, num_images)) != nullptr) {
@@ -644,7 +672,7 @@ void APD::CudaSpaceInitialization() {
 			(problem.params.use_edge || problem.params.use_limit) ? edge_host.ptr<uint8_t>(0) : nullptr,
 			(problem.params.use_label && !label_host.empty()) ? label_host.ptr<int32_t>(0) : nullptr));
 		weak_count = dvp_weak_count(ctx);
-		std::cout << "Weak count: " << weak_count << " / " << width * height << " = " << (float)weak_count / (float)(width * height) * 100 << "%" << std::endl;
+		ViewLog() << "Weak count: " << weak_count << " / " << width * height << " = " << (float)weak_count / (float)(width * height) * 100 << "%" << std::endl;
 		coarse_depth = coarse_normal = coarse_views = coarse_weak = coarse_radius = Mat();
 		lap("state upload (coarse maps, rescaled on the device)");
 		return;

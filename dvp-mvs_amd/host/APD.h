@@ -6,6 +6,7 @@
 // this header unchanged apart from the include set.
 #ifndef _APD_H_
 #define _APD_H_
+#include <ostream>
 #include "main.h"
 #include <functional>
 
@@ -52,6 +53,10 @@ Mat ReadImageColor(const path& image_path_jpg);     // cv::imread(IMREAD_COLOR) 
 Mat ResizeLinear(const Mat& src_f32, int new_cols, int new_rows);   // cv::resize(INTER_LINEAR), APD.cpp:1129
 // threads of the host-side pixel loops: min(32, hardware threads), DVP_HOST_THREADS overrides
 int HostThreads();
+// Where a view's progress lines go: std::cout, or — while several views of a pass are in flight, one per driver thread — the
+// calling thread's own buffer, which the driver prints in one piece when the view is done (SetViewLog(nullptr) ends it).
+std::ostream& ViewLog();
+void SetViewLog(std::ostream* buffer);
 void SetThisThreadHostThreads(int n);   // caps HostThreads() for the calling thread (helper threads beside the driver's main thread); 0: no cap
 void SetHostThreadShare(int world);   // caps HostThreads() at cores / world (one rank per GPU shares the host with its peers)
 // write-back cache of the per-view result files + background workers (host/store.cpp)

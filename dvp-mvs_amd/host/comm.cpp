@@ -280,6 +280,7 @@ void RankComm::BroadcastHost(void* host, size_t bytes, int root) {
 	if (rank_ != root) hip_ok(hipMemcpy(host, bounce_, bytes, hipMemcpyDeviceToHost), "stage out");
 }
 
+void RankComm::BindThisThread(int device) { hip_ok(hipSetDevice(device), "hipSetDevice"); }
 float* RankComm::DeviceAlloc(size_t count) {
 	void* p = nullptr;
 	hip_ok(hipMalloc(&p, (count ? count : 1) * sizeof(float)), "hipMalloc");

@@ -47,6 +47,7 @@ public:
 	// the communicator Abort()/the fatal hook act on (the driver has one)
 	static RankComm* Current();
 	// device memory helpers so that callers need no HIP headers
+	static void BindThisThread(int device);   // hipSetDevice for a driver thread other than main's (HIP's current device is per thread)
 	static float* DeviceAlloc(size_t count);
 	static void DeviceFree(float* p);
 	static void HostToDevice(float* dev, const float* host, size_t count);

@@ -340,6 +340,9 @@ void SetHostThreadShare(int world) {
 		p.cap = std::max<size_t>((size_t)1 << 30, p.cap / (size_t)world);
 	}
 }
+static thread_local std::ostream* t_view_log = nullptr;
+std::ostream& ViewLog() { return t_view_log ? *t_view_log : std::cout; }
+void SetViewLog(std::ostream* buffer) { t_view_log = buffer; }
 static thread_local int t_thread_cap = 0;
 void SetThisThreadHostThreads(int n) { t_thread_cap = n > 0 ? n : 0; }
 int HostThreads() {

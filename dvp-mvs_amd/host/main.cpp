@@ -20,6 +20,7 @@
 // result files); --jacobi selects the exchange semantics there too, which makes a run independent of the
 // number of ranks.  Result files are always written to a temporary name and renamed, so a reader never
 // sees a torn file.
+#include <sstream>
 #include "APD.h"
 #include <thread>
 #include "comm.h"
@@ -42,6 +43,8 @@ struct Options {
 	int collective_timeout_s = 600;
 	bool sync_io = false;
 	bool host_rescale = false;
+	int views_in_flight = 0;               // --views-in-flight N: that many views of a pass at once (default 2) where the order allows it and the level is small; 1 = never
+	long long in_flight_pixels = 2 << 20;  // ... "small" = at most this many pixels (--in-flight-pixels)
 	std::string job, transport = "rccl";
 	std::string fusion_kind = "eth";   // eth | tat-intermediate | tat-advanced (APD.h:52-54; the reference's main calls the first)
 };
@@ -150,8 +153,8 @@ int g_final_iteration = 15;
 bool g_device_maps = true;   // false (--sync-io / --host-rescale): planes are downloaded and unpacked on the host   // what the exchange step needs from a finished view
 
 ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
-	std::cout << "Processing image: " << std::setw(8) << std::setfill('0') << problem.ref_image_id << "..." << std::endl;
-	std::cout << "Iteration: " << problem.iteration << std::endl;
+	ViewLog() << "Processing image: " << std::setw(8) << std::setfill('0') << problem.ref_image_id << "..." << std::endl;
+	ViewLog() << "Iteration: " << problem.iteration << std::endl;
 	const auto start = std::chrono::steady_clock::now();
 	// DVP_HOST_TIMING=1: wall time of every host step of the view (where the non-GPU time goes)
 	static const bool host_timing = std::getenv("DVP_HOST_TIMING") != nullptr;
@@ -159,7 +162,7 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	auto lap = [&](const char* what) {
 		if (!host_timing) return;
 		const auto now = std::chrono::steady_clock::now();
-		std::cout << "  [host] " << what << ": " << std::chrono::duration_cast<std::chrono::microseconds>(now - lap_t).count() / 1000.0 << " ms" << std::endl;
+		ViewLog() << "  [host] " << what << ": " << std::chrono::duration_cast<std::chrono::microseconds>(now - lap_t).count() / 1000.0 << " ms" << std::endl;
 		lap_t = now;
 	};
 	APD APD(problem);
@@ -258,16 +261,16 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	lap("hand-over to the background worker");
 	const auto end = std::chrono::steady_clock::now();
 	const DvpTimings& t = APD.GetTimings();
-	std::cout << "Processing image: " << std::setw(8) << std::setfill('0') << problem.ref_image_id << " done!" << std::endl;
+	ViewLog() << "Processing image: " << std::setw(8) << std::setfill('0') << problem.ref_image_id << " done!" << std::endl;
 	if (host_timing) {   // where the GPU time of the view went, launch site by launch site (event pairs around each site: gaps between sites — a host that is late with the next launch — show as the difference to the total)
 		static const char* names[DVP_ST_COUNT] = { "gen_edge_inform", "find_nearest_strong", "gen_neighbours", "neighbour_update", "random_init", "strong_update", "ransac_fit", "weak_update", "get_depth_normal", "filter_strong", "depth_to_weak", "local_refine", "strong_prep" };
 		double sum = 0.0;
-		std::cout << "  [gpu]";
+		ViewLog() << "  [gpu]";
 		for (int i = 0; i < DVP_ST_COUNT; ++i)
-			if (t.stage_ms[i] > 0.0) { std::cout << " " << names[i] << " " << t.stage_ms[i]; sum += t.stage_ms[i]; }
-		std::cout << " | sites " << sum << " of total " << t.total_ms << " ms" << std::endl;
+			if (t.stage_ms[i] > 0.0) { ViewLog() << " " << names[i] << " " << t.stage_ms[i]; sum += t.stage_ms[i]; }
+		ViewLog() << " | sites " << sum << " of total " << t.total_ms << " ms" << std::endl;
 	}
-	std::cout << "Cost time: " << std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count() << " ms (GPU RunPatchMatch "
+	ViewLog() << "Cost time: " << std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count() << " ms (GPU RunPatchMatch "
 	          << t.total_ms << " ms, " << (double)width * height * problem.params.max_iterations / (t.total_ms * 1e3) << " Mpx/s/iter)" << std::endl;
 	return ViewResult{ depth };
 }
@@ -432,6 +435,8 @@ Options ParseOptions(int argc, char** argv) {
 		else if (s == "--labels") o.label_files = true;          // load labels_<s>.dmb (APD::SetUseLabelFiles)
 		else if (s == "--no-fusion") o.fusion = false;
 		else if (s == "--sync-io") o.sync_io = true;               // no result cache / background worker / device rescale: the reference's synchronous file flow
+		else if (s == "--views-in-flight") { if (a + 1 < argc) o.views_in_flight = std::max(1, atoi(argv[++a])); }
+		else if (s == "--in-flight-pixels") { if (a + 1 < argc) o.in_flight_pixels = atoll(argv[++a]); }
 		else if (s == "--host-rescale") o.host_rescale = true;     // the coarser level's maps are up-sampled on the host (APD::SetDeviceRescale(false))
 		else if (s == "--fusion") { if (a + 1 < argc) o.fusion_kind = argv[++a]; }
 	}
@@ -446,7 +451,7 @@ Options ParseOptions(int argc, char** argv) {
 
 int main(int argc, char** argv) {
 	if (argc < 2) {
-		std::cerr << "USAGE: apd dense_folder [gpu_index] [--max-src N] [--iters N] [--min-scale S] [--passes P] [--seed X] [--rank R --world N [--job ID]] [--jacobi] [--no-fusion]\n";
+		std::cerr << "USAGE: apd dense_folder [gpu_index] [--max-src N] [--iters N] [--min-scale S] [--passes P] [--seed X] [--rank R --world N [--job ID]] [--jacobi] [--no-fusion] [--views-in-flight N]\n";
 		return EXIT_FAILURE;
 	}
 	const Options opt = ParseOptions(argc, argv);
@@ -568,13 +573,55 @@ int main(int argc, char** argv) {
 				}
 			if (!views.empty()) start_edge_jobs(views);
 		}
-		for (size_t k = 0; k < owned.size(); ++k) {
-			Problem& problem = *owned[k];
-			if (pass.geom_index < 0 && opt.sync_io) GetProblemEdges(problem);   // main.cpp:480, synchronously
-			ViewResult r = ProcessProblem(problem);
-			if (exchange) mine[problem.index] = r.depth;
-			if (inplace) inplace->Update(problem.ref_image_id, r.depth);
+		// Views in flight.  The reference visits the views of a pass one after the other (main.cpp:479-486) and a view of a
+		// geometric pass reads the maps the views before it have just written — that order is kept.  Where no view reads another
+		// view's result of the SAME pass — a photometric pass, or any pass with the depth exchange (--jacobi / several ranks: maps of
+		// the previous pass) — and the level is small, two or more views run at once, each on its own engine context and stream:
+		// a 776x516 view is 6 k waves for a 256-CU part and 20 ms of kernels between 10 ms of host work (profiles/r04g_e2e_apd.txt).
+		// Same files either way (every view's inputs are fixed before the pass).
+		int in_flight = 1;
+		if (!opt.sync_io && (pass.geom_index < 0 || exchange) && !owned.empty()) {
+			int lw = 0, lh = 0;
+			if (APD::LevelSize(*owned[0], pass.scale, &lw, &lh) && (size_t)lw * lh <= (size_t)opt.in_flight_pixels) in_flight = opt.views_in_flight > 0 ? opt.views_in_flight : 2;
+			in_flight = (int)std::min<size_t>((size_t)std::max(1, in_flight), owned.size());
 		}
+		const auto pass_t0 = std::chrono::steady_clock::now();
+		if (in_flight <= 1) {
+			for (size_t k = 0; k < owned.size(); ++k) {
+				Problem& problem = *owned[k];
+				if (pass.geom_index < 0 && opt.sync_io) GetProblemEdges(problem);   // main.cpp:480, synchronously
+				ViewResult r = ProcessProblem(problem);
+				if (exchange) mine[problem.index] = r.depth;
+				if (inplace) inplace->Update(problem.ref_image_id, r.depth);
+			}
+		} else {
+			std::atomic<size_t> next{0};
+			std::mutex results;   // `mine`, the in-place maps, the order of the views' log blocks
+			std::vector<std::thread> workers;
+			const int team = std::max(2, HostThreads() / in_flight);
+			for (int wkr = 0; wkr < in_flight; ++wkr)
+				workers.emplace_back([&, team]() {
+					RankComm::BindThisThread(opt.gpu);   // HIP's current device is per thread
+					SetThisThreadHostThreads(team);
+					for (;;) {
+						const size_t k = next++;
+						if (k >= owned.size()) return;
+						Problem& problem = *owned[k];
+						std::ostringstream log;
+						SetViewLog(&log);
+						ViewResult r = ProcessProblem(problem);
+						SetViewLog(nullptr);
+						std::lock_guard<std::mutex> lk(results);
+						std::cout << log.str() << std::flush;
+						if (exchange) mine[problem.index] = r.depth;
+						if (inplace) inplace->Update(problem.ref_image_id, r.depth);
+					}
+				});
+			for (std::thread& t : workers) t.join();
+		}
+		if (std::getenv("DVP_HOST_TIMING"))
+			std::cout << "Pass " << it << ": " << owned.size() << " views in " << std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - pass_t0).count() / 1000.0
+			          << " ms, " << in_flight << " in flight" << std::endl;
 		// With peers, a view whose size differs from a source's takes that source's depth map from APD/<id>/depths.dmb
 		// (APD.cpp fallback from the resident maps to LoadResult): the owner's background writer must have put this
 		// pass' files on disk BEFORE the barrier lets anyone into the next pass, or the reader sees the previous pass'

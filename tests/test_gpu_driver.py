@@ -385,3 +385,47 @@ def test_apd_result_cache_and_background_worker_leave_the_same_files(tmp_path, W
             n += 1
     assert n >= NV * 6
     assert filecmp.cmp(os.path.join(outs["async"], "APD", "APD.ply"), os.path.join(outs["sync"], "APD", "APD.ply"), shallow=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["inplace", "jacobi"])
+def test_apd_views_in_flight_leave_the_same_files(tmp_path, mode):
+    """Several views of a pass at once, each on its own engine context and driver thread (main.cpp: photometric passes in the
+    reference's in-place order, every pass with the depth exchange), against one view after the other: every result file
+    byte-identical, the views' log blocks whole (one 'Processing image ... done!' per view and pass, never interleaved)."""
+    import filecmp
+    W, H, NV = 838, 126, 5
+    outs = {}
+    for tag, extra in (("one", ["--views-in-flight", "1"]), ("three", ["--views-in-flight", "3"]), ("default", [])):
+        d = str(tmp_path / tag)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), "3", "--jpg"])
+        out = subprocess.run([os.path.join(ROOT, "dvp-mvs_amd", "apd"), d, "0", "--iters", "2", "--passes", "1", "--min-scale", "1", "--seed", "7", "--no-fusion"]
+                             + (["--jacobi"] if mode == "jacobi" else []) + extra,
+                             capture_output=True, text=True, timeout=600, env=dict(os.environ, DVP_HOST_TIMING="1"))
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        passes = [ln for ln in out.stdout.split("\n") if ln.startswith("Pass ")]
+        assert len(passes) == 4, passes      # two levels x (photometric + one geometric pass)
+        flights = [int(ln.split(",")[1].split()[0]) for ln in passes]
+        if tag == "one":
+            assert flights == [1, 1, 1, 1]
+        elif mode == "jacobi":
+            assert flights == ([3] * 4 if tag == "three" else [2] * 4), passes
+        else:
+            assert flights == ([3, 1, 3, 1] if tag == "three" else [2, 1, 2, 1]), passes
+        # a view's block starts with its 'Processing image: N...' line and ends with 'Cost time'; blocks do not interleave
+        depth = 0
+        for ln in out.stdout.split("\n"):
+            if ln.startswith("Processing image:") and ln.endswith("..."):
+                assert depth == 0, ln
+                depth = 1
+            elif ln.startswith("Cost time:"):
+                assert depth == 1, ln
+                depth = 0
+        outs[tag] = d
+    for tag in ("three", "default"):
+        for v in range(NV):
+            ra, rb = (os.path.join(outs[t], "APD", "%08d" % v) for t in ("one", tag))
+            names = sorted(os.listdir(ra))
+            assert names == sorted(os.listdir(rb))
+            for fn in names:
+                assert filecmp.cmp(os.path.join(ra, fn), os.path.join(rb, fn), shallow=False), (tag, v, fn)
