@@ -30,7 +30,7 @@ BUFFERS = dict(planes=(0, np.float32, 4), costs=(1, np.float32, 1), selected_vie
 EXPORTS = ["dvp_ctx_create", "dvp_ctx_destroy", "dvp_last_error", "dvp_upload_images", "dvp_upload_depths",
            "dvp_upload_images_device", "dvp_upload_depths_device", "dvp_upload_cameras", "dvp_upload_state", "dvp_upload_state_rescaled",
            "dvp_reset_state", "dvp_save_state", "dvp_restore_state", "dvp_set_params", "dvp_set_seed", "dvp_set_sampler", "dvp_set_profiling", "dvp_image_format", "dvp_run_patchmatch",
-           "dvp_run_stage", "dvp_synchronize", "dvp_download_state", "dvp_download_maps", "dvp_buffer_bytes", "dvp_download_buffer",
+           "dvp_run_stage", "dvp_synchronize", "dvp_download_state", "dvp_download_maps", "dvp_download_maps_begin", "dvp_download_maps_finish", "dvp_buffer_bytes", "dvp_download_buffer",
            "dvp_upload_buffer", "dvp_weak_count", "dvp_get_timings", "dvp_reset_timings", "dvp_eval_cost_vectors",
            "dvp_bench_cost_kernel", "dvp_build_id"]
 

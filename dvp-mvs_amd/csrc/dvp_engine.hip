@@ -11,6 +11,8 @@
 #include <vector>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <condition_variable>
 
 using namespace dvp;
 
@@ -958,7 +960,13 @@ struct dvp_ctx {
 	int* weak_counts = nullptr;  // scratch of the device-side compaction: per-slot black / red counts, per-chunk counts, then 3 totals
 	int* weak_totals_host = nullptr;   // pinned: (black, red, all)
 	uint8_t* coarse = nullptr;   // staging of the coarser level's maps (dvp_upload_state_rescaled)
-	uint8_t* maps_out = nullptr; // staging of dvp_download_maps: depth [L] f32, normal [L][3] f32, states [L] u8
+	uint8_t* maps_out = nullptr; // staging of dvp_download_maps: depth [L] f32, normal [L][3] f32, states [L] u8, selected views [L] u32, radius [L] i32
+	// dvp_download_maps_begin / _finish: the copies to the host run on their own stream, from any thread, while this context is
+	// already on its next view; `dl_busy` = maps_out holds maps that have not been fetched yet
+	hipStream_t copy = nullptr;
+	std::mutex dl_m;
+	std::condition_variable dl_cv;
+	bool dl_busy = false;
 	size_t coarse_alloc = 0;
 	// dvp_save_state / dvp_restore_state: device-side copy of the per-pixel input state
 	f4* saved_planes = nullptr; uint32_t* saved_views = nullptr; uint8_t* saved_weak = nullptr; int* saved_radius = nullptr;
@@ -1129,6 +1137,11 @@ int dvp_ctx_destroy(dvp_ctx* c) {
 	if (!c) return 0;
 	// teardown: errors are not actionable here
 	(void)hipSetDevice(c->device);
+	{   // maps another thread is still fetching (dvp_download_maps_finish)
+		std::unique_lock<std::mutex> lk(c->dl_m);
+		c->dl_cv.wait(lk, [c] { return !c->dl_busy; });
+	}
+	if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	for (void* p : c->allocs) (void)hipFree(p);
@@ -1808,24 +1821,57 @@ int dvp_download_state(dvp_ctx* c, float* planes, uint32_t* views, uint8_t* weak
 	return 0;
 }
 
-int dvp_download_maps(dvp_ctx* c, float* depth, float* normal_xyz, uint32_t* views, uint8_t* weak, int32_t* radius) {
+static void download_done(dvp_ctx* c) {
+	{ std::lock_guard<std::mutex> lk(c->dl_m); c->dl_busy = false; }
+	c->dl_cv.notify_all();
+}
+int dvp_download_maps_begin(dvp_ctx* c, float* depth_device_copy) {
 	if (set_device(c)) return 1;
-	if (!depth || !normal_xyz || !weak) { c->error = "dvp_download_maps: depth, normal and weak_info are required"; return 1; }
+	{   // the previous view's maps must have been fetched
+		std::unique_lock<std::mutex> lk(c->dl_m);
+		c->dl_cv.wait(lk, [c] { return !c->dl_busy; });
+		c->dl_busy = true;
+	}
 	const size_t L = c->L;
-	if (!c->maps_out && dalloc(c, &c->maps_out, L * 17, false)) return 1;
+	auto fail = [c]() { download_done(c); return 1; };
+	if (!c->maps_out && dalloc(c, &c->maps_out, L * 25, false)) return fail();
 	float* d_depth = reinterpret_cast<float*>(c->maps_out);
 	float* d_normal = d_depth + L;
 	uint8_t* d_state = c->maps_out + L * 16;
 	hipLaunchKernelGGL(dvp_unpack_maps, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, c->stream, c->planes, c->weak_info, L, c->d.params.depth_min, c->d.params.depth_max,
 	                   d_depth, d_normal, d_state);
-	HIP_TRY(c, hipGetLastError());
-	HIP_TRY(c, hipMemcpyAsync(depth, d_depth, L * 4, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(normal_xyz, d_normal, L * 12, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(weak, d_state, L, hipMemcpyDeviceToHost, c->stream));
-	if (views) HIP_TRY(c, hipMemcpyAsync(views, c->selected_views, L * 4, hipMemcpyDeviceToHost, c->stream));
-	if (radius) HIP_TRY(c, hipMemcpyAsync(radius, c->radius, L * 4, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	if (hipGetLastError() != hipSuccess) { c->error = "dvp_download_maps_begin: launch failed"; return fail(); }
+	// the view maps and the radius map are live state: the next view's uploads overwrite them
+	if (hipMemcpyAsync(c->maps_out + L * 17, c->selected_views, L * 4, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+	    hipMemcpyAsync(c->maps_out + L * 21, c->radius, L * 4, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+	    (depth_device_copy && hipMemcpyAsync(depth_device_copy, d_depth, L * 4, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) ||
+	    hipStreamSynchronize(c->stream) != hipSuccess) { c->error = "dvp_download_maps_begin: device copies failed"; return fail(); }
 	return 0;
+}
+int dvp_download_maps_finish(dvp_ctx* c, float* depth, float* normal_xyz, uint32_t* views, uint8_t* weak, int32_t* radius) {
+	{
+		std::lock_guard<std::mutex> lk(c->dl_m);
+		if (!c->dl_busy) { c->error = "dvp_download_maps_finish without dvp_download_maps_begin"; return 1; }
+	}
+	auto fail = [c](const char* what) { c->error = what; download_done(c); return 1; };
+	if (hipSetDevice(c->device) != hipSuccess) return fail("hipSetDevice failed");
+	if (!depth || !normal_xyz || !weak) return fail("dvp_download_maps: depth, normal and weak_info are required");
+	if (!c->copy && hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+	const size_t L = c->L;
+	const uint8_t* m = c->maps_out;
+	if (hipMemcpyAsync(depth, m, L * 4, hipMemcpyDeviceToHost, c->copy) != hipSuccess ||
+	    hipMemcpyAsync(normal_xyz, m + L * 4, L * 12, hipMemcpyDeviceToHost, c->copy) != hipSuccess ||
+	    hipMemcpyAsync(weak, m + L * 16, L, hipMemcpyDeviceToHost, c->copy) != hipSuccess ||
+	    (views && hipMemcpyAsync(views, m + L * 17, L * 4, hipMemcpyDeviceToHost, c->copy) != hipSuccess) ||
+	    (radius && hipMemcpyAsync(radius, m + L * 21, L * 4, hipMemcpyDeviceToHost, c->copy) != hipSuccess) ||
+	    hipStreamSynchronize(c->copy) != hipSuccess) return fail("dvp_download_maps_finish: copies to the host failed");
+	download_done(c);
+	return 0;
+}
+int dvp_download_maps(dvp_ctx* c, float* depth, float* normal_xyz, uint32_t* views, uint8_t* weak, int32_t* radius) {
+	if (!depth || !normal_xyz || !weak) { c->error = "dvp_download_maps: depth, normal and weak_info are required"; return 1; }
+	if (dvp_download_maps_begin(c, nullptr)) return 1;
+	return dvp_download_maps_finish(c, depth, normal_xyz, views, weak, radius);
 }
 
 static void* buffer_ptr(dvp_ctx* c, int id, size_t* bytes) {

@@ -712,6 +712,22 @@ void APD::RunPatchMatchToMaps(Mat& depth, Mat& normal) {
 	DVP_SAFE_CALL(ctx, dvp_get_timings(ctx, &timings));
 }
 
+std::function<void()> APD::RunPatchMatchAndStageMaps(Mat& depth, Mat& normal, float* depth_device_copy) {
+	DVP_SAFE_CALL(ctx, dvp_run_patchmatch(ctx));
+	if (!problem.params.use_radius) radius_host = Mat::zeros(height, width, CV_32S);
+	depth = Mat(height, width, CV_32FC1);
+	normal = Mat(height, width, CV_32FC3);
+	DVP_SAFE_CALL(ctx, dvp_download_maps_begin(ctx, depth_device_copy));
+	DVP_SAFE_CALL(ctx, dvp_get_timings(ctx, &timings));
+	// (the Mats share their buffers with the copies held here: they stay alive with the function)
+	dvp_ctx* const c = ctx;
+	Mat d = depth, n = normal, v = selected_views_host, w = weak_info_host, r = problem.params.use_radius ? radius_host : Mat();
+	return [c, d, n, v, w, r]() mutable {
+		if (dvp_download_maps_finish(c, d.ptr<float>(0), n.ptr<float>(0), v.ptr<uint32_t>(0), w.ptr<uint8_t>(0), r.empty() ? nullptr : r.ptr<int32_t>(0)) != 0)
+			DvpFatal("dvp_download_maps_finish failed");   // (the context may be gone by now: its error text is not read)
+	};
+}
+
 float4 APD::GetPlaneHypothesis(int r, int c) { return plane_hypotheses_host[c + r * width]; }   // APD.cpp:1706-1708
 int APD::GetPixelSelectedViews(int r, int c) { return selected_views_host.at<int>(r, c); }
 void APD::SetPixelSelectedViews(int r, int c, int v) { selected_views_host.at<int>(r, c) = v; }

@@ -67,6 +67,7 @@ bool LoadResult(const path& file, Mat& m, bool will_modify = false);   // memory
 bool ResultExists(const path& file);
 void RunInBackground(std::function<void()> job);             // one worker, at most two jobs queued
 void FlushResults(bool drop_cache = false);                  // join jobs and writes
+void WaitBackgroundJobs();                                   // join the jobs only (their results are in the cache; the files may still be on their way)
 void ShutdownResultStore();
 // error convention of the reference (CudaSafeCall, APD.cpp:943-951): message on stderr + exit.  Every such exit of the
 // host library goes through DvpFatal; a multi-rank driver installs a hook that turns it into an agreed abort (comm.h).
@@ -86,6 +87,11 @@ public:
 	void SetDataPassHelperInCuda();
 	void RunPatchMatch();
 	void RunPatchMatchToMaps(Mat& depth, Mat& normal);   // extension: results as the driver's depth / normal maps (APD.cpp)
+	// ... in two steps (dvp_download_maps_begin / _finish): after StageMaps the context may go to the next view; the returned
+	// function copies the maps to the host — depth and normal (allocated here, filled by the call) and the state maps
+	// GetPixelStates / GetSelectedViews / GetRadiusMap returned — and may run on another thread after this object is gone.
+	// depth_device_copy: a device buffer of width * height floats that receives the depth map (or nullptr).
+	std::function<void()> RunPatchMatchAndStageMaps(Mat& depth, Mat& normal, float* depth_device_copy);
 	float4 GetPlaneHypothesis(int r, int c);
 	int GetPixelSelectedViews(int r, int c);
 	void SetPixelSelectedViews(int r, int c, int temp_selected_views);

@@ -152,7 +152,8 @@ struct ViewResult { Mat depth; };
 int g_final_iteration = 15;
 bool g_device_maps = true;   // false (--sync-io / --host-rescale): planes are downloaded and unpacked on the host   // what the exchange step needs from a finished view
 
-ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
+// `resident_depth(w, h)`: where on the device the view's new depth map goes for the views that read it as a source (or null)
+ViewResult ProcessProblem(const Problem& problem, const std::function<float*(int, int)>& resident_depth = nullptr) {   // main.cpp:267-419
 	ViewLog() << "Processing image: " << std::setw(8) << std::setfill('0') << problem.ref_image_id << "..." << std::endl;
 	ViewLog() << "Iteration: " << problem.iteration << std::endl;
 	const auto start = std::chrono::steady_clock::now();
@@ -177,13 +178,16 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	const int nsrc = (int)problem.src_image_ids.size();
 	const float dmin = APD.GetDepthMin(), dmax = APD.GetDepthMax();
 	Mat depth, normal;
-	if (g_device_maps) APD.RunPatchMatchToMaps(depth, normal);   // the unpack loop below, done by the engine before the download
+	// Device maps: the unpack loop below is done by the engine, and the maps travel to the host in the background job while
+	// the context is already on the next view (25 B per pixel: 27 ms of the 34 ms a full-size view spent outside its kernels)
+	std::function<void()> fetch_maps;
+	if (g_device_maps) fetch_maps = APD.RunPatchMatchAndStageMaps(depth, normal, resident_depth ? resident_depth(width, height) : nullptr);
 	else {
 		APD.RunPatchMatch();
 		depth = Mat(height, width, CV_32FC1);
 		normal = Mat(height, width, CV_32FC3);
 	}
-	lap("RunPatchMatch + download");
+	lap(g_device_maps ? "RunPatchMatch" : "RunPatchMatch + download");
 	Mat pixel_states = APD.GetPixelStates();
 	Mat views = APD.GetSelectedViews();
 	Mat radius = problem.params.use_radius ? APD.GetRadiusMap() : Mat();
@@ -207,7 +211,8 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	// of this view — the visibility clean-up and the remaining four files — is only read by this view's own next pass:
 	// it runs in the background while the GPU is already on the next view (store.cpp).
 	const path folder = problem.result_folder;
-	PublishResult(folder / "depths.dmb", depth);
+	if (fetch_maps) ExpectResult(folder / "depths.dmb");   // (a reader of the file waits for the job below; same-size views take the device copy)
+	else PublishResult(folder / "depths.dmb", depth);
 	for (const char* name : { "APD_normals.dmb", "weak.bin", "selected_views.bin" }) ExpectResult(folder / name);
 	if (problem.params.use_radius) ExpectResult(folder / "radius.bin");
 	const int scale_size = problem.scale_size;
@@ -215,6 +220,11 @@ ViewResult ProcessProblem(const Problem& problem) {   // main.cpp:267-419
 	const bool timing = host_timing;
 	RunInBackground([=]() mutable {
 		const auto t0 = std::chrono::steady_clock::now();
+		if (fetch_maps) {
+			fetch_maps();
+			PublishResult(folder / "depths.dmb", depth);
+			if (timing) std::cout << "  [background] maps to the host: " << std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() / 1000.0 << " ms" << std::endl;
+		}
 		// Visibility clean-up (main.cpp:311-363): per source view, every 4-connected region of pixels that do
 		// NOT select the view and is smaller than 20 * (8 / scale)^2 pixels is switched to "selected".
 		const int min_region = 20 * (8 / scale_size) * (8 / scale_size);
@@ -340,6 +350,22 @@ public:
 		}
 		RankComm::HostToDevice(s.dev, depth.ptr<float>(0), (size_t)s.w * s.h);
 		APD::SetResidentDepth(image_id, s.dev, s.w, s.h);
+	}
+	// ... or straight from the engine's staged maps (dvp_download_maps_begin): the slot the view's new map is copied to on
+	// the device, registered with Commit once it is there
+	float* Reserve(int image_id, int w, int h) {
+		Slot& s = maps_[image_id];
+		if (s.w != w || s.h != h) {
+			RankComm::DeviceFree(s.dev);
+			s.dev = RankComm::DeviceAlloc((size_t)w * h);
+			s.w = w;
+			s.h = h;
+		}
+		return s.dev;
+	}
+	void Commit(int image_id) {
+		const Slot& s = maps_[image_id];
+		if (s.dev) APD::SetResidentDepth(image_id, s.dev, s.w, s.h);
 	}
 	void Release() {
 		APD::ClearResidentDepths();
@@ -590,9 +616,15 @@ int main(int argc, char** argv) {
 			for (size_t k = 0; k < owned.size(); ++k) {
 				Problem& problem = *owned[k];
 				if (pass.geom_index < 0 && opt.sync_io) GetProblemEdges(problem);   // main.cpp:480, synchronously
-				ViewResult r = ProcessProblem(problem);
+				bool on_device = false;
+				ViewResult r = ProcessProblem(problem, [&](int w, int h) -> float* {
+					if (!inplace || !g_device_maps) return nullptr;
+					on_device = true;
+					return inplace->Reserve(problem.ref_image_id, w, h);
+				});
 				if (exchange) mine[problem.index] = r.depth;
-				if (inplace) inplace->Update(problem.ref_image_id, r.depth);
+				if (inplace && on_device) inplace->Commit(problem.ref_image_id);
+				else if (inplace) inplace->Update(problem.ref_image_id, r.depth);
 			}
 		} else {
 			std::atomic<size_t> next{0};
@@ -609,12 +641,19 @@ int main(int argc, char** argv) {
 						Problem& problem = *owned[k];
 						std::ostringstream log;
 						SetViewLog(&log);
-						ViewResult r = ProcessProblem(problem);
+						bool on_device = false;
+						ViewResult r = ProcessProblem(problem, [&](int w, int h) -> float* {
+							if (!inplace || !g_device_maps) return nullptr;
+							std::lock_guard<std::mutex> lk(results);
+							on_device = true;
+							return inplace->Reserve(problem.ref_image_id, w, h);
+						});
 						SetViewLog(nullptr);
 						std::lock_guard<std::mutex> lk(results);
 						std::cout << log.str() << std::flush;
 						if (exchange) mine[problem.index] = r.depth;
-						if (inplace) inplace->Update(problem.ref_image_id, r.depth);
+						if (inplace && on_device) inplace->Commit(problem.ref_image_id);
+						else if (inplace) inplace->Update(problem.ref_image_id, r.depth);
 					}
 				});
 			for (std::thread& t : workers) t.join();
@@ -628,6 +667,7 @@ int main(int argc, char** argv) {
 		// map (or none) depending on timing.  One rank has no other reader: its cache serves its own next pass.
 		for (auto& j : edge_jobs) j.get();
 		if (opt.world > 1) FlushResults();
+		if (exchange) WaitBackgroundJobs();      // (the maps of `mine` are filled by the views' background jobs)
 		if (exchange) exchange->Publish(mine);   // collective: also the barrier between passes
 		else comm.Barrier();
 		if (pass.geom_index == opt.geom_passes - 1 || (opt.geom_passes == 0 && pass.geom_index < 0)) std::cout << "Round: " << pass.level << " done\n";

@@ -189,6 +189,11 @@ void RunInBackground(std::function<void()> job) {
 	g.cv.notify_all();
 }
 
+void WaitBackgroundJobs() {
+	std::unique_lock<std::mutex> lk(g.m);
+	g.cv.wait(lk, [] { return g.jobs.empty() && g.jobs_running == 0; });
+}
+
 void FlushResults(bool drop_cache) {
 	std::unique_lock<std::mutex> lk(g.m);
 	g.cv.wait(lk, [] { return g.jobs.empty() && g.jobs_running == 0; });

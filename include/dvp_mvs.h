@@ -199,6 +199,15 @@ int dvp_download_state(dvp_ctx* ctx, float* planes_xyzw, uint32_t* selected_view
  * and weak_info are required. */
 int dvp_download_maps(dvp_ctx* ctx, float* depth, float* normal_xyz, uint32_t* selected_views,
                       uint8_t* weak_info, int32_t* radius);
+/* dvp_download_maps in two steps, for a driver that puts the next view on this context while the maps of the last one still
+ * travel (the reference downloads synchronously, APD.cpp:1616-1640; a 25-Mpx view is 640 MB = 27 ms of PCIe time between 900 ms
+ * of kernels).  _begin forms the maps in a staging buffer on the device — and, if depth_device_copy is not NULL, copies the
+ * depth map to that DEVICE buffer (width * height floats: the resident map other views read as a source) — and returns when
+ * the device is done with that; the context may then be reset, uploaded to and run again.  _finish copies the staged maps to
+ * the host on a stream of its own and may be called from another thread; the next _begin (and dvp_ctx_destroy) waits for it. */
+int dvp_download_maps_begin(dvp_ctx* ctx, float* depth_device_copy);
+int dvp_download_maps_finish(dvp_ctx* ctx, float* depth, float* normal_xyz, uint32_t* selected_views,
+                             uint8_t* weak_info, int32_t* radius);
 long long dvp_buffer_bytes(dvp_ctx* ctx, int buffer);
 int dvp_download_buffer(dvp_ctx* ctx, int buffer, void* dst);
 int dvp_upload_buffer(dvp_ctx* ctx, int buffer, const void* src);
