@@ -78,6 +78,8 @@ def lib():
         L.dvp_synchronize.argtypes = [vp]
         L.dvp_download_state.argtypes = [vp] * 5
         L.dvp_download_maps.argtypes = [vp] * 6
+        L.dvp_download_maps_begin.argtypes = [vp, vp]
+        L.dvp_download_maps_finish.argtypes = [vp] * 6
         L.dvp_buffer_bytes.restype = ctypes.c_longlong
         L.dvp_buffer_bytes.argtypes = [vp, ci]
         L.dvp_download_buffer.argtypes = [vp, ci, vp]
@@ -214,6 +216,22 @@ class Context:
         weak = np.empty(L, np.uint8)
         radius = np.empty(L, np.int32)
         self._ck(self.L.dvp_download_maps(self.h, _p(depth), _p(normal), _p(views), _p(weak), _p(radius)))
+        return depth, normal, views, weak, radius
+
+    def download_maps_begin(self, depth_device_copy=None):
+        """first step of download_maps: the maps are staged on the device (and the depth map copied to the device address
+        `depth_device_copy`, if given); the context may be reset / uploaded to / run again before download_maps_finish"""
+        self._ck(self.L.dvp_download_maps_begin(self.h, ctypes.c_void_p(depth_device_copy) if depth_device_copy else None))
+
+    def download_maps_finish(self):
+        """second step (any thread): the staged maps -> host"""
+        L = self.W * self.H
+        depth = np.empty(L, np.float32)
+        normal = np.empty((L, 3), np.float32)
+        views = np.empty(L, np.uint32)
+        weak = np.empty(L, np.uint8)
+        radius = np.empty(L, np.int32)
+        self._ck(self.L.dvp_download_maps_finish(self.h, _p(depth), _p(normal), _p(views), _p(weak), _p(radius)))
         return depth, normal, views, weak, radius
 
     def get(self, name):

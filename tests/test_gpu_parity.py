@@ -396,6 +396,44 @@ def test_download_maps_is_the_drivers_unpack_loop():
     assert (w2 == weak).all() and (v2 == views).all() and (r2 == radius).all() and count_diff(p2, planes) == 0
 
 
+def test_download_maps_in_two_steps_survives_the_next_view():
+    """dvp_download_maps_begin stages the maps on the device; the context is then given another view's state (and a finished
+    pass of it) before dvp_download_maps_finish fetches the FIRST view's maps from another thread — what the driver's
+    background job does.  Equal to the one-call download taken before; a finish without a begin is refused; the depth map
+    also lands in a device buffer of the caller's."""
+    import threading
+    import torch
+    W, H, S = 96, 64, 3
+    sc = synth.make_scene(W, H, S)
+    p = make_params(S + 1, max_iterations=1, state=synth.FIRST_INIT, use_APD=0)
+    g = capi().from_scene(sc, p, seed=5)
+    state = first_pass_state(sc)
+    g.upload_state(**state)
+    g.run_patchmatch()
+    want = g.download_maps()
+    assert g.L.dvp_download_maps_finish(g.h, None, None, None, None, None) != 0 and b"without" in g.L.dvp_last_error(g.h)
+    dev = torch.zeros(W * H, dtype=torch.float32, device="cuda:0")
+    g.download_maps_begin(dev.data_ptr())
+    # the next view on the same context: other planes, other states, another pass
+    rng = np.random.default_rng(9)
+    other = dict(state)
+    other["planes"] = rng.normal(size=(H * W, 4)).astype(np.float32)
+    other["weak"] = rng.integers(0, 3, H * W).astype(np.uint8)
+    other["views"] = rng.integers(1, 1 << S, H * W).astype(np.uint32)
+    g.upload_state(**other)
+    g.set_seed(99)
+    g.run_patchmatch()
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault("maps", g.download_maps_finish()))
+    t.start()
+    t.join()
+    for a, b in zip(want, got["maps"]):
+        assert count_diff(a, b) == 0
+    assert count_diff(dev.cpu().numpy(), want[0]) == 0
+    after = g.download_maps()
+    assert count_diff(after[0], want[0]) > 0      # (the second view's own maps are something else)
+
+
 def test_golden_weak_pass_engine():
     """the committed REFINE_ITER / weak-path fixture through the C ABI"""
     from test_oracle_kat import _golden_weak_pass
