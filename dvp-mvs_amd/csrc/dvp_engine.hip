@@ -13,6 +13,8 @@
 #include <cstring>
 #include <mutex>
 #include <condition_variable>
+#include <thread>
+#include <algorithm>
 
 using namespace dvp;
 
@@ -964,6 +966,7 @@ struct dvp_ctx {
 	// dvp_download_maps_begin / _finish: the copies to the host run on their own stream, from any thread, while this context is
 	// already on its next view; `dl_busy` = maps_out holds maps that have not been fetched yet
 	hipStream_t copy = nullptr;
+	uint8_t* maps_host = nullptr;   // pinned mirror of maps_out (one DMA, no staging through the runtime's pageable-copy path)
 	std::mutex dl_m;
 	std::condition_variable dl_cv;
 	bool dl_busy = false;
@@ -1142,6 +1145,7 @@ int dvp_ctx_destroy(dvp_ctx* c) {
 		c->dl_cv.wait(lk, [c] { return !c->dl_busy; });
 	}
 	if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
+	if (c->maps_host) (void)hipHostFree(c->maps_host);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	for (void* p : c->allocs) (void)hipFree(p);
@@ -1858,6 +1862,31 @@ int dvp_download_maps_finish(dvp_ctx* c, float* depth, float* normal_xyz, uint32
 	if (!depth || !normal_xyz || !weak) return fail("dvp_download_maps: depth, normal and weak_info are required");
 	if (!c->copy && hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
 	const size_t L = c->L;
+	// One DMA into pinned memory, then plain copies into the caller's (pageable) maps.  Copies straight into pageable memory go
+	// through the runtime's staging path: at 6208x4128 they took 45-50 ms instead of 13 and the driver thread's own uploads for
+	// the next view waited behind them (profiles/r05_ab_notes.txt).
+	if (!c->maps_host && hipHostMalloc(reinterpret_cast<void**>(&c->maps_host), L * 25, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->maps_host = nullptr; }
+	if (c->maps_host) {
+		if (hipMemcpyAsync(c->maps_host, c->maps_out, L * 25, hipMemcpyDeviceToHost, c->copy) != hipSuccess || hipStreamSynchronize(c->copy) != hipSuccess)
+			return fail("dvp_download_maps_finish: copy to the host failed");
+		struct Part { void* dst; size_t off, bytes; };
+		const Part parts[5] = { { depth, 0, L * 4 }, { normal_xyz, L * 4, L * 12 }, { weak, L * 16, L }, { views, L * 17, L * 4 }, { radius, L * 21, L * 4 } };
+		std::vector<std::thread> team;
+		const uint8_t* src = c->maps_host;
+		for (const Part& pt : parts) {
+			if (!pt.dst) continue;
+			const size_t chunk = (size_t)32 << 20;
+			if (pt.bytes <= chunk) { std::memcpy(pt.dst, src + pt.off, pt.bytes); continue; }
+			const int nt = (int)std::min<size_t>(4, (pt.bytes + chunk - 1) / chunk);
+			for (int t = 0; t < nt; ++t) {
+				const size_t b0 = pt.bytes * t / nt, b1 = pt.bytes * (t + 1) / nt;
+				team.emplace_back([=]() { std::memcpy(static_cast<uint8_t*>(pt.dst) + b0, src + pt.off + b0, b1 - b0); });
+			}
+		}
+		for (std::thread& t : team) t.join();
+		download_done(c);
+		return 0;
+	}
 	const uint8_t* m = c->maps_out;
 	if (hipMemcpyAsync(depth, m, L * 4, hipMemcpyDeviceToHost, c->copy) != hipSuccess ||
 	    hipMemcpyAsync(normal_xyz, m + L * 4, L * 12, hipMemcpyDeviceToHost, c->copy) != hipSuccess ||

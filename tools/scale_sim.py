@@ -43,6 +43,12 @@ def parse_log(path):
         m = re.match(r"Cost time: (\d+) ms \(GPU RunPatchMatch ([0-9.]+) ms", ln)
         if m and it is not None:
             passes.setdefault(it, []).append(max(float(m.group(1)), float(m.group(2))))
+        m = re.match(r"Pass (\d+): (\d+) views in ([0-9.]+) ms, (\d+) in flight", ln)
+        if m and int(m.group(4)) > 1 and int(m.group(1)) in passes:
+            # several views in flight: a view's own clock contains its neighbours' kernels; share the pass' clock out in proportion
+            v = passes[int(m.group(1))]
+            k = float(m.group(3)) / max(sum(v), 1e-9)
+            passes[int(m.group(1))] = [x * k for x in v]
     return [{"iteration": k, "views_ms": v} for k, v in sorted(passes.items())]
 
 
