@@ -481,6 +481,14 @@ int main(int argc, char** argv) {
 		return EXIT_FAILURE;
 	}
 	const Options opt = ParseOptions(argc, argv);
+	const bool main_timing = std::getenv("DVP_HOST_TIMING") != nullptr;
+	auto main_t = std::chrono::steady_clock::now();
+	auto main_lap = [&](const std::string& what) {   // DVP_HOST_TIMING: what the driver does between the passes
+		if (!main_timing) return;
+		const auto now = std::chrono::steady_clock::now();
+		std::cout << "[main] " << what << ": " << std::chrono::duration_cast<std::chrono::microseconds>(now - main_t).count() / 1000.0 << " ms" << std::endl;
+		main_t = now;
+	};
 	std::filesystem::create_directories(opt.dense_folder / "APD");
 	SetHostThreadShare(opt.world);
 	if (opt.world > 1) std::cout << "rank " << opt.rank << " of " << opt.world << ": " << HostThreads() << " host threads (of " << std::thread::hardware_concurrency() << " cores)" << std::endl;
@@ -512,7 +520,9 @@ int main(int argc, char** argv) {
 				for (int id : p.src_image_ids) mine.push_back(opt.dense_folder / "images" / (ToFormatIndex(id) + ".jpg"));
 		APD::PrefetchDecoded(mine);
 	}
+	main_lap("start-up (options, rendezvous, view graph, decode prefetch started)");
 	const int round_num = PyramidLevels(problems);
+	main_lap("PyramidLevels (first image decoded)");
 	std::cout << "Round nums: " << round_num << std::endl;
 
 	// the pass list: level i has scale 2^(round_num-1-i); levels run while the scale is >= min_scale
@@ -536,6 +546,7 @@ int main(int argc, char** argv) {
 	for (size_t it = 0; it < plan.size(); ++it) {
 		const Pass& pass = plan[it];
 		const bool new_level = pass.scale != shared_scale;
+		main_t = std::chrono::steady_clock::now();
 		if (new_level) {
 			ShareLevelImages(comm, problems, owner_of, pass.scale);
 			shared_scale = pass.scale;
@@ -548,6 +559,7 @@ int main(int argc, char** argv) {
 			if (owner_of[(size_t)problem.index] == opt.rank) owned.push_back(&problem);
 		}
 		if (new_level && !opt.sync_io) level_images.Fill(owned, pass.scale);
+		if (new_level) main_lap("level " + std::to_string(pass.level) + ": images shared + resident on the device");
 		// last pass of a level: the next level's context and float images are made by helper threads while the GPU works
 		if (!opt.sync_io && it + 1 < plan.size() && plan[it + 1].scale != pass.scale && !owned.empty()) {
 			int nw = 0, nh = 0;
@@ -611,6 +623,7 @@ int main(int argc, char** argv) {
 			if (APD::LevelSize(*owned[0], pass.scale, &lw, &lh) && (size_t)lw * lh <= (size_t)opt.in_flight_pixels) in_flight = opt.views_in_flight > 0 ? opt.views_in_flight : 2;
 			in_flight = (int)std::min<size_t>((size_t)std::max(1, in_flight), owned.size());
 		}
+		main_lap("pass " + std::to_string(it) + ": helpers started");
 		const auto pass_t0 = std::chrono::steady_clock::now();
 		if (in_flight <= 1) {
 			for (size_t k = 0; k < owned.size(); ++k) {
@@ -665,19 +678,24 @@ int main(int argc, char** argv) {
 		// (APD.cpp fallback from the resident maps to LoadResult): the owner's background writer must have put this
 		// pass' files on disk BEFORE the barrier lets anyone into the next pass, or the reader sees the previous pass'
 		// map (or none) depending on timing.  One rank has no other reader: its cache serves its own next pass.
+		main_t = std::chrono::steady_clock::now();
 		for (auto& j : edge_jobs) j.get();
 		if (opt.world > 1) FlushResults();
 		if (exchange) WaitBackgroundJobs();      // (the maps of `mine` are filled by the views' background jobs)
 		if (exchange) exchange->Publish(mine);   // collective: also the barrier between passes
 		else comm.Barrier();
+		main_lap("pass " + std::to_string(it) + ": helpers joined, exchange / barrier");
 		if (pass.geom_index == opt.geom_passes - 1 || (opt.geom_passes == 0 && pass.geom_index < 0)) std::cout << "Round: " << pass.level << " done\n";
 	}
+	main_t = std::chrono::steady_clock::now();
 	if (exchange) exchange->Release();
 	exchange.reset();
 	inplace.reset();
 	level_images.Release();
 	APD::ReleasePooledContext();
+	main_lap("contexts and resident maps released");
 	FlushResults();          // every result file of this rank is on disk before anyone (rank 0's fusion) reads the folder
+	main_lap("FlushResults (background jobs + file writes)");
 	comm.Barrier();
 	if (opt.fusion && opt.rank == 0) {
 		if (opt.fusion_kind == "tat-intermediate") RunFusion_TAT_Intermediate(opt.dense_folder, problems);
@@ -685,6 +703,7 @@ int main(int argc, char** argv) {
 		else RunFusion(opt.dense_folder, problems);
 	}
 	ShutdownResultStore();
+	main_lap("fusion + shutdown");
 	std::cout << "All done\n";
 	return EXIT_SUCCESS;
 }
