@@ -1,6 +1,6 @@
 // dvp_weak_phased.hpp — the weak-pixel update (CheckerboardPropagationWeak + PlaneHypothesisRefinementWeak,
-// APD.cu:2739-3089, 1897-2008) as SEVEN launches: evaluation launches with one wave per WEAK pixel and decision launches
-// with one LANE per WEAK pixel.
+// APD.cu:2739-3089, 1897-2008) as EIGHT launches: evaluation launches with one wave per group of 1-4 WEAK pixels and decision
+// launches with one LANE per WEAK pixel.
 //
 // Why.  weak_update_wave (dvp_weak_wave.hpp) keeps a pixel's whole update in one wave.  Its deformable-NCC items fill the
 // lanes, but everything between them — the joint view selection, the geometric-consistency table, the adoption rules,
@@ -15,12 +15,13 @@
 //   D1  lane   joint view selection, candidate costs (geometric term), best candidate        -> rec
 //   E1  wave   the current plane and the fit plane against the selected views                -> ev
 //   D2  lane   cost of the current plane, adoption of candidate / fit plane, the five refinement hypotheses
-//   E2  wave   hypotheses in range against the first selected view, the survivors against the rest -> ev
+//   E2a wave   hypotheses in range against the FIRST selected view; which can still be adopted    -> ev
+//   E2b wave   the survivors against the other selected views                                  -> ev
 //   D3  lane   adoption of the hypotheses, the final plane
 //   E3  lane   cost of the final plane with the plain bilateral NCC (the per-lane evaluator of the strong path)
 //
 // Between launches a pixel's state travels in a 256-byte record (WeakRec), its centre-patch table (36 x (w, w ref)) and
-// its cost vectors (8 x S floats) — per WEAK pixel, indexed like Dev::neighbours.  Every floating-point operation is the
+// its cost vectors (S x 8 floats, a view's eight candidates side by side: two 16-byte loads) — per WEAK pixel, indexed like Dev::neighbours.  Every floating-point operation is the
 // one weak_update_wave performs, on the same operands in the same order: same bits (tests: the phased form, the one-wave
 // form and the oracle agree launch site by launch site).  A WEAK pixel reads other pixels' state only from its anchors,
 // which are STRONG (GenNeighbours) and which no weak update writes, so the launches of one update need no ordering between

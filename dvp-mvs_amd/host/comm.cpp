@@ -1,5 +1,8 @@
 // comm.cpp — RankComm on RCCL (ncclBroadcast / ncclAllReduce over xGMI) or on host-staged TCP, see comm.h.
 #define __HIP_PLATFORM_AMD__ 1
+#include <string>
+#include <cctype>
+#include <sched.h>
 #include "comm.h"
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -280,6 +283,37 @@ void RankComm::BroadcastHost(void* host, size_t bytes, int root) {
 	if (rank_ != root) hip_ok(hipMemcpy(host, bounce_, bytes, hipMemcpyDeviceToHost), "stage out");
 }
 
+int RankComm::BindProcessNearDevice(int device) {
+	if (std::getenv("DVP_NO_NUMA_BIND")) return -1;
+	char bus[64] = { 0 };
+	if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+	std::string id(bus);
+	for (char& ch : id) ch = (char)std::tolower((unsigned char)ch);
+	int node = -1;
+	{
+		std::ifstream f("/sys/bus/pci/devices/" + id + "/numa_node");
+		if (!(f >> node) || node < 0) return -1;
+	}
+	std::string list;
+	{
+		std::ifstream f("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+		if (!std::getline(f, list) || list.empty()) return -1;
+	}
+	cpu_set_t want, have, both;
+	CPU_ZERO(&want);
+	for (size_t i = 0; i < list.size();) {   // "0-63,128-191"
+		size_t j = i;
+		long a = std::strtol(list.c_str() + i, nullptr, 10), b = a;
+		while (j < list.size() && list[j] != ',' && list[j] != '-') ++j;
+		if (j < list.size() && list[j] == '-') { b = std::strtol(list.c_str() + j + 1, nullptr, 10); while (j < list.size() && list[j] != ',') ++j; }
+		for (long c = a; c <= b && c < CPU_SETSIZE; ++c) CPU_SET((int)c, &want);
+		i = j + 1;
+	}
+	if (sched_getaffinity(0, sizeof(have), &have) != 0) return -1;
+	CPU_AND(&both, &want, &have);
+	if (CPU_COUNT(&both) == 0 || sched_setaffinity(0, sizeof(both), &both) != 0) return -1;
+	return node;
+}
 void RankComm::BindThisThread(int device) { hip_ok(hipSetDevice(device), "hipSetDevice"); }
 float* RankComm::DeviceAlloc(size_t count) {
 	void* p = nullptr;

@@ -47,6 +47,11 @@ public:
 	// the communicator Abort()/the fatal hook act on (the driver has one)
 	static RankComm* Current();
 	// device memory helpers so that callers need no HIP headers
+	// Confines the calling process to the CPUs of the NUMA node the device hangs off (sysfs: the PCI device's numa_node, the
+	// node's cpulist), so that its threads, its first-touched memory and the runtime's pinned buffers sit next to the GPU: on a
+	// two-socket host a process that started on the far socket moved a view's maps at a third of the rate.  No-op when the
+	// topology is not visible or DVP_NO_NUMA_BIND is set.  Returns the node (or -1).
+	static int BindProcessNearDevice(int device);
 	static void BindThisThread(int device);   // hipSetDevice for a driver thread other than main's (HIP's current device is per thread)
 	static float* DeviceAlloc(size_t count);
 	static void DeviceFree(float* p);

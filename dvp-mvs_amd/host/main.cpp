@@ -493,6 +493,10 @@ int main(int argc, char** argv) {
 	SetHostThreadShare(opt.world);
 	if (opt.world > 1) std::cout << "rank " << opt.rank << " of " << opt.world << ": " << HostThreads() << " host threads (of " << std::thread::hardware_concurrency() << " cores)" << std::endl;
 	APD::SetDevice(opt.gpu);
+	{   // before any thread is started and any large block is touched
+		const int node = RankComm::BindProcessNearDevice(opt.gpu);
+		if (node >= 0) std::cout << "GPU " << opt.gpu << " hangs off NUMA node " << node << ": process confined to its CPUs" << std::endl;
+	}
 	APD::SetSeed(opt.seed);
 	APD::SetUseLabelFiles(opt.label_files);
 	SetResultCache(!opt.sync_io);
