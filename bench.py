@@ -98,10 +98,20 @@ def sweep_split():
     return e != "0" and (GEOM or e == "2")
 
 
+WEAK_COUNT = 1 << 30   # WEAK pixels of the timed context (set in measure)
+
+
+def weak_one_launch_site():
+    """dvp_run_patchmatch issues both colours of a weak update as ONE launch site (colour 2) under this condition (dvp_engine.hip)"""
+    return os.environ.get("DVP_WEAK_PHASED", "1") != "0" and os.environ.get("DVP_WEAK_ANCHOR_TAB", "1") != "0" and "DVP_WEAK_SPLIT_COLOURS" not in os.environ
+
+
 def weak_phased():
     """the weak update runs as evaluation launches (a wave per group of WEAK pixels) + decision launches (a lane per WEAK pixel)
-    where the anchor table is on (dvp_engine.hip: launch_stage)"""
-    return os.environ.get("DVP_WEAK_PHASED", "1") != "0" and os.environ.get("DVP_WEAK_ANCHOR_TAB", "1") != "0"
+    where the anchor table is on and the launch holds at least DVP_WEAK_PHASED_MIN (8192) WEAK pixels; below that — and when the
+    switch is off — the one-wave kernel takes them (dvp_engine.hip: launch_stage)"""
+    tmin = int(os.environ.get("DVP_WEAK_PHASED_MIN", "8192"))
+    return os.environ.get("DVP_WEAK_PHASED", "1") != "0" and os.environ.get("DVP_WEAK_ANCHOR_TAB", "1") != "0" and (tmin <= 0 or WEAK_COUNT >= tmin)
 
 
 def extra_kernels(stage, S):
@@ -223,7 +233,7 @@ def cpu_baseline(pkg, args, cfg, S, iters, device=0):
         timed, what = time.time() - t0, "REFINE_ITER pass (geom against %s source depth maps, %.1f %% WEAK) after an untimed FIRST_INIT pass" % (args.src_depths, 100.0 * o.weak_count() / L)
         g.run_patchmatch()
     res = {"value": round(L * iters / timed / 1e6, 5), "unit": "Mpx/s/iter", "cores": ncores, "kind": "port",
-           "sample": "%dx%d view, S=%d, %d iterations, whole RunPatchMatch of the %s, oracle/ (g++ -O3, OpenMP over row blocks), %.1f s" % (w, h, S, iters, what, timed)}
+           "sample": "this repo's CPU restatement of the path (oracle/, g++ -O3, OpenMP over row blocks) — NOT the reference rebuilt for CPU, which cannot be built here (it needs nvcc, OpenCV, Boost): %dx%d view, S=%d, %d iterations, whole RunPatchMatch of the %s, %.1f s" % (w, h, S, iters, what, timed)}
     a, b = o.get("planes"), g.get("planes")
     diff = (a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))
     res["gpu_vs_cpu_plane_words_differing"] = int(diff.sum())
@@ -290,7 +300,9 @@ def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
          "useful_eval_rate_frac": round(gev / EVALUATOR_PEAK_GEVALS, 3) if (gev and stage != "weak_update") else None,
          "work_rate": {"what": "SURVEY 8(d) algorithmic bytes: NCC evaluations x 724 B / launch time — a work rate, NOT a bound (caches/LDS serve it)",
                        "bytes_per_eval": NCC_BYTES, "gbs": round(alg, 1) if alg else None,
-                       "over_hbm_peak": round(alg / HBM_PEAK_GBS, 4) if alg else None}}
+                       "over_hbm_peak": round(alg / HBM_PEAK_GBS, 4) if alg else None},
+         # SURVEY 8(d)'s own figure under its own name, next to `frac`: algorithmic bytes / time / 8 TB/s
+         "survey_8d_frac_of_hbm_peak": round(alg / HBM_PEAK_GBS, 4) if alg else None}
     if pmc and sec > 0:
         traffic = pmc.get("hbm_bytes_per_launch")
         insts = pmc.get("SQ_INSTS_VALU")
@@ -380,8 +392,8 @@ def dry_launch(args, json_fd, rank, local_rank, world):
 
 def per_iteration_ms(ctx, iters, view_index, weak):
     """SURVEY 7 (hard part 4): early iterations gather worse than converged ones — the launch sites of the iteration loop
-    (APD.cu:4478-4492) timed iteration by iteration in one extra, untimed pass issued stage by stage (dvp_run_stage; the same
-    launches dvp_run_patchmatch issues)."""
+    (APD.cu:4478-4492) timed iteration by iteration in one extra, untimed pass issued stage by stage (dvp_run_stage) with the
+    launch structure dvp_run_patchmatch uses: both colours of a weak update as one launch site (colour 2) where it does so."""
     ctx.set_seed(1234 + view_index)
     ctx.set_profiling(False)
     ctx.restore_state()
@@ -395,8 +407,11 @@ def per_iteration_ms(ctx, iters, view_index, weak):
         ctx.run_stage("strong_update", it, 1)
         if weak:
             ctx.run_stage("ransac_fit", it, 0)
-            ctx.run_stage("weak_update", it, 0)
-            ctx.run_stage("weak_update", it, 1)
+            if weak_one_launch_site():
+                ctx.run_stage("weak_update", it, 2)
+            else:
+                ctx.run_stage("weak_update", it, 0)
+                ctx.run_stage("weak_update", it, 1)
         ctx.synchronize()
         t = ctx.timings(reset=True)
         res.append({k: round(v, 3) for k, v in t["stage_ms"].items() if v > 0})
@@ -489,6 +504,9 @@ def measure(env, args, cfg_name, W, H, S, iters, weak_frac_arg, steps, warmup, p
         ctx.upload_state(planes=st[0], views=st[1], weak=st[2], radius=st[3])
         weak_frac = ctx.weak_count() / float(L)
         del st
+    global WEAK_COUNT
+    # the weak update's launch structure depends on the size of its launches: one site of black + red, or a colour each
+    WEAK_COUNT = ctx.weak_count() if weak_one_launch_site() else ctx.weak_count() // 2
     del deps
     ctx.save_state()
     ctx.synchronize()

@@ -14,6 +14,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <thread>
+#include <chrono>
 #include <algorithm>
 
 using namespace dvp;
@@ -894,6 +895,109 @@ extern "C" __global__ void __launch_bounds__(256, DVP_PROBE_LB) dvp_probe_b(cons
 	}
 	atomicAdd(&out[center], acc);
 }
+// ---- round 6: the SWEEP-shaped probe.  Work per pixel = DepthToWeak's: the 61 disparity slots around the
+// pixel's own plane + the current depth, against the views of `vmask`.  (C) lane = pixel, slots in a loop — the mapping of
+// dvp_sweep_eval; (D) wave = ONE pixel, lane = slot: the patch table is wave-uniform (288 B, read by LDS broadcast), a tap's 62
+// gathers walk one epipolar segment.  Both sum a pixel's costs views-inside-slots in the same order: identical bits.
+__device__ __forceinline__ float probe_slot_plane(const DvpCamera& rc, const f4 origin, float base_line, float disp, int k, int px, int py, const DvpParams& P, bool* in_range) {
+	float p_depth = origin.w;
+	*in_range = true;
+	if (k < 61) {
+		p_depth = rc.K[0] * base_line / (disp + (k - 30));
+		if (p_depth < P.depth_min || p_depth > P.depth_max) *in_range = false;
+	}
+	return distance_to_origin(rc, px, py, p_depth, origin);
+}
+extern "C" __global__ void __launch_bounds__(256, 2) dvp_probe_c(const Dev d, const LaunchArgs a, float* out, unsigned vmask) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	int px, py;
+	if (!block_to_pixel(blockIdx.x, lane, wave, a.tiles_x, a.tiles, a.rows, 0, 0, d.width, d.height, &px, &py)) return;
+	const int center = px + py * d.width;
+	const int S = d.num_images - 1;
+	PatchCtx c;
+	__shared__ f2 lds_tab[kTaps * kTaps * 256];
+	int radius, inc;
+	patch_geometry(d, center, &radius, &inc);
+	build_patch_ctx(d, px, py, radius, inc, 0, PatchTab{&lds_tab[threadIdx.x], 256}, &c);
+	const DvpCamera rc = load_camera(d, 0);
+	const f4 origin = normal_world_to_cam(rc, d.planes[center]);
+	const float base_line = 0.4f, disp = rc.K[0] * base_line / origin.w;
+	float acc = 0.0f;
+	for (int k = 0; k < 62; ++k) {
+		bool ok;
+		f4 pl = origin;
+		pl.w = probe_slot_plane(rc, origin, base_line, disp, k, px, py, d.params, &ok);
+		float t = 0.0f;
+		if (ok) for (int v = 0; v < S; ++v) if ((vmask >> v) & 1) t += ncc_old<0>(d, c, px, py, v + 1, pl);
+		acc += t;
+	}
+	out[center] = acc;
+}
+#ifndef DVP_PROBE_NPX
+#define DVP_PROBE_NPX 16
+#endif
+extern "C" __global__ void __launch_bounds__(64, DVP_PROBE_LB) dvp_probe_d(const Dev d, float* out, unsigned vmask) {
+	const int lane = threadIdx.x;
+	const int S = d.num_images - 1;
+	__shared__ f2 ctab[kTaps * kTaps];
+	__shared__ float caa[kTaps * kTaps];
+	__shared__ float tot[64];
+	// block -> run of DVP_PROBE_NPX pixels of one row: XCD b % 8 owns a 64-pixel column of a strip of 8, four runs per row, rows top to bottom
+	const int runs = 64 / DVP_PROBE_NPX;
+	const int tiles_x = (d.width + 63) / 64;
+	const int per_strip = 8 * d.height * runs;
+	const int st = (int)blockIdx.x / per_strip, rem = (int)blockIdx.x - st * per_strip;
+	const int w_last = tiles_x - st * 8 >= 8 ? 8 : tiles_x - st * 8;
+	const int col = rem % w_last, k2 = rem / w_last;
+	const int py = k2 / runs, x0 = (st * 8 + col) * 64 + (k2 - py * runs) * DVP_PROBE_NPX;
+	if (py >= d.height) return;
+	const DvpCamera rc = load_camera(d, 0);
+	for (int i = 0; i < DVP_PROBE_NPX; ++i) {
+		const int px = x0 + i;
+		if (px >= d.width) break;
+		const int center = px + py * d.width;
+		int radius, inc;
+		patch_geometry(d, center, &radius, &inc);
+		PatchCtx c;
+		c.radius = radius; c.inc = inc; c.fast = 1;
+		c.tab = PatchTab{ctab, 1};
+		if (lane < kTaps * kTaps) {
+			const int ty = lane / kTaps, tx = lane - ty * kTaps;
+			const float cpix = img_texel(d.images, d.org, d.pitch, d.width, d.height, px, py);
+			const float av = img_texel(d.images, d.org, d.pitch, d.width, d.height, px - radius + tx * inc, py - radius + ty * inc);
+			const float w = bilateral_weight((float)(-radius + tx * inc), (float)(-radius + ty * inc), av, cpix, d.params.sigma_spatial, d.params.sigma_color, 0);
+			const float wa = w * av;
+			ctab[lane] = mk2(w, wa);
+			caa[lane] = wa * av;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		{
+			float sr = 0.0f, srr = 0.0f, ws = 0.0f;
+			for (int ty = 0; ty < kTaps; ++ty) {
+				float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+				for (int tx = 0; tx < kTaps; ++tx) { const f2 t = ctab[ty * kTaps + tx]; a0 += t.y; a1 += caa[ty * kTaps + tx]; a2 += t.x; }
+				sr += a0; srr += a1; ws += a2;
+			}
+			c.sum_ref = sr; c.sum_ref_ref = srr; c.wsum = ws;
+		}
+		f4 origin = normal_world_to_cam(rc, d.planes[center]);
+		origin.x = uniform_f(origin.x); origin.y = uniform_f(origin.y); origin.z = uniform_f(origin.z); origin.w = uniform_f(origin.w);
+		const float base_line = 0.4f, disp = rc.K[0] * base_line / origin.w;
+		bool ok;
+		f4 pl = origin;
+		pl.w = probe_slot_plane(rc, origin, base_line, disp, lane, px, py, d.params, &ok);
+		float t = 0.0f;
+		if (lane < 62 && ok) for (int v = 0; v < S; ++v) if ((vmask >> v) & 1) t += ncc_old<0>(d, c, px, py, v + 1, pl);
+		tot[lane] = t;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (lane == 0) {
+			float acc = 0.0f;
+			for (int k = 0; k < 62; ++k) acc += tot[k];
+			out[center] = acc;
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+}
 extern "C" int dvp_probe(dvp_ctx* c, int mode, int K, int stride, int repeat, float* mean_ms, float* checksum);
 #endif
 
@@ -970,6 +1074,7 @@ struct dvp_ctx {
 	std::mutex dl_m;
 	std::condition_variable dl_cv;
 	bool dl_busy = false;
+	bool dl_fetching = false;   // a dvp_download_maps_finish call is running right now (it ends in bounded time)
 	size_t coarse_alloc = 0;
 	// dvp_save_state / dvp_restore_state: device-side copy of the per-pixel input state
 	f4* saved_planes = nullptr; uint32_t* saved_views = nullptr; uint8_t* saved_weak = nullptr; int* saved_radius = nullptr;
@@ -1141,8 +1246,9 @@ int dvp_ctx_destroy(dvp_ctx* c) {
 	// teardown: errors are not actionable here
 	(void)hipSetDevice(c->device);
 	{   // maps another thread is still fetching (dvp_download_maps_finish)
+		// (maps that were staged and never fetched — an exception between the two steps — are abandoned, not waited for)
 		std::unique_lock<std::mutex> lk(c->dl_m);
-		c->dl_cv.wait(lk, [c] { return !c->dl_busy; });
+		c->dl_cv.wait(lk, [c] { return !c->dl_fetching; });
 	}
 	if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
 	if (c->maps_host) (void)hipHostFree(c->maps_host);
@@ -1163,7 +1269,14 @@ int dvp_ctx_destroy(dvp_ctx* c) {
 #endif
 const char* dvp_build_id(void) { return DVP_BUILD_ID; }
 
-const char* dvp_last_error(const dvp_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+// dvp_download_maps_finish may run on another thread than the one that drives the context: its error text stays with
+// the calling thread instead of racing with the driver thread's writes to dvp_ctx::error
+struct FinishError { const dvp_ctx* c = nullptr; std::string msg; };
+static thread_local FinishError t_finish_error;
+const char* dvp_last_error(const dvp_ctx* c) {
+	if (c && t_finish_error.c == c && !t_finish_error.msg.empty()) return t_finish_error.msg.c_str();
+	return c ? c->error.c_str() : g_create_error.c_str();
+}
 
 // `pairs` != nullptr: `dst` is the staging set and the row-pair planes are produced from it
 static int upload_planes(dvp_ctx* c, float* dst, const float* const* src, int pitch_floats, hipMemcpyKind kind, float* pairs = nullptr) {
@@ -1787,6 +1900,10 @@ int dvp_run_patchmatch(dvp_ctx* c) {
 	for (int i = 0; i < c->d.params.max_iterations; ++i) {
 		if (launch_stage(c, DVP_ST_STRONG_UPDATE, i, 0)) return 1;
 		if (launch_stage(c, DVP_ST_STRONG_UPDATE, i, 1)) return 1;
+		// without WEAK pixels the three weak-path launches of an iteration do nothing but RANSACToGetFitPlane's copy
+		// fit plane = plane (APD.cu:4208-4211), which only the last iteration's launch leaves behind
+		if (c->d.weak_count == 0 && i == c->d.params.max_iterations - 1)
+			HIP_TRY(c, hipMemcpyAsync(c->fit_planes, c->planes, c->L * 16, hipMemcpyDeviceToDevice, c->stream));
 		if (c->d.weak_count > 0) {   // these three only touch WEAK pixels
 			if (launch_stage(c, DVP_ST_RANSAC_FIT, i, 0)) return 1;
 			// Black then red (APD.cu:4487-4489).  A WEAK pixel's update reads other pixels' state only at its anchors, which are STRONG
@@ -1826,14 +1943,20 @@ int dvp_download_state(dvp_ctx* c, float* planes, uint32_t* views, uint8_t* weak
 }
 
 static void download_done(dvp_ctx* c) {
-	{ std::lock_guard<std::mutex> lk(c->dl_m); c->dl_busy = false; }
+	{ std::lock_guard<std::mutex> lk(c->dl_m); c->dl_busy = false; c->dl_fetching = false; }
 	c->dl_cv.notify_all();
 }
 int dvp_download_maps_begin(dvp_ctx* c, float* depth_device_copy) {
 	if (set_device(c)) return 1;
-	{   // the previous view's maps must have been fetched
+	{   // the previous view's maps must have been fetched: its background job may not even have started yet, so this waits —
+		// but not for ever (a second _begin after a _finish that never comes would otherwise hang the driver thread)
+		int limit_s = 120;
+		if (const char* e = getenv("DVP_DOWNLOAD_WAIT_S")) limit_s = atoi(e);
 		std::unique_lock<std::mutex> lk(c->dl_m);
-		c->dl_cv.wait(lk, [c] { return !c->dl_busy; });
+		if (!c->dl_cv.wait_for(lk, std::chrono::seconds(limit_s > 0 ? limit_s : 1), [c] { return !c->dl_busy; })) {
+			c->error = "dvp_download_maps_begin: the maps staged by the previous dvp_download_maps_begin were never fetched (dvp_download_maps_finish)";
+			return 1;
+		}
 		c->dl_busy = true;
 	}
 	const size_t L = c->L;
@@ -1853,11 +1976,14 @@ int dvp_download_maps_begin(dvp_ctx* c, float* depth_device_copy) {
 	return 0;
 }
 int dvp_download_maps_finish(dvp_ctx* c, float* depth, float* normal_xyz, uint32_t* views, uint8_t* weak, int32_t* radius) {
+	t_finish_error.c = c;
+	t_finish_error.msg.clear();
 	{
 		std::lock_guard<std::mutex> lk(c->dl_m);
-		if (!c->dl_busy) { c->error = "dvp_download_maps_finish without dvp_download_maps_begin"; return 1; }
+		if (!c->dl_busy || c->dl_fetching) { t_finish_error.msg = "dvp_download_maps_finish without dvp_download_maps_begin"; return 1; }
+		c->dl_fetching = true;
 	}
-	auto fail = [c](const char* what) { c->error = what; download_done(c); return 1; };
+	auto fail = [c](const char* what) { t_finish_error.msg = what; download_done(c); return 1; };
 	if (hipSetDevice(c->device) != hipSuccess) return fail("hipSetDevice failed");
 	if (!depth || !normal_xyz || !weak) return fail("dvp_download_maps: depth, normal and weak_info are required");
 	if (!c->copy && hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
@@ -2068,7 +2194,9 @@ int dvp_probe(dvp_ctx* c, int mode, int K, int stride, int repeat, float* mean_m
 		if (i == 1) HIP_TRY(c, hipEventRecord(ev.a, c->stream));
 		HIP_TRY(c, hipMemsetAsync(c->scratch_out, 0, c->L * 4, c->stream));
 		if (mode == 0) hipLaunchKernelGGL(dvp_probe_a, dim3(g.grid()), dim3(256), 0, c->stream, c->d, a, c->scratch_out, K, stride);
-		else hipLaunchKernelGGL(dvp_probe_b, dim3((waves + 3) / 4), dim3(256), 0, c->stream, c->d, c->scratch_out, K, stride);
+		else if (mode == 1) hipLaunchKernelGGL(dvp_probe_b, dim3((waves + 3) / 4), dim3(256), 0, c->stream, c->d, c->scratch_out, K, stride);
+		else if (mode == 2) hipLaunchKernelGGL(dvp_probe_c, dim3(g.grid()), dim3(256), 0, c->stream, c->d, a, c->scratch_out, (unsigned)K);   // K = view mask
+		else hipLaunchKernelGGL(dvp_probe_d, dim3((unsigned)(g.tiles_x * c->H * (64 / DVP_PROBE_NPX))), dim3(64), 0, c->stream, c->d, c->scratch_out, (unsigned)K);
 	}
 	HIP_TRY(c, hipEventRecord(ev.b, c->stream));
 	HIP_TRY(c, hipGetLastError());

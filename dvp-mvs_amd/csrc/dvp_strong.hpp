@@ -1221,7 +1221,11 @@ DVP_HD void sweep_eval_px(const Dev& d, int px, int py, int v, int stage, PatchT
 	{
 		int radius, inc;
 		patch_geometry(d, center, &radius, &inc);
+#if defined(DVP_ABL_SWEEP_NO_TABLE)   // timing ablations (wrong results): where the launch site's time goes, profiles/r06_sweep_ablation.txt
+		c.tab = tab; c.radius = radius; c.inc = inc; c.fast = 1; c.sum_ref = 1.0f; c.sum_ref_ref = 2.0f; c.wsum = 1.0f;
+#else
 		build_patch_ctx(d, px, py, radius, inc, 0, tab, &c);
+#endif
 	}
 	const int cw = sweep_window(P);
 	float* out = d.sweep_cost + sweep_cost_index(d, v, 0, center);
@@ -1236,12 +1240,19 @@ DVP_HD void sweep_eval_px(const Dev& d, int px, int py, int v, int stage, PatchT
 		}
 		f4 pl = origin;
 		pl.w = distance_to_origin(rc, px, py, p_depth, pl);
+#if defined(DVP_ABL_SWEEP_NO_EVAL)
+		const float ncc = pl.w * 1e-3f;
+#else
 		const float ncc = ncc_old<SMP>(d, c, px, py, v + 1, pl);
+#endif
 		if (nevals) *nevals += 1;
 #if defined(DVP_ABL_SWEEP_NO_GEOM)   // timing ablation (wrong results)
 		const float gc = 0.0f;
 #else
 		const float gc = !P.geom_consistency ? 0.0f : (cams ? geom_cost_cams(d, cams[0], cams[1], v + 1, px, py, pl) : geom_cost(d, px, py, v + 1, pl));
+#endif
+#if defined(DVP_ABL_SWEEP_NO_STORE)
+		if (ncc + gc != 12345.678f) continue;   // (never equal: costs are at most 5)
 #endif
 		if (extra) {
 			float t = ncc;

@@ -88,7 +88,7 @@ struct PooledCtx {
 // no destructors: at static-destruction time the HIP runtime may already be gone; the driver calls
 // APD::ReleasePooledContext() before it returns.  Several slots: the driver keeps up to that many views of a pass in
 // flight at the coarse levels, each on its own context (main.cpp).
-constexpr size_t kPoolSlots = 4;
+constexpr size_t kPoolSlots = (size_t)APD::kMaxViewsInFlight;
 std::vector<PooledCtx>& g_pool = *new std::vector<PooledCtx>;
 std::mutex g_ctx_mutex;   // g_pool, g_prewarm, the resident-map registries
 dvp_ctx* take_pooled(int device, int w, int h, int ni) {
@@ -105,10 +105,11 @@ void give_pooled(dvp_ctx* ctx, int device, int w, int h, int ni) {
 	std::vector<dvp_ctx*> drop;
 	{
 		std::lock_guard<std::mutex> lock(g_ctx_mutex);
-		// contexts of another shape belong to a level that is over (or to a view of another size): they go first
-		for (size_t i = 0; i < g_pool.size();)
-			if (g_pool[i].device != device || g_pool[i].w != w || g_pool[i].h != h || g_pool[i].ni != ni) { drop.push_back(g_pool[i].ctx); g_pool.erase(g_pool.begin() + (long)i); }
-			else ++i;
+		// a full pool makes room by dropping a context of ANOTHER shape first (a level that is over, or a view of another
+		// size: with views of mixed sizes in flight those stay while there is room — recreating one costs ~0.3 s at large sizes)
+		if (g_pool.size() >= kPoolSlots)
+			for (size_t i = 0; i < g_pool.size(); ++i)
+				if (g_pool[i].device != device || g_pool[i].w != w || g_pool[i].h != h || g_pool[i].ni != ni) { drop.push_back(g_pool[i].ctx); g_pool.erase(g_pool.begin() + (long)i); break; }
 		if (g_pool.size() >= kPoolSlots) drop.push_back(ctx);
 		else g_pool.push_back(PooledCtx{ ctx, device, w, h, ni });
 	}
@@ -125,16 +126,29 @@ struct PrewarmedCtx {
 	dvp_ctx* ctx = nullptr;
 	int device = 0, w = 0, h = 0, ni = 0;
 	bool active = false;
+	bool claimed = false;   // a caller of take_prewarmed is joining the worker
 };
 PrewarmedCtx& g_prewarm = *new PrewarmedCtx;   // never destroyed: an exit() while the helper runs must not meet a joinable std::thread's destructor
 dvp_ctx* take_prewarmed(int device, int w, int h, int ni) {   // nullptr when there is none that fits
-	std::lock_guard<std::mutex> lock(g_ctx_mutex);
-	if (!g_prewarm.active) return nullptr;
-	if (g_prewarm.worker.joinable()) g_prewarm.worker.join();
-	g_prewarm.active = false;
-	dvp_ctx* c = g_prewarm.ctx;
-	g_prewarm.ctx = nullptr;
-	if (c && (g_prewarm.device != device || g_prewarm.w != w || g_prewarm.h != h || g_prewarm.ni != ni)) { dvp_ctx_destroy(c); c = nullptr; }
+	std::thread worker;
+	{
+		std::lock_guard<std::mutex> lock(g_ctx_mutex);
+		if (!g_prewarm.active || g_prewarm.claimed) return nullptr;
+		g_prewarm.claimed = true;            // this caller joins the helper — outside the lock: the other driver threads
+		worker = std::move(g_prewarm.worker);   // keep taking pooled contexts meanwhile
+	}
+	if (worker.joinable()) worker.join();
+	dvp_ctx* c = nullptr;
+	bool fits = false;
+	{
+		std::lock_guard<std::mutex> lock(g_ctx_mutex);
+		c = g_prewarm.ctx;
+		g_prewarm.ctx = nullptr;
+		fits = g_prewarm.device == device && g_prewarm.w == w && g_prewarm.h == h && g_prewarm.ni == ni;
+		g_prewarm.active = false;
+		g_prewarm.claimed = false;
+	}
+	if (c && !fits) { dvp_ctx_destroy(c); c = nullptr; }
 	return c;
 }
 }
@@ -323,17 +337,32 @@ void APD::InsertCachedImage(const Problem& problem, int image_id, const Mat& ima
 namespace {
 struct ResidentDepth { const float* ptr; int w, h; };
 std::map<int, ResidentDepth> g_resident_depths;
+std::mutex g_resident_mutex;   // both registries: the driver's view threads register and look up concurrently
 }
-void APD::SetResidentDepth(int image_id, const float* device_ptr, int width, int height) { g_resident_depths[image_id] = ResidentDepth{ device_ptr, width, height }; }
-void APD::ClearResidentDepths() { g_resident_depths.clear(); }
+void APD::SetResidentDepth(int image_id, const float* device_ptr, int width, int height) {
+	std::lock_guard<std::mutex> lock(g_resident_mutex);
+	g_resident_depths[image_id] = ResidentDepth{ device_ptr, width, height };
+}
+void APD::UnsetResidentDepth(int image_id) {
+	std::lock_guard<std::mutex> lock(g_resident_mutex);
+	g_resident_depths.erase(image_id);
+}
+void APD::ClearResidentDepths() {
+	std::lock_guard<std::mutex> lock(g_resident_mutex);
+	g_resident_depths.clear();
+}
 namespace {
 struct ResidentImage { const float* ptr; int w, h, orig_w, orig_h; };
 std::map<std::pair<int, int>, ResidentImage> g_resident_images;   // (image id, scale)
 }
 void APD::SetResidentImage(int image_id, int scale, const float* device_ptr, int width, int height, int orig_width, int orig_height) {
+	std::lock_guard<std::mutex> lock(g_resident_mutex);
 	g_resident_images[{ image_id, scale }] = ResidentImage{ device_ptr, width, height, orig_width, orig_height };
 }
-void APD::ClearResidentImages() { g_resident_images.clear(); }
+void APD::ClearResidentImages() {
+	std::lock_guard<std::mutex> lock(g_resident_mutex);
+	g_resident_images.clear();
+}
 namespace { void (*g_resident_download)(float*, const float*, size_t) = nullptr; }
 void APD::SetResidentDownloader(void (*copy)(float*, const float*, size_t)) { g_resident_download = copy; }
 
@@ -415,21 +444,28 @@ void APD::InuputInitialization() {
 		depths_device.clear();
 		std::vector<int> ids(1, problem.ref_image_id);
 		ids.insert(ids.end(), problem.src_image_ids.begin(), problem.src_image_ids.end());
-		bool resident = !g_resident_depths.empty();
-		for (int id : ids) {
-			auto it = g_resident_depths.find(id);
-			resident = resident && it != g_resident_depths.end() && it->second.w == width && it->second.h == height;
+		// a snapshot of the registry entries this view needs, taken under the registries' lock
+		std::map<int, ResidentDepth> res_depths;
+		bool resident;
+		{
+			std::lock_guard<std::mutex> lock(g_resident_mutex);
+			resident = !g_resident_depths.empty();
+			for (int id : ids) {
+				auto it = g_resident_depths.find(id);
+				if (it != g_resident_depths.end()) res_depths[id] = it->second;
+				resident = resident && it != g_resident_depths.end() && it->second.w == width && it->second.h == height;
+			}
 		}
 		if (resident) {   // previous-pass maps already on this device (multi-GPU exchange / --jacobi)
-			for (int id : ids) depths_device.push_back(g_resident_depths[id].ptr);
+			for (int id : ids) depths_device.push_back(res_depths[id].ptr);
 		} else {
 			for (int id : ids) {
 				Mat depth;
 				// A map of another size (views of unequal size).  With a depth exchange (--jacobi / several ranks) the resident
 				// copy IS the previous pass' map, on every rank alike: it is fetched and rescaled.  The owner's file would be the
 				// previous pass' or this pass' map depending on how far the owner has come — never read it then.
-				auto it = g_resident_depths.find(id);
-				if (it != g_resident_depths.end() && g_resident_download) {
+				auto it = res_depths.find(id);
+				if (it != res_depths.end() && g_resident_download) {
 					depth = Mat(it->second.h, it->second.w, CV_32FC1);
 					g_resident_download(depth.ptr<float>(0), it->second.ptr, (size_t)it->second.w * it->second.h);
 				} else
@@ -638,7 +674,10 @@ void APD::CudaSpaceInitialization() {
 	}
 	lap("context");
 	std::vector<const float*> ptrs(num_images);
-	bool resident_images = !g_resident_images.empty();
+	bool resident_images;
+	{
+	std::lock_guard<std::mutex> resident_lock(g_resident_mutex);   // held over the look-ups only
+	resident_images = !g_resident_images.empty();
 	for (int i = 0; i < num_images && resident_images; ++i) {
 		// A source image of another ORIGINAL size than the reference is padded / cropped to the reference's original size on the
 		// host and resized after that (APD.cpp:1071-1079): the resident copy — the file resized at its own size — is not that
@@ -648,6 +687,7 @@ void APD::CudaSpaceInitialization() {
 		resident_images = it != g_resident_images.end() && it->second.w == width && it->second.h == height &&
 		                  it->second.orig_w == ref_orig_width && it->second.orig_h == ref_orig_height;
 		if (resident_images) ptrs[i] = it->second.ptr;
+	}
 	}
 	if (resident_images) DVP_SAFE_CALL(ctx, dvp_upload_images_device(ctx, ptrs.data(), width));
 	else {

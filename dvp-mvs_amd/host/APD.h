@@ -134,6 +134,8 @@ public:
 	static void SetResidentImage(int image_id, int scale, const float* device_ptr, int width, int height, int orig_width, int orig_height);
 	static void ClearResidentImages();
 	static void SetResidentDepth(int image_id, const float* device_ptr, int width, int height);
+	static constexpr int kMaxViewsInFlight = 4;    // = the engine-context pool's slots (APD.cpp): more views in flight would recreate contexts per view
+	static void UnsetResidentDepth(int image_id);   // before the registered block is freed / replaced
 	static void ClearResidentDepths();
 	static void SetResidentDownloader(void (*copy)(float* host, const float* device, size_t count));   // device -> host copy used when a resident map of another size has to be rescaled on the host
 	const DvpTimings& GetTimings() const { return timings; }

@@ -343,6 +343,7 @@ public:
 	void Update(int image_id, const Mat& depth) {
 		Slot& s = maps_[image_id];
 		if (s.w != depth.cols || s.h != depth.rows) {
+			APD::UnsetResidentDepth(image_id);   // the registry must not name a freed block, not even until the new one is registered
 			RankComm::DeviceFree(s.dev);
 			s.dev = RankComm::DeviceAlloc((size_t)depth.cols * depth.rows);
 			s.w = depth.cols;
@@ -356,6 +357,7 @@ public:
 	float* Reserve(int image_id, int w, int h) {
 		Slot& s = maps_[image_id];
 		if (s.w != w || s.h != h) {
+			APD::UnsetResidentDepth(image_id);   // ... until Commit
 			RankComm::DeviceFree(s.dev);
 			s.dev = RankComm::DeviceAlloc((size_t)w * h);
 			s.w = w;
@@ -461,7 +463,7 @@ Options ParseOptions(int argc, char** argv) {
 		else if (s == "--labels") o.label_files = true;          // load labels_<s>.dmb (APD::SetUseLabelFiles)
 		else if (s == "--no-fusion") o.fusion = false;
 		else if (s == "--sync-io") o.sync_io = true;               // no result cache / background worker / device rescale: the reference's synchronous file flow
-		else if (s == "--views-in-flight") { if (a + 1 < argc) o.views_in_flight = std::max(1, atoi(argv[++a])); }
+		else if (s == "--views-in-flight") { if (a + 1 < argc) o.views_in_flight = std::min(APD::kMaxViewsInFlight, std::max(1, atoi(argv[++a]))); }   // one pooled engine context per view in flight
 		else if (s == "--in-flight-pixels") { if (a + 1 < argc) o.in_flight_pixels = atoll(argv[++a]); }
 		else if (s == "--host-rescale") o.host_rescale = true;     // the coarser level's maps are up-sampled on the host (APD::SetDeviceRescale(false))
 		else if (s == "--fusion") { if (a + 1 < argc) o.fusion_kind = argv[++a]; }

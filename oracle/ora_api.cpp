@@ -193,6 +193,47 @@ int ora_run_stage(void* c, int stage, int iter, int colour) {
 	return 0;
 }
 
+// The per-pixel body of one launch on a LIST of pixels (px = x0, y0, x1, y1, ...): full-size parity on samples.  Every launch
+// site is a per-pixel function of the pre-launch state (the strong update reads its neighbours from the snapshot taken here),
+// so the listed pixels get exactly what the whole launch would give them.  Half launches keep the reference's pixel map
+// (APD.cu:3093-3100, 4421-4428): a listed pixel the launch of this colour does not visit is left alone.  Returns the number of
+// listed pixels the launch visits, -1 for an unknown stage.
+int ora_run_stage_pixels(void* c, int stage, int iter, int colour, const int* px, int n) {
+	Ctx& h = *(Ctx*)c;
+	const int W = h.width, H = h.height;
+	const int rows_half = ((H / 2) + 15) / 16 * 16;
+	const bool half = stage == ST_STRONG_UPDATE || stage == ST_WEAK_UPDATE || stage == ST_FILTER_STRONG;
+	if (stage < ST_GEN_EDGE_INFORM || stage > ST_LOCAL_REFINE) return -1;
+	if (stage == ST_STRONG_UPDATE) { h.planes_snap = h.planes; h.costs_snap = h.costs; }
+	int visited = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : visited)
+	for (int i = 0; i < n; ++i) {
+		const int2 p = make_int2(px[2 * i], px[2 * i + 1]);
+		if (p.x < 0 || p.y < 0 || p.x >= W || p.y >= H) continue;
+		if (half) {
+			const int r = p.y - ((p.x & 1) ^ colour);
+			if (r < 0 || (r & 1) || r / 2 >= rows_half) continue;
+		}
+		const bool weak = h.weak_info[p.x + p.y * W] == WEAK;
+		++visited;
+		switch (stage) {
+		case ST_GEN_EDGE_INFORM: GenEdgeInform_px(h, p); break;
+		case ST_FIND_NEAREST_STRONG: FindNearestStrongPoint_px(h, p); break;
+		case ST_GEN_NEIGHBOURS: GenNeighbours_px(h, p); break;
+		case ST_NEIGHBOUR_UPDATE: NeigbourUpdate_px(h, p); break;
+		case ST_RANDOM_INIT: RandomInitialization_px(h, p); break;
+		case ST_STRONG_UPDATE: if (!weak) CheckerboardPropagationStrong_px(h, p, iter); break;
+		case ST_RANSAC_FIT: RANSACToGetFitPlane_px(h, p, iter); break;
+		case ST_WEAK_UPDATE: if (weak) CheckerboardPropagationWeak_px(h, p, iter); break;
+		case ST_GET_DEPTH_NORMAL: GetDepthandNormal_px(h, p); break;
+		case ST_FILTER_STRONG: if (!weak) CheckerboardFilterStrong_px(h, p); break;
+		case ST_DEPTH_TO_WEAK: DepthToWeak_px(h, p); break;
+		case ST_LOCAL_REFINE: LocalRefine_px(h, p); break;
+		}
+	}
+	return visited;
+}
+
 // APD::RunPatchMatch (APD.cu:4406-4532).  Returns seconds spent in the iteration loop
 // (APD.cu:4478-4492) through *iter_seconds when non-null.
 int ora_run_patchmatch(void* c, double* iter_seconds) {

@@ -169,6 +169,14 @@ class Oracle:
         r = self.L.ora_run_stage(self.h, STAGES[name], it, colour)
         assert r == 0
 
+    def run_stage_pixels(self, name, it, colour, px):
+        """the launch's per-pixel body on the listed pixels only (px: [n, 2] of (x, y)); returns how many of them the launch visits"""
+        a = np.ascontiguousarray(px, np.int32).reshape(-1, 2)
+        self.L.ora_run_stage_pixels.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        r = self.L.ora_run_stage_pixels(self.h, STAGES[name], it, colour, _p(a), len(a))
+        assert r >= 0
+        return r
+
     def run_patchmatch(self):
         if self.L._pre != "ora_":
             self.L._L.emu_run_patchmatch.argtypes = [ctypes.c_void_p]

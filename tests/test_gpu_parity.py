@@ -434,6 +434,29 @@ def test_download_maps_in_two_steps_survives_the_next_view():
     assert count_diff(after[0], want[0]) > 0      # (the second view's own maps are something else)
 
 
+def test_staged_maps_that_are_never_fetched_do_not_hang_the_context(monkeypatch):
+    """a second dvp_download_maps_begin without a dvp_download_maps_finish fails after a bounded wait instead of
+    blocking for ever, and a context whose staged maps were never fetched can still be destroyed."""
+    import time
+    monkeypatch.setenv("DVP_DOWNLOAD_WAIT_S", "1")
+    W, H, S = 64, 48, 2
+    sc = synth.make_scene(W, H, S)
+    p = make_params(S + 1, max_iterations=1, state=synth.FIRST_INIT, use_APD=0)
+    g = capi().from_scene(sc, p, seed=5)
+    g.upload_state(**first_pass_state(sc))
+    g.run_patchmatch()
+    g.download_maps_begin()
+    t0 = time.time()
+    assert g.L.dvp_download_maps_begin(g.h, None) != 0 and b"never fetched" in g.L.dvp_last_error(g.h)
+    assert time.time() - t0 < 10
+    maps = g.download_maps_finish()          # the staged maps are still there
+    assert np.isfinite(maps[0]).any()
+    g.download_maps_begin()
+    t0 = time.time()
+    g.close()                                # staged, never fetched: abandoned
+    assert time.time() - t0 < 10
+
+
 def test_golden_weak_pass_engine():
     """the committed REFINE_ITER / weak-path fixture through the C ABI"""
     from test_oracle_kat import _golden_weak_pass
