@@ -32,7 +32,8 @@ EXPORTS = ["dvp_ctx_create", "dvp_ctx_destroy", "dvp_last_error", "dvp_upload_im
            "dvp_reset_state", "dvp_save_state", "dvp_restore_state", "dvp_set_params", "dvp_set_seed", "dvp_set_sampler", "dvp_set_profiling", "dvp_image_format", "dvp_run_patchmatch",
            "dvp_run_stage", "dvp_synchronize", "dvp_download_state", "dvp_download_maps", "dvp_download_maps_begin", "dvp_download_maps_finish", "dvp_buffer_bytes", "dvp_download_buffer",
            "dvp_upload_buffer", "dvp_weak_count", "dvp_get_timings", "dvp_reset_timings", "dvp_eval_cost_vectors",
-           "dvp_bench_cost_kernel", "dvp_build_id"]
+           "dvp_bench_cost_kernel", "dvp_build_id",
+           "dvp_fuse_create", "dvp_fuse_destroy", "dvp_fuse_last_error", "dvp_fuse_set_view", "dvp_fuse_view", "dvp_fuse_count", "dvp_fuse_download", "dvp_fuse_last_rounds"]
 
 
 class DvpTimings(ctypes.Structure):

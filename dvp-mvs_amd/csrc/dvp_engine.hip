@@ -1246,8 +1246,14 @@ int dvp_ctx_destroy(dvp_ctx* c) {
 	// teardown: errors are not actionable here
 	(void)hipSetDevice(c->device);
 	{   // maps another thread is still fetching (dvp_download_maps_finish)
-		// (maps that were staged and never fetched — an exception between the two steps — are abandoned, not waited for)
+		// The driver relies on this wait: it hands a context back (and may destroy it) while the view's background job has
+		// not fetched the staged maps yet.  Bounded all the same: maps that were staged and are never fetched — an exception
+		// between the two steps — count as abandoned after DVP_DOWNLOAD_WAIT_S (120) seconds; a fetch that is RUNNING is
+		// always waited for.
+		int limit_s = 120;
+		if (const char* e = getenv("DVP_DOWNLOAD_WAIT_S")) limit_s = atoi(e);
 		std::unique_lock<std::mutex> lk(c->dl_m);
+		c->dl_cv.wait_for(lk, std::chrono::seconds(limit_s > 0 ? limit_s : 1), [c] { return !c->dl_busy; });
 		c->dl_cv.wait(lk, [c] { return !c->dl_fetching; });
 	}
 	if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }

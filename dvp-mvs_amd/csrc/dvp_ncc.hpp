@@ -338,6 +338,31 @@ DVP_HD float geom_cost_cams(const Dev& d, const DvpCamera& rc, const DvpCamera& 
 	return fminf(3.0f, sqrtf(dc * dc + dr * dr));
 }
 
+// geom_cost_cams in two halves, so that a caller can put an NCC evaluation between the depth-map fetch and its use (the fetch is
+// a dependent load at the end of a chain of divisions: dvp_sweep_eval waited for it once per (slot, view)).  Same operations on
+// the same operands in the same order as geom_cost_cams.
+struct GeomFetch { f2 sp; float src_depth; };
+DVP_HD GeomFetch geom_cost_fetch(const Dev& d, const DvpCamera& rc, const DvpCamera& sc, int v, int px, int py, const f4 plane) {
+	const float* dimg = d.depths + (size_t)v * d.plane_stride;
+	const float depth = depth_from_plane(rc, plane, px, py);
+	const f3 fwd = point_on_world((float)px, (float)py, depth, rc);
+	GeomFetch g;
+	float sd;
+	project_on_camera(fwd, sc, &g.sp, &sd);
+	const float cx = fminf(fmaxf(g.sp.x, -1.0f), (float)d.width);
+	const float cy = fminf(fmaxf(g.sp.y, -1.0f), (float)d.height);
+	g.src_depth = tex_texel(dimg, d.org, d.pitch, d.width, d.height, (int)cx, (int)cy);
+	return g;
+}
+DVP_HD float geom_cost_finish(const DvpCamera& rc, const DvpCamera& sc, int px, int py, const GeomFetch& g) {
+	if (g.src_depth == 0.0f) return 3.0f;
+	const f3 back = point_on_world(g.sp.x, g.sp.y, g.src_depth, sc);
+	f2 bp;
+	float rd;
+	project_on_camera(back, rc, &bp, &rd);
+	const float dc = px - bp.x, dr = py - bp.y;
+	return fminf(3.0f, sqrtf(dc * dc + dr * dr));
+}
 
 }  // namespace dvp
 #endif

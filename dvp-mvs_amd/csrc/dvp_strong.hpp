@@ -1223,6 +1223,7 @@ DVP_HD void sweep_eval_px(const Dev& d, int px, int py, int v, int stage, PatchT
 		patch_geometry(d, center, &radius, &inc);
 #if defined(DVP_ABL_SWEEP_NO_TABLE)   // timing ablations (wrong results): where the launch site's time goes, profiles/r06_sweep_ablation.txt
 		c.tab = tab; c.radius = radius; c.inc = inc; c.fast = 1; c.sum_ref = 1.0f; c.sum_ref_ref = 2.0f; c.wsum = 1.0f;
+		for (int t = 0; t < kTaps * kTaps; ++t) tab.set(t, mk2(d.nb_cos, d.nb_sin * (float)t));   // (written, so the evaluator stays alive)
 #else
 		build_patch_ctx(d, px, py, radius, inc, 0, tab, &c);
 #endif
@@ -1240,6 +1241,12 @@ DVP_HD void sweep_eval_px(const Dev& d, int px, int py, int v, int stage, PatchT
 		}
 		f4 pl = origin;
 		pl.w = distance_to_origin(rc, px, py, p_depth, pl);
+		// the geometric term's depth-map fetch is issued before the NCC evaluation and used after it
+		GeomFetch gf;
+		const bool split_geom = P.geom_consistency && cams != nullptr;
+#if !defined(DVP_ABL_SWEEP_NO_GEOM) && !defined(DVP_SWEEP_GEOM_AFTER)
+		if (split_geom) gf = geom_cost_fetch(d, cams[0], cams[1], v + 1, px, py, pl);
+#endif
 #if defined(DVP_ABL_SWEEP_NO_EVAL)
 		const float ncc = pl.w * 1e-3f;
 #else
@@ -1248,11 +1255,13 @@ DVP_HD void sweep_eval_px(const Dev& d, int px, int py, int v, int stage, PatchT
 		if (nevals) *nevals += 1;
 #if defined(DVP_ABL_SWEEP_NO_GEOM)   // timing ablation (wrong results)
 		const float gc = 0.0f;
-#else
+#elif defined(DVP_SWEEP_GEOM_AFTER)   // round 5's order (A/B)
 		const float gc = !P.geom_consistency ? 0.0f : (cams ? geom_cost_cams(d, cams[0], cams[1], v + 1, px, py, pl) : geom_cost(d, px, py, v + 1, pl));
+#else
+		const float gc = !P.geom_consistency ? 0.0f : (split_geom ? geom_cost_finish(cams[0], cams[1], px, py, gf) : geom_cost(d, px, py, v + 1, pl));
 #endif
 #if defined(DVP_ABL_SWEEP_NO_STORE)
-		if (ncc + gc != 12345.678f) continue;   // (never equal: costs are at most 5)
+		if (ncc + gc != d.nb_thresh * 1e30f) continue;   // (never equal; a runtime value, so nothing is folded away)
 #endif
 		if (extra) {
 			float t = ncc;

@@ -105,11 +105,14 @@ void give_pooled(dvp_ctx* ctx, int device, int w, int h, int ni) {
 	std::vector<dvp_ctx*> drop;
 	{
 		std::lock_guard<std::mutex> lock(g_ctx_mutex);
-		// a full pool makes room by dropping a context of ANOTHER shape first (a level that is over, or a view of another
-		// size: with views of mixed sizes in flight those stay while there is room — recreating one costs ~0.3 s at large sizes)
-		if (g_pool.size() >= kPoolSlots)
-			for (size_t i = 0; i < g_pool.size(); ++i)
-				if (g_pool[i].device != device || g_pool[i].w != w || g_pool[i].h != h || g_pool[i].ni != ni) { drop.push_back(g_pool[i].ctx); g_pool.erase(g_pool.begin() + (long)i); break; }
+		// contexts of another shape belong to a level that is over (or to a view of another size): they go first, at once.
+		// (Round 6 tried keeping them while the pool has room — ADVICE r05: views of mixed sizes in flight recreate contexts —
+		// and measured the opposite of a gain on the ten-view schedule: the old level's contexts were then freed LATER, while
+		// another view was inside its launches, and every hipFree stalls that view's own allocations: first weak update of a
+		// level 490 ms instead of 6, profiles/r06_ab_notes.txt.)
+		for (size_t i = 0; i < g_pool.size();)
+			if (g_pool[i].device != device || g_pool[i].w != w || g_pool[i].h != h || g_pool[i].ni != ni) { drop.push_back(g_pool[i].ctx); g_pool.erase(g_pool.begin() + (long)i); }
+			else ++i;
 		if (g_pool.size() >= kPoolSlots) drop.push_back(ctx);
 		else g_pool.push_back(PooledCtx{ ctx, device, w, h, ni });
 	}

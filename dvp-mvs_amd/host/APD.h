@@ -27,7 +27,9 @@ bool ExportPointCloud(const path& point_cloud_path, std::vector<PointList>& poin
 std::string ToFormatIndex(int index);                                                  // APD.cpp:978-982
 template <typename TYPE>
 void RescaleMatToTargetSize(const Mat& src, Mat& dst, int target_width, int target_height);   // APD.cpp:1773-1795
-void RunFusion(const path& dense_folder, const std::vector<Problem>& problems);        // APD.cpp:1809-1960
+void RunFusion(const path& dense_folder, const std::vector<Problem>& problems);        // APD.cpp:1809-1960 (on the device: dvp_fuse_*, include/dvp_mvs.h)
+void SetFusionOnHost(bool on);          // RunFusion on the host's cores instead (same points, same order, same bits)
+void SetFusionDevice(int device);       // the GPU RunFusion uses (default 0)
 void RunFusion_TAT_Intermediate(const path& dense_folder, const std::vector<Problem>& problems);   // APD.cpp:1962-2130
 void RunFusion_TAT_advanced(const path& dense_folder, const std::vector<Problem>& problems);       // APD.cpp:2132-2279
 Mat EdgeSegment(const int scale, const Mat& srcImage, int mode = 0, bool useCanny = false);   // APD.cpp:348-499 (mode 0 + Canny only)

@@ -12,6 +12,7 @@
 // produce a second copy when their own view's turn comes.  Claims make the result depend on the visiting
 // order, which is therefore the reference's (view order, rows, columns, sources).
 #include "APD.h"
+#include "../csrc/dvp_fuse_math.hpp"   // acos / exp as specified functions: host, device kernels and the CPU restatement agree bit for bit
 #include <cfloat>
 #include <chrono>
 #include <future>
@@ -47,8 +48,8 @@ struct Witness { int view, x, y; };
 
 // angle between two unit normals; acos of a value rounded past 1 is NaN -> 0 (APD.cpp:1797-1806)
 float normal_angle(const Vec3f& a, const Vec3f& b) {
-	const float ang = acosf(a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
-	return ang == ang ? ang : 0.0f;
+	const float va[3] = { a[0], a[1], a[2] }, vb[3] = { b[0], b[1], b[2] };
+	return dvp::fuse_angle(va, vb);
 }
 
 // colour image of a view brought to its depth map's resolution; the intrinsics follow the size
@@ -105,7 +106,96 @@ bool load_view(const path& dense_folder, const Problem& problem, FusionView* v) 
 
 }  // namespace
 
+namespace {
+bool g_fusion_on_host = false;
+int g_fusion_device = 0;
+}
+void SetFusionOnHost(bool on) { g_fusion_on_host = on; }
+void SetFusionDevice(int device) { g_fusion_device = device; }
+
+// RunFusion through the engine's C ABI (dvp_fuse_*, csrc/dvp_fuse.hip): this function keeps what the reference does around
+// the scan — maps, colour images and cameras in (APD.cpp:1836-1871), the .ply out (:1955-1958)
+static void RunFusionDevice(const path& dense_folder, const std::vector<Problem>& problems) {
+	const auto t_start = std::chrono::steady_clock::now();
+	auto seconds_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+	const int n_views = (int)problems.size();
+	std::vector<FusionView> views(n_views);
+	std::vector<Mat> blocks(n_views);
+	const bool use_block = std::filesystem::exists(dense_folder / "blocks");
+	int max_id = -1;
+	for (const Problem& p : problems) max_id = std::max(max_id, p.ref_image_id);
+	std::vector<int> slot_of_id(max_id + 1, -1);
+	for (int i = 0; i < n_views; ++i) {
+		std::cout << "Reading image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
+		slot_of_id[problems[i].ref_image_id] = i;
+	}
+	dvp_fuse* job = nullptr;
+	if (dvp_fuse_create(g_fusion_device, std::max(1, n_views), &job) != 0) DvpFatal(std::string("dvp_fuse_create failed: ") + dvp_fuse_last_error(nullptr));
+	std::vector<char> loaded(n_views, 0);
+	// maps from the result cache or the files + one colour JPEG per view on helper threads; the uploads in view order behind them
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::min(HostThreads(), 8))
+	for (int i = 0; i < n_views; ++i) {
+		loaded[i] = load_view(dense_folder, problems[i], &views[i]) ? 1 : 0;
+		if (use_block) blocks[i] = load_block_mask(dense_folder, problems[i].ref_image_id);
+		if (!loaded[i]) continue;
+		FusionView& v = views[i];
+		Mat bgr = v.colour;   // rows may carry padding: the ABI takes packed arrays
+		std::vector<uint8_t> packed;
+		const uint8_t* bgr_ptr = bgr.data;
+		if (bgr.step != (size_t)3 * v.cols()) {
+			packed.resize((size_t)3 * v.cols() * v.rows());
+			for (int y = 0; y < v.rows(); ++y) std::memcpy(packed.data() + (size_t)3 * v.cols() * y, bgr.data + bgr.step * y, (size_t)3 * v.cols());
+			bgr_ptr = packed.data();
+		}
+		const Mat& bl = blocks[i];
+		const bool with_block = use_block && !bl.empty() && bl.cols == v.cols() && bl.rows == v.rows();
+		int rc;
+#pragma omp critical(dvp_fuse_upload)
+		rc = dvp_fuse_set_view(job, i, &v.cam, v.cols(), v.rows(), v.depth.ptr<float>(0), v.normal.ptr<float>(0), v.weak.data, bgr_ptr, with_block ? bl.data : nullptr);
+		if (rc != 0) DvpFatal(std::string("dvp_fuse_set_view failed: ") + dvp_fuse_last_error(job));
+		if (use_block && !bl.empty() && !with_block) DvpFatal("RunFusion: a blocks/ mask of another size than the view's maps");
+		v.depth = Mat(); v.normal = Mat(); v.colour = Mat(); v.weak = Mat();   // on the device now
+	}
+	for (int i = 0; i < n_views; ++i)
+		if (!loaded[i]) std::cerr << "RunFusion: no depth/normal maps for view " << problems[i].ref_image_id << std::endl;
+	const double t_load = seconds_since(t_start);
+	const auto t_fuse0 = std::chrono::steady_clock::now();
+	int rounds_max = 0;
+	long long rest_sum = 0;
+	for (int i = 0; i < n_views; ++i) {
+		std::cout << "Fusing image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
+		if (!loaded[i]) continue;
+		std::vector<int> sources;
+		for (int id : problems[i].src_image_ids)
+			if (id >= 0 && id <= max_id && slot_of_id[id] >= 0 && loaded[slot_of_id[id]]) sources.push_back(slot_of_id[id]);
+		if (dvp_fuse_view(job, i, sources.data(), (int)sources.size()) != 0) DvpFatal(std::string("dvp_fuse_view failed: ") + dvp_fuse_last_error(job));
+		int rounds = 0, rest = 0;
+		dvp_fuse_last_rounds(job, &rounds, &rest);
+		rounds_max = std::max(rounds_max, rounds);
+		rest_sum += rest;
+	}
+	std::vector<PointList> cloud((size_t)dvp_fuse_count(job));
+	static_assert(sizeof(PointList) == 24, "six floats");
+	if (dvp_fuse_download(job, cloud.empty() ? nullptr : &cloud[0].coord.x) != 0) DvpFatal(std::string("dvp_fuse_download failed: ") + dvp_fuse_last_error(job));
+	dvp_fuse_destroy(job);
+	const double t_fuse = seconds_since(t_fuse0);
+	const auto t_write0 = std::chrono::steady_clock::now();
+	const path ply_path = dense_folder / "APD" / "APD.ply";
+	ExportPointCloud(ply_path, cloud);
+	std::cout << "Fusion: " << cloud.size() << " points -> " << ply_path << std::endl;
+	std::cout << "  [fusion] device " << g_fusion_device << ": read maps + images + upload " << t_load << " s, fuse + download " << t_fuse << " s (at most " << rounds_max
+	          << " resolve rounds per view, " << rest_sum << " pixels finished sequentially), write " << seconds_since(t_write0) << " s" << std::endl;
+}
+
+static void RunFusionHost(const path& dense_folder, const std::vector<Problem>& problems);
 void RunFusion(const path& dense_folder, const std::vector<Problem>& problems) {
+	if (g_fusion_on_host) RunFusionHost(dense_folder, problems);
+	else RunFusionDevice(dense_folder, problems);
+}
+
+// The same scan on the host's cores (apd --fusion-on host; the form rounds 3-5 shipped): kept as a second implementation the
+// tests compare with the device path and the sequential restatement.
+static void RunFusionHost(const path& dense_folder, const std::vector<Problem>& problems) {
 	const auto t_start = std::chrono::steady_clock::now();
 	auto seconds_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
 	const int n_views = (int)problems.size();
@@ -196,7 +286,7 @@ void RunFusion(const path& dense_folder, const std::vector<Problem>& problems) {
 						const float ang = normal_angle(n_ref, S.normal.at<Vec3f>(sy, sx));
 						if (err < 2.0f && rel < 0.01f && ang < 0.174533f) {
 							const uint8_t* c = S.bgr(sx, sy);
-							out[n++] = Candidate{ s, sy * S.cols() + sx, (float)std::exp(-(err + 200 * rel + ang * 10)), { c[0], c[1], c[2] } };
+							out[n++] = Candidate{ s, sy * S.cols() + sx, dvp::fuse_expf(-(err + 200 * rel + ang * 10)), { c[0], c[1], c[2] } };
 						}
 					}
 					bl.count[p] = (short)n;

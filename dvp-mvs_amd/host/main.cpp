@@ -2,7 +2,7 @@
 // `class APD`, one process per GPU.
 //   apd <dense_folder> [gpu_index] [--max-src N] [--iters N] [--min-scale S] [--passes P] [--seed X]
 //       [--rank R --world N --job ID [--transport rccl|host] [--collective-timeout SEC]] [--jacobi] [--labels]
-//       [--no-fusion | --fusion eth|tat-intermediate|tat-advanced]
+//       [--no-fusion | --fusion eth|tat-intermediate|tat-advanced] [--fusion-on device|host]
 //
 // Schedule.  The image pyramid has round_num levels (the longer side is halved until <= 800).  Level i
 // runs one "A" pass without geometric consistency — FIRST_INIT from scratch / the Depth-Anything prior
@@ -46,6 +46,7 @@ struct Options {
 	int views_in_flight = 0;               // --views-in-flight N: that many views of a pass at once (default 2) where the order allows it and the level is small; 1 = never
 	long long in_flight_pixels = 2 << 20;  // ... "small" = at most this many pixels (--in-flight-pixels)
 	std::string job, transport = "rccl";
+	bool fusion_on_host = false;           // --fusion-on host: RunFusion on the host's cores instead of the GPU (same .ply)
 	std::string fusion_kind = "eth";   // eth | tat-intermediate | tat-advanced (APD.h:52-54; the reference's main calls the first)
 };
 
@@ -467,6 +468,7 @@ Options ParseOptions(int argc, char** argv) {
 		else if (s == "--in-flight-pixels") { if (a + 1 < argc) o.in_flight_pixels = atoll(argv[++a]); }
 		else if (s == "--host-rescale") o.host_rescale = true;     // the coarser level's maps are up-sampled on the host (APD::SetDeviceRescale(false))
 		else if (s == "--fusion") { if (a + 1 < argc) o.fusion_kind = argv[++a]; }
+		else if (s == "--fusion-on") { if (a + 1 < argc) o.fusion_on_host = std::string(argv[++a]) == "host"; }   // device (default) | host
 	}
 	if (o.world > 1) o.jacobi = true;
 	if (o.job.empty())   // a launcher-provided id; with --world > 1 RankComm refuses to start without one
@@ -706,7 +708,11 @@ int main(int argc, char** argv) {
 	if (opt.fusion && opt.rank == 0) {
 		if (opt.fusion_kind == "tat-intermediate") RunFusion_TAT_Intermediate(opt.dense_folder, problems);
 		else if (opt.fusion_kind == "tat-advanced") RunFusion_TAT_advanced(opt.dense_folder, problems);
-		else RunFusion(opt.dense_folder, problems);
+		else {
+			SetFusionOnHost(opt.fusion_on_host);
+			SetFusionDevice(opt.gpu);
+			RunFusion(opt.dense_folder, problems);
+		}
 	}
 	ShutdownResultStore();
 	main_lap("fusion + shutdown");

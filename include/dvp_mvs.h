@@ -185,7 +185,8 @@ int dvp_image_format(const dvp_ctx* ctx);
 
 /* ---- run (APD::RunPatchMatch, APD.cu:4406-4532) ---------------------------------------------- */
 int dvp_run_patchmatch(dvp_ctx* ctx);
-/* one launch site of the sequence; colour: 0 = Black*, 1 = Red* for the half launches */
+/* one launch site of the sequence; colour: 0 = Black*, 1 = Red* for the half launches (weak update also 2 = both colours as
+ * one launch site, which is how dvp_run_patchmatch issues it: the two launches commute) */
 int dvp_run_stage(dvp_ctx* ctx, int stage, int iter, int colour);
 int dvp_synchronize(dvp_ctx* ctx);
 
@@ -226,6 +227,32 @@ int dvp_eval_cost_vectors(dvp_ctx* ctx, const int32_t* px, const float* planes, 
 /* sha256 of the kernel sources the library was built from (tools/csrc_hash.py), + the extra flags of a variant build */
 const char* dvp_build_id(void);
 int dvp_bench_cost_kernel(dvp_ctx* ctx, int repeat, float* mean_kernel_ms, uint64_t* evals_per_launch);
+
+/* ---- depth-map fusion (RunFusion, APD.cpp:1809-1960) on the device ------------------------------
+ * Replaces the body of the reference's host loop over views / pixels / sources: the geometric tests of every (pixel, source)
+ * pair (Get3DPointonWorld + ProjectCamera + GetAngle, APD.cpp:1893-1931), the consistency vote (:1926-1929), the acceptance
+ * (:1934) and the claims on the witnesses (`masks[...]`, :1888, 1911, 1942) — same points, same order, same bits as the
+ * sequential scan (dvp-mvs_amd/csrc/dvp_fuse.hip says how the order-dependent claims are resolved in parallel).  The caller
+ * keeps what the reference does around it: reading maps / images / cameras (:1836-1871) and writing the .ply (:1955-1958).
+ * One job = one scene on one device.  acos / exp are the specified functions of csrc/dvp_fuse_math.hpp. */
+typedef struct dvp_fuse dvp_fuse;
+int dvp_fuse_create(int device, int num_views, dvp_fuse** out);
+int dvp_fuse_destroy(dvp_fuse* job);
+const char* dvp_fuse_last_error(const dvp_fuse* job);        /* job == NULL: the error of a failed dvp_fuse_create */
+/* the maps of view slot `view` (host pointers, copied): camera with the intrinsics ALREADY rescaled to the maps' size
+ * (RescaleImageAndCamera, APD.cpp:1750-1771), depth [rows*cols], normal [rows*cols*3], weak_info [rows*cols] or NULL
+ * (every pixel STRONG), bgr [rows*cols*3] (the colour image at the maps' size), block [rows*cols] or NULL
+ * (blocks/mask_<id>.jpg: reference pixels below 128 are skipped, APD.cpp:1885-1887) */
+int dvp_fuse_set_view(dvp_fuse* job, int view, const DvpCamera* cam, int cols, int rows, const float* depth,
+                      const float* normal_xyz, const uint8_t* weak_info, const uint8_t* bgr, const uint8_t* block);
+/* one iteration of the reference's outer loop (APD.cpp:1874): view slot `view` scanned against the source slots `src`
+ * (pair.txt order, sources without maps left out); accepted points are appended to the cloud in scan order */
+int dvp_fuse_view(dvp_fuse* job, int view, const int* src, int num_src);
+long long dvp_fuse_count(const dvp_fuse* job);               /* points so far */
+/* dvp_fuse_count() records of six floats — x y z b g r, struct PointList (main.h:69-72) — in scan order */
+int dvp_fuse_download(dvp_fuse* job, float* points);
+/* statistics of the last dvp_fuse_view: rounds of the parallel claim resolution, pixels left to the sequential finish */
+int dvp_fuse_last_rounds(const dvp_fuse* job, int* rounds, int* rest);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@
 #include "ora_common.h"
 #include <cfloat>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -43,9 +44,48 @@ void ProjectCamera(const float3 PointX, const Camera camera, float2& point, floa
 	point.x = (camera.K[0] * tmp.x + camera.K[1] * tmp.y + camera.K[2] * tmp.z) / depth;
 	point.y = (camera.K[3] * tmp.x + camera.K[4] * tmp.y + camera.K[5] * tmp.z) / depth;
 }
+// acos as the fusion's numerics contract specifies it (the oracle's own statement of dvp-mvs_amd/csrc/dvp_fuse_math.hpp): binary32,
+// one IEEE operation per step, three ranges — a rational R(z) ~ (asin(x) - x) / x^3 below 0.5, acos(x) = 2 asin(sqrt((1 - x) / 2))
+// with a split square root above, mirrored below -0.5.  The reference calls libm's acos (APD.cpp:1800), whose low-order bits
+// depend on the C library it is linked with; like it, this is < 1 ulp from the true value.
+float acos_contract(float x) {
+	const float pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+	const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f, pS2 = -8.6563630030e-03f, qS1 = -7.0662963390e-01f;
+	uint32_t hx;
+	std::memcpy(&hx, &x, 4);
+	const uint32_t ix = hx & 0x7fffffffu;
+	if (ix >= 0x3f800000u) {
+		if (ix == 0x3f800000u) return (hx >> 31) ? pi + 2.0f * pio2_lo : 0.0f;
+		return (x - x) / (x - x);
+	}
+	if (ix < 0x3f000000u) {
+		if (ix <= 0x32800000u) return pio2_hi + pio2_lo;
+		const float z = x * x;
+		const float r = (z * (pS0 + z * (pS1 + z * pS2))) / (1.0f + z * qS1);
+		return pio2_hi - (x - (pio2_lo - x * r));
+	}
+	if (hx >> 31) {
+		const float z = (1.0f + x) * 0.5f;
+		const float p = z * (pS0 + z * (pS1 + z * pS2)), q = 1.0f + z * qS1;
+		const float s = sqrtf(z);
+		const float w = (p / q) * s - pio2_lo;
+		return pi - 2.0f * (s + w);
+	}
+	const float z = (1.0f - x) * 0.5f;
+	const float s = sqrtf(z);
+	uint32_t is;
+	std::memcpy(&is, &s, 4);
+	is &= 0xfffff000u;
+	float df;
+	std::memcpy(&df, &is, 4);
+	const float c = (z - df * df) / (s + df);
+	const float p = z * (pS0 + z * (pS1 + z * pS2)), q = 1.0f + z * qS1;
+	const float w = (p / q) * s + c;
+	return 2.0f * (df + w);
+}
 float GetAngle(const float* v1, const float* v2) {   // APD.cpp:1797-1806
 	float dot_product = v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2];
-	float angle = acosf(dot_product);
+	float angle = acos_contract(dot_product);
 	if (angle != angle) return 0.0f;
 	return angle;
 }
@@ -101,7 +141,7 @@ int ora_run_fusion(int num_images, int rows, int cols, const Camera* cameras, co
 							used_list[j].x = src_c;
 							used_list[j].y = src_r;
 							float tmp_index = reproj_error + 200 * relative_depth_diff + angle * 10;
-							dynamic_consistency += std::exp(-tmp_index);
+							dynamic_consistency += ora::dvp_expf_contract(-tmp_index);   // exp by the contract (ora_common.h), as the engine's
 							num_consistent++;
 						}
 					}

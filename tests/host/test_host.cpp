@@ -84,6 +84,8 @@ static int fuse_folder(const path& folder) {
 		for (int j = 0; j < k; ++j) { int id; float sc; in >> id >> sc; if (sc > 0) p.src_image_ids.push_back(id); }
 		problems.push_back(p);
 	}
+	const char* on = std::getenv("DVP_FUSION_ON");   // host: the scan on the host's cores; default: the device path (dvp_fuse_*)
+	SetFusionOnHost(on && std::string(on) == "host");
 	const char* kind = std::getenv("DVP_FUSION_KIND");
 	if (kind && std::string(kind) == "tat-intermediate") RunFusion_TAT_Intermediate(folder, problems);
 	else if (kind && std::string(kind) == "tat-advanced") RunFusion_TAT_advanced(folder, problems);

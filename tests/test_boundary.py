@@ -93,8 +93,16 @@ def test_fusion_cpu(tmp_path):
         write_binmat(os.path.join(r, "APD_normals.dmb"), np.tile(n.astype(np.float32), (H, W, 1)), 21)
         write_binmat(os.path.join(r, "weak.bin"), np.ones((H, W), np.uint8), 0)
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "host")])
-    out = subprocess.run([os.path.join(ROOT, "tests", "host", "test_host"), "--fuse", d], capture_output=True, text=True)
+    # the host flavour of RunFusion (apd --fusion-on host); on a GPU box the same folder also goes through the device path
+    # (dvp_fuse_*), which must leave the same file
+    host_env = dict(os.environ, DVP_FUSION_ON="host")
+    out = subprocess.run([os.path.join(ROOT, "tests", "host", "test_host"), "--fuse", d], capture_output=True, text=True, env=host_env)
     assert out.returncode == 0, out.stdout[-500:] + out.stderr[-500:]
+    if os.path.exists("/dev/kfd"):
+        ply_host = open(os.path.join(d, "APD", "APD.ply"), "rb").read()
+        dev = subprocess.run([os.path.join(ROOT, "tests", "host", "test_host"), "--fuse", d], capture_output=True, text=True)
+        assert dev.returncode == 0 and "resolve rounds" in dev.stdout, dev.stdout[-500:] + dev.stderr[-500:]
+        assert open(os.path.join(d, "APD", "APD.ply"), "rb").read() == ply_host
     # the Tanks & Temples acceptance rules (APD.cpp:1962-2279): k >= 2 agreeing witnesses within k-scaled,
     # much tighter thresholds (0.25 k px, k / 3500): with nearest-pixel witnesses on a 96x64 grid only part
     # of the pixels qualify; the advanced variant (no normal test, k / 3000) keeps more
@@ -105,7 +113,7 @@ def test_fusion_cpu(tmp_path):
         n2 = int(open(os.path.join(d, "APD", "APD.ply"), "rb").read(300).decode("latin1").split("element vertex ")[1].split("\n")[0])
         counts[kind] = n2
     assert 0.1 * W * H < counts["tat-intermediate"] < counts["tat-advanced"] < NV * W * H, counts
-    out = subprocess.run([os.path.join(ROOT, "tests", "host", "test_host"), "--fuse", d], capture_output=True, text=True)
+    out = subprocess.run([os.path.join(ROOT, "tests", "host", "test_host"), "--fuse", d], capture_output=True, text=True, env=host_env)
     raw = open(os.path.join(d, "APD", "APD.ply"), "rb").read()
     head, body = raw.split(b"end_header\n", 1)
     npts = int(head.decode().split("element vertex ")[1].split("\n")[0])

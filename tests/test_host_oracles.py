@@ -42,10 +42,24 @@ def _read_ply(path):
 
 @pytest.mark.parametrize("kind,with_blocks", [("eth", False), ("eth", True), ("tat-intermediate", False), ("tat-intermediate", True), ("tat-advanced", False)])
 def test_fusion_equals_sequential_restatement(tmp_path, kind, with_blocks):
-    """RunFusion / RunFusion_TAT_Intermediate / RunFusion_TAT_advanced (host/fusion.cpp) against the sequential restatements
-    of APD.cpp:1809-1960 / 1962-2130 / 2132-2279 (oracle/ora_host.cpp): the same points in the same order, coordinates
-    bit for bit, colours as the PLY stores them."""
-    W, H, NV, NSRC = 80, 56, 5, (3 if kind == "eth" else 4)
+    """RunFusion / RunFusion_TAT_Intermediate / RunFusion_TAT_advanced on the host's cores (host/fusion.cpp) against the
+    sequential restatements of APD.cpp:1809-1960 / 1962-2130 / 2132-2279 (oracle/ora_host.cpp): the same points in the same
+    order, coordinates bit for bit, colours as the PLY stores them."""
+    _fusion_case(tmp_path, kind, with_blocks, "host")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_blocks,size", [(False, (80, 56)), (True, (80, 56)), (False, (333, 250))])
+def test_device_fusion_equals_sequential_restatement(tmp_path, with_blocks, size):
+    """RunFusion as the driver runs it — on the GPU through dvp_fuse_* (csrc/dvp_fuse.hip: candidates in parallel, the
+    order-dependent claims resolved in rounds) — against the same sequential restatement: the same point list.  The larger
+    case has tens of thousands of pixels that share witnesses (several resolve rounds)."""
+    _fusion_case(tmp_path, "eth", with_blocks, "device", size=size)
+
+
+def _fusion_case(tmp_path, kind, with_blocks, where, size=(80, 56)):
+    W, H = size
+    NV, NSRC = 5, (3 if kind == "eth" else 4)
     depth_noise = 0.0012 if kind == "eth" else 0.0004   # the graded variants accept k / 3500 ... k / 3000 of relative depth difference
     d = str(tmp_path / "scene")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), str(NSRC)], stdout=subprocess.DEVNULL)
@@ -83,7 +97,10 @@ def test_fusion_equals_sequential_restatement(tmp_path, kind, with_blocks):
             fn = os.path.join(d, "blocks", "mask_%d.jpg" % v)
             Image.fromarray(m, "L").save(fn, quality=95)
             blocks.append(np.ascontiguousarray(np.array(Image.open(fn).convert("L"))))
-    out = _host_tool("--fuse", d, env=dict(os.environ, DVP_FUSION_KIND=kind))
+    out = _host_tool("--fuse", d, env=dict(os.environ, DVP_FUSION_KIND=kind, DVP_FUSION_ON=where))
+    if where == "device":
+        assert "resolve rounds" in out.stdout, out.stdout[-400:]
+        print(out.stdout.strip().split("\n")[-1])
     assert out.returncode == 0, out.stdout[-600:] + out.stderr[-600:]
     got = _read_ply(os.path.join(d, "APD", "APD.ply"))
 
