@@ -585,6 +585,41 @@ extern "C" __global__ void __launch_bounds__(256) dvp_gen_candidates(const Dev d
 		gen_candidates_px(d, px, py, (int)blockIdx.y);
 }
 
+// ... and the same for the ANCHOR pixels only (dvp_run_patchmatch).  The weak update is the records' one reader, and it reads
+// them at the anchors of WEAK pixels (make_anchor_record, wave_ncc_new: the anchor's eight offsets per view, APD.cu:938-952) —
+// after GenNeighbours that is a few percent of the image where the reference's GenEdgeInform fills every pixel x view (52 ms
+// of side-stream work at 6208x4128, S = 9).  Three launches: mark the anchors of the WEAK list, compact the marks into a
+// list (any order), one lane per (listed pixel, view).  They read the selected-view map as GenEdgeInform saw it (a snapshot
+// taken before RandomInitialization rewrites it), so the records are those of the full launch.
+extern "C" __global__ void __launch_bounds__(256) dvp_anchor_mask(const Dev d, const ListArgs a, uint8_t* mask) {
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	if (t >= a.count) return;
+	const int center = d.weak_list[a.base + t];
+	const s2* nb = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
+	for (int k = 1; k < DVP_NEIGHBOUR_NUM; ++k) {
+		const s2 q = nb[k];
+		if (q.x >= 0 && q.y >= 0 && q.x < d.width && q.y < d.height) mask[(size_t)q.y * d.width + q.x] = 1;
+	}
+}
+extern "C" __global__ void __launch_bounds__(256) dvp_mask_compact(const uint8_t* mask, size_t L, unsigned* list, unsigned* n_list) {
+	const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+	const bool go = p < L && mask[p] != 0;
+	const unsigned long long m = __ballot(go);
+	if (!m) return;
+	const int lane = threadIdx.x & 63;
+	unsigned base = 0;
+	if (lane == __builtin_ctzll(m)) base = atomicAdd(n_list, (unsigned)__popcll(m));
+	base = __shfl(base, __builtin_ctzll(m), 64);
+	if (go) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)p;
+}
+extern "C" __global__ void __launch_bounds__(256) dvp_gen_candidates_list(const Dev d, const unsigned* list, const unsigned* n_list) {
+	const unsigned t = blockIdx.x * 256 + threadIdx.x;
+	if (t >= *n_list) return;
+	const int center = (int)list[t];
+	const int py = center / d.width, px = center - py * d.width;
+	gen_candidates_px(d, px, py, (int)blockIdx.y);
+}
+
 extern "C" __global__ void dvp_pack_bits_transposed(const uint8_t* __restrict__ map, uint32_t* __restrict__ bits, int W, int H, int tiles_x, size_t words, int equals) {
 	const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (w < words) bits[w] = pack_edge_word_t(map, W, H, tiles_x, w, equals);
@@ -1014,6 +1049,17 @@ struct dvp_ctx {
 	hipStream_t stream = nullptr;
 	// second stream of dvp_run_patchmatch: the visibility-prior candidates (VALU-bound, read by the weak updates only)
 	// run beside the latency-bound list kernels of the weak path's preparation
+	// visibility-prior candidates at anchor pixels only (dvp_run_patchmatch; DVP_CAND_MASK=0: every pixel, as dvp_run_stage)
+	// Which form pays depends on the WEAK share: the full launch runs on the side stream beside the latency-bound anchor search and
+	// is hidden when that takes long enough (>= ~4.5 % WEAK at 6208x4128: bench cfg3, 6.9 % — masked there it would run beside
+	// RandomInit and the strong update instead and cost them 28 ms); at the 1-3 % WEAK of the real schedule's full-size passes the
+	// anchor search is over after 12-38 ms and the full launch was 50-60 ms exposed per view (profiles/r06_e2e_apd.txt).
+	// DVP_CAND_MASK=1 / 0 forces a form; default: masked below 4 % WEAK.
+	int cand_mask_mode = -1;
+	bool cand_mask_on = true;
+	uint8_t* cand_mask = nullptr;
+	unsigned *cand_list = nullptr, *cand_n = nullptr;
+	uint32_t* sel_snap = nullptr;
 	hipStream_t side = nullptr;
 	hipEvent_t side_fork = nullptr, side_join = nullptr;
 	Dev d{};
@@ -1170,6 +1216,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	if (const char* e = getenv("DVP_SWEEP_SPLIT")) { c->sweep_split = atoi(e) != 0; c->sweep_force = atoi(e) == 2; }
 	if (const char* e = getenv("DVP_WEAK_ANCHOR_TAB")) c->anchor_tab_off = atoi(e) == 0;   // A/B measurements and the tests of the per-item form
 	if (const char* e = getenv("DVP_GN_WAVE")) c->gn_wave = atoi(e) != 0;
+	if (const char* e = getenv("DVP_CAND_MASK")) c->cand_mask_mode = atoi(e) != 0 ? 1 : 0;
 	if (const char* e = getenv("DVP_WEAK_PHASED")) c->weak_phased = atoi(e) != 0;
 	if (const char* e = getenv("DVP_WEAK_PHASED_MIN")) c->weak_phased_min = atoi(e);
 	if (const char* e = getenv("DVP_WEAK_RUNS")) {
@@ -1885,7 +1932,19 @@ int dvp_run_patchmatch(dvp_ctx* c) {
 	// The candidates read the images, the sector tables and selected_views (which RandomInitialization is the first
 	// to write) and are read by the weak updates: they run on the side stream from here to just before RandomInit.
 	const bool side_work = c->d.weak_count > 0;
-	if (side_work) {
+	bool masked = side_work && c->cand_mask_on && (c->cand_mask_mode == 1 || (c->cand_mask_mode < 0 && (size_t)c->d.weak_count * 25 < c->L));
+	if (masked && !c->cand_mask) {   // mark bytes, anchor list, snapshot of the selected-view map: 9 bytes per pixel
+		void *m = nullptr, *l = nullptr, *n = nullptr, *sv = nullptr;
+		if (hipMalloc(&m, c->L) != hipSuccess || hipMalloc(&l, c->L * 4) != hipSuccess || hipMalloc(&n, 4) != hipSuccess || hipMalloc(&sv, (c->L + c->W) * 4) != hipSuccess) {
+			(void)hipGetLastError();
+			for (void* p : { m, l, n, sv }) if (p) (void)hipFree(p);
+			c->cand_mask_on = masked = false;   // no room: every pixel, as before
+		} else {
+			for (void* p : { m, l, n, sv }) c->allocs.push_back(p);
+			c->cand_mask = (uint8_t*)m; c->cand_list = (unsigned*)l; c->cand_n = (unsigned*)n; c->sel_snap = (uint32_t*)sv;
+		}
+	}
+	if (side_work && !masked) {
 		if (!c->sector_taps) { c->error = "dvp_set_params must be called before running kernels"; return 1; }
 		HIP_TRY(c, hipEventRecord(c->side_fork, c->stream));
 		HIP_TRY(c, hipStreamWaitEvent(c->side, c->side_fork, 0));
@@ -1900,7 +1959,28 @@ int dvp_run_patchmatch(dvp_ctx* c) {
 	if (launch_stage(c, DVP_ST_FIND_NEAREST_STRONG, 0, 0)) return 1;
 	if (launch_stage(c, DVP_ST_GEN_NEIGHBOURS, 0, 0)) return 1;
 	if (launch_stage(c, DVP_ST_NEIGHBOUR_UPDATE, 0, 0)) return 1;
-	if (side_work) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_join, 0));
+	if (side_work && !masked) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_join, 0));
+	if (masked) {
+		// the anchors are known now; RandomInitialization is the first to rewrite the selected views the candidates read: they
+		// get a snapshot and run beside RandomInit and the first strong updates, joined in front of the first weak update
+		if (!c->sector_taps) { c->error = "dvp_set_params must be called before running kernels"; return 1; }
+		HIP_TRY(c, hipMemcpyAsync(c->sel_snap, c->selected_views, (c->L + c->W) * 4, hipMemcpyDeviceToDevice, c->stream));
+		HIP_TRY(c, hipEventRecord(c->side_fork, c->stream));
+		HIP_TRY(c, hipStreamWaitEvent(c->side, c->side_fork, 0));
+		HIP_TRY(c, hipMemsetAsync(c->cand_mask, 0, c->L, c->side));
+		HIP_TRY(c, hipMemsetAsync(c->cand_n, 0, 4, c->side));
+		ListArgs la;
+		la.base = 0; la.count = c->d.weak_black + c->d.weak_red; la.iter = 0; la.covered_rows = 0; la.group = 1; la.run = 1;
+		if (la.count > 0) hipLaunchKernelGGL(dvp_anchor_mask, dim3((la.count + 255) / 256), dim3(256), 0, c->side, c->d, la, c->cand_mask);
+		hipLaunchKernelGGL(dvp_mask_compact, dim3((unsigned)((c->L + 255) / 256)), dim3(256), 0, c->side, c->cand_mask, c->L, c->cand_list, c->cand_n);
+		// (the list's length stays on the device: the grid covers the at most 11 anchors per WEAK pixel, blocks past the end leave)
+		const size_t most = std::min(c->L, (size_t)la.count * (DVP_NEIGHBOUR_NUM - 1));
+		Dev dsnap = c->d;
+		dsnap.selected_views = c->sel_snap;
+		if (most > 0) hipLaunchKernelGGL(dvp_gen_candidates_list, dim3((unsigned)((most + 255) / 256), (unsigned)(c->NI - 1)), dim3(256), 0, c->side, dsnap, c->cand_list, c->cand_n);
+		HIP_TRY(c, hipGetLastError());
+		HIP_TRY(c, hipEventRecord(c->side_join, c->side));
+	}
 	if (launch_stage(c, DVP_ST_RANDOM_INIT, 0, 0)) return 1;
 	HIP_TRY(c, hipEventRecord(itl.a, c->stream));
 	for (int i = 0; i < c->d.params.max_iterations; ++i) {
@@ -1911,6 +1991,7 @@ int dvp_run_patchmatch(dvp_ctx* c) {
 		if (c->d.weak_count == 0 && i == c->d.params.max_iterations - 1)
 			HIP_TRY(c, hipMemcpyAsync(c->fit_planes, c->planes, c->L * 16, hipMemcpyDeviceToDevice, c->stream));
 		if (c->d.weak_count > 0) {   // these three only touch WEAK pixels
+			if (masked && i == 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_join, 0));   // the anchors' candidate records
 			if (launch_stage(c, DVP_ST_RANSAC_FIT, i, 0)) return 1;
 			// Black then red (APD.cu:4487-4489).  A WEAK pixel's update reads other pixels' state only at its anchors, which are STRONG
 			// (GenNeighbours) and which no weak update writes: the two launches commute, and as the eight launches of the phased form
@@ -1923,6 +2004,7 @@ int dvp_run_patchmatch(dvp_ctx* c) {
 			}
 		}
 	}
+	if (masked && c->d.params.max_iterations <= 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_join, 0));
 	HIP_TRY(c, hipEventRecord(itl.b, c->stream));
 	if (launch_stage(c, DVP_ST_GET_DEPTH_NORMAL, 0, 0)) return 1;
 	if (launch_stage(c, DVP_ST_FILTER_STRONG, 0, 0)) return 1;

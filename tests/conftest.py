@@ -13,6 +13,9 @@ if ROOT not in sys.path:
 # The engine hands a launch of fewer than 8192 WEAK pixels to the one-wave kernel (the eight launches of the phased weak update
 # cost more than they save there).  The parity scenes are small: without this every test would exercise the one-wave form only.
 os.environ.setdefault("DVP_WEAK_PHASED_MIN", "0")
+# dvp_run_patchmatch forms the visibility-prior records at anchor pixels only when less than 4 % of the view is WEAK (the full
+# launch is hidden behind the anchor search above that); the parity scenes have more: force the masked form, the one with logic in it.
+os.environ.setdefault("DVP_CAND_MASK", "1")
 
 
 def pytest_configure(config):

@@ -125,7 +125,7 @@ def _oracle_like(r):
 
 
 def _sampled_stage_parity(name, weak_frac, n_random):
-    r = _engine_for(name, weak_frac, env=dict(DVP_WEAK_PHASED_MIN=None))   # the shipped dispatch (tests/conftest.py forces 0 for the small scenes)
+    r = _engine_for(name, weak_frac, env=dict(DVP_WEAK_PHASED_MIN=None, DVP_CAND_MASK="1"))   # the shipped weak-update dispatch (tests/conftest.py forces 0 for the small scenes); candidates at anchors only
     g, W, H, S, iters = r["g"], r["W"], r["H"], r["S"], r["iters"]
     L = W * H
     o = _oracle_like(r)
@@ -170,17 +170,30 @@ def _sampled_stage_parity(name, weak_frac, n_random):
     o.close()
     print("%s: %d sampled pixels (%d WEAK), %d buffer comparisons, %.0f s" % (name, len(px), int(was_weak.sum()), compared, time.time() - t0))
     # ---- the forms at full size, all pixels: one dvp_run_patchmatch from the same inputs ----
+    # dvp_run_patchmatch forms the visibility-prior records at the ANCHOR pixels only (their one reader is the weak update, at
+    # the anchors of WEAK pixels): `candidate` is compared there, every other buffer everywhere
+    nbs = final["neighbours"].reshape(-1, 12, 2)[:, 1:, :].reshape(-1, 2).astype(np.int64)
+    anchors = np.unique(nbs[nbs[:, 0] >= 0][:, 1] * W + nbs[nbs[:, 0] >= 0][:, 0]) if wc > 0 else np.zeros(0, np.int64)
+
+    def same_as_final(eng, what):
+        for n in CHECKED:
+            a, b = final[n], eng.get(n)
+            if n == "candidate":
+                a, b = a.reshape(L, -1)[anchors], b.reshape(L, -1)[anchors]
+            assert count_diff(a, b) == 0, "%s: %s in %s" % (name, what, n)
+
+    g.set("candidate", np.zeros_like(final["candidate"]))      # (nothing left over from the launch-by-launch run)
     g.restore_state()
     g.run_patchmatch()
-    for n in CHECKED:
-        assert count_diff(final[n], g.get(n)) == 0, "%s: dvp_run_patchmatch and the launch-by-launch run differ in %s" % (name, n)
+    same_as_final(g, "dvp_run_patchmatch and the launch-by-launch run differ")
+    if wc > 0:
+        assert len(anchors) > 1000 and len(anchors) < 0.6 * L
     g.close()
     del g, r
     # ... and with every monolithic fall-back form
-    r2 = _engine_for(name, weak_frac, env=dict(DVP_STRONG_SPLIT="0", DVP_SWEEP_SPLIT="0", DVP_WEAK_PHASED="0"))
+    r2 = _engine_for(name, weak_frac, env=dict(DVP_STRONG_SPLIT="0", DVP_SWEEP_SPLIT="0", DVP_WEAK_PHASED="0", DVP_CAND_MASK="0"))
     r2["g"].run_patchmatch()
-    for n in CHECKED:
-        assert count_diff(final[n], r2["g"].get(n)) == 0, "%s: the fall-back forms differ from the default forms in %s" % (name, n)
+    same_as_final(r2["g"], "the fall-back forms differ from the default forms")
     r2["g"].close()
 
 
