@@ -43,7 +43,7 @@ VALU_MEASURED_PEAK_GINST = 977.5
 VALU_CEILING_BY_WAVES = {1: 501.6, 2: 761.6, 3: 852.3, 4: 896.1, 6: 943.3, 8: 977.5}
 GATHER_ROOF_GLINES = 51.4   # tools/gather_peak.hip on MI355X (profiles/r02_gather_peak.txt): 128-byte line requests per second of 16-byte gathers = 6.6 TB/s
 WAVES_PER_SIMD = {"strong_update": 2, "depth_to_weak": 2, "local_refine": 2, "random_init": 2, "weak_update": 4}
-PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_r05.json")
+PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_r06.json")
 EVALUATOR_PEAK_GEVALS = 32.7   # the 36-tap evaluator alone at 2 waves per SIMD (tools/pv_probe.py, profiles/r03_pv_probe.txt): what a launch site of NCC evaluations can reach at best
 
 
@@ -243,7 +243,7 @@ def cpu_baseline(pkg, args, cfg, S, iters, device=0):
 
 
 def pmc_lookup(kernel, W, H, S):
-    """PMC counters of `kernel` at exactly this problem size (profiles/pmc_r05.json, written by
+    """PMC counters of `kernel` at exactly this problem size (profiles/pmc_r06.json, written by
     tools/pmc_table.py from separate rocprofv3 --pmc passes of this bench ON THE SAME KERNEL SOURCES) or None."""
     t, _ = pmc_table()
     if RIG != "rotated" or SRC_DEPTHS != "estimated":     # the table is collected on the default workload
@@ -253,7 +253,7 @@ def pmc_lookup(kernel, W, H, S):
 
 def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
     """Roofline entry of one launch site; a reader can recompute every fraction from profiles/ alone:
-      frac (bound "valu")  = SQ_INSTS_VALU per launch (profiles/pmc_r05.json) / live launch time / 1228.8 G/s
+      frac (bound "valu")  = SQ_INSTS_VALU per launch (profiles/pmc_r06.json) / live launch time / 1228.8 G/s
                              (guide peak: 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 v_fma_f32);
       valu_frac_of_measured_issue_peak = same rate / 977.5 G/s (tools/valu_peak.hip, 8 waves per SIMD);
       valu_frac_of_occupancy_ceiling   = same rate / the measured ceiling at the kernel's own waves per SIMD;
@@ -268,7 +268,7 @@ def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
     sec = avg_ms * 1e-3
     alg = evals_per_launch * NCC_BYTES / sec / 1e9 if (sec > 0 and evals_per_launch) else None
     pmc = pmc_lookup(k, W, H, S)
-    SUMMED = ("hbm_bytes_per_launch", "SQ_INSTS_VALU", "TCC_MISS", "TCC_HIT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU")
+    SUMMED = ("hbm_bytes_per_launch", "SQ_INSTS_VALU", "TCC_MISS", "TCC_HIT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "TCP_TOTAL_CACHE_ACCESSES", "TCP_TCC_READ_REQ")
     if pmc and primary_launches(stage) != 1:   # the table holds per-launch averages: a site that launches a kernel twice has twice of each
         pmc = dict(pmc)
         for c in SUMMED:
@@ -290,6 +290,8 @@ def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
         pmc["lane_utilisation"] = round(tc / act, 4) if act else None
         if pmc.get("TCC_HIT") is not None and pmc.get("TCC_MISS"):
             pmc["l2_hit_rate"] = round(pmc["TCC_HIT"] / (pmc["TCC_HIT"] + pmc["TCC_MISS"]), 4)
+        if pmc.get("TCP_TOTAL_CACHE_ACCESSES") and pmc.get("TCP_TCC_READ_REQ") is not None:
+            pmc["l1_hit_rate"] = round(1.0 - min(1.0, pmc["TCP_TCC_READ_REQ"] / pmc["TCP_TOTAL_CACHE_ACCESSES"]), 4)
         if pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAIT_ANY") is not None:
             pmc["wait_any_frac"] = round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4)
     gev = evals_per_launch / sec / 1e9 if (sec > 0 and evals_per_launch) else None
@@ -326,7 +328,7 @@ def roofline_of(stage, S, W, H, avg_ms, evals_per_launch):
                  valu_instr_per_launch=insts,
                  valu_instr_per_wave_eval=round(insts * 64.0 / evals_per_launch, 1) if (insts and evals_per_launch) else None,
                  pmc_source="profiles/%s[%s|%dx%d|S%d], %s" % (os.path.basename(PMC_TABLE), k, W, H, S, pmc_table()[1]))
-        for c in ("l2_hit_rate", "wait_any_frac", "lane_utilisation"):
+        for c in ("l2_hit_rate", "l1_hit_rate", "wait_any_frac", "lane_utilisation"):
             if c in pmc:
                 r[c] = pmc[c]
         if traffic and evals_per_launch:

@@ -110,7 +110,7 @@ struct Dev {
 	int* search_pos;           // [16][L]: sample positions of the strong update's 16 propagation slots (strong_search_px)
 	// split strong update (dvp_strong_eval / _decide / _refine): the cost vectors of the 16 propagation slots + the current plane,
 	// [slot][view][row * half_w + x / 2] (a red/black launch touches every second pixel of a row), or null
-	float* slot_costs;         // [17][S][half_w * H]
+	float* slot_costs;         // [half_w * H][17][S] (dvp_strong.hpp: slot_cost_index)
 	float* strong_rec;         // [SR_FIELDS][half_w * H]: hand-over from dvp_strong_decide to dvp_strong_refine
 	// DepthToWeak + LocalRefine as view-compacted passes (dvp_strong.hpp: sweep_*), or null (the fused per-pixel kernel)
 	f4* sweep_rec;             // [2][L]: (camera-frame normal, depth) and (mean baseline, disparity, weight sum, flags) per pixel

@@ -244,6 +244,9 @@ __device__ __forceinline__ void strong_decide_body(const Dev& d, const LaunchArg
 #define DVP_LB_DECIDE 4
 #endif
 #define DVP_DECIDE_KERNEL(MV) extern "C" __global__ void __launch_bounds__(256, DVP_LB_DECIDE) dvp_strong_decide_v##MV(const Dev d, const LaunchArgs a) { strong_decide_body<MV>(d, a); }
+// (Round 6 built the same decisions with the wave's 64 cost records staged in LDS by coalesced loads — 39 KB per wave at S = 9, i.e.
+// four waves per CU: 17.8 ms per cfg3 launch against 8.0 for the plain loads below on the pixel-major records; removed,
+// profiles/r06_ab_notes.txt.)
 DVP_DECIDE_KERNEL(4)
 DVP_DECIDE_KERNEL(6)
 DVP_DECIDE_KERNEL(8)
@@ -1816,7 +1819,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 				// monolithic kernel below instead, which gives the same bits (test_strong_update_forms_equal_the_oracle)
 				const size_t Lh = (size_t)((c->W + 1) / 2) * c->H;
 				void *sc = nullptr, *sr = nullptr;
-				if (getenv("DVP_TEST_SPLIT_ALLOC_FAIL") /* test hook: take the fallback */ || hipMalloc(&sc, (size_t)kSlotCount * (c->NI - 1) * Lh * sizeof(*c->slot_costs)) != hipSuccess || hipMalloc(&sr, (size_t)SR_FIELDS * Lh * sizeof(*c->strong_rec)) != hipSuccess) {
+				if (getenv("DVP_TEST_SPLIT_ALLOC_FAIL") /* test hook: take the fallback */ || hipMalloc(&sc, (size_t)kSlotCount * (c->NI - 1) * Lh * sizeof(*c->slot_costs) + 64 /* load_slot_costs reads whole 16-byte pieces */) != hipSuccess || hipMalloc(&sr, (size_t)SR_FIELDS * Lh * sizeof(*c->strong_rec)) != hipSuccess) {
 					(void)hipGetLastError();   // clear the sticky out-of-memory status
 					if (sc) (void)hipFree(sc);
 					c->strong_split = false;

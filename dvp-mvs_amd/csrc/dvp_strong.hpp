@@ -471,9 +471,38 @@ constexpr int kSlotCur = 16;                 // slot_costs slot of the pixel's c
 constexpr int kSlotCount = 17;
 enum { SR_PLANE = 0, SR_DEPTH = 4, SR_COST = 5, SR_CENTER = 6, SR_DRAND = 7, SR_DPERT = 8, SR_NRAND = 9, SR_DUP = 12 /* 3 words: strong_slot_sources */, SR_FIELDS = 15 };
 DVP_HD size_t half_index(const Dev& d, int px, int py) { return (size_t)py * d.half_w + (size_t)(px >> 1); }
+// Layout of Dev::slot_costs.  Round 6: [pixel of the colour][slot][view] — a pixel's 17 x S costs are one contiguous record.
+// The evaluation launch's lanes are (pixel, slot) items, pixel-major: neighbouring lanes now write neighbouring 4 S-byte
+// vectors (rounds 3-5, [slot][view][pixel]: 64 lines per store instruction), and a lane of the decision launch finds its 17 x S
+// costs in five cache lines instead of 153 (strong update 466 -> 455 ms per cfg3 pass).
+#ifndef DVP_SLOT_LAYOUT
+#define DVP_SLOT_LAYOUT 1   // 0: [slot][view][pixel] (A/B)
+#endif
 DVP_HD size_t slot_cost_index(const Dev& d, int slot, int v, int px, int py) {
 	const size_t Lh = (size_t)d.half_w * (size_t)d.height;
-	return (size_t)(slot * (d.params.num_images - 1) + v) * Lh + half_index(d, px, py);
+	const int S = d.params.num_images - 1;
+#if DVP_SLOT_LAYOUT
+	return (half_index(d, px, py) * kSlotCount + (size_t)slot) * (size_t)S + (size_t)v;
+#else
+	return (size_t)(slot * S + v) * Lh + half_index(d, px, py);
+#endif
+}
+// where the decision step finds cost(slot, view) of its pixel: base[slot * slot_stride + view * view_stride]
+struct SlotCostView { const float* base; size_t slot_stride, view_stride; };
+DVP_HD SlotCostView slot_cost_view(const Dev& d, int px, int py) {
+	const size_t Lh = (size_t)d.half_w * (size_t)d.height;
+	const int S = d.params.num_images - 1;
+	SlotCostView r;
+#if DVP_SLOT_LAYOUT
+	r.base = d.slot_costs + half_index(d, px, py) * kSlotCount * (size_t)S;
+	r.slot_stride = (size_t)S;
+	r.view_stride = 1;
+#else
+	r.base = d.slot_costs + half_index(d, px, py);
+	r.slot_stride = (size_t)S * Lh;
+	r.view_stride = Lh;
+#endif
+	return r;
 }
 // Round 4: the cost vector of a slot is a pure function of (pixel, plane), and the 17 planes of a pixel repeat — the
 // edge-adaptive and the fixed search of a direction often end on the same pixel, and propagation itself makes neighbours
@@ -547,10 +576,29 @@ DVP_HD void strong_eval_px(const Dev& d, int px, int py, PatchTab tab, unsigned 
 	for (uint32_t m = uniq; m; m &= m - 1) strong_eval_item<SMP>(d, c, px, py, dvp_ctz(m), true, nevals);
 }
 
+// the S (<= MV) costs of one slot.  Pixel-major records hold them contiguously: 16-byte loads (4-byte aligned; the pieces beyond
+// S belong to the next slot — the buffer carries 64 bytes of slack after the last record — and are not used)
+template <int MV>
+DVP_HD void load_slot_costs(const float* sc, size_t view_stride, int S, float* out) {
+#if defined(__HIP_DEVICE_COMPILE__) && DVP_SLOT_LAYOUT
+	typedef float f4v __attribute__((ext_vector_type(4), aligned(4)));
+	constexpr int Q = (MV + 3) / 4;
+	f4v q[Q];
+#pragma unroll
+	for (int i = 0; i < Q; ++i) q[i] = reinterpret_cast<const f4v*>(sc)[i];
+#pragma unroll
+	for (int v = 0; v < MV; ++v) out[v] = v < S ? q[v >> 2][v & 3] : 0.0f;
+#else
+#pragma unroll
+	for (int v = 0; v < MV; ++v) out[v] = v < S ? sc[(size_t)v * view_stride] : 0.0f;
+#endif
+}
+
 // Everything of strong_update_px between the propagation evaluations and the refinement evaluations, statement for
 // statement, with the cost vectors in registers (all loops over directions / views are unrolled; MV >= S).
 template <int MV>
 DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
+	const SlotCostView cv = slot_cost_view(d, px, py);
 	const int W = d.width;
 	const int center = py * W + px;
 	const DvpParams& P = d.params;
@@ -578,10 +626,7 @@ DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
 		if (pos >= 0) {
 			flag |= 1u << k;
 			positions[k] = pos;
-			const float* sc = d.slot_costs + (size_t)(strong_slot_source(dw0, dw1, dw2, k) * S) * Lh + hi;
-#pragma unroll
-			for (int v = 0; v < MV; ++v)
-				if (v < S) ca[k][v] = sc[(size_t)v * Lh];
+			load_slot_costs<MV>(cv.base + (size_t)strong_slot_source(dw0, dw1, dw2, k) * cv.slot_stride, cv.view_stride, S, ca[k]);
 		}
 	}
 #pragma unroll
@@ -592,12 +637,10 @@ DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
 			flag |= 1u << k;
 			float cb[MV];
 			int good0 = 0, good1 = 0, bad0 = 0, bad1 = 0;
-			const float* sc = d.slot_costs + (size_t)(strong_slot_source(dw0, dw1, dw2, 8 + k) * S) * Lh + hi;
+			load_slot_costs<MV>(cv.base + (size_t)strong_slot_source(dw0, dw1, dw2, 8 + k) * cv.slot_stride, cv.view_stride, S, cb);
 #pragma unroll
 			for (int j = 0; j < MV; ++j) {
-				cb[j] = 0.0f;
 				if (j < S) {
-					cb[j] = sc[(size_t)j * Lh];
 					const float a = ca[k][j], b = cb[j];
 					if (a < good_thr) good0++;
 					if (a > 1.2f) bad0++;
@@ -710,7 +753,7 @@ DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
 	float cn = 0.0f;
 #pragma unroll
 	for (int v = 0; v < MV; ++v)
-		if (v < S && vw[v] > 0) cn += vw[v] * d.slot_costs[(size_t)((int)dw2 * S + v) * Lh + hi];
+		if (v < S && vw[v] > 0) cn += vw[v] * cv.base[(size_t)(int)dw2 * cv.slot_stride + (size_t)v * cv.view_stride];
 	float cost_now = cn / weight_norm;
 	const float costs_center = cost_now;
 	f4 plane_now = d.planes_snap[center];

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Fold the PMC passes of tools/pmc_collect.sh into profiles/pmc_r05.json.
-usage: pmc_table.py OUTDIR [TABLE=profiles/pmc_r05.json]
+"""Fold the PMC passes of tools/pmc_collect.sh into profiles/pmc_r06.json.
+usage: pmc_table.py OUTDIR [TABLE=profiles/pmc_r06.json]
 
 Per kernel only the launches of the bench's LAST step are averaged (the untimed FIRST_INIT pass and
 the counting warm-up step launch the same kernels earlier): the last `launches_per_step[kernel]`
@@ -12,7 +12,8 @@ L2's fabric-side request counters (Infinity-Cache hits included).  On gfx950 FET
 128-byte requests of 16 B/lane reads at 64 bytes: the fetch part is doubled; WRITE_SIZE is
 uncalibrated and reported raw.  SQ_INSTS_* count wave-level instructions; SQ_WAVE_CYCLES / SQ_WAIT_* /
 SQ_ACTIVE_INST_* count quad-cycles.  lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) of one pass: the share of the
-lanes that were switched on while the VALU worked (0.96 for dvp_strong_eval, 0.47 for dvp_strong_refine)."""
+lanes that were switched on while the VALU worked (0.96 for dvp_strong_eval, 0.47 for dvp_strong_refine).  l1_hit_rate = 1 - TCP_TCC_READ_REQ /
+TCP_TOTAL_CACHE_ACCESSES (the vector L1s' read requests to the L2 over their tag look-ups, summed over the CUs)."""
 import collections
 import csv
 import glob
@@ -43,12 +44,12 @@ def per_kernel_last(path, launches_per_step):
 
 def main():
     out = sys.argv[1]
-    table_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_r05.json")
+    table_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_r06.json")
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     sha = bench.csrc_sha256()
     ids = set()
-    for name in ("fetch", "write", "sq1", "sq2", "sq3"):   # the library that produced the counters must be the tree's
+    for name in ("fetch", "write", "sq1", "sq2", "sq3", "tcp"):   # the library that produced the counters must be the tree's
         js = os.path.join(out, name + ".json")
         if os.path.exists(js):
             ids.add(json.loads(open(js).read().strip().splitlines()[-1]).get("library_build_id"))
@@ -61,7 +62,7 @@ def main():
             table = old
     merged = collections.defaultdict(dict)
     cfg = None
-    for name in ("fetch", "write", "sq1", "sq2", "sq3"):
+    for name in ("fetch", "write", "sq1", "sq2", "sq3", "tcp"):
         js = os.path.join(out, name + ".json")
         cs = glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True)
         if not (os.path.exists(js) and cs):
@@ -84,6 +85,9 @@ def main():
             v["hbm_bytes_per_launch"] = v["fetch_bytes_per_launch_corrected_x2"] + v["write_bytes_per_launch"]
         if v.get("TCC_HIT", 0) + v.get("TCC_MISS", 0) > 0:
             v["l2_hit_rate"] = round(v["TCC_HIT"] / (v["TCC_HIT"] + v["TCC_MISS"]), 4)
+        # L1 (TCP): line requests that went on to the L2 against all cache accesses of the CU's vector L1 (round 6)
+        if v.get("TCP_TOTAL_CACHE_ACCESSES", 0) > 0 and "TCP_TCC_READ_REQ" in v:
+            v["l1_hit_rate"] = round(1.0 - min(1.0, v["TCP_TCC_READ_REQ"] / v["TCP_TOTAL_CACHE_ACCESSES"]), 4)
         if v.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in v:
             v["wait_any_frac"] = round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 4)
         if v.get("SQ_WAVE_CYCLES") and "SQ_ACTIVE_INST_VALU" in v:
