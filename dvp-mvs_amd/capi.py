@@ -33,7 +33,7 @@ EXPORTS = ["dvp_ctx_create", "dvp_ctx_destroy", "dvp_last_error", "dvp_upload_im
            "dvp_run_stage", "dvp_synchronize", "dvp_download_state", "dvp_download_maps", "dvp_download_maps_begin", "dvp_download_maps_finish", "dvp_buffer_bytes", "dvp_download_buffer",
            "dvp_upload_buffer", "dvp_weak_count", "dvp_get_timings", "dvp_reset_timings", "dvp_eval_cost_vectors",
            "dvp_bench_cost_kernel", "dvp_build_id",
-           "dvp_fuse_create", "dvp_fuse_destroy", "dvp_fuse_last_error", "dvp_fuse_set_view", "dvp_fuse_view", "dvp_fuse_count", "dvp_fuse_download", "dvp_fuse_last_rounds"]
+           "dvp_fuse_create", "dvp_fuse_destroy", "dvp_fuse_last_error", "dvp_fuse_set_view", "dvp_fuse_view", "dvp_fuse_view_graded", "dvp_fuse_count", "dvp_fuse_download", "dvp_fuse_last_rounds"]
 
 
 class DvpTimings(ctypes.Structure):

@@ -290,6 +290,186 @@ __global__ void __launch_bounds__(1024) fuse_emit(const EmitArgs a) {
 	o[5] = ((float)R.bgr[3 * p + 2] + sr) / (nw + 1);
 }
 
+// ---- the Tanks & Temples variants (RunFusion_TAT_Intermediate / _advanced, APD.cpp:1962-2130 / 2132-2279) ------------------
+// Same geometry per (pixel, source); what differs: a pixel is NOT skipped for being claimed, witnesses that are claimed do not
+// count, a kept pixel claims ITSELF — so the claim flags a view reads belong to OTHER views and stand still during its scan —
+// and the acceptance is graded: the first k = 2 .. #sources with at least k sources inside k-scaled thresholds.  The one
+// sequential thing is a quirk the port keeps: the per-source residuals are ONE array per view, overwritten only when a source
+// yields a comparison — a source that drops out keeps voting with the residuals of the last pixel it was compared for
+// (APD.cpp:2051, 2078-2090).  "The last pixel q <= p with a comparison for source j" is an inclusive maximum scan of
+// (compared ? q : -1) over the raster order:
+//   graded_gather   per pixel and source: the comparison (error, depth difference, angle, source pixel) or none; per block
+//                   and source the last pixel with a comparison
+//   (host)          running maximum over the blocks -> what each block inherits
+//   graded_decide   per block: the scan inside the block, then per pixel the residuals in force, the smallest k each source
+//                   agrees from (the thresholds grow with k), the first k with k agreeing sources, the agreeing set
+//   graded_emit     accepted pixels in raster order, colours, self-claims
+struct GradedArgs {
+	const FuseView* views;
+	int ref, ns, advanced;
+	const int* src;             // [ns] view slots, -1 = a source without maps (it never yields a comparison)
+	float* f_err; float* f_rel; float* f_ang; int* f_pix;   // [ns][L] comparisons, f_pix < 0: none
+	uint8_t* is_ref;            // [L]
+	int* block_last;            // [blocks][ns] last pixel of the block with a comparison for the source, -1
+	const int* block_carry;     // [blocks][ns] ... of all earlier blocks
+	int* last_idx;              // [ns][L] the pixel whose comparison is in force
+	uint8_t* decision;          // [L] 1 = kept
+	unsigned long long* agree;  // [L] the sources that agree at the accepted k
+	size_t L;
+};
+constexpr int kGradedBlock = 256;
+
+__global__ void __launch_bounds__(kGradedBlock) graded_gather(const GradedArgs a) {
+	__shared__ int s_last[64];
+	const FuseView& R = a.views[a.ref];
+	const size_t L = a.L;
+	const size_t p = (size_t)blockIdx.x * kGradedBlock + threadIdx.x;
+	if (threadIdx.x < 64) s_last[threadIdx.x] = -1;
+	__syncthreads();
+	bool ref = false;
+	if (p < L) {
+		const int y = (int)(p / R.cols), x = (int)(p - (size_t)y * R.cols);
+		const float z = R.depth[p];
+		ref = !(R.block && R.block[p] < 128) && !(z <= 0.0f);
+		if (ref) {
+			const f3 X = fuse_lift(R, x, y, z);
+			const float nr[3] = { R.normal[3 * p], R.normal[3 * p + 1], R.normal[3 * p + 2] };
+			for (int j = 0; j < a.ns; ++j) {
+				int pix = -1;
+				float err = 0.0f, rel = 0.0f, ang = 0.0f;
+				if (a.src[j] >= 0) {
+					const FuseView& S = a.views[a.src[j]];
+					f2 q;
+					float zq;
+					fuse_project(X, S.cam, &q, &zq);
+					const int sx = fuse_round(q.x), sy = fuse_round(q.y);
+					if (sx >= 0 && sx < S.cols && sy >= 0 && sy < S.rows) {
+						const size_t sp = (size_t)sy * S.cols + sx;
+						const float zs = S.depth[sp];
+						if (!(S.claimed[sp] == 1 || zs <= 0.0f)) {
+							f2 back;
+							float z_seen;
+							fuse_project(fuse_lift(S, sx, sy, zs), R.cam, &back, &z_seen);
+							const double ex = (double)(x - back.x), ey = (double)(y - back.y);
+							err = (float)sqrt(ex * ex + ey * ey);
+							rel = fabsf(z_seen - z) / z;
+							const float ns3[3] = { S.normal[3 * sp], S.normal[3 * sp + 1], S.normal[3 * sp + 2] };
+							ang = fuse_angle(nr, ns3);
+							pix = (int)sp;
+						}
+					}
+				}
+				a.f_err[(size_t)j * L + p] = err; a.f_rel[(size_t)j * L + p] = rel; a.f_ang[(size_t)j * L + p] = ang; a.f_pix[(size_t)j * L + p] = pix;
+				if (pix >= 0) atomicMax(&s_last[j], (int)p);
+			}
+		} else {
+			for (int j = 0; j < a.ns; ++j) a.f_pix[(size_t)j * L + p] = -1;
+		}
+		a.is_ref[p] = ref ? 1 : 0;
+	}
+	__syncthreads();
+	if (threadIdx.x < a.ns) a.block_last[(size_t)blockIdx.x * a.ns + threadIdx.x] = s_last[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(kGradedBlock) graded_decide(const GradedArgs a) {
+	__shared__ int s_wave[kGradedBlock / 64];
+	__shared__ uint8_t s_k[64 * kGradedBlock];     // [source][thread]: the smallest k the source agrees from (255: never)
+	const float dist_base = 0.25f, depth_base = a.advanced ? 1.0f / 3000.0f : 1.0f / 3500.0f;
+	const float angle_base = 0.06981317007977318f, angle_grad = 0.05235987755982988f;   // 4 and 3 degrees
+	const size_t L = a.L;
+	const size_t p = (size_t)blockIdx.x * kGradedBlock + threadIdx.x;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const bool in = p < L;
+	const bool ref = in && a.is_ref[p] != 0;
+	for (int j = 0; j < a.ns; ++j) {
+		// inclusive maximum scan of (comparison ? p : -1) over the block, then what the block inherits
+		int v = (in && a.f_pix[(size_t)j * L + p] >= 0) ? (int)p : -1;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const int t = __shfl_up(v, o, 64);
+			if (lane >= o && t > v) v = t;
+		}
+		__syncthreads();                       // (s_wave of the previous source has been read)
+		if (lane == 63) s_wave[wave] = v;
+		__syncthreads();
+		for (int w = 0; w < wave; ++w) if (s_wave[w] > v) v = s_wave[w];
+		const int carry = a.block_carry[(size_t)blockIdx.x * a.ns + j];
+		if (carry > v) v = carry;
+		uint8_t kj = 255;
+		if (ref) {
+			a.last_idx[(size_t)j * L + p] = v;
+			if (v >= 0) {
+				const float err = a.f_err[(size_t)j * L + v], rel = a.f_rel[(size_t)j * L + v], ang = a.f_ang[(size_t)j * L + v];
+				for (int k = 2; k <= a.ns; ++k)
+					if (err < k * dist_base && rel < k * depth_base && (a.advanced || ang < (k * angle_grad + angle_base))) { kj = (uint8_t)k; break; }
+			}
+		}
+		s_k[j * kGradedBlock + threadIdx.x] = kj;
+	}
+	if (!ref) { if (in) a.decision[p] = 0; return; }
+	uint8_t dec = 0;
+	unsigned long long agree = 0;
+	for (int k = 2; k <= a.ns; ++k) {
+		int count = 0;
+		unsigned long long m = 0;
+		for (int j = 0; j < a.ns; ++j)
+			if (s_k[j * kGradedBlock + threadIdx.x] <= k) { ++count; m |= 1ull << j; }
+		if (count >= k) { dec = 1; agree = m; break; }
+	}
+	a.decision[p] = dec;
+	a.agree[p] = agree;
+}
+
+struct GradedEmitArgs {
+	const FuseView* views;
+	int ref, ns, advanced;
+	const int* src;
+	const int* last_idx;
+	const int* f_pix;
+	const uint8_t* decision;
+	const unsigned long long* agree;
+	size_t L;
+	const unsigned long long* block_base;
+	float* out;
+};
+__global__ void __launch_bounds__(1024) graded_emit(const GradedEmitArgs a) {
+	__shared__ unsigned wave_n[16];
+	const FuseView& R = a.views[a.ref];
+	const size_t p = (size_t)blockIdx.x * 1024 + threadIdx.x;
+	const bool acc = p < a.L && a.decision[p] == 1;
+	const unsigned long long m = __ballot(acc);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (lane == 0) wave_n[wave] = (unsigned)__popcll(m);
+	__syncthreads();
+	if (!acc) return;
+	unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+	for (int w = 0; w < wave; ++w) rank += wave_n[w];
+	const int y = (int)(p / R.cols), x = (int)(p - (size_t)y * R.cols);
+	const f3 X = fuse_lift(R, x, y, R.depth[p]);
+	float sum[3] = { (float)R.bgr[3 * p], (float)R.bgr[3 * p + 1], (float)R.bgr[3 * p + 2] };
+	if (!a.advanced) {
+		const unsigned long long agree = a.agree[p];
+		int count = 0;
+		for (int j = 0; j < a.ns; ++j) {
+			if (!((agree >> j) & 1)) continue;
+			// the colour under the residual in force: the source pixel of the comparison the residual came from (APD.cpp:2101-2108)
+			const FuseView& S = a.views[a.src[j]];
+			const int q = a.last_idx[(size_t)j * a.L + p];
+			const int sp = a.f_pix[(size_t)j * a.L + q];
+			int sx = sp % S.cols, sy = sp / S.cols;
+			sx = sx < S.cols - 1 ? sx : S.cols - 1;
+			sy = sy < S.rows - 1 ? sy : S.rows - 1;
+			const size_t si = (size_t)sy * S.cols + sx;
+			sum[0] += S.bgr[3 * si]; sum[1] += S.bgr[3 * si + 1]; sum[2] += S.bgr[3 * si + 2];
+			++count;
+		}
+		sum[0] /= (count + 1.0f); sum[1] /= (count + 1.0f); sum[2] /= (count + 1.0f);
+	}
+	float* o = a.out + (a.block_base[blockIdx.x] + rank) * 6;
+	o[0] = X.x; o[1] = X.y; o[2] = X.z; o[3] = sum[0]; o[4] = sum[1]; o[5] = sum[2];
+	R.claimed[p] = 1;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -314,6 +494,11 @@ struct dvp_fuse {
 	unsigned long long* live = nullptr;
 	unsigned *list_a = nullptr, *list_b = nullptr, *counters = nullptr, *block_count = nullptr;
 	unsigned long long* block_base = nullptr;
+	// the graded variants' extra arrays
+	float *g_rel = nullptr, *g_ang = nullptr;
+	int *g_last = nullptr, *g_block_last = nullptr, *g_block_carry = nullptr;
+	size_t g_cap_L = 0;
+	int g_cap_ns = 0;
 	unsigned round_serial = 0, view_serial = 0;
 	// the cloud: one device block per fused view
 	struct Segment { float* dev; long long n; };
@@ -352,6 +537,8 @@ int dvp_fuse_destroy(dvp_fuse* f) {
 	for (void* p : f->allocs) (void)hipFree(p);
 	for (auto& s : f->segments) (void)hipFree(s.dev);
 	(void)hipFree(f->views_dev);
+	for (void* p : { (void*)f->g_rel, (void*)f->g_ang, (void*)f->g_last, (void*)f->g_block_last, (void*)f->g_block_carry })
+		if (p) (void)hipFree(p);
 	for (void* p : { (void*)f->cand_view, (void*)f->cand_pix, (void*)f->cand_vote, (void*)f->count, (void*)f->decision, (void*)f->live, (void*)f->list_a, (void*)f->list_b,
 	                 (void*)f->counters, (void*)f->block_count, (void*)f->block_base, (void*)f->src_dev })
 		if (p) (void)hipFree(p);
@@ -534,6 +721,91 @@ int dvp_fuse_view(dvp_fuse* f, int v, const int* src, int num_src) {
 		hipLaunchKernelGGL(fuse_emit, dim3(blocks), dim3(1024), 0, f->stream, ea);
 		FUSE_TRY(f, hipGetLastError());
 		FUSE_TRY(f, hipStreamSynchronize(f->stream));   // `base` is read by the copy above
+		f->total += (long long)n_points;
+	}
+	return 0;
+}
+
+// One iteration of the outer loop of RunFusion_TAT_Intermediate (advanced = 0, APD.cpp:1962-2130) / RunFusion_TAT_advanced
+// (advanced = 1, APD.cpp:2132-2279): `src` holds ALL sources of the view in pair.txt order, -1 for one without maps (it takes
+// part in the count of sources the acceptance loop runs to, but never yields a comparison).
+int dvp_fuse_view_graded(dvp_fuse* f, int v, const int* src, int num_src, int advanced) {
+	if (!f) return 1;
+	if (v < 0 || v >= f->num_views || !f->have[v] || num_src < 0 || (num_src > 0 && !src)) { f->error = "dvp_fuse_view_graded: bad arguments"; return 1; }
+	if (num_src > 64) { f->error = "dvp_fuse_view_graded: more than 64 source views"; return 1; }
+	for (int j = 0; j < num_src; ++j)
+		if (src[j] >= f->num_views || (src[j] >= 0 && (!f->have[src[j]] || src[j] == v))) { f->error = "dvp_fuse_view_graded: bad source slot"; return 1; }
+	FUSE_TRY(f, hipSetDevice(f->device));
+	if (f->views_dirty) {
+		FUSE_TRY(f, hipMemcpyAsync(f->views_dev, f->views.data(), sizeof(FuseView) * f->num_views, hipMemcpyHostToDevice, f->stream));
+		FUSE_TRY(f, hipStreamSynchronize(f->stream));
+		f->views_dirty = false;
+	}
+	const FuseView& R = f->views[v];
+	const size_t L = (size_t)R.cols * R.rows;
+	const int ns = std::max(num_src, 1);
+	if (fuse_reserve(f, L, ns)) return 1;
+	const unsigned gblocks = (unsigned)((L + kGradedBlock - 1) / kGradedBlock);
+	if (L > f->g_cap_L || ns > f->g_cap_ns) {
+		for (void** p : { (void**)&f->g_rel, (void**)&f->g_ang, (void**)&f->g_last, (void**)&f->g_block_last, (void**)&f->g_block_carry }) { if (*p) (void)hipFree(*p); *p = nullptr; }
+		const size_t nL = std::max(L, f->g_cap_L);
+		const int nn = std::max(ns, f->g_cap_ns);
+		const size_t nb = (nL + kGradedBlock - 1) / kGradedBlock;
+		f->g_cap_L = 0; f->g_cap_ns = 0;
+		if (hipMalloc((void**)&f->g_rel, (size_t)nn * nL * 4) != hipSuccess || hipMalloc((void**)&f->g_ang, (size_t)nn * nL * 4) != hipSuccess || hipMalloc((void**)&f->g_last, (size_t)nn * nL * 4) != hipSuccess ||
+		    hipMalloc((void**)&f->g_block_last, nb * nn * 4) != hipSuccess || hipMalloc((void**)&f->g_block_carry, nb * nn * 4) != hipSuccess) {
+			(void)hipGetLastError();
+			f->error = "dvp_fuse_view_graded: out of device memory";
+			return 1;
+		}
+		f->g_cap_L = nL; f->g_cap_ns = nn;
+	}
+	if (num_src > 0) FUSE_TRY(f, hipMemcpyAsync(f->src_dev, src, (size_t)num_src * 4, hipMemcpyHostToDevice, f->stream));
+	GradedArgs ga;
+	ga.views = f->views_dev; ga.ref = v; ga.ns = num_src; ga.advanced = advanced ? 1 : 0; ga.src = f->src_dev;
+	ga.f_err = f->cand_vote; ga.f_rel = f->g_rel; ga.f_ang = f->g_ang; ga.f_pix = f->cand_pix;
+	ga.is_ref = reinterpret_cast<uint8_t*>(f->count); ga.block_last = f->g_block_last; ga.block_carry = f->g_block_carry;
+	ga.last_idx = f->g_last; ga.decision = f->decision; ga.agree = f->live; ga.L = L;
+	hipLaunchKernelGGL(graded_gather, dim3(gblocks), dim3(kGradedBlock), 0, f->stream, ga);
+	FUSE_TRY(f, hipGetLastError());
+	std::vector<int> last((size_t)gblocks * ns), carry((size_t)gblocks * ns);
+	if (num_src > 0) {
+		FUSE_TRY(f, hipMemcpyAsync(last.data(), f->g_block_last, (size_t)gblocks * num_src * 4, hipMemcpyDeviceToHost, f->stream));
+		FUSE_TRY(f, hipStreamSynchronize(f->stream));
+		std::vector<int> run(num_src, -1);
+		for (unsigned b = 0; b < gblocks; ++b)
+			for (int j = 0; j < num_src; ++j) {
+				carry[(size_t)b * num_src + j] = run[j];
+				run[j] = std::max(run[j], last[(size_t)b * num_src + j]);
+			}
+		FUSE_TRY(f, hipMemcpyAsync(f->g_block_carry, carry.data(), (size_t)gblocks * num_src * 4, hipMemcpyHostToDevice, f->stream));
+	}
+	hipLaunchKernelGGL(graded_decide, dim3(gblocks), dim3(kGradedBlock), 0, f->stream, ga);
+	FUSE_TRY(f, hipGetLastError());
+	EmitArgs ea;
+	ea.views = f->views_dev; ea.ref = v; ea.cand_view = nullptr; ea.cand_pix = nullptr; ea.count = nullptr;
+	ea.decision = f->decision; ea.live = nullptr; ea.L = L; ea.block_count = f->block_count; ea.block_base = f->block_base; ea.out = nullptr;
+	const unsigned blocks = (unsigned)((L + 1023) / 1024);
+	hipLaunchKernelGGL(fuse_count, dim3(blocks), dim3(1024), 0, f->stream, ea);
+	FUSE_TRY(f, hipGetLastError());
+	std::vector<unsigned> bc(blocks);
+	FUSE_TRY(f, hipMemcpyAsync(bc.data(), f->block_count, (size_t)blocks * 4, hipMemcpyDeviceToHost, f->stream));
+	FUSE_TRY(f, hipStreamSynchronize(f->stream));   // (also: `carry` has been read)
+	std::vector<unsigned long long> base(blocks);
+	unsigned long long n_points = 0;
+	for (unsigned b = 0; b < blocks; ++b) { base[b] = n_points; n_points += bc[b]; }
+	f->last_rounds = 0; f->last_rest = 0;
+	if (n_points > 0) {
+		float* seg = nullptr;
+		if (hipMalloc((void**)&seg, (size_t)n_points * 24) != hipSuccess) { (void)hipGetLastError(); f->error = "dvp_fuse_view_graded: out of device memory for the points"; return 1; }
+		f->segments.push_back(dvp_fuse::Segment{ seg, (long long)n_points });
+		FUSE_TRY(f, hipMemcpyAsync(f->block_base, base.data(), (size_t)blocks * 8, hipMemcpyHostToDevice, f->stream));
+		GradedEmitArgs ge;
+		ge.views = f->views_dev; ge.ref = v; ge.ns = num_src; ge.advanced = advanced ? 1 : 0; ge.src = f->src_dev; ge.last_idx = f->g_last; ge.f_pix = f->cand_pix;
+		ge.decision = f->decision; ge.agree = f->live; ge.L = L; ge.block_base = f->block_base; ge.out = seg;
+		hipLaunchKernelGGL(graded_emit, dim3(blocks), dim3(1024), 0, f->stream, ge);
+		FUSE_TRY(f, hipGetLastError());
+		FUSE_TRY(f, hipStreamSynchronize(f->stream));
 		f->total += (long long)n_points;
 	}
 	return 0;

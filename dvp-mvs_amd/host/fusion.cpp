@@ -115,7 +115,8 @@ void SetFusionDevice(int device) { g_fusion_device = device; }
 
 // RunFusion through the engine's C ABI (dvp_fuse_*, csrc/dvp_fuse.hip): this function keeps what the reference does around
 // the scan — maps, colour images and cameras in (APD.cpp:1836-1871), the .ply out (:1955-1958)
-static void RunFusionDevice(const path& dense_folder, const std::vector<Problem>& problems) {
+// kind: 0 = RunFusion, 1 = RunFusion_TAT_Intermediate, 2 = RunFusion_TAT_advanced
+static void RunFusionDevice(const path& dense_folder, const std::vector<Problem>& problems, int kind = 0) {
 	const auto t_start = std::chrono::steady_clock::now();
 	auto seconds_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
 	const int n_views = (int)problems.size();
@@ -166,9 +167,14 @@ static void RunFusionDevice(const path& dense_folder, const std::vector<Problem>
 		std::cout << "Fusing image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
 		if (!loaded[i]) continue;
 		std::vector<int> sources;
-		for (int id : problems[i].src_image_ids)
-			if (id >= 0 && id <= max_id && slot_of_id[id] >= 0 && loaded[slot_of_id[id]]) sources.push_back(slot_of_id[id]);
-		if (dvp_fuse_view(job, i, sources.data(), (int)sources.size()) != 0) DvpFatal(std::string("dvp_fuse_view failed: ") + dvp_fuse_last_error(job));
+		for (int id : problems[i].src_image_ids) {
+			const int slot = (id >= 0 && id <= max_id && slot_of_id[id] >= 0 && loaded[slot_of_id[id]]) ? slot_of_id[id] : -1;
+			if (kind != 0) sources.push_back(slot);          // the graded variants count every listed source (APD.cpp:2048)
+			else if (slot >= 0) sources.push_back(slot);     // RunFusion skips the ones without maps
+		}
+		const int rc = kind == 0 ? dvp_fuse_view(job, i, sources.data(), (int)sources.size())
+		                         : dvp_fuse_view_graded(job, i, sources.data(), (int)sources.size(), kind == 2 ? 1 : 0);
+		if (rc != 0) DvpFatal(std::string("dvp_fuse_view failed: ") + dvp_fuse_last_error(job));
 		int rounds = 0, rest = 0;
 		dvp_fuse_last_rounds(job, &rounds, &rest);
 		rounds_max = std::max(rounds_max, rounds);
@@ -501,5 +507,11 @@ void RunFusionGraded(const path& dense_folder, const std::vector<Problem>& probl
 	std::cout << "Fusion: " << cloud.size() << " points -> " << ply_path << std::endl;
 }
 }  // namespace
-void RunFusion_TAT_Intermediate(const path& dense_folder, const std::vector<Problem>& problems) { RunFusionGraded(dense_folder, problems, false); }
-void RunFusion_TAT_advanced(const path& dense_folder, const std::vector<Problem>& problems) { RunFusionGraded(dense_folder, problems, true); }
+void RunFusion_TAT_Intermediate(const path& dense_folder, const std::vector<Problem>& problems) {
+	if (g_fusion_on_host) RunFusionGraded(dense_folder, problems, false);
+	else RunFusionDevice(dense_folder, problems, 1);
+}
+void RunFusion_TAT_advanced(const path& dense_folder, const std::vector<Problem>& problems) {
+	if (g_fusion_on_host) RunFusionGraded(dense_folder, problems, true);
+	else RunFusionDevice(dense_folder, problems, 2);
+}

@@ -248,6 +248,9 @@ int dvp_fuse_set_view(dvp_fuse* job, int view, const DvpCamera* cam, int cols, i
 /* one iteration of the reference's outer loop (APD.cpp:1874): view slot `view` scanned against the source slots `src`
  * (pair.txt order, sources without maps left out); accepted points are appended to the cloud in scan order */
 int dvp_fuse_view(dvp_fuse* job, int view, const int* src, int num_src);
+/* ... and of RunFusion_TAT_Intermediate (advanced = 0, APD.cpp:1962-2130) / RunFusion_TAT_advanced (advanced = 1,
+ * APD.cpp:2132-2279): `src` holds ALL sources of the view in pair.txt order, -1 for a source without maps */
+int dvp_fuse_view_graded(dvp_fuse* job, int view, const int* src, int num_src, int advanced);
 long long dvp_fuse_count(const dvp_fuse* job);               /* points so far */
 /* dvp_fuse_count() records of six floats — x y z b g r, struct PointList (main.h:69-72) — in scan order */
 int dvp_fuse_download(dvp_fuse* job, float* points);

@@ -108,7 +108,7 @@ def test_fusion_cpu(tmp_path):
     # of the pixels qualify; the advanced variant (no normal test, k / 3000) keeps more
     counts = {}
     for kind in ("tat-intermediate", "tat-advanced"):
-        o2 = subprocess.run([os.path.join(ROOT, "tests", "host", "test_host"), "--fuse", d], capture_output=True, text=True, env=dict(os.environ, DVP_FUSION_KIND=kind))
+        o2 = subprocess.run([os.path.join(ROOT, "tests", "host", "test_host"), "--fuse", d], capture_output=True, text=True, env=dict(host_env, DVP_FUSION_KIND=kind))
         assert o2.returncode == 0, o2.stderr[-500:]
         n2 = int(open(os.path.join(d, "APD", "APD.ply"), "rb").read(300).decode("latin1").split("element vertex ")[1].split("\n")[0])
         counts[kind] = n2
