@@ -481,7 +481,7 @@ Options ParseOptions(int argc, char** argv) {
 
 int main(int argc, char** argv) {
 	if (argc < 2) {
-		std::cerr << "USAGE: apd dense_folder [gpu_index] [--max-src N] [--iters N] [--min-scale S] [--passes P] [--seed X] [--rank R --world N [--job ID]] [--jacobi] [--no-fusion] [--views-in-flight N]\n";
+		std::cerr << "USAGE: apd dense_folder [gpu_index] [--max-src N] [--iters N] [--min-scale S] [--passes P] [--seed X] [--rank R --world N [--job ID]] [--jacobi] [--no-fusion | --fusion KIND] [--fusion-on device|host] [--views-in-flight N]\n";
 		return EXIT_FAILURE;
 	}
 	const Options opt = ParseOptions(argc, argv);
@@ -706,13 +706,11 @@ int main(int argc, char** argv) {
 	main_lap("FlushResults (background jobs + file writes)");
 	comm.Barrier();
 	if (opt.fusion && opt.rank == 0) {
+		SetFusionOnHost(opt.fusion_on_host);   // all three variants run on the GPU (dvp_fuse_*) unless --fusion-on host
+		SetFusionDevice(opt.gpu);
 		if (opt.fusion_kind == "tat-intermediate") RunFusion_TAT_Intermediate(opt.dense_folder, problems);
 		else if (opt.fusion_kind == "tat-advanced") RunFusion_TAT_advanced(opt.dense_folder, problems);
-		else {
-			SetFusionOnHost(opt.fusion_on_host);
-			SetFusionDevice(opt.gpu);
-			RunFusion(opt.dense_folder, problems);
-		}
+		else RunFusion(opt.dense_folder, problems);
 	}
 	ShutdownResultStore();
 	main_lap("fusion + shutdown");
