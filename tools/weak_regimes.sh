@@ -1,7 +1,7 @@
 # The weak path at the WEAK shares the schedule really produces: bench lines at 6.9 % (default), 25 % and,
 # on a 1552x1032 view, 90 % WEAK.  usage (GPU box, repo root): bash tools/weak_regimes.sh <tag>   -> gpurun_out/<tag>_weak*.json
 cd $GRAFT_REPO_ROOT
-T=${1:-r05}
+T=${1:-r06}
 run() { timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline $2 > gpurun_out/${T}_$1.json 2> gpurun_out/${T}_$1.err;
   python - <<PY
 import json
