@@ -478,11 +478,20 @@ DVP_HD size_t half_index(const Dev& d, int px, int py) { return (size_t)py * d.h
 #ifndef DVP_SLOT_LAYOUT
 #define DVP_SLOT_LAYOUT 1   // 0: [slot][view][pixel] (A/B)
 #endif
+// place of a slot's vector inside the pixel's record: the decision step takes the slots in pairs (k, 8 + k) — the adaptive and the
+// fixed-stride sample of direction k — so the pairs lie side by side and a lane walks its record front to back, every cache line once
+DVP_HD int slot_place(int slot) {
+#if DVP_SLOT_LAYOUT
+	return slot < 8 ? 2 * slot : (slot < 16 ? 2 * (slot - 8) + 1 : slot);
+#else
+	return slot;
+#endif
+}
 DVP_HD size_t slot_cost_index(const Dev& d, int slot, int v, int px, int py) {
 	const size_t Lh = (size_t)d.half_w * (size_t)d.height;
 	const int S = d.params.num_images - 1;
 #if DVP_SLOT_LAYOUT
-	return (half_index(d, px, py) * kSlotCount + (size_t)slot) * (size_t)S + (size_t)v;
+	return (half_index(d, px, py) * kSlotCount + (size_t)slot_place(slot)) * (size_t)S + (size_t)v;
 #else
 	return (size_t)(slot * S + v) * Lh + half_index(d, px, py);
 #endif
@@ -620,24 +629,26 @@ DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
 		for (int v = 0; v < MV; ++v) ca[k][v] = 0.0f;
 	}
 	ca[0][0] = 2.0f;   // `= { 2.0f }` sets one element (APD.cu:2032)
+	// The reference walks slots 0-7 (APD.cu:2047-2090) and then slots 8-15 (APD.cu:2104-2137); direction k of the second walk only
+	// looks at what direction k of the first left, so the two are taken together here, direction by direction
 #pragma unroll
-	for (int k = 0; k < 8; ++k) {      // slots 0-7 (APD.cu:2047-2090)
-		const int pos = d.search_pos[(size_t)k * L + center];
-		if (pos >= 0) {
-			flag |= 1u << k;
-			positions[k] = pos;
-			load_slot_costs<MV>(cv.base + (size_t)strong_slot_source(dw0, dw1, dw2, k) * cv.slot_stride, cv.view_stride, S, ca[k]);
+	for (int k = 0; k < 8; ++k) {
+		{
+			const int pos = d.search_pos[(size_t)k * L + center];
+			if (pos >= 0) {
+				flag |= 1u << k;
+				positions[k] = pos;
+				load_slot_costs<MV>(cv.base + (size_t)slot_place(strong_slot_source(dw0, dw1, dw2, k)) * cv.slot_stride, cv.view_stride, S, ca[k]);
+			}
 		}
-	}
-#pragma unroll
-	for (int k = 0; k < 8; ++k) {      // slots 8-15: the fixed-stride sample replaces the adaptive one if it is better (APD.cu:2104-2137)
+		// slot 8 + k: the fixed-stride sample replaces the adaptive one if it is better
 		const int pos = d.search_pos[(size_t)(8 + k) * L + center];
 		if (pos >= 0) {
 			const bool had = (flag >> k) & 1;
 			flag |= 1u << k;
 			float cb[MV];
 			int good0 = 0, good1 = 0, bad0 = 0, bad1 = 0;
-			load_slot_costs<MV>(cv.base + (size_t)strong_slot_source(dw0, dw1, dw2, 8 + k) * cv.slot_stride, cv.view_stride, S, cb);
+			load_slot_costs<MV>(cv.base + (size_t)slot_place(strong_slot_source(dw0, dw1, dw2, 8 + k)) * cv.slot_stride, cv.view_stride, S, cb);
 #pragma unroll
 			for (int j = 0; j < MV; ++j) {
 				if (j < S) {
@@ -753,7 +764,7 @@ DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
 	float cn = 0.0f;
 #pragma unroll
 	for (int v = 0; v < MV; ++v)
-		if (v < S && vw[v] > 0) cn += vw[v] * cv.base[(size_t)(int)dw2 * cv.slot_stride + (size_t)v * cv.view_stride];
+		if (v < S && vw[v] > 0) cn += vw[v] * cv.base[(size_t)slot_place((int)dw2) * cv.slot_stride + (size_t)v * cv.view_stride];
 	float cost_now = cn / weight_norm;
 	const float costs_center = cost_now;
 	f4 plane_now = d.planes_snap[center];
