@@ -299,6 +299,33 @@ def test_run_scenes_two_in_flight_equals_one_after_the_other(tmp_path):
                 assert a.shape == (H, W) and np.array_equal(a, b), (tag, i, v)
 
 
+def test_run_scenes_two_ranks_per_scene_two_scenes_in_flight(tmp_path):
+    """The cfg4 way of running a node — every scene on all ranks, two scenes in flight — with TWO ranks per scene (host transport:
+    both on the box's one GPU, four `apd` processes at a time): the files of each scene are those of its single-rank `--jacobi`
+    run (the same data flow with one rank)."""
+    scenes = []
+    for i, (W, H, NV) in enumerate(((112, 80, 5), (96, 64, 4), (104, 72, 3))):
+        for tag in ("one", "two"):
+            d = str(tmp_path / ("%s_scene%d" % (tag, i)))
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), str(NV), "2"], stdout=subprocess.DEVNULL)
+        scenes.append((W, H, NV))
+    common = ["--iters", "1", "--passes", "2", "--min-scale", "1", "--seed", "33", "--no-fusion"]
+    for i in range(len(scenes)):
+        so, se = _apd(str(tmp_path / ("one_scene%d" % i)), "--jacobi", *common).communicate(timeout=600)
+    tool = os.path.join(ROOT, "tools", "run_scenes.py")
+    out = subprocess.run([sys.executable, tool, "--gpus", "2", "--gpu-map", "0,0", "--transport", "host", "--mode", "node", "--in-flight", "2",
+                          "--log-dir", str(tmp_path / "logs")] + [str(tmp_path / ("two_scene%d" % i)) for i in range(len(scenes))] + ["--"] + common,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "3 scene(s)" in out.stdout and "2 in flight" in out.stdout
+    for i, (W, H, NV) in enumerate(scenes):
+        for v in range(NV):
+            for name in ("depths.dmb", "APD_normals.dmb"):
+                a = read_binmat(os.path.join(str(tmp_path / ("one_scene%d" % i)), "APD", "%08d" % v, name))
+                b = read_binmat(os.path.join(str(tmp_path / ("two_scene%d" % i)), "APD", "%08d" % v, name))
+                assert a.shape[:2] == (H, W) and np.array_equal(a, b), (i, v, name)
+
+
 def test_apd_rank_failure_takes_the_job_down(tmp_path):
     """A rank that hits a fatal error (here: the image of one of ITS views is unreadable) must not leave its peer hanging
     in a collective: DvpFatal -> RankComm::Abort drops the .abort marker, the peer's wait sees it and exits non-zero too."""

@@ -15,7 +15,7 @@ else runs (the driver tests compare the files):
                           `node` as soon as one scene is larger than the fair share (ETH3D: facade, 76 of 454 views).
 
 Scenes are started longest first (predicted cost = views x pixels of the first image, read from the file header).
-usage: run_scenes.py [--gpus N] [--mode node|scenes] [--in-flight M] [--transport rccl|host] scene_folder ... [-- apd options]"""
+usage: run_scenes.py [--gpus N] [--gpu-map d0,d1,...] [--mode node|scenes] [--in-flight M] [--transport rccl|host] scene_folder ... [-- apd options]"""
 import argparse
 import os
 import struct
@@ -119,10 +119,16 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2)
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"])
     ap.add_argument("--log-dir", default="")
+    ap.add_argument("--gpu-map", default="", help="device of rank 0,1,... (default: rank r on GPU r); several ranks on one device need --transport host (tests on a one-GPU box)")
     a = ap.parse_args(argv)
     n = a.gpus or gpu_count()
     if n < 1:
         raise SystemExit("run_scenes.py: no GPU found on this node")
+    devices = [int(t) for t in a.gpu_map.split(",")] if a.gpu_map else list(range(n))
+    if len(devices) != n:
+        raise SystemExit("run_scenes.py: --gpu-map needs one device per rank (%d)" % n)
+    if len(set(devices)) < n and a.transport != "host":
+        raise SystemExit("run_scenes.py: two ranks on one device need --transport host (RCCL refuses them)")
     log_dir = a.log_dir or os.path.join(a.scenes[0], "..")
     os.makedirs(log_dir, exist_ok=True)
     queue = sorted(a.scenes, key=lambda s: -scene_cost(s))
@@ -145,9 +151,9 @@ def main():
                     failed.append((s, rc))
 
     if a.mode == "scenes":
-        threads = [threading.Thread(target=worker, args=([g], g)) for g in range(n)]
+        threads = [threading.Thread(target=worker, args=([devices[g]], g)) for g in range(n)]
     else:
-        threads = [threading.Thread(target=worker, args=(list(range(n)), k)) for k in range(max(1, a.in_flight))]
+        threads = [threading.Thread(target=worker, args=(list(devices), k)) for k in range(max(1, a.in_flight))]
     for t in threads:
         t.start()
     for t in threads:
