@@ -149,7 +149,7 @@ def kernel_name(stage, S):
                            (("dvp_weak_update_wave_u8" if IMAGE_FORMAT else "dvp_weak_update_wave") + ("" if os.environ.get("DVP_WEAK_ANCHOR_TAB", "1") != "0" else "_notab")),
             "depth_to_weak": "dvp_sweep_eval" if sweep_split() else "dvp_depth_to_weak_refine",   # dvp_run_patchmatch: DepthToWeak + LocalRefine as one launch site
             "gen_neighbours": "dvp_gen_neighbours_search" if os.environ.get("DVP_GN_WAVE", "0") not in ("", "0") else "dvp_gen_neighbours_list",
-            "ransac_fit": "dvp_ransac_fit_plane_list", "find_nearest_strong": "dvp_find_nearest_strong_list",
+            "ransac_fit": "dvp_ransac_fit_plane_wave" if os.environ.get("DVP_RANSAC_WAVE", "0") not in ("", "0") else "dvp_ransac_fit_plane_list", "find_nearest_strong": "dvp_find_nearest_strong_list",
             "neighbour_update": "dvp_neighbour_update_list"}.get(stage, "dvp_" + stage)
 
 

@@ -365,6 +365,16 @@ extern "C" __global__ void __launch_bounds__(256) dvp_gen_neighbours_list(const 
 }
 DVP_KERNEL_LIST(dvp_neighbour_update_list, DVP_ST_NEIGHBOUR_UPDATE, 1)
 DVP_KERNEL_LIST(dvp_ransac_fit_plane_list, DVP_ST_RANSAC_FIT, 1)
+// ... and the same launch site with one wave per WEAK pixel, lane = draw (dvp_weak_wave.hpp: ransac_fit_plane_wave; DVP_RANSAC_WAVE=1 —
+// measured no faster than the lane kernel, whose 0.18 lane utilisation turns out not to be what it waits for: kept as the record of that)
+extern "C" __global__ void __launch_bounds__(64) dvp_ransac_fit_plane_wave(const Dev d, const ListArgs a) {
+	__shared__ RansacShared sh[1];
+	const int t = list_block(blockIdx.x, gridDim.x, kWaveRun * 4);
+	if (t >= a.count) return;
+	const int center = d.weak_list[a.base + t];
+	const int py = center / d.width, px = center - py * d.width;
+	ransac_fit_plane_wave(d, px, py, a.iter, sh[0]);
+}
 
 // Black/RedPixelUpdateWeak (APD.cu:4487-4489): one WAVE per WEAK pixel of the list segment, per-pixel state in LDS
 // (dvp_weak_wave.hpp)
@@ -1088,6 +1098,7 @@ struct dvp_ctx {
 	bool eval_items = true;      // DVP_EVAL_ITEMS=0: dvp_strong_eval with a pixel per lane instead of (pixel, slot) items over the lanes
 	bool refine_lanes = true;    // DVP_REFINE_LANES=0: dvp_strong_refine with the wave in lock step over hypotheses and views
 	f4* sweep_rec = nullptr; float* sweep_cost = nullptr; float* sweep_pc = nullptr;   // DepthToWeak + LocalRefine as view-compacted passes (allocated at the first fused launch)
+	bool ransac_wave = false;    // DVP_RANSAC_WAVE=1: RANSACToGetFitPlane one wave per WEAK pixel, lane = draw (round 6: measured no faster, 16.1 vs 15.9 ms at cfg3, 55.6 vs 49.0 at 25 % WEAK)
 	bool sweep_split = true;     // DVP_SWEEP_SPLIT=0, or the buffers did not fit: the fused per-pixel kernel
 	bool sweep_force = false;    // DVP_SWEEP_SPLIT=2: the passes also without the geometric term (tests)
 	bool gn_wave = false;        // DVP_GN_WAVE=1: GenNeighbours' search as one wave per WEAK pixel (dvp_gen_neighbours_search; measured slower)
@@ -1219,6 +1230,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	if (const char* e = getenv("DVP_SWEEP_SPLIT")) { c->sweep_split = atoi(e) != 0; c->sweep_force = atoi(e) == 2; }
 	if (const char* e = getenv("DVP_WEAK_ANCHOR_TAB")) c->anchor_tab_off = atoi(e) == 0;   // A/B measurements and the tests of the per-item form
 	if (const char* e = getenv("DVP_GN_WAVE")) c->gn_wave = atoi(e) != 0;
+	if (const char* e = getenv("DVP_RANSAC_WAVE")) c->ransac_wave = atoi(e) != 0;
 	if (const char* e = getenv("DVP_CAND_MASK")) c->cand_mask_mode = atoi(e) != 0 ? 1 : 0;
 	if (const char* e = getenv("DVP_WEAK_PHASED")) c->weak_phased = atoi(e) != 0;
 	if (const char* e = getenv("DVP_WEAK_PHASED_MIN")) c->weak_phased_min = atoi(e);
@@ -1761,7 +1773,10 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 				hipLaunchKernelGGL(dvp_gen_neighbours_fit, dim3(la.count), dim3(64), 0, c->stream, c->d, la);
 				break;
 			case DVP_ST_NEIGHBOUR_UPDATE: hipLaunchKernelGGL(ex ? dvp_neighbour_update_list_exact : dvp_neighbour_update_list, lg, block, 0, c->stream, c->d, la); break;
-			case DVP_ST_RANSAC_FIT: hipLaunchKernelGGL(ex ? dvp_ransac_fit_plane_list_exact : dvp_ransac_fit_plane_list, lg, block, 0, c->stream, c->d, la); break;
+			case DVP_ST_RANSAC_FIT:
+				if (c->ransac_wave) hipLaunchKernelGGL(dvp_ransac_fit_plane_wave, dim3(la.count), dim3(64), 0, c->stream, c->d, la);
+				else hipLaunchKernelGGL(ex ? dvp_ransac_fit_plane_list_exact : dvp_ransac_fit_plane_list, lg, block, 0, c->stream, c->d, la);
+				break;
 			case DVP_ST_WEAK_UPDATE:
 				if (ensure_anchor_table(c, la.covered_rows)) return 1;
 				if (c->d.anchor_tab && ensure_weak_phase_buffers(c)) return 1;

@@ -105,7 +105,15 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 	else if (STAGE == kStageStrongEval) { if (d.weak_info[center] != DVP_WEAK) strong_eval_px<SMP>(d, px, py, tab, nevals); }
 	else if (STAGE == kStageStrongRefine) { if (d.weak_info[center] != DVP_WEAK) strong_refine_px<SMP>(d, px, py, tab, nevals); }
 	else if (STAGE == kStageStrongRefineLanes) { if (d.weak_info[center] != DVP_WEAK) strong_refine_px<SMP, true>(d, px, py, tab, nevals); }
-	else if (STAGE == DVP_ST_RANSAC_FIT) ransac_fit_plane_px(d, px, py, iter);
+	else if (STAGE == DVP_ST_RANSAC_FIT) {
+		// device: one lane per WEAK pixel, or (DVP_RANSAC_WAVE=1) one wave per WEAK pixel (dvp_ransac_fit_plane_wave); the host emulation follows the switch
+#if !defined(__HIPCC__)
+		const char* rw = getenv("DVP_RANSAC_WAVE");
+		if (rw && atoi(rw) != 0) { RansacShared sh; ransac_fit_plane_wave(d, px, py, iter, sh); }
+		else
+#endif
+		ransac_fit_plane_px(d, px, py, iter);
+	}
 	else if (STAGE == DVP_ST_WEAK_UPDATE) {
 		// device: own launch shape (one wave per WEAK pixel, dvp_weak_update_wave); this branch is the
 		// host emulation of that wave (tests/emul): DVP_LANES loops over the 64 lanes

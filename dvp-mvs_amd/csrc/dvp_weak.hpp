@@ -525,6 +525,52 @@ DVP_HD void neighbour_update_px(const Dev& d, int px, int py) {
 }
 
 // ---- RANSACToGetFitPlane (APD.cu:4195-4404) -----------------------------------------------------
+// the adaptive patch radius RANSACToGetFitPlane leaves (APD.cu:4352-4402): from the area of the winning triangle (Heron), capped by the
+// nearest of its corners, by the nearest edge pixel of the eight rays and by the nearest label boundary; rounded down to 2r % 5 == 0
+DVP_HD int ransac_patch_radius(const Dev& d, int px, int py, int center, s2 A, s2 B, s2 C, bool edge_limit) {
+	const DvpParams& P = d.params;
+	const float a = sqrtf((float)((A.x - B.x) * (A.x - B.x) + (A.y - B.y) * (A.y - B.y)));
+	const float b = sqrtf((float)((B.x - C.x) * (B.x - C.x) + (B.y - C.y) * (B.y - C.y)));
+	const float c = sqrtf((float)((C.x - A.x) * (C.x - A.x) + (C.y - A.y) * (C.y - A.y)));
+	const float pp = (float)((a + b + c) / 2.0);
+	const float Sa = sqrtf(pp * (pp - a) * (pp - b) * (pp - c));
+	const double rr = floor(sqrtf(Sa) / 2.0);
+	int radius = (rr == rr) ? (int)rr : 0;
+	const float Ad = sqrtf((float)((A.x - px) * (A.x - px) + (A.y - py) * (A.y - py)));
+	const float Bd = sqrtf((float)((B.x - px) * (B.x - px) + (B.y - py) * (B.y - py)));
+	const float Cd = sqrtf((float)((C.x - px) * (C.x - px) + (C.y - py) * (C.y - py)));
+	const float min_dis = DVP_MIN(DVP_MIN(Ad, Bd), Cd);
+	if (2.5 * min_dis < radius) radius = (int)min_dis;
+	if (edge_limit) {
+		if (P.use_edge) {
+			float med = FLT_MAX;
+			const s2* en = d.edge_neigh + (size_t)center * 8;
+			for (int k = 0; k < 8; ++k) {
+				const s2 ep = en[k];
+				if (ep.x == -1 || ep.y == -1) continue;
+				const float dist = sqrtf((float)((ep.x - px) * (ep.x - px) + (ep.y - py) * (ep.y - py)));
+				med = DVP_MIN(med, dist);
+			}
+			if (med < radius) radius = (int)med;
+		}
+		if (P.use_label) {
+			float mbd = FLT_MAX;
+			const s2* lb = d.label_boundary + (size_t)d.neighbours_map[center] * 8;
+			for (int k = 0; k < 8; ++k) {
+				const s2 bp = lb[k];
+				if (bp.x == -1 || bp.y == -1) continue;
+				const double ex = (double)(px - bp.x), ey = (double)(py - bp.y);
+				const float dist = (float)sqrt(ex * ex + ey * ey);
+				mbd = DVP_MIN(mbd, dist);
+			}
+			if (mbd < radius) radius = (int)mbd;
+		}
+	}
+	if (radius < 0) radius = 0;
+	while ((radius << 1) % 5 != 0) radius--;
+	return radius;
+}
+
 DVP_HD void ransac_fit_plane_px(const Dev& d, int px, int py, int iter) {
 	const int W = d.width;
 	const int center = px + py * W;
@@ -645,46 +691,7 @@ DVP_HD void ransac_fit_plane_px(const Dev& d, int px, int py, int iter) {
 	if (dp > 0) { best_plane.x = -best_plane.x; best_plane.y = -best_plane.y; best_plane.z = -best_plane.z; best_plane.w = -best_plane.w; }
 	d.fit_planes[center] = best_plane;
 	if (P.use_radius) {
-		const s2 A = sp[use_a], B = sp[use_b], C = sp[use_c];
-		const float a = sqrtf((float)((A.x - B.x) * (A.x - B.x) + (A.y - B.y) * (A.y - B.y)));
-		const float b = sqrtf((float)((B.x - C.x) * (B.x - C.x) + (B.y - C.y) * (B.y - C.y)));
-		const float c = sqrtf((float)((C.x - A.x) * (C.x - A.x) + (C.y - A.y) * (C.y - A.y)));
-		const float pp = (float)((a + b + c) / 2.0);
-		const float Sa = sqrtf(pp * (pp - a) * (pp - b) * (pp - c));
-		const double rr = floor(sqrtf(Sa) / 2.0);
-		int radius = (rr == rr) ? (int)rr : 0;
-		const float Ad = sqrtf((float)((A.x - px) * (A.x - px) + (A.y - py) * (A.y - py)));
-		const float Bd = sqrtf((float)((B.x - px) * (B.x - px) + (B.y - py) * (B.y - py)));
-		const float Cd = sqrtf((float)((C.x - px) * (C.x - px) + (C.y - py) * (C.y - py)));
-		const float min_dis = DVP_MIN(DVP_MIN(Ad, Bd), Cd);
-		if (2.5 * min_dis < radius) radius = (int)min_dis;
-		if (edge_limit) {
-			if (P.use_edge) {
-				float med = FLT_MAX;
-				const s2* en = d.edge_neigh + (size_t)center * 8;
-				for (int k = 0; k < 8; ++k) {
-					const s2 ep = en[k];
-					if (ep.x == -1 || ep.y == -1) continue;
-					const float dist = sqrtf((float)((ep.x - px) * (ep.x - px) + (ep.y - py) * (ep.y - py)));
-					med = DVP_MIN(med, dist);
-				}
-				if (med < radius) radius = (int)med;
-			}
-			if (P.use_label) {
-				float mbd = FLT_MAX;
-				const s2* lb = d.label_boundary + (size_t)d.neighbours_map[center] * 8;
-				for (int k = 0; k < 8; ++k) {
-					const s2 bp = lb[k];
-					if (bp.x == -1 || bp.y == -1) continue;
-					const double ex = (double)(px - bp.x), ey = (double)(py - bp.y);
-					const float dist = (float)sqrt(ex * ex + ey * ey);
-					mbd = DVP_MIN(mbd, dist);
-				}
-				if (mbd < radius) radius = (int)mbd;
-			}
-		}
-		if (radius < 0) radius = 0;
-		while ((radius << 1) % 5 != 0) radius--;
+		const int radius = ransac_patch_radius(d, px, py, center, sp[use_a], sp[use_b], sp[use_c], edge_limit);
 		d.radius[center] = radius < P.strong_radius ? 0 : radius;
 	}
 }

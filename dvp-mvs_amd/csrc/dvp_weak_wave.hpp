@@ -1738,5 +1738,194 @@ DVP_HD void gen_neighbours_fit_wave(const Dev& d, int px, int py, FitShared& sh)
 	if (DVP_LANE0) d.weak_reliable[center] = 1;
 }
 
+// ---- RANSACToGetFitPlane (APD.cu:4195-4404) with one WAVE per WEAK pixel (round 6; DVP_RANSAC_WAVE=1, not the default: measured no
+// faster than the lane kernel — 16.1 vs 15.9 ms per cfg3 pass, 55.6 vs 49.0 at 25 % WEAK; profiles/r06_ab_notes.txt) -------------
+// ransac_fit_plane_px (dvp_weak.hpp) is the definition: one lane walks its pixel's 50 draws.  Every draw consumes exactly three
+// numbers of the counter-based generator, so draw t is a pure function of t: here lane t owns draw t (lane utilisation of the
+// lane-per-pixel launch: 0.18 — pixels differ in how many draws survive the cheap tests, and a survivor costs three line walks
+// and a residual loop).  What is ordered in the reference is (i) whose orientation a cached line test takes — the first draw in
+// draw order that asks for the pair, all three pairs of a draw before the next draw's (APD.cu:4283-4299) — resolved as in
+// gen_neighbours_fit_wave: the requests of the surviving draws in draw order, 64 at a time, a request is a first asker when its
+// pair is neither marked by an earlier batch nor asked by a lower lane; (ii) the strict minimum over the draws, taken in draw order.
+struct RansacShared {
+	s2 sp[DVP_NEIGHBOUR_NUM];
+	f3 sp3[DVP_NEIGHBOUR_NUM], spn[DVP_NEIGHBOUR_NUM];
+	uint32_t trip[64];             // draw t: a | b << 8 | c << 16
+	uint8_t plist[64];             // the draws that passed the cheap tests, in draw order
+	int req_idx[64], mark[64];
+	uint8_t req_from[64], req_to[64];
+	uint16_t walk[64];             // first askers: from | to << 8 (at most 55 unordered pairs)
+	uint32_t seen[2], hit[2];      // 55 pair bits
+	float cost[64];                // per surviving draw: residual sum, < 0: no plane
+	f4 plane[64];
+	int n_pass, n_walk, cnt;
+};
+
+DVP_HD void ransac_fit_plane_wave(const Dev& d, int px, int py, int iter, RansacShared& sh) {
+	const int W = d.width;
+	const int center = px + py * W;
+	const DvpParams& P = d.params;
+	if (d.weak_info[center] != DVP_WEAK) { if (DVP_LANE0) d.fit_planes[center] = d.planes[center]; return; }
+	const DvpCamera cam = load_camera(d, 0);
+	Rng r_limit(d.seed, (uint32_t)center, rng_site(PH_RANSAC, iter, SUB_LIMIT));
+	const uint32_t site = rng_site(PH_RANSAC, iter, SUB_RANSAC);
+	bool edge_limit = false;
+	if (P.use_limit) {
+		edge_limit = true;
+		if (P.use_edge) {
+			const float complex_val = d.complex_[d.neighbours_map[center]];
+			const float rp = r_limit.uniform() - FLT_EPSILON;
+			if (rp < complex_val) edge_limit = false;
+		}
+	}
+	if (DVP_LANE0) { sh.cnt = 0; sh.n_pass = 0; sh.n_walk = 0; sh.seen[0] = sh.seen[1] = 0u; sh.hit[0] = sh.hit[1] = 0u; }
+	DVP_LANES(l) sh.mark[l] = -1;
+	wave_sync();
+	// the anchors that exist, in list order
+	const s2* nbs = d.neighbours + (size_t)d.neighbours_map[center] * DVP_NEIGHBOUR_NUM;
+	DVP_LANES(l) {
+		const int i = l + 1;
+		s2 tp = mks2(-1, -1);
+		if (i < DVP_NEIGHBOUR_NUM) tp = nbs[i];
+		const bool valid = i < DVP_NEIGHBOUR_NUM && !(tp.x == -1 || tp.y == -1);
+		const int slot = wave_ordered_slot(valid, &sh.cnt);
+		if (valid) {
+			sh.sp[slot] = tp;
+			const f4 pl = d.planes[tp.x + tp.y * W];
+			const float depth = depth_from_plane(cam, pl, tp.x, tp.y);
+			float X[3];
+			get_3d_point(cam, tp.x, tp.y, depth, X);
+			sh.sp3[slot] = mk3(X[0], X[1], X[2]);
+			sh.spn[slot] = mk3(pl.x, pl.y, pl.z);
+		}
+	}
+	wave_sync();
+	const int cnt = sh.cnt;
+	if (cnt < 3) { if (DVP_LANE0) d.fit_planes[center] = d.planes[center]; return; }
+	// ---- the 50 draws (APD.cu:4262-4330): indices, normals, pixel inside the triangle ----
+	DVP_LANES(t) {
+		bool pass = false;
+		if (t < 50) {
+			const int ai = (int)(rand_u32(d.seed, (uint32_t)center, site, 3u * t) % (uint32_t)cnt);
+			const int bi = (int)(rand_u32(d.seed, (uint32_t)center, site, 3u * t + 1u) % (uint32_t)cnt);
+			const int ci = (int)(rand_u32(d.seed, (uint32_t)center, site, 3u * t + 2u) % (uint32_t)cnt);
+			sh.trip[t] = (uint32_t)ai | ((uint32_t)bi << 8) | ((uint32_t)ci << 16);
+			if (!(ai == bi || bi == ci || ai == ci)) {
+				const f3 AN = sh.spn[ai], BN = sh.spn[bi], CN = sh.spn[ci];
+				pass = !(AN.x * BN.x + AN.y * BN.y + AN.z * BN.z < 0.9f || AN.x * CN.x + AN.y * CN.y + AN.z * CN.z < 0.9f ||
+				         BN.x * CN.x + BN.y * CN.y + BN.z * CN.z < 0.9f) && point_in_triangle(sh.sp[ai], sh.sp[bi], sh.sp[ci], px, py);
+			}
+		}
+		const int slot = wave_ordered_slot(pass, &sh.n_pass);
+		if (pass) sh.plist[slot] = (uint8_t)t;
+	}
+	wave_sync();
+	const int n_pass = sh.n_pass;
+	// ---- line tests: who asks first (orientation), then the walks ----
+	if (edge_limit) {
+		for (int r0 = 0; r0 < 3 * n_pass; r0 += 64) {
+			DVP_LANES(l) {
+				const int r = r0 + l, j = r / 3, e = r - 3 * j;
+				int idx = -1;
+				if (r < 3 * n_pass) {
+					const uint32_t tr = sh.trip[sh.plist[j]];
+					const int p[4] = { (int)(tr & 255u), (int)((tr >> 8) & 255u), (int)((tr >> 16) & 255u), (int)(tr & 255u) };
+					idx = gn_pair_index(p[e], p[e + 1]);
+					sh.req_from[l] = (uint8_t)p[e];
+					sh.req_to[l] = (uint8_t)p[e + 1];
+				}
+				sh.req_idx[l] = idx;
+			}
+			wave_sync();
+			DVP_LANES(l) {
+				const int idx = sh.req_idx[l];
+				if (idx < 0 || ((sh.seen[idx >> 5] >> (idx & 31)) & 1u)) continue;
+				bool dup = false;
+				for (int m = 0; m < l; ++m) dup = dup || sh.req_idx[m] == idx;
+				if (dup) continue;
+				sh.walk[wave_counter_add(&sh.n_walk)] = (uint16_t)(sh.req_from[l] | (sh.req_to[l] << 8));
+				sh.mark[l] = idx;
+			}
+			wave_sync();
+			DVP_LANES(l) {
+				const int idx = sh.mark[l];
+				if (idx >= 0) { wave_bits_or(&sh.seen[idx >> 5], 1u << (idx & 31)); sh.mark[l] = -1; }
+			}
+			wave_sync();
+		}
+		const int n_walk = sh.n_walk;   // <= 55
+		DVP_LANES(l) {
+			if (l >= n_walk) continue;
+			const int a = sh.walk[l] & 255, b = sh.walk[l] >> 8;
+			if (bresenham_hits_edge(d, sh.sp[a].x, sh.sp[a].y, sh.sp[b].x, sh.sp[b].y)) {
+				const int idx = gn_pair_index(a, b);
+				wave_bits_or(&sh.hit[idx >> 5], 1u << (idx & 31));
+			}
+		}
+		wave_sync();
+	}
+	// ---- the surviving draws: plane through the three points, residual over the others ----
+	DVP_LANES(l) {
+		if (l >= n_pass) continue;
+		sh.cost[l] = -1.0f;
+		const uint32_t tr = sh.trip[sh.plist[l]];
+		const int ai = (int)(tr & 255u), bi = (int)((tr >> 8) & 255u), ci = (int)((tr >> 16) & 255u);
+		if (edge_limit) {
+			const int i0 = gn_pair_index(ai, bi), i1 = gn_pair_index(bi, ci), i2 = gn_pair_index(ci, ai);
+			if (((sh.hit[i0 >> 5] >> (i0 & 31)) | (sh.hit[i1 >> 5] >> (i1 & 31)) | (sh.hit[i2 >> 5] >> (i2 & 31))) & 1u) continue;
+		}
+		const f3 A = sh.sp3[ai], B = sh.sp3[bi], C = sh.sp3[ci];
+		const f3 AC = mk3(A.x - C.x, A.y - C.y, A.z - C.z);
+		const f3 BC = mk3(B.x - C.x, B.y - C.y, B.z - C.z);
+		f4 cv;
+		cv.x = AC.y * BC.z - BC.y * AC.z;
+		cv.y = -(AC.x * BC.z - BC.x * AC.z);
+		cv.z = AC.x * BC.y - BC.x * AC.y;
+		cv.w = 0.0f;
+		if ((cv.x == 0 && cv.y == 0 && cv.z == 0) || cv.x != cv.x || cv.y != cv.y || cv.z != cv.z) continue;
+		normalize3(&cv);
+		cv.w = -(cv.x * A.x + cv.y * A.y + cv.z * A.z);
+		float temp_cost = 0.0f;
+		for (int si = 0; si < cnt; ++si) {
+			if (si == ai || si == bi || si == ci) continue;
+			const float fx = (sh.sp[si].x - cam.K[2]) / cam.K[0];
+			const float fy = (sh.sp[si].y - cam.K[5]) / cam.K[4];
+			const float fit_depth = -cv.w / (cv.x * fx + cv.y * fy + cv.z);
+			temp_cost += fabsf(fit_depth - sh.sp3[si].z);
+		}
+		sh.plane[l] = cv;
+		// (a residual sum is >= 0 or NaN; NaN never wins the strict comparison below: stored as "no plane")
+		sh.cost[l] = temp_cost == temp_cost ? temp_cost : -1.0f;
+	}
+	wave_sync();
+	// ---- the strict minimum in draw order (APD.cu:4340-4350) ----
+	float min_cost = FLT_MAX;
+	int best = -1;
+	for (int j = 0; j < n_pass; ++j) {
+		const float cst = sh.cost[j];
+		if (cst >= 0.0f && cst < min_cost) { min_cost = cst; best = j; }
+	}
+	if (best < 0) {
+		if (DVP_LANE0) {
+			d.fit_planes[center] = mk4(0, 0, 0, 0);
+			if (P.use_radius) d.radius[center] = P.strong_radius;
+		}
+		return;
+	}
+	f4 best_plane = sh.plane[best];
+	const uint32_t btr = sh.trip[sh.plist[best]];
+	const int use_a = (int)(btr & 255u), use_b = (int)((btr >> 8) & 255u), use_c = (int)((btr >> 16) & 255u);
+	const float depth = depth_from_plane(cam, d.planes[center], px, py);
+	const f4 vdir = view_direction(cam, px, py, depth);
+	const float dp = best_plane.x * vdir.x + best_plane.y * vdir.y + best_plane.z * vdir.z;
+	if (dp > 0) { best_plane.x = -best_plane.x; best_plane.y = -best_plane.y; best_plane.z = -best_plane.z; best_plane.w = -best_plane.w; }
+	if (DVP_LANE0) d.fit_planes[center] = best_plane;
+	if (P.use_radius) {
+		const s2 A = sh.sp[use_a], B = sh.sp[use_b], C = sh.sp[use_c];
+		const int radius = ransac_patch_radius(d, px, py, center, A, B, C, edge_limit);
+		if (DVP_LANE0) d.radius[center] = radius < P.strong_radius ? 0 : radius;
+	}
+}
+
 }  // namespace dvp
 #endif

@@ -203,6 +203,16 @@ def test_gen_neighbours_search_forms_equal_the_oracle(form, seed, monkeypatch):
         gen_neighbours_case(seed, _pair, rotate_time=2)   # 16 directions in the slots 0,1, 4,5, ... (dir_index = 4 * octant + rotation)
 
 
+@pytest.mark.parametrize("form", ["wave", "per_lane"])
+def test_ransac_fit_plane_forms_equal_the_oracle(form, monkeypatch):
+    """RANSACToGetFitPlane one wave per WEAK pixel with a lane per draw (dvp_ransac_fit_plane_wave: who asks a cached line test
+    first decides its orientation, the strict minimum in draw order) and one lane per WEAK pixel (the definition): all launch
+    sites of a REFINE_ITER pass with anchors, edges (use_limit) and adaptive radii against the oracle."""
+    monkeypatch.setenv("DVP_RANSAC_WAVE", "1" if form == "wave" else "0")
+    many_views_case(5, _pair, lambda sc, p: O.from_scene(sc, p, cls=O.Oracle))
+    gen_neighbours_case(1, _pair)
+
+
 def many_views_case(S, pair, make_engine):
     W, H = 88, 64
     sc = synth.make_scene(W, H, S)

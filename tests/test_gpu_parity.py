@@ -188,6 +188,15 @@ def test_gen_neighbours_search_forms_equal_the_oracle(form, seed, monkeypatch):
     gen_neighbours_case(seed, _pair)
 
 
+@pytest.mark.parametrize("form", ["wave", "per_lane"])
+def test_ransac_fit_plane_forms_equal_the_oracle(form, monkeypatch):
+    """RANSACToGetFitPlane on the GPU: one wave per WEAK pixel with a lane per draw (default) and one lane per WEAK pixel"""
+    from test_emul_parity import many_views_case, gen_neighbours_case
+    monkeypatch.setenv("DVP_RANSAC_WAVE", "1" if form == "wave" else "0")
+    many_views_case(5, _pair, lambda sc, p: capi().from_scene(sc, p))
+    gen_neighbours_case(1, _pair)
+
+
 @pytest.mark.parametrize("form", ["split", "split_lockstep_refine", "monolithic"])
 @pytest.mark.parametrize("S", [3, 5, 9, 12])
 def test_strong_update_forms_equal_the_oracle(form, S, monkeypatch):
