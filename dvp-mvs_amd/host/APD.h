@@ -30,6 +30,7 @@ void RescaleMatToTargetSize(const Mat& src, Mat& dst, int target_width, int targ
 void RunFusion(const path& dense_folder, const std::vector<Problem>& problems);        // APD.cpp:1809-1960 (on the device: dvp_fuse_*, include/dvp_mvs.h)
 void SetFusionOnHost(bool on);          // RunFusion on the host's cores instead (same points, same order, same bits)
 void SetFusionDevice(int device);       // the GPU RunFusion uses (default 0)
+void ExportDepthImagePointCloud(const path& point_cloud_path, const path& image_path, const path& cam_path, Mat& depth, float depth_min, float depth_max);   // APD.cpp:2281-2314
 void RunFusion_TAT_Intermediate(const path& dense_folder, const std::vector<Problem>& problems);   // APD.cpp:1962-2130
 void RunFusion_TAT_advanced(const path& dense_folder, const std::vector<Problem>& problems);       // APD.cpp:2132-2279
 Mat EdgeSegment(const int scale, const Mat& srcImage, int mode = 0, bool useCanny = false);   // APD.cpp:348-499 (mode 0 + Canny only)

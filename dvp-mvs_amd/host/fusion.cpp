@@ -106,6 +106,33 @@ bool load_view(const path& dense_folder, const Problem& problem, FusionView* v) 
 
 }  // namespace
 
+// ExportDepthImagePointCloud (APD.cpp:2281-2314; the reference's driver has the call commented out, main.cpp:413): every pixel of ONE
+// depth map inside [depth_min, depth_max] lifted to the world, coloured from the view's image, columns outer / rows inner as the source
+// has it, written as a .ply — the single-view debug cloud.
+void ExportDepthImagePointCloud(const path& point_cloud_path, const path& image_path, const path& cam_path, Mat& depth, float depth_min, float depth_max) {
+	FusionView v;
+	ReadCameraOrDie(cam_path, v.cam);
+	v.set_centre();
+	Mat bgr = ReadImageColor(image_path);
+	if (bgr.empty()) bgr = Mat::zeros(depth.rows, depth.cols, CV_8UC3);
+	v.cam.width = bgr.cols;
+	v.cam.height = bgr.rows;
+	v.depth = depth;
+	v.colour = fit_colour(bgr, depth.cols, depth.rows, &v.cam);   // RescaleImageAndCamera (APD.cpp:1750-1771)
+	std::vector<PointList> cloud;
+	for (int i = 0; i < depth.cols; i++)
+		for (int j = 0; j < depth.rows; j++) {
+			const float z = depth.at<float>(j, i);
+			if (z < depth_min || z > depth_max || z != z) continue;
+			const uint8_t* c = v.bgr(i, j);
+			PointList pt;
+			pt.coord = v.lift(i, j, z);
+			pt.color = float3{ (float)c[0], (float)c[1], (float)c[2] };
+			cloud.push_back(pt);
+		}
+	ExportPointCloud(point_cloud_path, cloud);
+}
+
 namespace {
 bool g_fusion_on_host = false;
 int g_fusion_device = 0;

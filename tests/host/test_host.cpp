@@ -148,6 +148,12 @@ static int dump_prior(const path& folder, int id, int W, int H, const path& out)
 
 int main(int argc, char** argv) {
 	if (argc > 2 && std::string(argv[1]) == "--fuse") return fuse_folder(argv[2]);
+	if (argc > 6 && std::string(argv[1]) == "--depth-cloud") {   // --depth-cloud depths.dmb image cam out.ply dmin dmax
+		Mat depth;
+		if (!ReadBinMat(argv[2], depth)) return 2;
+		ExportDepthImagePointCloud(argv[5], argv[3], argv[4], depth, (float)atof(argv[6]), argc > 7 ? (float)atof(argv[7]) : 1e30f);
+		return 0;
+	}
 	if (argc > 4 && std::string(argv[1]) == "--edges") return dump_edges(argv[2], std::atoi(argv[3]), argv[4]);
 	if (argc > 6 && std::string(argv[1]) == "--prior") return dump_prior(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), argv[6]);
 	if (argc > 4 && std::string(argv[1]) == "--jpeg") return dump_jpeg(argv[2], argv[3], std::atoi(argv[4]));

@@ -148,6 +148,48 @@ def _fusion_case(tmp_path, kind, with_blocks, where, size=(80, 56)):
         assert n < 0.75 * W * H * 1.6
 
 
+def test_depth_image_point_cloud(tmp_path):
+    """ExportDepthImagePointCloud (APD.cpp:2281-2314): the depth map of ONE view as a cloud — depths inside the range, no NaN,
+    columns outer / rows inner, Get3DPointonWorld in binary32, colours of the image — against numpy."""
+    W, H = 60, 44
+    d = str(tmp_path / "scene")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dataset.py"), d, str(W), str(H), "2", "1"], stdout=subprocess.DEVNULL)
+    sc = synth.make_scene(W, H, 1)
+    rng = np.random.default_rng(3)
+    dep = sc["depth_gt"][0].astype(np.float32).copy()
+    dep[rng.random(dep.shape) < 0.1] = 0.0
+    dep[rng.random(dep.shape) < 0.05] = np.nan
+    dep[rng.random(dep.shape) < 0.05] = 100.0
+    rgb = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+    _write_binmat(os.path.join(d, "dep.dmb"), dep, 5)
+    img = os.path.join(d, "images", "colour.ppm")
+    with open(img, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (W, H))
+        f.write(rgb.tobytes())
+    ply = os.path.join(d, "one.ply")
+    out = _host_tool("--depth-cloud", os.path.join(d, "dep.dmb"), img, os.path.join(d, "cams", "00000000_cam.txt"), ply, 2.0, 8.0)
+    assert out.returncode == 0, out.stderr[-400:]
+    got = _read_ply(ply)
+    cam = sc["cameras"][0]
+    K, R, t = cam["K"].astype(np.float32), cam["R"].astype(np.float32), cam["t"].astype(np.float32)
+    f32 = np.float32
+    C = [-(R[0 + k] * t[0] + R[3 + k] * t[1] + R[6 + k] * t[2]) for k in range(3)]
+    want_xyz, want_bgr = [], []
+    for i in range(W):
+        for j in range(H):
+            z = dep[j, i]
+            if np.isnan(z) or z < 2.0 or z > 8.0:
+                continue
+            px = z * (f32(i) - K[2]) / K[0]
+            py = z * (f32(j) - K[5]) / K[4]
+            want_xyz.append([(R[0] * px + R[3] * py + R[6] * z) + C[0], (R[1] * px + R[4] * py + R[7] * z) + C[1], (R[2] * px + R[5] * py + R[8] * z) + C[2]])
+            want_bgr.append(rgb[j, i, ::-1])
+    want_xyz = np.array(want_xyz, np.float32)
+    assert len(got) == len(want_xyz) > 0.5 * W * H
+    assert np.array_equal(got["xyz"].view(np.uint32), want_xyz.view(np.uint32))
+    assert np.array_equal(got["bgr"], np.array(want_bgr, np.uint8))
+
+
 def _np_canny(img, low, high):
     """Canny as OpenCV documents it for 8-bit input, aperture 3, L2gradient = true — written independently of
     host/edges.cpp with array operations: Sobel with replicated border, squared magnitude against squared thresholds,
