@@ -74,6 +74,22 @@ DVP_HD void build_patch_ctx(const Dev& d, int px, int py, int radius, int inc, i
 		for (int tx = 0; tx < kTaps; ++tx)
 			av[ty * kTaps + tx] = img_texel(ref, d.org, P, W, H, px - radius + tx * inc, py - radius + ty * inc);
 	sched_fence();
+	// The spatial half of the weight, -sqrt(i^2 + j^2) / (2 sigma_s^2), depends on the tap offsets only.  With 2 radius = 5 inc
+	// (the default 5 / 2 and every adaptive radius: multiples of 5 with inc = 2 radius / 5) the six offsets per axis are
+	// -r .. r symmetric, and i^2 + j^2 = j^2 + i^2 in binary32 too: 6 distinct values instead of 36 square roots and divisions
+	// per table — the same bits, a quarter of a table build's instructions (round 6).
+	float sterm[3][3];
+	const bool sym = wave_all(!colour_only && 2 * radius == 5 * inc);
+	if (sym) {
+#pragma unroll
+		for (int a = 0; a < 3; ++a)
+#pragma unroll
+			for (int b = a; b < 3; ++b) {
+				const float xd = (float)(-radius + a * inc), yd = (float)(-radius + b * inc);
+				const float spatial_dist = sqrtf(xd * xd + yd * yd);
+				sterm[a][b] = sterm[b][a] = -spatial_dist / (2.0f * sig_s * sig_s);
+			}
+	}
 	float sr = 0.0f, srr = 0.0f, ws = 0.0f;
 #pragma unroll
 	for (int ty = 0; ty < kTaps; ++ty) {          // rows outer, columns inner (tap order)
@@ -83,7 +99,8 @@ DVP_HD void build_patch_ctx(const Dev& d, int px, int py, int radius, int inc, i
 		for (int tx = 0; tx < kTaps; ++tx) {
 			const int i = -radius + tx * inc;
 			const float a = av[ty * kTaps + tx];
-			const float w = bilateral_weight((float)i, (float)j, a, cpix, sig_s, sig_c, colour_only);
+			const float w = sym ? dvp_expf(sterm[tx < 3 ? tx : 5 - tx][ty < 3 ? ty : 5 - ty] - fabsf(a - cpix) / (2.0f * sig_c * sig_c))
+			                    : bilateral_weight((float)i, (float)j, a, cpix, sig_s, sig_c, colour_only);
 			const float wa = w * a;
 			tab.set(ty * kTaps + tx, mk2(w, wa));
 			sr_row += wa;
