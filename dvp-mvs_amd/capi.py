@@ -27,7 +27,7 @@ BUFFERS = dict(planes=(0, np.float32, 4), costs=(1, np.float32, 1), selected_vie
                label_boundary=(14, np.int16, 2), complex=(15, np.float32, 1), radius=(16, np.int32, 1))
 
 # every symbol include/dvp_mvs.h declares
-EXPORTS = ["dvp_ctx_create", "dvp_ctx_destroy", "dvp_last_error", "dvp_upload_images", "dvp_upload_depths",
+EXPORTS = ["dvp_ctx_create", "dvp_ctx_destroy", "dvp_ctx_reserve", "dvp_last_error", "dvp_upload_images", "dvp_upload_depths",
            "dvp_upload_images_device", "dvp_upload_depths_device", "dvp_upload_cameras", "dvp_upload_state", "dvp_upload_state_rescaled",
            "dvp_reset_state", "dvp_save_state", "dvp_restore_state", "dvp_set_params", "dvp_set_seed", "dvp_set_sampler", "dvp_set_profiling", "dvp_image_format", "dvp_run_patchmatch",
            "dvp_run_stage", "dvp_synchronize", "dvp_download_state", "dvp_download_maps", "dvp_download_maps_begin", "dvp_download_maps_finish", "dvp_buffer_bytes", "dvp_download_buffer",
@@ -59,6 +59,7 @@ def lib():
         vp, ci = ctypes.c_void_p, ctypes.c_int
         L.dvp_ctx_create.argtypes = [ci, ci, ci, ci, ctypes.POINTER(vp)]
         L.dvp_ctx_destroy.argtypes = [vp]
+        L.dvp_ctx_reserve.argtypes = [vp, ci, ci]
         L.dvp_last_error.restype = ctypes.c_char_p
         L.dvp_last_error.argtypes = [vp]
         for n in ("dvp_upload_images", "dvp_upload_depths", "dvp_upload_images_device", "dvp_upload_depths_device"):
@@ -164,6 +165,10 @@ class Context:
         assert a.dtype.itemsize == 76
         self._ck(self.L.dvp_set_params(self.h, _p(a)))
         self.params = a
+
+    def reserve(self, weak_pixels=0, flags=3):
+        """optional buffers ahead of their first use (include/dvp_mvs.h: dvp_ctx_reserve)"""
+        self._ck(self.L.dvp_ctx_reserve(self.h, int(weak_pixels), int(flags)))
 
     def set_seed(self, seed):
         self._ck(self.L.dvp_set_seed(self.h, seed))

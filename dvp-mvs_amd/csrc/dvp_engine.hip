@@ -1626,16 +1626,16 @@ int dvp_set_profiling(dvp_ctx* c, int on) { c->profiling = on != 0; sync_dev_str
 // anything that can change the anchors (GenNeighbours, NeigbourUpdate), the offsets (GenEdgeInform), the images or the WEAK
 // list; the iterations of a pass then share it.  A table that does not fit is not an error: the kernels that form the
 // reference side per item give the same bits.
-static int ensure_anchor_table(dvp_ctx* c, int covered_rows) {
-	if (c->anchor_tab_off) return 0;
-	if (c->anchor_tab_valid) return 0;
-	const int wc = c->d.weak_black + c->d.weak_red;
-	const size_t need = (size_t)wc * (size_t)(c->NI - 1) * kAnchors;
-	if (need > c->anchor_tab_alloc) {
+// room in the anchor table for `wc` WEAK pixels (grown with half as much again on top: the views of a level differ in their WEAK
+// counts, and every regrow is a device-wide free + a multi-GB allocation)
+static int grow_anchor_table(dvp_ctx* c, size_t wc) {
+	const size_t need = wc * (size_t)(c->NI - 1) * kAnchors;
+	if (c->anchor_tab_off || need <= c->anchor_tab_alloc) return 0;
+	{
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
 		dfree(c, &c->anchor_tab);
 		c->anchor_tab_alloc = 0;
-		const size_t cap = need + need / 4;
+		const size_t cap = need + need / 2;
 		void* q = nullptr;
 		size_t got = cap;
 		if (hipMalloc(&q, cap * sizeof(AnchorRec)) != hipSuccess) {
@@ -1653,7 +1653,17 @@ static int ensure_anchor_table(dvp_ctx* c, int covered_rows) {
 		c->allocs.push_back(q);
 		c->anchor_tab = (AnchorRec*)q;
 		c->anchor_tab_alloc = got;
+		sync_dev_struct(c);
 	}
+	return 0;
+}
+static int ensure_anchor_table(dvp_ctx* c, int covered_rows) {
+	if (c->anchor_tab_off) return 0;
+	if (c->anchor_tab_valid) return 0;
+	const int wc = c->d.weak_black + c->d.weak_red;
+	const size_t need = (size_t)wc * (size_t)(c->NI - 1) * kAnchors;
+	if (grow_anchor_table(c, (size_t)wc)) return 1;
+	if (c->anchor_tab_off) return 0;
 	c->anchor_tab_valid = true;
 	sync_dev_struct(c);
 	ListArgs la;
@@ -1668,14 +1678,15 @@ static int ensure_anchor_table(dvp_ctx* c, int covered_rows) {
 
 // hand-over buffers of the phased weak update (624 + 32 S bytes per WEAK pixel: 1.6 GB at 6208x4128 with 7 % WEAK, S = 9).  A
 // context that cannot have them keeps the one-wave kernel: the same bits.
-static int ensure_weak_phase_buffers(dvp_ctx* c) {
+static int grow_weak_phase_buffers(dvp_ctx* c, size_t wc);
+static int ensure_weak_phase_buffers(dvp_ctx* c) { return grow_weak_phase_buffers(c, (size_t)(c->d.weak_black + c->d.weak_red)); }
+static int grow_weak_phase_buffers(dvp_ctx* c, size_t wc) {
 	if (!c->weak_phased) return 0;
-	const size_t wc = (size_t)(c->d.weak_black + c->d.weak_red);
 	if (wc <= c->weak_phase_alloc) return 0;
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	dfree(c, &c->weak_rec); dfree(c, &c->weak_ctab); dfree(c, &c->weak_ev);
 	c->weak_phase_alloc = 0;
-	const size_t cap = std::min<size_t>(c->L, wc + wc / 4), S = (size_t)c->NI - 1;
+	const size_t cap = std::min<size_t>(c->L, wc + wc / 2), S = (size_t)c->NI - 1;
 	void *r = nullptr, *t = nullptr, *e = nullptr;
 	if (getenv("DVP_TEST_WEAK_PHASE_ALLOC_FAIL") /* test hook: take the fallback */ || hipMalloc(&r, cap * sizeof(WeakRec)) != hipSuccess ||
 	    hipMalloc(&t, cap * kTaps * kTaps * sizeof(f2)) != hipSuccess || hipMalloc(&e, cap * 8 * S * sizeof(float)) != hipSuccess) {
@@ -1692,6 +1703,45 @@ static int ensure_weak_phase_buffers(dvp_ctx* c) {
 	c->weak_phase_alloc = cap;
 	sync_dev_struct(c);
 	return 0;
+}
+
+// The optional buffers of the split strong update and of the view-compacted sweep passes: allocated at the first launch that
+// wants them — or ahead of it by dvp_ctx_reserve, off the critical path (a multi-GB hipMalloc inside a launch site took 0.5-1 s
+// of a view on some boxes: profiles/r06_ab_notes.txt).  A context that cannot have them keeps the monolithic / fused kernels.
+static void ensure_strong_split_buffers(dvp_ctx* c) {
+	if (c->slot_costs || !c->strong_split || c->NI - 1 > 16) return;
+	// 17 x S floats per pixel of one colour (7.8 GB at 6208x4128, S = 9): a part that cannot spare them runs the
+	// monolithic kernel instead, which gives the same bits (test_strong_update_forms_equal_the_oracle)
+	const size_t Lh = (size_t)((c->W + 1) / 2) * c->H;
+	void *sc = nullptr, *sr = nullptr;
+	if (getenv("DVP_TEST_SPLIT_ALLOC_FAIL") /* test hook: take the fallback */ || hipMalloc(&sc, (size_t)kSlotCount * (c->NI - 1) * Lh * sizeof(*c->slot_costs) + 64 /* load_slot_costs reads whole 16-byte pieces */) != hipSuccess || hipMalloc(&sr, (size_t)SR_FIELDS * Lh * sizeof(*c->strong_rec)) != hipSuccess) {
+		(void)hipGetLastError();   // clear the sticky out-of-memory status
+		if (sc) (void)hipFree(sc);
+		c->strong_split = false;
+		fprintf(stderr, "dvp: no room for the split strong update's cost buffer (%.1f GB); using the monolithic kernel\n", (double)kSlotCount * (c->NI - 1) * Lh * 4 / 1e9);
+	} else {
+		c->allocs.push_back(sc); c->allocs.push_back(sr);
+		c->slot_costs = (decltype(c->slot_costs))sc; c->strong_rec = (decltype(c->strong_rec))sr;
+		sync_dev_struct(c);
+	}
+}
+static void ensure_sweep_buffers(dvp_ctx* c) {
+	if (c->sweep_cost || !c->sweep_split) return;
+	// 73 floats per (pixel, view) + 61 + 8 per pixel (67 GB at 6208x4128, S = 9): a context that cannot have them keeps the fused kernel
+	const size_t L = c->L;
+	void *r = nullptr, *sc = nullptr, *pc = nullptr;
+	if (getenv("DVP_TEST_SWEEP_ALLOC_FAIL") || hipMalloc(&r, 2 * L * sizeof(f4)) != hipSuccess || hipMalloc(&pc, 61 * L * sizeof(float)) != hipSuccess ||
+	    hipMalloc(&sc, (size_t)(c->NI - 1) * kSweepFields * L * sizeof(float)) != hipSuccess) {
+		(void)hipGetLastError();
+		if (r) (void)hipFree(r);
+		if (pc) (void)hipFree(pc);
+		c->sweep_split = false;
+		fprintf(stderr, "dvp: no room for the view-compacted DepthToWeak's cost buffer (%.1f GB); using the fused kernel\n", (double)(c->NI - 1) * kSweepFields * L * 4 / 1e9);
+	} else {
+		c->allocs.push_back(r); c->allocs.push_back(sc); c->allocs.push_back(pc);
+		c->sweep_rec = (f4*)r; c->sweep_cost = (float*)sc; c->sweep_pc = (float*)pc;
+		sync_dev_struct(c);
+	}
 }
 
 static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused = false) {
@@ -1829,22 +1879,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 	case DVP_ST_RANDOM_INIT: hipLaunchKernelGGL(c->d.sampler ? dvp_random_init_exact : dvp_random_init, grid, block, 0, c->stream, c->d, a); break;
 	case DVP_ST_STRONG_UPDATE:
 		if (c->strong_split && c->NI - 1 <= 16) {
-			if (!c->slot_costs) {
-				// 17 x S floats per pixel of one colour (7.8 GB at 6208x4128, S = 9): a part that cannot spare them runs the
-				// monolithic kernel below instead, which gives the same bits (test_strong_update_forms_equal_the_oracle)
-				const size_t Lh = (size_t)((c->W + 1) / 2) * c->H;
-				void *sc = nullptr, *sr = nullptr;
-				if (getenv("DVP_TEST_SPLIT_ALLOC_FAIL") /* test hook: take the fallback */ || hipMalloc(&sc, (size_t)kSlotCount * (c->NI - 1) * Lh * sizeof(*c->slot_costs) + 64 /* load_slot_costs reads whole 16-byte pieces */) != hipSuccess || hipMalloc(&sr, (size_t)SR_FIELDS * Lh * sizeof(*c->strong_rec)) != hipSuccess) {
-					(void)hipGetLastError();   // clear the sticky out-of-memory status
-					if (sc) (void)hipFree(sc);
-					c->strong_split = false;
-					fprintf(stderr, "dvp: no room for the split strong update's cost buffer (%.1f GB); using the monolithic kernel\n", (double)kSlotCount * (c->NI - 1) * Lh * 4 / 1e9);
-				} else {
-					c->allocs.push_back(sc); c->allocs.push_back(sr);
-					c->slot_costs = (decltype(c->slot_costs))sc; c->strong_rec = (decltype(c->strong_rec))sr;
-					sync_dev_struct(c);
-				}
-			}
+			ensure_strong_split_buffers(c);
 		}
 		if (c->strong_split && c->NI - 1 <= 16) {
 			const int S = c->NI - 1;
@@ -1871,23 +1906,7 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 		// the passes pay where the views diverge and the geometric term rides along (cfg3: 622 -> 536 ms, cfg5: 48 -> 44); a pass
 		// without the geometric term (FIRST_INIT; cfg2, S = 5) measures 63 ms against the fused kernel's 59: DVP_SWEEP_SPLIT=2 forces the passes there too
 		const bool sweep_passes = fused && c->sweep_split && (c->d.params.geom_consistency || c->sweep_force);
-		if (sweep_passes && !c->sweep_cost) {
-			// 73 floats per (pixel, view) + 61 + 8 per pixel (67 GB at 6208x4128, S = 9): a context that cannot have them keeps the fused kernel
-			const size_t L = c->L;
-			void *r = nullptr, *sc = nullptr, *pc = nullptr;
-			if (getenv("DVP_TEST_SWEEP_ALLOC_FAIL") || hipMalloc(&r, 2 * L * sizeof(f4)) != hipSuccess || hipMalloc(&pc, 61 * L * sizeof(float)) != hipSuccess ||
-			    hipMalloc(&sc, (size_t)(c->NI - 1) * kSweepFields * L * sizeof(float)) != hipSuccess) {
-				(void)hipGetLastError();
-				if (r) (void)hipFree(r);
-				if (pc) (void)hipFree(pc);
-				c->sweep_split = false;
-				fprintf(stderr, "dvp: no room for the view-compacted DepthToWeak's cost buffer (%.1f GB); using the fused kernel\n", (double)(c->NI - 1) * kSweepFields * L * 4 / 1e9);
-			} else {
-				c->allocs.push_back(r); c->allocs.push_back(sc); c->allocs.push_back(pc);
-				c->sweep_rec = (f4*)r; c->sweep_cost = (float*)sc; c->sweep_pc = (float*)pc;
-				sync_dev_struct(c);
-			}
-		}
+		if (sweep_passes) ensure_sweep_buffers(c);
 		if (sweep_passes && c->sweep_split) {
 			const bool ex = c->d.sampler != 0;
 			LaunchArgs s0 = a, s1 = a, sb = a;
@@ -1930,6 +1949,23 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 int dvp_run_stage(dvp_ctx* c, int stage, int iter, int colour) {
 	if (set_device(c)) return 1;
 	return launch_stage(c, stage, iter, colour);
+}
+
+// Optional buffers ahead of their first use (a helper thread of the driver calls this on the context it prepares for the next
+// pyramid level): flags bit 0 = the split strong update's cost block, bit 1 = the view-compacted sweep passes' buffers;
+// weak_pixels > 0: anchor table and hand-over buffers of the weak update for that many WEAK pixels.  Nothing here is required —
+// every launch site allocates what it lacks — and a buffer that does not fit selects the fall-back form exactly as there.
+int dvp_ctx_reserve(dvp_ctx* c, int weak_pixels, int flags) {
+	if (set_device(c)) return 1;
+	if (flags & 1) ensure_strong_split_buffers(c);
+	if (flags & 2) ensure_sweep_buffers(c);
+	if (weak_pixels > 0) {
+		const size_t wc = std::min<size_t>((size_t)weak_pixels, c->L);
+		if (grow_anchor_table(c, wc)) return 1;
+		if (c->anchor_tab && grow_weak_phase_buffers(c, wc)) return 1;
+		c->anchor_tab_valid = false;
+	}
+	return 0;
 }
 
 int dvp_synchronize(dvp_ctx* c) {

@@ -28,6 +28,7 @@ std::string ToFormatIndex(int index);                                           
 template <typename TYPE>
 void RescaleMatToTargetSize(const Mat& src, Mat& dst, int target_width, int target_height);   // APD.cpp:1773-1795
 void RunFusion(const path& dense_folder, const std::vector<Problem>& problems);        // APD.cpp:1809-1960 (on the device: dvp_fuse_*, include/dvp_mvs.h)
+void PrefetchFusionImages(const path& dense_folder, const std::vector<Problem>& problems);   // decode the views' colour images ahead of RunFusion (helper threads)
 void SetFusionOnHost(bool on);          // RunFusion on the host's cores instead (same points, same order, same bits)
 void SetFusionDevice(int device);       // the GPU RunFusion uses (default 0)
 void ExportDepthImagePointCloud(const path& point_cloud_path, const path& image_path, const path& cam_path, Mat& depth, float depth_min, float depth_max);   // APD.cpp:2281-2314

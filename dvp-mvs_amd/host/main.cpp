@@ -631,6 +631,8 @@ int main(int argc, char** argv) {
 			if (APD::LevelSize(*owned[0], pass.scale, &lw, &lh) && (size_t)lw * lh <= (size_t)opt.in_flight_pixels) in_flight = opt.views_in_flight > 0 ? opt.views_in_flight : 2;
 			in_flight = (int)std::min<size_t>((size_t)std::max(1, in_flight), owned.size());
 		}
+		// the fusion's colour images are decoded while the last pass runs (rank 0 fuses)
+		if (it + 1 == plan.size() && opt.fusion && opt.rank == 0 && !opt.sync_io) PrefetchFusionImages(opt.dense_folder, problems);
 		main_lap("pass " + std::to_string(it) + ": helpers started");
 		const auto pass_t0 = std::chrono::steady_clock::now();
 		if (in_flight <= 1) {

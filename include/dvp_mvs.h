@@ -171,6 +171,12 @@ int dvp_reset_state(dvp_ctx* ctx);
  * APD.cpp:984-987) gives the reference for free. */
 int dvp_save_state(dvp_ctx* ctx);
 int dvp_restore_state(dvp_ctx* ctx);
+/* Optional buffers of the context ahead of their first use — what a driver's helper thread calls on the context it prepares
+ * for the next pyramid level, so that no multi-GB allocation lands inside a view's launches (the reference allocates everything in
+ * CudaSpaceInitialization, APD.cpp:1497-1613).  flags: bit 0 = the split strong update's cost block, bit 1 = the view-compacted
+ * DepthToWeak / LocalRefine passes' buffers; weak_pixels > 0: the weak update's anchor table and hand-over buffers for that many
+ * WEAK pixels.  Never required: every launch site allocates what it lacks. */
+int dvp_ctx_reserve(dvp_ctx* ctx, int weak_pixels, int flags);
 int dvp_set_params(dvp_ctx* ctx, const DvpParams* params);                     /* APD.cpp:1607-1608 */
 /* The reference seeds cuRAND with clock64() (APD.cu:1270); here the seed is explicit. */
 int dvp_set_seed(dvp_ctx* ctx, uint64_t seed);

@@ -466,6 +466,35 @@ def test_staged_maps_that_are_never_fetched_do_not_hang_the_context(monkeypatch)
     assert time.time() - t0 < 10
 
 
+def test_reserved_buffers_change_nothing():
+    """dvp_ctx_reserve (the driver's helper thread calls it on the context it prepares for the next level): a context whose
+    optional buffers — split strong update, sweep passes, anchor table, weak hand-over — were allocated ahead, with room for
+    fewer or more WEAK pixels than the pass has, gives the bits of one that allocates them inside its launches."""
+    from test_baseline_configs import _two_pass
+    W, H, S, iters = 160, 120, 5, 2
+    sc = synth.make_scene(W, H, S)
+    made = []
+
+    def make(reserve):
+        def f(scene, p):
+            g = capi().from_scene(scene, p)
+            if reserve is not None:
+                g.reserve(weak_pixels=reserve, flags=3)
+            made.append(g)
+            return g
+        return f
+    outs = []
+    for reserve in (None, 50, W * H):
+        e = _two_pass(make(reserve), sc, S, iters, 0.08)
+        assert e.weak_count() > 500
+        e.run_patchmatch()
+        outs.append({n: e.get(n) for n in ("planes", "costs", "selected_views", "weak_info", "radius", "fit_planes", "view_weight")})
+        e.close()
+    for other in outs[1:]:
+        for n, a in outs[0].items():
+            assert count_diff(a, other[n]) == 0, n
+
+
 def test_golden_weak_pass_engine():
     """the committed REFINE_ITER / weak-path fixture through the C ABI"""
     from test_oracle_kat import _golden_weak_pass
