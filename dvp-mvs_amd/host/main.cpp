@@ -704,7 +704,10 @@ int main(int argc, char** argv) {
 	level_images.Release();
 	APD::ReleasePooledContext();
 	main_lap("contexts and resident maps released");
-	FlushResults();          // every result file of this rank is on disk before anyone (rank 0's fusion) reads the folder
+	// Several ranks: every result file of this rank is on disk before rank 0's fusion reads the folder.  One rank: the fusion takes
+	// the maps from the result cache (LoadResult waits for a map whose background job has not published it yet), so the last views'
+	// files are written while it runs; ShutdownResultStore waits for them.
+	if (opt.world > 1 || opt.sync_io) FlushResults();
 	main_lap("FlushResults (background jobs + file writes)");
 	comm.Barrier();
 	if (opt.fusion && opt.rank == 0) {
