@@ -114,7 +114,7 @@ struct Dev {
 	float* strong_rec;         // [SR_FIELDS][half_w * H]: hand-over from dvp_strong_decide to dvp_strong_refine
 	// DepthToWeak + LocalRefine as view-compacted passes (dvp_strong.hpp: sweep_*), or null (the fused per-pixel kernel)
 	f4* sweep_rec;             // [2][L]: (camera-frame normal, depth) and (mean baseline, disparity, weight sum, flags) per pixel
-	float* sweep_cost;         // [S][kSweepFields][L]: per (view, sweep slot, pixel) costs written by dvp_sweep_eval
+	float* sweep_cost;         // [L/64][S][kSweepFields][64] (sweep_cost_index): per (view, sweep slot, pixel) costs written by dvp_sweep_eval
 	float* sweep_pc;           // [61][L]: the folded cost line of the central window, handed from the first decision pass to the second
 	int half_w;
 	uint32_t* edge_bits;       // the edge map as 32x32-pixel bit tiles (128 B each), see edge_bit()

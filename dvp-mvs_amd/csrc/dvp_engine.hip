@@ -1731,7 +1731,7 @@ static void ensure_sweep_buffers(dvp_ctx* c) {
 	const size_t L = c->L;
 	void *r = nullptr, *sc = nullptr, *pc = nullptr;
 	if (getenv("DVP_TEST_SWEEP_ALLOC_FAIL") || hipMalloc(&r, 2 * L * sizeof(f4)) != hipSuccess || hipMalloc(&pc, 61 * L * sizeof(float)) != hipSuccess ||
-	    hipMalloc(&sc, (size_t)(c->NI - 1) * kSweepFields * L * sizeof(float)) != hipSuccess) {
+	    hipMalloc(&sc, sweep_cost_floats(L, c->NI - 1) * sizeof(float)) != hipSuccess) {
 		(void)hipGetLastError();
 		if (r) (void)hipFree(r);
 		if (pc) (void)hipFree(pc);

@@ -1211,9 +1211,30 @@ constexpr int kSweepExtra = 72;     // sweep_cost field of the current depth: nc
 constexpr int kSweepFields = 73;    // [0, 61): slot pd + 30 — ncc for |pd| <= 5, ncc + factor * geom otherwise; [61, 72): geom of slot |pd| <= 5
 enum { SWF_VALID = 1, SWF_REFINE = 2, SWF_PEAK = 4 };
 DVP_HD int sweep_window(const DvpParams& P) { int cw = P.weak_peak_radius + 1; if (cw < 5) cw = 5; if (cw > 30) cw = 30; return cw; }
+// sweep_cost, the per (view, field, pixel) record.  DVP_SWEEP_LAYOUT 1 (default): [group of 64 pixels][view][field][64] — the 73 fields
+// of a (group, view) are 18.7 KB in a row: an evaluation launch (one view) fills them slot after slot, a decision pass reads a view's 50
+// slots from 50 neighbouring 256-byte lines.  0: [view][field][pixel] (rounds 4-5): the same slots lie L floats apart — 9 x 50 streams
+// 100 MB from each other per wave (dvp_sweep_decide2 read its 48 GB at 2.4 TB/s, profiles/pmc_r06.json).
+#ifndef DVP_SWEEP_LAYOUT
+#define DVP_SWEEP_LAYOUT 1
+#endif
+DVP_HD size_t sweep_cost_floats(size_t L, int S) { return ((L + 63) / 64) * 64 * (size_t)S * kSweepFields; }
+DVP_HD size_t sweep_field_stride(const Dev& d) {   // between field f and f + 1 of the same (view, pixel)
+#if DVP_SWEEP_LAYOUT == 1
+	(void)d;
+	return 64;
+#else
+	return (size_t)d.width * (size_t)d.height;
+#endif
+}
 DVP_HD size_t sweep_cost_index(const Dev& d, int v, int f, int center) {
+#if DVP_SWEEP_LAYOUT == 1
+	const int S = d.params.num_images - 1;
+	return (((size_t)(center >> 6) * S + v) * kSweepFields + (size_t)f) * 64 + (size_t)(center & 63);
+#else
 	const size_t L = (size_t)d.width * (size_t)d.height;
 	return ((size_t)v * kSweepFields + (size_t)f) * L + (size_t)center;
+#endif
 }
 DVP_HD bool sweep_is_border(const Dev& d, int px, int py) { return px < 6 || py < 6 || px >= d.width - 6 || py >= d.height - 6; }
 
@@ -1284,6 +1305,7 @@ DVP_HD void sweep_eval_px(const Dev& d, int px, int py, int v, int stage, PatchT
 	}
 	const int cw = sweep_window(P);
 	float* out = d.sweep_cost + sweep_cost_index(d, v, 0, center);
+	const size_t FS = sweep_field_stride(d);
 	const int k0 = stage == 0 ? 0 : 2 * cw + 1, k1 = stage == 0 ? 2 * cw + 1 + (refine ? 1 : 0) : 61;
 	for (int k = k0; k < k1; ++k) {
 		const bool extra = stage == 0 && k == 2 * cw + 1;   // LocalRefine's current-depth slot
@@ -1320,14 +1342,14 @@ DVP_HD void sweep_eval_px(const Dev& d, int px, int py, int v, int stage, PatchT
 		if (extra) {
 			float t = ncc;
 			if (P.geom_consistency) t += P.geom_factor * gc;
-			out[(size_t)kSweepExtra * L] = t;
+			out[(size_t)kSweepExtra * FS] = t;
 		} else if (pd >= -5 && pd <= 5) {
-			out[(size_t)(pd + 30) * L] = ncc;
-			if (P.geom_consistency) out[(size_t)(61 + pd + 5) * L] = gc;
+			out[(size_t)(pd + 30) * FS] = ncc;
+			if (P.geom_consistency) out[(size_t)(61 + pd + 5) * FS] = gc;
 		} else {
 			float cst = ncc;
 			if (P.geom_consistency) cst += P.geom_factor * gc;
-			out[(size_t)(pd + 30) * L] = cst;
+			out[(size_t)(pd + 30) * FS] = cst;
 		}
 	}
 }
@@ -1341,7 +1363,7 @@ DVP_HD void sweep_eval_px(const Dev& d, int px, int py, int v, int stage, PatchT
 DVP_HD void sweep_fold(const Dev& d, int center, int pd, uint32_t sel, const uint8_t* vw, bool both, float* pc_out, float* lr_out) {
 	const DvpParams& P = d.params;
 	const int S = P.num_images - 1;
-	const size_t L = (size_t)d.width * (size_t)d.height;
+	const size_t FS = sweep_field_stride(d);
 	float pc = 0.0f, lr = 0.0f;
 	for (int v = 0; v < S; ++v) {
 		if (!is_set(sel, v)) continue;
@@ -1349,11 +1371,11 @@ DVP_HD void sweep_fold(const Dev& d, int center, int pd, uint32_t sel, const uin
 		const float* in = d.sweep_cost + sweep_cost_index(d, v, 0, center);
 		float ncc = 0.0f, gc = 0.0f, cst;
 		if (pd >= -5 && pd <= 5) {
-			ncc = in[(size_t)(pd + 30) * L];
+			ncc = in[(size_t)(pd + 30) * FS];
 			cst = ncc;
-			if (P.geom_consistency) { gc = in[(size_t)(61 + pd + 5) * L]; cst += P.geom_factor * gc; }
+			if (P.geom_consistency) { gc = in[(size_t)(61 + pd + 5) * FS]; cst += P.geom_factor * gc; }
 		} else {
-			cst = in[(size_t)(pd + 30) * L];
+			cst = in[(size_t)(pd + 30) * FS];
 		}
 		const float tc = 0.0f + cst;
 		pc += tc * vw[v];
@@ -1439,6 +1461,7 @@ DVP_HD void sweep_decide2_px(const Dev& d, int px, int py) {
 	const uint32_t sel = d.selected_views[center];
 	const uint8_t* vw = d.view_weight + (size_t)center * 32;
 	const int cw = sweep_window(P);
+	const size_t FS = sweep_field_stride(d);
 	uint64_t live = 0;   // slots outside the window that are inside the depth range
 	for (int pd = -30; pd <= 30; ++pd) {
 		if (pd >= -cw && pd <= cw) continue;
@@ -1457,7 +1480,7 @@ DVP_HD void sweep_decide2_px(const Dev& d, int px, int py) {
 		for (int i = 0; i < 61; ++i) {
 			const int pd = i - 30;
 			if (pd >= -cw && pd <= cw) continue;          // (uniform; cw >= 5: the slots with separate ncc / geom fields are all inside)
-			const float cst = in[(size_t)i * L];
+			const float cst = in[(size_t)i * FS];
 			if ((live >> i) & 1) {
 				const float tc = 0.0f + cst;
 				p_costs[i] += tc * w;

@@ -518,7 +518,7 @@ int emu_run_stage(void* c, int stage, int iter, int colour) {
 		const size_t L = (size_t)e.W * e.H;
 		const int S = e.NI - 1;
 		e.sweep_rec.assign(2 * L, mk4(0, 0, 0, 0));
-		e.sweep_cost.assign((size_t)S * kSweepFields * L, -7.0f);   // (a value no decision may ever read)
+		e.sweep_cost.assign(sweep_cost_floats(L, S), -7.0f);   // (a value no decision may ever read)
 		e.sweep_pc.assign(61 * L, -7.0f);
 		refresh(e);
 		const long long n = (long long)L;
