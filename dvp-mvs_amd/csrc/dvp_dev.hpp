@@ -23,6 +23,19 @@
 #define DVP_HD inline
 #define DVP_HD_NOINLINE inline
 #endif
+// Streaming hints for records that are written once and read once by a later launch (the sweep passes' and the strong update's cost
+// records): non-temporal stores / loads, so that they do not push the image rows the evaluators gather out of L2.  Same values either way.
+// DVP_STREAM_HINTS bits: 1 sweep-cost stores, 2 sweep-cost loads, 4 slot-cost stores, 8 slot-cost loads.
+#ifndef DVP_STREAM_HINTS
+#define DVP_STREAM_HINTS 3   // sweep-cost records: depth_to_weak site 521.4 -> 517.1 ms at cfg3; the slot-cost records (12) lose 42 ms: the decision launch re-reads their lines through L2 (profiles/r06_ab_notes.txt)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DVP_NT_STORE(bit, p, v) do { if ((DVP_STREAM_HINTS) & (bit)) __builtin_nontemporal_store((v), (p)); else *(p) = (v); } while (0)
+#define DVP_NT_LOAD(bit, p) (((DVP_STREAM_HINTS) & (bit)) ? __builtin_nontemporal_load(p) : *(p))
+#else
+#define DVP_NT_STORE(bit, p, v) (*(p) = (v))
+#define DVP_NT_LOAD(bit, p) (*(p))
+#endif
 
 namespace dvp {
 

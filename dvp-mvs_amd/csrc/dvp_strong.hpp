@@ -561,7 +561,7 @@ DVP_HD void strong_eval_item(const Dev& d, const PatchCtx& c, int px, int py, in
 	const f4 plane = d.planes_snap[pos];
 	for (int v = 0; v < S; ++v) {
 		const float cost = ncc_old<SMP>(d, c, px, py, v + 1, plane);
-		if (store) d.slot_costs[slot_cost_index(d, slot, v, px, py)] = cost;
+		if (store) DVP_NT_STORE(4, &d.slot_costs[slot_cost_index(d, slot, v, px, py)], cost);
 	}
 	if (nevals && store) *nevals += (unsigned long long)S;
 }
@@ -594,7 +594,7 @@ DVP_HD void load_slot_costs(const float* sc, size_t view_stride, int S, float* o
 	constexpr int Q = (MV + 3) / 4;
 	f4v q[Q];
 #pragma unroll
-	for (int i = 0; i < Q; ++i) q[i] = reinterpret_cast<const f4v*>(sc)[i];
+	for (int i = 0; i < Q; ++i) q[i] = DVP_NT_LOAD(8, &reinterpret_cast<const f4v*>(sc)[i]);
 #pragma unroll
 	for (int v = 0; v < MV; ++v) out[v] = v < S ? q[v >> 2][v & 3] : 0.0f;
 #else
@@ -1342,14 +1342,14 @@ DVP_HD void sweep_eval_px(const Dev& d, int px, int py, int v, int stage, PatchT
 		if (extra) {
 			float t = ncc;
 			if (P.geom_consistency) t += P.geom_factor * gc;
-			out[(size_t)kSweepExtra * FS] = t;
+			DVP_NT_STORE(1, &out[(size_t)kSweepExtra * FS], t);
 		} else if (pd >= -5 && pd <= 5) {
-			out[(size_t)(pd + 30) * FS] = ncc;
-			if (P.geom_consistency) out[(size_t)(61 + pd + 5) * FS] = gc;
+			DVP_NT_STORE(1, &out[(size_t)(pd + 30) * FS], ncc);
+			if (P.geom_consistency) DVP_NT_STORE(1, &out[(size_t)(61 + pd + 5) * FS], gc);
 		} else {
 			float cst = ncc;
 			if (P.geom_consistency) cst += P.geom_factor * gc;
-			out[(size_t)(pd + 30) * FS] = cst;
+			DVP_NT_STORE(1, &out[(size_t)(pd + 30) * FS], cst);
 		}
 	}
 }
@@ -1371,11 +1371,11 @@ DVP_HD void sweep_fold(const Dev& d, int center, int pd, uint32_t sel, const uin
 		const float* in = d.sweep_cost + sweep_cost_index(d, v, 0, center);
 		float ncc = 0.0f, gc = 0.0f, cst;
 		if (pd >= -5 && pd <= 5) {
-			ncc = in[(size_t)(pd + 30) * FS];
+			ncc = DVP_NT_LOAD(2, &in[(size_t)(pd + 30) * FS]);
 			cst = ncc;
-			if (P.geom_consistency) { gc = in[(size_t)(61 + pd + 5) * FS]; cst += P.geom_factor * gc; }
+			if (P.geom_consistency) { gc = DVP_NT_LOAD(2, &in[(size_t)(61 + pd + 5) * FS]); cst += P.geom_factor * gc; }
 		} else {
-			cst = in[(size_t)(pd + 30) * FS];
+			cst = DVP_NT_LOAD(2, &in[(size_t)(pd + 30) * FS]);
 		}
 		const float tc = 0.0f + cst;
 		pc += tc * vw[v];
@@ -1480,7 +1480,7 @@ DVP_HD void sweep_decide2_px(const Dev& d, int px, int py) {
 		for (int i = 0; i < 61; ++i) {
 			const int pd = i - 30;
 			if (pd >= -cw && pd <= cw) continue;          // (uniform; cw >= 5: the slots with separate ncc / geom fields are all inside)
-			const float cst = in[(size_t)i * FS];
+			const float cst = DVP_NT_LOAD(2, &in[(size_t)i * FS]);
 			if ((live >> i) & 1) {
 				const float tc = 0.0f + cst;
 				p_costs[i] += tc * w;
