@@ -1406,6 +1406,61 @@ DVP_HD void sweep_decide1_px(const Dev& d, int px, int py) {
 	const int cw = sweep_window(P);
 	float lr_costs[11];
 	unsigned lr_live = 0;
+	float cost_now = 0.0f;
+#if !defined(DVP_SWEEP_FOLD_BRANCHY)
+	if (cw == 5) {
+		// The default window: the 11 slots are LocalRefine's too.  View outside, the view's 23 fields fetched together, the sums as
+		// selects — every slot's sum still receives its terms in view order (sweep_fold below, slot outside with a load per (slot, view)
+		// inside two branches, is the same arithmetic: 150 dependent round trips per pixel, 8.3 ms for 25 GB at cfg3).
+		const size_t FS = sweep_field_stride(d);
+		float pc[11], lr[11];
+		unsigned in_range = 0;
+#pragma unroll
+		for (int i = 0; i < 11; ++i) {
+			pc[i] = 0.0f; lr[i] = 0.0f;
+			const float p_depth = rc.K[0] * base_line / (disp + (i - 5));
+			if (!(p_depth < P.depth_min || p_depth > P.depth_max)) in_range |= 1u << i;
+		}
+		for (int v = 0; v < S; ++v) {
+			if (!is_set(sel, v)) continue;
+			if (vw[v] == 0) continue;
+			const float* in = d.sweep_cost + sweep_cost_index(d, v, 0, center);
+			const float w = vw[v];
+			float ncc[11], gc[11];
+#pragma unroll
+			for (int i = 0; i < 11; ++i) {
+				ncc[i] = DVP_NT_LOAD(2, &in[(size_t)(25 + i) * FS]);
+				gc[i] = 0.0f;
+				if (P.geom_consistency) gc[i] = DVP_NT_LOAD(2, &in[(size_t)(61 + i) * FS]);
+			}
+			const float extra = DVP_NT_LOAD(2, &in[(size_t)kSweepExtra * FS]);
+			sched_fence();
+#pragma unroll
+			for (int i = 0; i < 11; ++i) {
+				float cst = ncc[i];
+				if (P.geom_consistency) cst += P.geom_factor * gc[i];
+				const float tc = 0.0f + cst;
+				const float t = pc[i] + tc * w;
+				pc[i] = ((in_range >> i) & 1) ? t : pc[i];
+				float u = lr[i] + ncc[i] * w;   // ncc*w and (factor*geom)*w added separately, APD.cu:4124-4126
+				if (P.geom_consistency) u += (P.geom_factor * gc[i] * w);
+				lr[i] = ((in_range >> i) & 1) ? u : lr[i];
+			}
+			const float cn = cost_now + extra * w;
+			cost_now = refine ? cn : cost_now;
+		}
+#pragma unroll
+		for (int i = 0; i < 11; ++i) {
+			float pcv = 2.0f;
+			if ((in_range >> i) & 1) {
+				pcv = DVP_MIN(2.0f, pc[i] / weight_normal);
+				if (refine) { lr_costs[i] = lr[i] / weight_normal; lr_live |= 1u << i; }
+			}
+			d.sweep_pc[(size_t)(25 + i) * L + center] = pcv;
+		}
+	} else
+#endif
+	{
 	for (int pd = -cw; pd <= cw; ++pd) {
 		const float p_depth = rc.K[0] * base_line / (disp + pd);
 		float pcv = 2.0f;
@@ -1419,6 +1474,13 @@ DVP_HD void sweep_decide1_px(const Dev& d, int px, int py) {
 		}
 		d.sweep_pc[(size_t)(pd + 30) * L + center] = pcv;
 	}
+	if (refine)
+		for (int v = 0; v < S; ++v) {
+			if (!is_set(sel, v)) continue;
+			if (vw[v] == 0) continue;
+			cost_now += d.sweep_cost[sweep_cost_index(d, v, kSweepExtra, center)] * vw[v];
+		}
+	}
 	bool central_peak = false;
 	for (int i = 30 - P.weak_peak_radius; i <= 30 + P.weak_peak_radius; ++i) {
 		if (i < 2 || i > 58) continue;
@@ -1428,13 +1490,7 @@ DVP_HD void sweep_decide1_px(const Dev& d, int px, int py) {
 	if (!central_peak) d.weak_info[center] = DVP_WEAK;
 	else d.sweep_rec[L + center].w = (float)(flags | SWF_PEAK);
 	if (!refine) return;
-	// ---- LocalRefine: the current depth (cost_now, APD.cu:4080-4090), then the minimum over the sweep slots ----
-	float cost_now = 0.0f;
-	for (int v = 0; v < S; ++v) {
-		if (!is_set(sel, v)) continue;
-		if (vw[v] == 0) continue;
-		cost_now += d.sweep_cost[sweep_cost_index(d, v, kSweepExtra, center)] * vw[v];
-	}
+	// ---- LocalRefine: the current depth (cost_now, APD.cu:4080-4090: summed with the folds above), then the minimum over the sweep slots ----
 	cost_now /= weight_normal;
 	float lr_min = 2.0f;
 	int best_pd = -6;
@@ -1448,7 +1504,10 @@ DVP_HD void sweep_decide1_px(const Dev& d, int px, int py) {
 
 // (the window is 11 slots at the default radius: the slot-outside fold of sweep_fold measures 8 ms per cfg3 launch, the unrolled
 // view-outside form used below for the rest of the line 13 — 168 registers and a predicate per slot)
-DVP_HD void sweep_decide2_px(const Dev& d, int px, int py) {
+// CW: the window half-width known at compile time (5 at the default weak_peak_radius), 0 = read from the parameters.  With a run-time
+// window every slot's `inside the window?` is a scalar branch around its load, and a wait at every join.
+template <int CW>
+DVP_HD void sweep_decide2_cw(const Dev& d, int px, int py) {
 	const int W = d.width;
 	const int center = px + py * W;
 	const size_t L = (size_t)W * (size_t)d.height;
@@ -1460,7 +1519,7 @@ DVP_HD void sweep_decide2_px(const Dev& d, int px, int py) {
 	const float base_line = info.x, disp = info.y, weight_normal = info.z;
 	const uint32_t sel = d.selected_views[center];
 	const uint8_t* vw = d.view_weight + (size_t)center * 32;
-	const int cw = sweep_window(P);
+	const int cw = CW > 0 ? CW : sweep_window(P);
 	const size_t FS = sweep_field_stride(d);
 	uint64_t live = 0;   // slots outside the window that are inside the depth range
 	for (int pd = -30; pd <= 30; ++pd) {
@@ -1476,15 +1535,28 @@ DVP_HD void sweep_decide2_px(const Dev& d, int px, int py) {
 		if (vw[v] == 0) continue;
 		const float* in = d.sweep_cost + sweep_cost_index(d, v, 0, center);
 		const float w = vw[v];
+		// every slot of the view is fetched — a slot outside the depth range holds whatever an earlier launch left, its sum is not
+		// used — and the sums are selects, not branches: with `if (live) { load; add }` the compiler kept each load inside its branch
+		// with a wait behind it, 50 dependent round trips per view (20.0 ms for 48 GB at cfg3, r06_kernel_stats; DVP_SWEEP_FOLD_BRANCHY)
+		float cst[61];
 #pragma unroll
 		for (int i = 0; i < 61; ++i) {
 			const int pd = i - 30;
+			cst[i] = 0.0f;
 			if (pd >= -cw && pd <= cw) continue;          // (uniform; cw >= 5: the slots with separate ncc / geom fields are all inside)
-			const float cst = DVP_NT_LOAD(2, &in[(size_t)i * FS]);
-			if ((live >> i) & 1) {
-				const float tc = 0.0f + cst;
-				p_costs[i] += tc * w;
-			}
+#if defined(DVP_SWEEP_FOLD_BRANCHY)
+			if ((live >> i) & 1)
+#endif
+			cst[i] = DVP_NT_LOAD(2, &in[(size_t)i * FS]);
+		}
+		sched_fence();
+#pragma unroll
+		for (int i = 0; i < 61; ++i) {
+			const int pd = i - 30;
+			if (pd >= -cw && pd <= cw) continue;
+			const float tc = 0.0f + cst[i];
+			const float t = p_costs[i] + tc * w;
+			p_costs[i] = ((live >> i) & 1) ? t : p_costs[i];
 		}
 	}
 #pragma unroll
@@ -1526,6 +1598,10 @@ DVP_HD void sweep_decide2_px(const Dev& d, int px, int py) {
 		state = (var > 0.2f) ? DVP_STRONG : DVP_WEAK;
 	}
 	d.weak_info[center] = state;
+}
+DVP_HD void sweep_decide2_px(const Dev& d, int px, int py) {
+	if (sweep_window(d.params) == 5) sweep_decide2_cw<5>(d, px, py);
+	else sweep_decide2_cw<0>(d, px, py);
 }
 
 }  // namespace dvp
