@@ -283,20 +283,29 @@ DVP_HD bool make_anchor_record(const Dev& d, int center, int v0, int k, AnchorRe
 	}
 	AnchorRec& r = *out;
 	float a_sr = 0.0f, a_srr = 0.0f, a_sw = 0.0f;
+	// the nine texels first (one round trip; fetched inside the tap loop they were nine, each behind the `default ring` branch)
+	int ti[9], tj[9];
+	float tav[9];
 #pragma unroll
 	for (int t = 0; t < 9; ++t) {
 		int i = 0, j = 0;
 		if (t < 8) {
 			i = cand[t].x;
 			j = cand[t].y;
-			if (i == 0 && j == 0) {   // default +-5 ring (APD.cu:943-952): {-5,0,5}^2 without its centre, x-major
-				const int u = t + (t >= 4 ? 1 : 0);
-				i = (u / 3 - 1) * 5;
-				j = (u % 3 - 1) * 5;
-			}
+			const bool ring = i == 0 && j == 0;   // default +-5 ring (APD.cu:943-952): {-5,0,5}^2 without its centre, x-major
+			const int u = t + (t >= 4 ? 1 : 0);
+			i = ring ? (u / 3 - 1) * 5 : i;
+			j = ring ? (u % 3 - 1) * 5 : j;
 		}
+		ti[t] = i; tj[t] = j;
+		tav[t] = ref_texel_t<FMT>(d, nb.x + i, nb.y + j);
+	}
+	sched_fence();
+#pragma unroll
+	for (int t = 0; t < 9; ++t) {
+		const int i = ti[t], j = tj[t];
 		const int tx = nb.x + i, ty = nb.y + j;
-		const float av = ref_texel_t<FMT>(d, tx, ty);
+		const float av = tav[t];
 		const float w = bilateral_weight((float)i, (float)j, av, cpix, d.params.sigma_spatial, d.params.sigma_color, 1);
 		const float wa = w * av;
 		a_sr += wa;

@@ -1,0 +1,7 @@
+mkdir -p gpurun_out/r06
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_baseline_configs.py -x -q -m gpu > gpurun_out/r06/parity_tests.log 2>&1
+tail -3 gpurun_out/r06/parity_tests.log
+run() { DVP_MVS_LIB=$2 timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-per-iteration 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], {k: round(v,1) for k,v in d['stage_ms_per_step'].items() if v > 20})"; }
+run tree ""
+for v in "$@"; do run $v $PWD/build/variants/$v.so; done
+run tree ""
