@@ -681,9 +681,12 @@ int main(int argc, char** argv) {
 				});
 			for (std::thread& t : workers) t.join();
 		}
-		if (std::getenv("DVP_HOST_TIMING"))
-			std::cout << "Pass " << it << ": " << owned.size() << " views in " << std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - pass_t0).count() / 1000.0
-			          << " ms, " << in_flight << " in flight" << std::endl;
+		if (std::getenv("DVP_HOST_TIMING")) {   // (one write: the background jobs of the pass' views may still be printing their own timing lines)
+			std::ostringstream line;
+			line << "Pass " << it << ": " << owned.size() << " views in " << std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - pass_t0).count() / 1000.0
+			     << " ms, " << in_flight << " in flight\n";
+			std::cout << line.str() << std::flush;
+		}
 		// With peers, a view whose size differs from a source's takes that source's depth map from APD/<id>/depths.dmb
 		// (APD.cpp fallback from the resident maps to LoadResult): the owner's background writer must have put this
 		// pass' files on disk BEFORE the barrier lets anyone into the next pass, or the reader sees the previous pass'
