@@ -165,13 +165,16 @@ void APD::PrewarmContext(int w, int h, int ni) {
 		dvp_ctx* c = nullptr;
 		if (dvp_ctx_create(device, w, h, ni, &c) != 0) c = nullptr;   // (the view that needs it will try again and report)
 		// ... with its optional buffers: the next level's first views would otherwise allocate them inside their launches (the split
-		// strong update's 7.8 GB, the sweep passes' 67 GB, the anchor table: 0.5-1 s of a full-size view on some boxes).  WEAK pixels:
-		// room for as many as 16 GB of anchor table + hand-over records hold (1408 S + 544 + 32 S bytes each), at most 90 % of the
-		// view — 4.6 % of a 25-Mpx view with 9 sources (its passes have 1-3 %), 18 % at 3104x2064, most of a coarse level; a view with
-		// more grows the table once, as before.
+		// strong update's 7.8 GB, the sweep passes' 67 GB, the anchor table).  Fresh device memory costs 31-40 ms per GB on this part
+		// (tools/micro/alloc_time.hip: hipMalloc of 16 / 48 / 120 GB = 0.54 / 1.9 / 3.7 s on an idle GPU; the views running meanwhile wait
+		// for part of it), so the room for WEAK pixels (1408 S + 544 + 32 S bytes each: anchor table + hand-over records) is sized by
+		// what the levels of a coarse-to-fine schedule hold, at most 90 % of the view: 48 GB below 8 Mpx — all of a 1552x1032 level
+		// (its passes are 83-97 % WEAK), 55 % at 3104x2064 (17-38 %) — and 24 GB above — 7 % of a 25-Mpx view with 9 sources (1-6 %).
+		// A view with more grows the table once, inside its weak update (1.1-1.7 s with the 16 GB of the first version at 3104x2064).
 		if (c) {
 			const long long per_px = 1408ll * (ni - 1) + 544 + 32ll * (ni - 1);
-			const long long room = std::min<long long>((long long)w * h * 9 / 10, 16000000000ll / per_px);
+			const long long budget = (long long)w * h <= 8000000ll ? 48000000000ll : 24000000000ll;
+			const long long room = std::min<long long>((long long)w * h * 9 / 10, budget / per_px);
 			(void)dvp_ctx_reserve(c, (int)std::min<long long>(room, 2000000000ll), 3);
 		}
 		g_prewarm.ctx = c;
