@@ -129,6 +129,8 @@ struct Dev {
 	f4* sweep_rec;             // [2][L]: (camera-frame normal, depth) and (mean baseline, disparity, weight sum, flags) per pixel
 	float* sweep_cost;         // [L/64][S][kSweepFields][64] (sweep_cost_index): per (view, sweep slot, pixel) costs written by dvp_sweep_eval
 	float* sweep_pc;           // [61][L]: the folded cost line of the central window, handed from the first decision pass to the second
+	int sweep_px0;             // sweep passes in bands of rows (a context told to keep sweep_cost small): sweep_cost holds the pixels from this linear index on,
+	int sweep_row0, sweep_row1;   // and the decision passes of a band take the rows [row0, row1) (row1 == 0: the whole image)
 	int half_w;
 	uint32_t* edge_bits;       // the edge map as 32x32-pixel bit tiles (128 B each), see edge_bit()
 	int edge_tiles_x;

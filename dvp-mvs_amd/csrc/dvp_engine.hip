@@ -16,6 +16,7 @@
 #include <thread>
 #include <chrono>
 #include <algorithm>
+#include <cmath>
 
 using namespace dvp;
 
@@ -263,6 +264,7 @@ template <int WHAT>
 __device__ __forceinline__ void sweep_light_body(const Dev& d, const LaunchArgs& a) {
 	int px, py;
 	if (!block_to_pixel(blockIdx.x, threadIdx.x & 63, threadIdx.x >> 6, a.tiles_x, a.tiles, a.rows, 0, 0, d.width, d.height, &px, &py)) return;
+	if (WHAT != 0 && d.sweep_row1 > 0 && (py < d.sweep_row0 || py >= d.sweep_row1)) return;   // a band's decision pass
 	if (WHAT == 0) sweep_prepare_px(d, px, py);
 	else if (WHAT == 1) sweep_decide1_px(d, px, py);
 	else sweep_decide2_px(d, px, py);
@@ -303,6 +305,7 @@ __device__ __forceinline__ void sweep_eval_body(const Dev& d, const LaunchArgs& 
 		if (w_last >= 8) { ty = rem >> 3; tx = st * 8 + (rem & 7); }
 		else { ty = rem / w_last; tx = st * 8 + (rem - ty * w_last); }
 	}
+	ty += a.rows;   // first tile row of the launch (a band of the image; 0: all of it)
 	const int x = tx * 64 + lane;
 	int n = 0;
 	for (int r = 0; r < kSweepRows; ++r) {
@@ -1101,6 +1104,8 @@ struct dvp_ctx {
 	bool ransac_wave = false;    // DVP_RANSAC_WAVE=1: RANSACToGetFitPlane one wave per WEAK pixel, lane = draw (round 6: measured no faster, 16.1 vs 15.9 ms at cfg3, 55.6 vs 49.0 at 25 % WEAK)
 	bool sweep_split = true;     // DVP_SWEEP_SPLIT=0, or the buffers did not fit: the fused per-pixel kernel
 	bool sweep_force = false;    // DVP_SWEEP_SPLIT=2: the passes also without the geometric term (tests)
+	double sweep_band_gb = 0.0;  // DVP_SWEEP_BAND_GB=g: sweep_cost holds a band of rows of at most g GB and the passes run band after band (0: the whole image, 67 GB at 6208x4128 with 9 sources)
+	int sweep_band_rows = 0;     // rows of a band (a multiple of the evaluation tile's rows); 0 = not banded
 	bool gn_wave = false;        // DVP_GN_WAVE=1: GenNeighbours' search as one wave per WEAK pixel (dvp_gen_neighbours_search; measured slower)
 	float* costs = nullptr; float* costs_snap = nullptr; float* complex_ = nullptr;
 	uint32_t* selected_views = nullptr;
@@ -1188,6 +1193,7 @@ static void sync_dev_struct(dvp_ctx* c) {
 	d.plane_stride = (size_t)c->pitch * (c->H + 2 * kImgPad);
 	d.images = c->images; d.images8 = c->images8_ok ? c->images8 : nullptr; d.img8_tiles_x = img8_tiles_x(c->W); d.img8_plane_bytes = (size_t)img8_tiles_x(c->W) * img8_tiles_y(c->H) * 128; d.depths = c->depths; d.cameras = c->cameras; d.views = c->views; d.sector_taps = c->sector_taps; d.sector_start = c->sector_start;
 	d.search_pos = c->search_pos;
+	d.sweep_px0 = 0; d.sweep_row0 = 0; d.sweep_row1 = 0;   // (set per band by the sweep passes' launches)
 	d.sweep_rec = c->sweep_rec; d.sweep_cost = c->sweep_cost; d.sweep_pc = c->sweep_pc; d.slot_costs = c->slot_costs; d.strong_rec = c->strong_rec; d.half_w = (c->W + 1) / 2;
 	d.planes = c->planes; d.planes_snap = c->planes_snap; d.costs = c->costs; d.costs_snap = c->costs_snap;
 	d.selected_views = c->selected_views; d.view_weight = c->view_weight; d.weak_info = c->weak_info;
@@ -1228,6 +1234,7 @@ int dvp_ctx_create(int device, int width, int height, int num_images, dvp_ctx** 
 	if (const char* e = getenv("DVP_REFINE_LANES")) c->refine_lanes = atoi(e) != 0;
 	if (const char* e = getenv("DVP_EVAL_ITEMS")) c->eval_items = atoi(e) != 0;
 	if (const char* e = getenv("DVP_SWEEP_SPLIT")) { c->sweep_split = atoi(e) != 0; c->sweep_force = atoi(e) == 2; }
+	if (const char* e = getenv("DVP_SWEEP_BAND_GB")) c->sweep_band_gb = atof(e);
 	if (const char* e = getenv("DVP_WEAK_ANCHOR_TAB")) c->anchor_tab_off = atoi(e) == 0;   // A/B measurements and the tests of the per-item form
 	if (const char* e = getenv("DVP_GN_WAVE")) c->gn_wave = atoi(e) != 0;
 	if (const char* e = getenv("DVP_RANSAC_WAVE")) c->ransac_wave = atoi(e) != 0;
@@ -1730,8 +1737,21 @@ static void ensure_sweep_buffers(dvp_ctx* c) {
 	// 73 floats per (pixel, view) + 61 + 8 per pixel (67 GB at 6208x4128, S = 9): a context that cannot have them keeps the fused kernel
 	const size_t L = c->L;
 	void *r = nullptr, *sc = nullptr, *pc = nullptr;
+	// the cost records of the whole image, or of a band of rows when the context is told to keep them small (fresh device memory is 31-40 ms
+	// per GB on this part, tools/micro/alloc_time.hip: 2.3 s for a 25-Mpx view's 67 GB)
+	size_t band_px = L;
+	c->sweep_band_rows = 0;
+	if (c->sweep_band_gb > 0.0) {
+		const double whole = (double)sweep_cost_floats(L, c->NI - 1) * sizeof(float);
+		const int bands = (int)std::ceil(whole / (c->sweep_band_gb * 1e9));
+		if (bands > 1) {
+			int rows = (c->H + bands - 1) / bands;
+			rows = (rows + kSweepRows - 1) / kSweepRows * kSweepRows;
+			if (rows < c->H) { c->sweep_band_rows = rows; band_px = (size_t)rows * c->W; }
+		}
+	}
 	if (getenv("DVP_TEST_SWEEP_ALLOC_FAIL") || hipMalloc(&r, 2 * L * sizeof(f4)) != hipSuccess || hipMalloc(&pc, 61 * L * sizeof(float)) != hipSuccess ||
-	    hipMalloc(&sc, sweep_cost_floats(L, c->NI - 1) * sizeof(float)) != hipSuccess) {
+	    hipMalloc(&sc, sweep_cost_floats(band_px, c->NI - 1) * sizeof(float)) != hipSuccess) {
 		(void)hipGetLastError();
 		if (r) (void)hipFree(r);
 		if (pc) (void)hipFree(pc);
@@ -1915,12 +1935,29 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 			s0.tiles_x = s1.tiles_x = etx; s0.tiles = s1.tiles = etx * ety;
 			const dim3 egrid((unsigned)(etx * ety), (unsigned)(c->NI - 1));
 			hipLaunchKernelGGL(dvp_sweep_prepare, grid, block, 0, c->stream, c->d, a);
-			hipLaunchKernelGGL(ex ? dvp_sweep_eval_exact : dvp_sweep_eval, egrid, dim3(64), 0, c->stream, c->d, s0);
-			hipLaunchKernelGGL(dvp_sweep_decide1, grid, block, 0, c->stream, c->d, a);
-			if (sweep_window(c->d.params) < 30) {
-				hipLaunchKernelGGL(ex ? dvp_sweep_eval_exact : dvp_sweep_eval, egrid, dim3(64), 0, c->stream, c->d, s1);
+			// evaluate / decide / evaluate / decide over the whole image, or band of rows after band of rows through the one band-sized
+			// cost buffer (every pass is per pixel: same bits)
+			const int band_rows = c->sweep_band_rows > 0 ? c->sweep_band_rows : c->H;
+			for (int row0 = 0; row0 < c->H; row0 += band_rows) {
+				Dev db = c->d;
+				LaunchArgs b0 = s0, b1 = s1;
+				dim3 bgrid = egrid;
+				b0.rows = b1.rows = 0;
+				if (c->sweep_band_rows > 0) {
+					const int row1 = std::min(c->H, row0 + band_rows);
+					db.sweep_px0 = row0 * c->W; db.sweep_row0 = row0; db.sweep_row1 = row1;
+					const int bty = (row1 - row0 + kSweepRows - 1) / kSweepRows;
+					b0.rows = b1.rows = row0 / kSweepRows;
+					b0.tiles = b1.tiles = etx * bty;
+					bgrid = dim3((unsigned)(etx * bty), (unsigned)(c->NI - 1));
+				}
+				hipLaunchKernelGGL(ex ? dvp_sweep_eval_exact : dvp_sweep_eval, bgrid, dim3(64), 0, c->stream, db, b0);
+				hipLaunchKernelGGL(dvp_sweep_decide1, grid, block, 0, c->stream, db, a);
+				if (sweep_window(c->d.params) < 30) {
+					hipLaunchKernelGGL(ex ? dvp_sweep_eval_exact : dvp_sweep_eval, bgrid, dim3(64), 0, c->stream, db, b1);
+				}
+				hipLaunchKernelGGL(dvp_sweep_decide2, grid, block, 0, c->stream, db, a);
 			}
-			hipLaunchKernelGGL(dvp_sweep_decide2, grid, block, 0, c->stream, c->d, a);
 			if (c->W >= 12 && c->H >= 12) {
 				const long long frame = 12ll * c->W + 12ll * (c->H - 12);
 				hipLaunchKernelGGL(ex ? dvp_sweep_border_exact : dvp_sweep_border, dim3((unsigned)((frame + 63) / 64)), dim3(64), 0, c->stream, c->d, sb);

@@ -1230,7 +1230,8 @@ DVP_HD size_t sweep_field_stride(const Dev& d) {   // between field f and f + 1 
 DVP_HD size_t sweep_cost_index(const Dev& d, int v, int f, int center) {
 #if DVP_SWEEP_LAYOUT == 1
 	const int S = d.params.num_images - 1;
-	return (((size_t)(center >> 6) * S + v) * kSweepFields + (size_t)f) * 64 + (size_t)(center & 63);
+	const int rel = center - d.sweep_px0;   // (the band's first pixel; 0 when the buffer holds the whole image)
+	return (((size_t)(rel >> 6) * S + v) * kSweepFields + (size_t)f) * 64 + (size_t)(rel & 63);
 #else
 	const size_t L = (size_t)d.width * (size_t)d.height;
 	return ((size_t)v * kSweepFields + (size_t)f) * L + (size_t)center;

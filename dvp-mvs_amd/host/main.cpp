@@ -494,6 +494,11 @@ int main(int argc, char** argv) {
 		main_t = now;
 	};
 	std::filesystem::create_directories(opt.dense_folder / "APD");
+	// The engine's sweep passes through a band of rows of at most 24 GB of cost records (the whole 25-Mpx view with 9 sources: 67 GB =
+	// 2.3 s of fresh device memory, part of which the views running meanwhile wait for; 3 bands cost a geometric full-size pass 10 ms
+	// per view in drained launches, 5 bands 20): a full-size context is 64 GB instead of 107.  Measured neutral on the ten-view
+	// schedule (32.8 s either way).  DVP_SWEEP_BAND_GB in the environment wins; 0 = whole image.
+	setenv("DVP_SWEEP_BAND_GB", "24", 0);
 	SetHostThreadShare(opt.world);
 	if (opt.world > 1) std::cout << "rank " << opt.rank << " of " << opt.world << ": " << HostThreads() << " host threads (of " << std::thread::hardware_concurrency() << " cores)" << std::endl;
 	APD::SetDevice(opt.gpu);

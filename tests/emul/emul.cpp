@@ -67,6 +67,7 @@ void refresh(Emu& e) {
 	d.search_pos = e.search_pos.data();
 	d.slot_costs = e.slot_costs.data(); d.strong_rec = e.strong_rec.data(); d.half_w = (e.W + 1) / 2;
 	d.sweep_rec = e.sweep_rec.data(); d.sweep_cost = e.sweep_cost.data(); d.sweep_pc = e.sweep_pc.data();
+	d.sweep_px0 = 0; d.sweep_row0 = 0; d.sweep_row1 = 0;   // (the engine's bands of rows: a launch-level matter, the whole image here)
 	d.planes = e.planes.data(); d.planes_snap = e.planes_snap.data();
 	d.costs = e.costs.data(); d.costs_snap = e.costs_snap.data();
 	d.selected_views = e.selected_views.data();

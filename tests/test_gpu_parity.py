@@ -171,6 +171,29 @@ def test_fused_sweeps_equal_the_two_launches(geom, form, wpr, monkeypatch):
     assert steps.timings()["stage_launches"]["local_refine"] == 1
 
 
+@pytest.mark.parametrize("band_gb", ["0.0004", "0.006"])
+def test_sweep_passes_in_bands_of_rows_leave_the_same_bits(band_gb, monkeypatch):
+    """DVP_SWEEP_BAND_GB: the sweep passes' cost records hold a band of rows and the passes run band after band (apd sets it: the
+    records of a whole 25-Mpx view are 67 GB of fresh device memory).  Every pass is per pixel: same results as with the whole
+    image in one go, and as the oracle.  150 x 97, S = 4: 17 MB of records -> 7 bands of one 14-row tile row / 3 bands of three at these limits."""
+    W, H, S = 150, 97, 4
+    sc = synth.make_scene(W, H, S)
+    p = make_params(S + 1, max_iterations=2, state=synth.FIRST_INIT, use_APD=0, geom_consistency=1)
+    p["depth_min"] = np.float32(3.2)
+    st = first_pass_state(sc)
+    monkeypatch.setenv("DVP_SWEEP_SPLIT", "2")
+    whole = capi().from_scene(sc, p, depths=sc["depth_gt"])
+    monkeypatch.setenv("DVP_SWEEP_BAND_GB", band_gb)
+    bands = capi().from_scene(sc, p, depths=sc["depth_gt"])
+    ora = O.from_scene(sc, p, depths=sc["depth_gt"])
+    for x in (whole, bands, ora):
+        x.upload_state(**st)
+        x.run_patchmatch()
+    for n in ("planes", "weak_info", "radius", "costs", "selected_views"):
+        assert count_diff(whole.get(n), bands.get(n)) == 0, n
+        assert count_diff(bands.get(n), ora.get(n)) == 0, n
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_find_nearest_strong_ring_order(seed):
     from test_emul_parity import find_nearest_strong_case
