@@ -601,6 +601,20 @@ extern "C" __global__ void __launch_bounds__(256) dvp_gen_candidates(const Dev d
 		gen_candidates_px(d, px, py, (int)blockIdx.y);
 }
 
+// all views of a pixel by one lane (gen_candidates_views_px: the tap weights once instead of once per view)
+extern "C" __global__ void __launch_bounds__(256) dvp_gen_candidates_views(const Dev d, const LaunchArgs a) {
+	int px, py;
+	if (block_to_pixel(blockIdx.x, threadIdx.x & 63, threadIdx.x >> 6, a.tiles_x, a.tiles, a.rows, 0, 0, d.width, d.height, &px, &py))
+		gen_candidates_views_px<kCandGroup>(d, px, py, (int)blockIdx.y * kCandGroup);
+}
+extern "C" __global__ void __launch_bounds__(256) dvp_gen_candidates_views_list(const Dev d, const unsigned* list, const unsigned* n_list) {
+	const unsigned t = blockIdx.x * 256 + threadIdx.x;
+	if (t >= *n_list) return;
+	const int center = (int)list[t];
+	const int py = center / d.width, px = center - py * d.width;
+	gen_candidates_views_px<kCandGroup>(d, px, py, (int)blockIdx.y * kCandGroup);
+}
+
 // ... and the same for the ANCHOR pixels only (dvp_run_patchmatch).  The weak update is the records' one reader, and it reads
 // them at the anchors of WEAK pixels (make_anchor_record, wave_ncc_new: the anchor's eight offsets per view, APD.cu:938-952) —
 // after GenNeighbours that is a few percent of the image where the reference's GenEdgeInform fills every pixel x view (52 ms
@@ -1893,7 +1907,10 @@ static int launch_stage(dvp_ctx* c, int stage, int iter, int colour, bool fused 
 	}
 	switch (stage) {
 	case DVP_ST_GEN_EDGE_INFORM:
-		if (!fused) hipLaunchKernelGGL(dvp_gen_candidates, dim3(g.grid(), (unsigned)(c->NI - 1)), block, 0, c->stream, c->d, a);   // fused: dvp_run_patchmatch issued them on the side stream
+		if (!fused) {   // fused: dvp_run_patchmatch issued them on the side stream
+			if (gen_candidates_all_views(c->d)) hipLaunchKernelGGL(dvp_gen_candidates_views, dim3(g.grid(), (unsigned)((c->NI - 1 + kCandGroup - 1) / kCandGroup)), block, 0, c->stream, c->d, a);
+			else hipLaunchKernelGGL(dvp_gen_candidates, dim3(g.grid(), (unsigned)(c->NI - 1)), block, 0, c->stream, c->d, a);
+		}
 		hipLaunchKernelGGL(c->d.sampler ? dvp_gen_edge_inform_exact : dvp_gen_edge_inform, grid, block, 0, c->stream, c->d, a);
 		break;
 	case DVP_ST_RANDOM_INIT: hipLaunchKernelGGL(c->d.sampler ? dvp_random_init_exact : dvp_random_init, grid, block, 0, c->stream, c->d, a); break;
@@ -2042,7 +2059,8 @@ int dvp_run_patchmatch(dvp_ctx* c) {
 		const LaunchGeom g = make_geom(c->W, c->H, false);
 		LaunchArgs a;
 		a.tiles_x = g.tiles_x; a.tiles = g.tiles; a.rows = g.rows; a.half = 0; a.colour = 0; a.iter = 0;
-		hipLaunchKernelGGL(dvp_gen_candidates, dim3(g.grid(), (unsigned)(c->NI - 1)), dim3(256), 0, c->side, c->d, a);
+		if (gen_candidates_all_views(c->d)) hipLaunchKernelGGL(dvp_gen_candidates_views, dim3(g.grid(), (unsigned)((c->NI - 1 + kCandGroup - 1) / kCandGroup)), dim3(256), 0, c->side, c->d, a);
+		else hipLaunchKernelGGL(dvp_gen_candidates, dim3(g.grid(), (unsigned)(c->NI - 1)), dim3(256), 0, c->side, c->d, a);
 		HIP_TRY(c, hipGetLastError());
 		HIP_TRY(c, hipEventRecord(c->side_join, c->side));
 	}
@@ -2068,7 +2086,8 @@ int dvp_run_patchmatch(dvp_ctx* c) {
 		const size_t most = std::min(c->L, (size_t)la.count * (DVP_NEIGHBOUR_NUM - 1));
 		Dev dsnap = c->d;
 		dsnap.selected_views = c->sel_snap;
-		if (most > 0) hipLaunchKernelGGL(dvp_gen_candidates_list, dim3((unsigned)((most + 255) / 256), (unsigned)(c->NI - 1)), dim3(256), 0, c->side, dsnap, c->cand_list, c->cand_n);
+		if (most > 0 && gen_candidates_all_views(dsnap)) hipLaunchKernelGGL(dvp_gen_candidates_views_list, dim3((unsigned)((most + 255) / 256), (unsigned)((c->NI - 1 + kCandGroup - 1) / kCandGroup)), dim3(256), 0, c->side, dsnap, c->cand_list, c->cand_n);
+		else if (most > 0) hipLaunchKernelGGL(dvp_gen_candidates_list, dim3((unsigned)((most + 255) / 256), (unsigned)(c->NI - 1)), dim3(256), 0, c->side, dsnap, c->cand_list, c->cand_n);
 		HIP_TRY(c, hipGetLastError());
 		HIP_TRY(c, hipEventRecord(c->side_join, c->side));
 	}

@@ -81,7 +81,8 @@ DVP_HD void run_pixel(const Dev& d, int px, int py, int iter, unsigned long long
 	if (STAGE == DVP_ST_GEN_EDGE_INFORM) {
 		gen_edge_inform_px(d, px, py);
 #if !defined(__HIP_DEVICE_COMPILE__)   // device: own launch shape, pixels x views (dvp_gen_candidates)
-		for (int v = 0; v < d.params.num_images - 1; ++v) gen_candidates_px(d, px, py, v);
+		if (gen_candidates_all_views(d)) { for (int v0 = 0; v0 < d.params.num_images - 1; v0 += kCandGroup) gen_candidates_views_px<kCandGroup>(d, px, py, v0); }   // (as the engine chooses)
+		else for (int v = 0; v < d.params.num_images - 1; ++v) gen_candidates_px(d, px, py, v);
 #endif
 	}
 	else if (STAGE == DVP_ST_FIND_NEAREST_STRONG) find_nearest_strong_px(d, px, py);

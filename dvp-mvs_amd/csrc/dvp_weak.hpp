@@ -56,7 +56,8 @@ DVP_HD void edge_ray_line(const Dev& d, int k, int line, int what = 0) {
 // pixel sees view v are binned into twelve 30-degree sectors (at most 20 per sector, visit order), each
 // sector keeps its heaviest offset (first one among equals: the reference's stable bubble sort), the
 // twelve winners are sorted by weight and the top eight stored.
-// Launch shape: pixels x views (the view is wave-uniform), one pass over the window per lane, the twelve
+// Launch shape (this function: more than 32 views, or another window than the default; else gen_candidates_views_px below):
+// pixels x views (the view is wave-uniform), one pass over the window per lane, the twelve
 // winners in registers.  (Round 1 walked the window once per pixel for all views and kept S x 12 running
 // maxima in a dynamically indexed private array: 3.2 KB of scratch per lane, 330 GB of write-back per
 // launch at 6208x4128.)  For the default window (weak_radius = 5, main.h:104; the reference never
@@ -136,6 +137,101 @@ DVP_HD void gen_candidates_px(const Dev& d, int px, int py, int v) {
 #pragma unroll
 	for (int k = 0; k < 8; ++k) rec.o[k] = mks2(win[k].i, win[k].j);
 	*reinterpret_cast<Cand8*>(d.candidate + cand_index(d, center, v)) = rec;   // two 16-byte stores
+}
+
+// The same records for ALL source views of a pixel by one lane (round 6).  A tap's weight does not depend on the view — only
+// whether the tap's pixel sees it does — so the pixels x views launch evaluated every weight (an exp among ~35 instructions) and
+// fetched every texel and selected-view word S times (52 ms per 25-Mpx launch with S = 9).  Here: one pass over the window, the
+// weight once, S running sector maxima in registers (views unrolled over MV, nothing indexed dynamically), and instead of twelve
+// winners per view to sort at the end, each view's sorted top eight kept as the sectors finish: inserting the sectors' winners in
+// sector order, each BELOW the entries that are not lighter, is the reference's stable bubble sort (APD.cu:3786-3792) step by step,
+// and an entry that falls out of the first eight cannot come back.  Empty sectors take part with weight 0 and offset (0, 0) as they
+// do there (a view no tap sees: eight zero offsets either way).  weak_radius == 5 (dvp_sector5.inc) only; a lane takes MV views, the
+// launch has ceil(S / MV) lanes per pixel.
+template <int MV>
+DVP_HD void gen_candidates_views_px(const Dev& d, int px, int py, int v0 = 0) {   // views v0 .. v0 + MV - 1
+	const int W = d.width, H = d.height;
+	const int center = px + py * W;
+	const DvpParams& P = d.params;
+	const int S = P.num_images - 1;
+	const float* ref = d.images;
+	const float cpix = img_texel(ref, d.org, d.pitch, W, H, px, py);
+	float top_w[MV][8];
+	uint32_t top_o[MV][8];   // offset as the record stores it: (uint16)i | (uint16)j << 16
+#pragma unroll
+	for (int v = 0; v < MV; ++v)
+#pragma unroll
+		for (int k = 0; k < 8; ++k) { top_w[v][k] = -1.0f; top_o[v][k] = 0u; }   // (-1: below every weight, an empty place)
+#pragma unroll
+	for (int r = 0; r < 12; ++r) {
+		float bw[MV];
+		uint32_t bo[MV];
+		uint32_t has = 0;
+#pragma unroll
+		for (int v = 0; v < MV; ++v) { bw[v] = 0.0f; bo[v] = 0u; }
+#pragma unroll
+		for (int t = 0; t < kSector5Max; ++t) {
+			if (t >= kSector5Count[r]) continue;
+			const int i = kSector5[r][t][0], j = kSector5[r][t][1];
+			const int x = px + i, y = py + j;
+			const bool in = x >= 0 && x < W && y >= 0 && y < H;
+			const uint32_t sv = d.selected_views[clampi(y, 0, H - 1) * W + clampi(x, 0, W - 1)];   // (in-bounds; used only when `in`)
+			const float a = img_texel(ref, d.org, d.pitch, W, H, x, y);
+			const float w = bilateral_weight((float)i, (float)j, a, cpix, P.sigma_spatial, P.sigma_color, 1);
+			const uint32_t o = ((uint32_t)i & 0xffffu) | ((uint32_t)j << 16);
+			const uint32_t seen = in ? (sv >> v0) : 0u;
+#pragma unroll
+			for (int v = 0; v < MV; ++v) {
+				const bool take = ((seen >> v) & 1u) && (!((has >> v) & 1u) || w > bw[v]);
+				bw[v] = take ? w : bw[v];
+				bo[v] = take ? o : bo[v];
+				has |= take ? (1u << v) : 0u;
+			}
+		}
+		// the sector's winners into the views' lists
+#pragma unroll
+		for (int v = 0; v < MV; ++v) {
+			const float w = bw[v];
+			const uint32_t o = bo[v];
+#pragma unroll
+			for (int k = 7; k >= 1; --k) {
+				const bool from_above = top_w[v][k - 1] < w;   // the entry above is lighter: it moves down to k
+				const bool here = top_w[v][k] < w;              // (else) the new entry lands at k if k's is lighter
+				top_o[v][k] = from_above ? top_o[v][k - 1] : (here ? o : top_o[v][k]);
+				top_w[v][k] = from_above ? top_w[v][k - 1] : (here ? w : top_w[v][k]);
+			}
+			const bool first = top_w[v][0] < w;
+			top_o[v][0] = first ? o : top_o[v][0];
+			top_w[v][0] = first ? w : top_w[v][0];
+		}
+	}
+#pragma unroll
+	for (int v = 0; v < MV; ++v) {
+		if (v0 + v >= S) continue;
+		uint32_t* out = reinterpret_cast<uint32_t*>(d.candidate + cand_index(d, center, v0 + v));
+#if defined(__HIP_DEVICE_COMPILE__)
+		typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+		u4 lo, hi;
+		lo.x = top_o[v][0]; lo.y = top_o[v][1]; lo.z = top_o[v][2]; lo.w = top_o[v][3];
+		hi.x = top_o[v][4]; hi.y = top_o[v][5]; hi.z = top_o[v][6]; hi.w = top_o[v][7];
+		reinterpret_cast<u4*>(out)[0] = lo;
+		reinterpret_cast<u4*>(out)[1] = hi;
+#else
+		for (int k = 0; k < 8; ++k) d.candidate[cand_index(d, center, v0 + v) + k] = mks2((int)(int16_t)(top_o[v][k] & 0xffffu), (int)(int16_t)(top_o[v][k] >> 16));
+#endif
+	}
+}
+#ifndef DVP_CAND_GROUP
+#define DVP_CAND_GROUP 5   // 25-Mpx launch, S = 9: 42 ms (10: 110 ms at one wave per SIMD, 3: 47, 1: 97; a lane per (pixel, view) with a sort at the end: 53)
+#endif
+constexpr int kCandGroup = DVP_CAND_GROUP;   // views per lane (16 + 2 registers each); the launch has ceil(S / kCandGroup) lanes per pixel
+constexpr int kCandViewsMax = 32;
+DVP_HD bool gen_candidates_all_views(const Dev& d) {
+#if defined(DVP_GEI_GENERIC) || defined(DVP_CAND_PER_VIEW)
+	return false;
+#else
+	return d.params.weak_radius == 5 && d.params.num_images - 1 <= kCandViewsMax;
+#endif
 }
 
 // the per-pixel rest of GenEdgeInform (APD.cu:3796-3890); candidates: gen_candidates_px, edge_neigh: edge_ray_line
