@@ -118,7 +118,7 @@ def extra_kernels(stage, S):
     """the other kernels a launch site's timer covers: [(kernel, launches per launch of the site)]; their counters are added to
     the first one's"""
     if stage == "gen_neighbours":
-        return [("dvp_gen_neighbours_fit", 1)]       # (dvp_gen_candidates runs on the side stream, outside its launch site's timer)
+        return [("dvp_gen_neighbours_fit", 1)]       # (dvp_gen_candidates_views runs on the side stream, outside its launch site's timer)
     if stage == "strong_update" and S <= 16 and os.environ.get("DVP_STRONG_SPLIT", "1") != "0":
         return [(decide_kernel(S), 1), ("dvp_strong_refine_lanes" if os.environ.get("DVP_REFINE_LANES", "1") != "0" else "dvp_strong_refine", 1)]
     if stage == "weak_update" and weak_phased():     # the weak update as eight launches (dvp_weak_phased.hpp)
@@ -595,7 +595,7 @@ def measure(env, args, cfg_name, W, H, S, iters, weak_frac_arg, steps, warmup, p
             "launches_per_step": dict([(kernel_name(k, S), primary_launches(k) * tm["stage_launches"][k] // steps) for k in stage_ms if k != "strong_prep"] +
                                       [(extra, mult * tm["stage_launches"][k] // steps) for k in stage_ms for extra, mult in extra_kernels(k, S)] +
                                       [(extra, tm["stage_launches"][k] // steps) for k, extra in
-                                       (("gen_edge_inform", "dvp_gen_candidates"), ("strong_prep", "dvp_strong_search")) if k in stage_ms] +
+                                       (("gen_edge_inform", "dvp_gen_candidates_views"), ("strong_prep", "dvp_strong_search")) if k in stage_ms] +
                                       ([("dvp_weak_anchor_table", 1)] if ("weak_update" in stage_ms and os.environ.get("DVP_WEAK_ANCHOR_TAB", "1") != "0") else [])),
             "ncc_evals_per_step": {k: int(v) for k, v in evals["ncc_evals"].items() if v > 0},
             "Gevals_per_s": {k: round(evals["ncc_evals"][k] / (tm["stage_ms"][k] / steps * 1e-3) / 1e9, 3)
