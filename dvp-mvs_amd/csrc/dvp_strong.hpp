@@ -89,6 +89,103 @@ DVP_HD f4 random_normal_yzl(const Dev& d, int px, int py, Rng& rng, float depth)
 	return random_normal_yzl_sel(d, px, py, rng, depth, d.selected_views[py * d.width + px]);
 }
 
+// The same draw for the split strong update's decision launch (S <= MV <= 16 views, unrolled).  random_normal_yzl_sel walks the
+// views with `if (!selected) continue`, fetches the source depth of each inside that loop and appends to vd[index++]: one dependent
+// round trip per selected view and a dynamically indexed private array (scratch) that the rejection loop re-reads on every try —
+// half of dvp_strong_decide's 8.6 ms at cfg3 (timing ablation, profiles/r06_ab_notes.txt 20).  Here: the depth texels of all views
+// fetched together (clamped addresses, the value used only where the reference reads it), the directions in registers behind a
+// mask.  Same operations per selected view, same random numbers; the order in which a candidate is tested against the directions
+// does not matter (it has to face away from all of them), and with at most 16 views the reference's limit of 19 never binds.
+template <int MV>
+DVP_HD f4 random_normal_yzl_views(const Dev& d, int px, int py, Rng& rng, float depth, uint32_t sel) {
+	static_assert(MV <= 16, "the reference keeps at most 19 source directions (APD.cu:546)");
+	const int W = d.width, H = d.height;
+	const int S = d.params.num_images - 1;
+	const DvpCamera rc = load_camera(d, 0);
+	f3 vd0;
+	{
+		const f4 v0 = view_direction(rc, px, py, depth);
+		vd0 = mk3(v0.x, v0.y, v0.z);
+	}
+	const f3 fwd = point_on_world((float)px, (float)py, depth, rc);
+	int ixs[MV], iys[MV], txs[MV], tys[MV];
+	float dep[MV];
+	uint32_t inside = 0;
+#pragma unroll
+	for (int v = 1; v <= MV; ++v) {
+		const int vv = v <= S ? v : S;   // (a view that exists; beyond S the result is not used)
+		const DvpCamera sc = load_camera(d, vv);
+		f2 sp;
+		float sd;
+		project_on_camera(fwd, sc, &sp, &sd);
+		const float sx = fminf(fmaxf(sp.x, -32768.0f), 32767.0f);
+		const float sy = fminf(fmaxf(sp.y, -32768.0f), 32767.0f);
+		const int ix = (int)((float)(int)sx + 0.5f), iy = (int)((float)(int)sy + 0.5f);   // APD.cu:525
+		ixs[v - 1] = ix; iys[v - 1] = iy;
+		txs[v - 1] = (int)sx; tys[v - 1] = (int)sy;
+		if (ix >= 0 && ix < W && iy >= 0 && iy < H) inside |= 1u << (v - 1);
+	}
+	if (d.params.geom_consistency) {   // (without it there are no depth planes)
+#pragma unroll
+		for (int v = 1; v <= MV; ++v) {
+			const int vv = v <= S ? v : S;
+			dep[v - 1] = tex_texel(d.depths + (size_t)vv * d.plane_stride, d.org, d.pitch, W, H, txs[v - 1], tys[v - 1]);   // (clamped inside tex_texel)
+		}
+	} else {
+#pragma unroll
+		for (int v = 1; v <= MV; ++v) dep[v - 1] = 1.0f;
+	}
+	sched_fence();
+	f3 vd[MV];
+	uint32_t valid = 0;
+#pragma unroll
+	for (int v = 1; v <= MV; ++v) {
+		const int vv = v <= S ? v : S;
+		const DvpCamera sc = load_camera(d, vv);
+		float src_depth = 1.0f;   // reference leaves it uninitialised outside the image (APD.cu:526)
+		if (d.params.geom_consistency && ((inside >> (v - 1)) & 1u)) src_depth = dep[v - 1];
+		const f4 dir = view_direction(sc, ixs[v - 1], iys[v - 1], src_depth);
+		float Rc[9];
+		for (int i = 0; i < 3; ++i)
+			for (int j = 0; j < 3; ++j) {
+				float acc = 0.0f;
+				for (int k = 0; k < 3; ++k) acc += rc.R[i * 3 + k] * sc.R[j * 3 + k];
+				Rc[i * 3 + j] = acc;
+			}
+		const float b0 = dir.x, b1 = dir.y, b2 = dir.x;
+		const float f0 = Rc[0] * b0 + Rc[1] * b1 + Rc[2] * b2;
+		const float f1 = Rc[3] * b0 + Rc[4] * b1 + Rc[5] * b2;
+		const float f2_ = Rc[6] * b0 + Rc[7] * b1 + Rc[7] * b2;
+		const float norm = sqrtf(f0 * f0 + f1 * f1 + f2_ * f2_);
+		vd[v - 1] = mk3(f0 / norm, f1 / norm, f2_ / norm);
+		if (v <= S && is_set(sel, v - 1)) valid |= 1u << (v - 1);
+	}
+	int times = 200;
+	f4 n = mk4(0, 0, 0, 0);
+	while (times > 0) {
+		float q1 = 1.0f, q2 = 1.0f, s = 2.0f;
+		while (s >= 1.0f) {
+			q1 = 2.0f * rng.uniform() - 1.0f;
+			q2 = 2.0f * rng.uniform() - 1.0f;
+			s = q1 * q1 + q2 * q2;
+		}
+		const float sq = sqrtf(1.0f - s);
+		n.x = 2.0f * q1 * sq;
+		n.y = 2.0f * q2 * sq;
+		n.z = 1.0f - 2.0f * s;
+		bool ok = !(n.x * vd0.x + n.y * vd0.y + n.z * vd0.z > 0.0f);
+#pragma unroll
+		for (int i = 0; i < MV; i++) {
+			const float dp = n.x * vd[i].x + n.y * vd[i].y + n.z * vd[i].z;
+			if (((valid >> i) & 1u) && dp > 0.0f) ok = false;
+		}
+		if (ok) break;
+		times--;
+	}
+	normalize3(&n);
+	return n;
+}
+
 // RandomInitialization (APD.cu:1273-1309)
 template <int SMP>
 DVP_HD void random_init_px(const Dev& d, int px, int py, PatchTab tab, unsigned long long* nevals) {
@@ -616,6 +713,7 @@ DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
 	const size_t L = (size_t)W * d.height;
 	const size_t Lh = (size_t)d.half_w * (size_t)d.height, hi = half_index(d, px, py);
 	const float good_thr = 0.8f * dvp_expf((iter) * (iter) / (-90.0f));
+	const uint32_t sel_entry = d.selected_views[center];   // (the pixel's own word: no other pixel of this colour writes it)
 	float ca[8][MV];
 	uint32_t flag = 0;
 	int positions[8];
@@ -792,8 +890,13 @@ DVP_HD void strong_decide_px(const Dev& d, int px, int py, int iter) {
 	Rng rn(d.seed, (uint32_t)center, rng_site(PH_STRONG, iter, SUB_NORMAL));
 	Rng rp(d.seed, (uint32_t)center, rng_site(PH_STRONG, iter, SUB_DEPTH_PERT));
 	const float depth_rand = rd.uniform() * (P.depth_max - P.depth_min) + P.depth_min;
-	if (selected_views_written) d.selected_views[center] = sel_mask;   // read by random_normal_yzl
+	if (selected_views_written) d.selected_views[center] = sel_mask;   // (what random_normal_yzl reads)
+#if defined(DVP_DECIDE_YZL_GENERIC)   // A/B: the per-view walk with its scratch array
 	const f4 n_rand = random_normal_yzl(d, px, py, rn, depth_now);
+#else
+	const f4 n_rand = MV <= 16 ? random_normal_yzl_views<(MV <= 16 ? MV : 16)>(d, px, py, rn, depth_now, selected_views_written ? sel_mask : sel_entry)
+	                           : random_normal_yzl(d, px, py, rn, depth_now);
+#endif
 	const float dmin_p = (1 - 0.02f) * depth_now, dmax_p = (1 + 0.02f) * depth_now;
 	const float depth_pert = rp.uniform() * (dmax_p - dmin_p) + dmin_p;
 	float* rec = d.strong_rec + hi;
