@@ -224,7 +224,11 @@ ViewResult ProcessProblem(const Problem& problem, const std::function<float*(int
 		if (fetch_maps) {
 			fetch_maps();
 			PublishResult(folder / "depths.dmb", depth);
-			if (timing) std::cout << "  [background] maps to the host: " << std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() / 1000.0 << " ms" << std::endl;
+			if (timing) {   // (one write per line: the driver threads print their views' blocks meanwhile)
+				std::ostringstream line;
+				line << "  [background] maps to the host: " << std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() / 1000.0 << " ms\n";
+				std::cout << line.str() << std::flush;
+			}
 		}
 		// Visibility clean-up (main.cpp:311-363): per source view, every 4-connected region of pixels that do
 		// NOT select the view and is smaller than 20 * (8 / scale)^2 pixels is switched to "selected".
@@ -266,8 +270,11 @@ ViewResult ProcessProblem(const Problem& problem, const std::function<float*(int
 			writeDepthDmb(folder / "depths_geom.dmb", depth);
 			writeNormalDmb(folder / "normals.dmb", normal);
 		}
-		if (timing) std::cout << "  [background] visibility-mask clean-up + publish: "
-		                      << std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() / 1000.0 << " ms" << std::endl;
+		if (timing) {
+			std::ostringstream line;
+			line << "  [background] visibility-mask clean-up + publish: " << std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() / 1000.0 << " ms\n";
+			std::cout << line.str() << std::flush;
+		}
 	});
 	lap("hand-over to the background worker");
 	const auto end = std::chrono::steady_clock::now();
